@@ -1,0 +1,170 @@
+/*
+ * orca_hip.h - C ABI of liborca_hip.so, the MI355X (gfx950) implementation of
+ * the Orca hot path (Encoder -> Encoder2/Encoder3 -> Decoder cascade).
+ *
+ * The reference (jzhoulab/orca) has no FFI / plugin registry: the hot path is
+ * reached through a duck-typed Python model protocol.
+ * Each entry point below states which reference call it replaces; the Python
+ * host in orca_amd/ binds them with ctypes (INTEGRATION.md shows the stub a
+ * reference maintainer would add).
+ *
+ * Conventions
+ *  - plain C types only; every function returns 0 (ORCA_OK) or a negative
+ *    ORCA_E* code and records a message retrievable with orca_last_error()
+ *    (thread-local).  No exceptions cross the boundary.
+ *  - all `const float*` / `float*` data arguments are CALLER-OWNED DEVICE
+ *    pointers (e.g. torch.Tensor.data_ptr() of a ROCm tensor) unless the
+ *    parameter name ends in `_host`.
+ *  - strides are in ELEMENTS (floats), so non-contiguous torch views (the
+ *    `.transpose(1,2)` of orca_predict.py:334, the `[:, :, s:s+250]` slices of
+ *    :358) are passed without a copy.
+ *  - work is enqueued asynchronously on the HIP stream the context was
+ *    created with (or was last given via orca_ctx_set_stream); the library
+ *    never synchronises the device on the forward path.
+ *  - the library owns only its weight copies (orca_net) and a per-context
+ *    workspace that grows on demand.
+ *  - one orca_ctx per (host thread, GPU).  No global mutable state.
+ */
+#ifndef ORCA_HIP_H
+#define ORCA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORCA_OK 0
+#define ORCA_EINVAL (-1)  /* bad argument / shape mismatch            */
+#define ORCA_EHIP (-2)    /* a HIP runtime call failed                */
+#define ORCA_ENOMEM (-3)  /* workspace / weight allocation failed     */
+#define ORCA_ENODEV (-4)  /* no usable gfx950 device                  */
+
+#define ORCA_ABI_VERSION 1
+
+typedef struct orca_ctx orca_ctx;
+typedef struct orca_net orca_net;
+
+/* Which reference nn.Module an orca_net stands for. */
+enum orca_net_kind {
+  ORCA_NET_ENCODER = 1,    /* orca_modules.Encoder     (orca_modules.py:803-980)   */
+  ORCA_NET_ENCODER2 = 2,   /* orca_modules.Encoder2    (orca_modules.py:984-1169)  */
+  ORCA_NET_ENCODER3 = 3,   /* orca_modules.Encoder3    (orca_modules.py:1279-1406) */
+  ORCA_NET_DECODER = 4,    /* orca_modules.Decoder     (orca_modules.py:16-488)    */
+  ORCA_NET_DECODER_1M = 5  /* orca_modules.Decoder_1m  (orca_modules.py:491-800)   */
+};
+
+/* Decoder(upsample_mode=...) of orca_modules.py:17,430; containers use bilinear
+ * (orca_models.py:45-50). */
+#define ORCA_UPSAMPLE_NEAREST 0
+#define ORCA_UPSAMPLE_BILINEAR 1
+
+/* One convolution with eval-mode BatchNorm already folded into it on the host
+ * (w' = w*gamma/sqrt(var+1e-5), b' = (b-mean)*gamma/sqrt(var+1e-5)+beta).
+ * weight_host: [cout][cin][ksize] (1-D, ksize=9) or [cout][cin][ksize][ksize]
+ * (2-D, ksize=3 or 1), fp32, row-major exactly as in the reference checkpoints
+ * (`*.statedict`, orca_models.py:53-123). */
+typedef struct orca_conv_desc {
+  const float* weight_host;
+  const float* bias_host;
+  int32_t cout;
+  int32_t cin;
+  int32_t ksize;
+  int32_t dilation;
+} orca_conv_desc;
+
+/* ---- library / context ------------------------------------------------- */
+
+int orca_abi_version(void);
+const char* orca_last_error(void);
+
+/* Number of visible HIP devices (0 if none; never fails). */
+int orca_device_count(void);
+
+/* Replaces: implicit torch device/stream state used by `.cuda()` at
+ * orca_predict.py:334.  hip_stream may be NULL (default stream). */
+int orca_ctx_create(int device, void* hip_stream, orca_ctx** out);
+int orca_ctx_destroy(orca_ctx* ctx);
+int orca_ctx_set_stream(orca_ctx* ctx, void* hip_stream);
+/* Bytes of device workspace currently held by the context. */
+int orca_ctx_workspace_bytes(orca_ctx* ctx, size_t* out);
+/* Free the workspace (it is re-grown on demand). */
+int orca_ctx_release_workspace(orca_ctx* ctx);
+
+/* ---- weights -------------------------------------------------------------
+ * Replaces: nn.Module.load_state_dict + .cuda() of the reference containers
+ * (orca_models.py:53-133).  `convs` lists the folded convolutions of the module
+ * in forward order (documented per kind in DESIGN.md section "conv order");
+ * shapes are validated against the architecture.  The library re-lays the
+ * weights out for its MFMA kernels and keeps the device copy until
+ * orca_net_free. */
+int orca_net_create(orca_ctx* ctx, int kind, const orca_conv_desc* convs, int n_convs,
+                    int upsample_mode, orca_net** out);
+int orca_net_free(orca_net* net);
+
+/* ---- forward passes -------------------------------------------------------- */
+
+/* Replaces: model.net0(x) = Encoder.forward (orca_modules.py:929-980).
+ * x: [B,4,L] fp32 with element strides (sx_b,sx_c,sx_l); any float content
+ * (one-hot rows, 0.25 'N' rows, ...).  Computes output bins [bin_lo,bin_hi)
+ * (4000 bp each; bin_hi<=0 means "to the end") and writes
+ * out[b*so_b + c*so_c + (bin-bin_lo)], c<128.  A sub-range is how the
+ * independent sequence blocks shard across GPUs.
+ * chunk_bp: internal processing chunk (multiple of 4000; <=0 = default);
+ * chunks carry a 112 kb input halo each side exactly like the reference's
+ * 800 kb blocks, so results do not depend on it. */
+int orca_encoder_forward(orca_ctx* ctx, orca_net* net, const float* x, int64_t sx_b, int64_t sx_c,
+                         int64_t sx_l, int B, int64_t L, int64_t bin_lo, int64_t bin_hi, float* out,
+                         int64_t so_b, int64_t so_c, int64_t chunk_bp);
+
+/* Number of 4 kb bins Encoder emits for an L-bp input (floor through the
+ * 4,4,5,5,5,2 pooling chain). */
+int64_t orca_encoder_num_bins(int64_t L);
+
+/* Replaces: model.net(enc0) / model.net1(enc0) = Encoder2.forward
+ * (orca_modules.py:1151-1169) and Encoder3.forward (:1388-1406).
+ * x: [B,128,n] (strides in elements), n divisible by 2^nlev (nlev = 5 / 3).
+ * outs: HOST array of nlev+1 device pointers; outs[i] receives the
+ * contiguous [B,128,n>>i] encoding (fine -> coarse, as the reference returns). */
+int orca_unet_forward(orca_ctx* ctx, orca_net* net, const float* x, int64_t sx_b, int64_t sx_c,
+                      int64_t sx_l, int B, int n, float* const* outs_host, int n_outs);
+
+/* Replaces: model.denets[level].forward(x, distenc, y) = Decoder.forward
+ * (orca_modules.py:461-488).  x: [B,128,n] slice of an encoding (n<=256,
+ * 250 in the reference); distenc: [B,1,n,n] log-background (sd_b may be 0
+ * for the `.expand` of orca_predict.py:353); y: NULL or the [B,1,n/2,n/2]
+ * crop of the coarser prediction (orca_predict.py:374-379).
+ * out: contiguous [B,1,n,n].  accumulate!=0 adds into out instead of
+ * overwriting (used for `+ denet_1_pt(...)`, orca_predict.py:362-366). */
+int orca_decoder_forward(orca_ctx* ctx, orca_net* net, const float* x, int64_t sx_b, int64_t sx_c,
+                         int64_t sx_l, const float* distenc, int64_t sd_b, int64_t sd_h, int64_t sd_w,
+                         const float* y, int64_t sy_b, int64_t sy_h, int64_t sy_w, int B, int n,
+                         float* out, int accumulate);
+
+/* Replaces: model.denet_1_pt.forward(x) = Decoder_1m.forward (orca_modules.py:782-800). */
+int orca_decoder1m_forward(orca_ctx* ctx, orca_net* net, const float* x, int64_t sx_b, int64_t sx_c,
+                           int64_t sx_l, int B, int n, float* out, int accumulate);
+
+/* Replaces: the strand merge `0.5*fwd + 0.5*rev[::-1, ::-1]`
+ * (orca_predict.py:514-523) for contiguous [n,n] maps. */
+int orca_strand_merge(orca_ctx* ctx, const float* fwd, const float* rev, float* out, int n);
+
+/* ---- single-layer entry points (kernel unit tests; same kernels the nets use) ---
+ * y = [relu](conv1d_k9(x) + b) [+ r1] [+ r2], all [B,C,n] with row stride ld
+ * (elements) and batch stride bs.  w/b as in orca_conv_desc (host, folded).
+ * tile: 0 = auto, else force the position-tile size (32/64/256). */
+int orca_conv1d_forward(orca_ctx* ctx, const orca_conv_desc* conv, const float* x, int64_t x_bs, int64_t ldx,
+                        float* y, int64_t y_bs, int64_t ldy, const float* r1, const float* r2, int B, int64_t n,
+                        int relu, int tile);
+/* y = [relu](conv2d_3x3_dilated(x) + b) [+ r]; x: contiguous [B,cin,n,n], y/r: [B,cout,n,n]. */
+int orca_conv2d_forward(orca_ctx* ctx, const orca_conv_desc* conv, const float* x, float* y, const float* r,
+                        int B, int n, int relu);
+/* y[c][m] = max_{j<k} x[c][k*m+j]  (nn.MaxPool1d(k,k)); x: [rows][ldx], y: [rows][ldy]. */
+int orca_maxpool1d_forward(orca_ctx* ctx, const float* x, int64_t ldx, float* y, int64_t ldy, int64_t rows,
+                           int64_t n_out, int k);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ORCA_HIP_H */

@@ -1,0 +1,80 @@
+"""ctypes binding of liborca_hip.so (include/orca_hip.h).
+
+The library is built in-tree (``make -C orca_amd/csrc`` or
+``__graft_entry__.build()``).  There is NO fallback: if the shared object is
+missing, or an entry point fails, an exception is raised.
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "liborca_hip.so")
+
+ORCA_NET_ENCODER, ORCA_NET_ENCODER2, ORCA_NET_ENCODER3, ORCA_NET_DECODER, ORCA_NET_DECODER_1M = 1, 2, 3, 4, 5
+ORCA_UPSAMPLE_NEAREST, ORCA_UPSAMPLE_BILINEAR = 0, 1
+
+
+class OrcaHipError(RuntimeError):
+    pass
+
+
+class ConvDesc(ctypes.Structure):
+    _fields_ = [("weight_host", c_void_p), ("bias_host", c_void_p), ("cout", c_int32), ("cin", c_int32),
+                ("ksize", c_int32), ("dilation", c_int32)]
+
+
+# name -> (restype, argtypes); every symbol declared in include/orca_hip.h
+SIGNATURES = {
+    "orca_abi_version": (c_int, []),
+    "orca_last_error": (c_char_p, []),
+    "orca_device_count": (c_int, []),
+    "orca_ctx_create": (c_int, [c_int, c_void_p, POINTER(c_void_p)]),
+    "orca_ctx_destroy": (c_int, [c_void_p]),
+    "orca_ctx_set_stream": (c_int, [c_void_p, c_void_p]),
+    "orca_ctx_workspace_bytes": (c_int, [c_void_p, POINTER(c_size_t)]),
+    "orca_ctx_release_workspace": (c_int, [c_void_p]),
+    "orca_net_create": (c_int, [c_void_p, c_int, POINTER(ConvDesc), c_int, c_int, POINTER(c_void_p)]),
+    "orca_net_free": (c_int, [c_void_p]),
+    "orca_encoder_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_int64, c_int64,
+                                     c_int64, c_void_p, c_int64, c_int64, c_int64]),
+    "orca_encoder_num_bins": (c_int64, [c_int64]),
+    "orca_unet_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_int,
+                                  POINTER(c_void_p), c_int]),
+    "orca_decoder_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64,
+                                     c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_void_p, c_int]),
+    "orca_decoder1m_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_void_p, c_int]),
+    "orca_strand_merge": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int]),
+    "orca_conv1d_forward": (c_int, [c_void_p, POINTER(ConvDesc), c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
+                                    c_void_p, c_void_p, c_int, c_int64, c_int, c_int]),
+    "orca_conv2d_forward": (c_int, [c_void_p, POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_int, c_int, c_int]),
+    "orca_maxpool1d_forward": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int]),
+}
+
+_lib = None
+
+
+def load():
+    """Load liborca_hip.so (once) and set the prototypes.  Raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OrcaHipError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `make -C orca_amd/csrc` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.orca_abi_version() != 1:
+        raise OrcaHipError("liborca_hip ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().orca_last_error()
+        raise OrcaHipError(f"{what} failed (code {rc}): {msg.decode('utf8', 'replace') if msg else ''}")

@@ -1,0 +1,165 @@
+// misc_kernels.h - the small HBM-bound kernels around the convolutions:
+// input staging, max-pool, nearest/bilinear upsampling, the pairwise outer sum,
+// the 1x1 "final" head with symmetrisation, and the strand merge.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "conv_kernels.h"
+
+// x[b] viewed as [4][L] with element strides (sc, sl)  ->  y [4][ld] channel-major.
+// The reference feeds `seq.transpose(1,2)` of a [B,L,4] array (orca_predict.py:334),
+// i.e. sc=1, sl=4: one float4 per position.
+__global__ void seq_to_channel_major_kernel(const float* __restrict__ x, long sc, long sl, long L, float* __restrict__ y, long ld) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= L) return;
+  float v0, v1, v2, v3;
+  if (sc == 1 && sl == 4 && ((reinterpret_cast<uintptr_t>(x) & 15) == 0)) {
+    const float4 q = reinterpret_cast<const float4*>(x)[i];
+    v0 = q.x; v1 = q.y; v2 = q.z; v3 = q.w;
+  } else {
+    v0 = x[i * sl]; v1 = x[i * sl + sc]; v2 = x[i * sl + 2 * sc]; v3 = x[i * sl + 3 * sc];
+  }
+  y[i] = v0; y[ld + i] = v1; y[2 * ld + i] = v2; y[3 * ld + i] = v3;
+}
+
+// nn.MaxPool1d(k, k): y[r][m] = max_j x[r][k*m+j]
+template <int K>
+__global__ void maxpool1d_kernel(const float* __restrict__ x, long ldx, float* __restrict__ y, long ldy, long n_out) {
+  const long m = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long r = blockIdx.y;
+  if (m >= n_out) return;
+  const float* p = x + r * ldx + (long)K * m;
+  float v;
+  if (K == 4 && (ldx & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) & 15) == 0)) {
+    const float4 q = *reinterpret_cast<const float4*>(p);
+    v = fmaxf(fmaxf(q.x, q.y), fmaxf(q.z, q.w));
+  } else if (K == 2 && (ldx & 1) == 0 && ((reinterpret_cast<uintptr_t>(x) & 7) == 0)) {
+    const float2 q = *reinterpret_cast<const float2*>(p);
+    v = fmaxf(q.x, q.y);
+  } else {
+    v = p[0];
+#pragma unroll
+    for (int j = 1; j < K; ++j) v = fmaxf(v, p[j]);
+  }
+  y[r * ldy + m] = v;
+}
+
+// nn.Upsample(scale_factor=2) (nearest, 1-D): y[r][m] = x[r][m>>1]
+__global__ void upsample1d_x2_kernel(const float* __restrict__ x, long ldx, float* __restrict__ y, long ldy, long n_out) {
+  const long m = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long r = blockIdx.y;
+  if (m >= n_out) return;
+  y[r * ldy + m] = x[r * ldx + (m >> 1)];
+}
+
+// generic strided 2-D copy: dst[r*ldd + c] = src[r*lds_ + c*scol]
+__global__ void copy2d_kernel(const float* __restrict__ src, long lds_, long scol, float* __restrict__ dst, long ldd, long cols) {
+  const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long r = blockIdx.y;
+  if (c >= cols) return;
+  dst[r * ldd + c] = src[r * lds_ + c * scol];
+}
+
+// Decoder input (orca_modules.py:462-463): mat[c][i][j] = x[c][i] + x[c][j] (c<128),
+// channel 128 = distenc[i][j] (if given), remaining pad channels = 0.
+// out layout [cpad][n][256]; one thread writes a float4 of columns.
+__global__ void outer_sum_kernel(const float* __restrict__ x, long sx_c, long sx_l, const float* __restrict__ de, long sd_h, long sd_w,
+                                 float* __restrict__ out, int n, int cpad) {
+  const int j4 = threadIdx.x;  // 0..63 -> columns 4*j4..4*j4+3
+  const int i = blockIdx.x;
+  const int c = blockIdx.y;
+  float v[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int j = 4 * j4 + e;
+    float t = 0.f;
+    if (j < n) {
+      if (c < 128) t = x[c * sx_c + i * sx_l] + x[c * sx_c + j * sx_l];
+      else if (c == 128 && de) t = de[i * sd_h + j * sd_w];
+    }
+    v[e] = t;
+  }
+  *reinterpret_cast<float4*>(out + ((long)c * n + i) * ORCA_LDW + 4 * j4) = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+// nn.Upsample(scale_factor=(2,2), mode) of y [n/2][n/2] written into ONE channel plane
+// [n][256] (orca_modules.py:430,468); the 7 pad planes behind it are zeroed.
+// bilinear = PyTorch align_corners=False: src = max((dst+0.5)/2-0.5, 0).
+__global__ void upsample2d_x2_kernel(const float* __restrict__ y, long sy_h, long sy_w, float* __restrict__ out, int n, int bilinear, int nplanes) {
+  const int j = threadIdx.x;
+  const int i = blockIdx.x;
+  const int p = blockIdx.y;
+  float v = 0.f;
+  const int h = n / 2;
+  if (p == 0 && j < n) {
+    if (!bilinear) {
+      v = y[(i >> 1) * sy_h + (j >> 1) * sy_w];
+    } else {
+      const float fy = fmaxf(0.5f * (i + 0.5f) - 0.5f, 0.f), fx = fmaxf(0.5f * (j + 0.5f) - 0.5f, 0.f);
+      const int y0 = (int)fy, x0 = (int)fx;
+      const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < h - 1 ? 1 : 0);
+      const float ly = fy - y0, lx = fx - x0;
+      const float hy = 1.f - ly, hx = 1.f - lx;
+      v = hy * (hx * y[y0 * sy_h + x0 * sy_w] + lx * y[y0 * sy_h + x1 * sy_w]) +
+          ly * (hx * y[y1 * sy_h + x0 * sy_w] + lx * y[y1 * sy_h + x1 * sy_w]);
+    }
+  }
+  out[((long)p * n + i) * ORCA_LDW + j] = v;
+}
+
+// `final` head (orca_modules.py:423-428) + symmetrisation (:488):
+// f(i,j) = w2 . relu(W1 cur[:,i,j] + b1) + b2 ; out[i][j] = 0.5 f(i,j) + 0.5 f(j,i) (+= if accumulate)
+struct FinalArgs {
+  const float* cur;  // [64][n][256]
+  const float* w1;   // [5][64] (BN folded)
+  const float* b1;   // [5]
+  const float* w2;   // [5]
+  const float* b2;   // [1]
+  float* out;        // [n][n]
+  long cur_bs, out_bs;
+  int n;
+  int accumulate;
+};
+
+__global__ void final_sym_kernel(FinalArgs a) {
+  __shared__ float w1s[5 * 64], b1s[5], w2s[5], b2s;
+  for (int t = threadIdx.x; t < 320; t += blockDim.x) w1s[t] = a.w1[t];
+  if (threadIdx.x < 5) { b1s[threadIdx.x] = a.b1[threadIdx.x]; w2s[threadIdx.x] = a.w2[threadIdx.x]; }
+  if (threadIdx.x == 0) b2s = a.b2[0];
+  __syncthreads();
+  const int j = threadIdx.x, i = blockIdx.x, b = blockIdx.y, n = a.n;
+  if (j >= n) return;
+  const float* cur = a.cur + (long)b * a.cur_bs;
+  const long cs = (long)n * ORCA_LDW;
+  float h1[5], h2[5];
+#pragma unroll
+  for (int o = 0; o < 5; ++o) { h1[o] = b1s[o]; h2[o] = b1s[o]; }
+  for (int c = 0; c < 64; ++c) {
+    const float u = cur[c * cs + (long)i * ORCA_LDW + j];
+    const float v = cur[c * cs + (long)j * ORCA_LDW + i];
+#pragma unroll
+    for (int o = 0; o < 5; ++o) { h1[o] = fmaf(w1s[o * 64 + c], u, h1[o]); h2[o] = fmaf(w1s[o * 64 + c], v, h2[o]); }
+  }
+  float f1 = b2s, f2 = b2s;
+#pragma unroll
+  for (int o = 0; o < 5; ++o) { f1 = fmaf(w2s[o], fmaxf(h1[o], 0.f), f1); f2 = fmaf(w2s[o], fmaxf(h2[o], 0.f), f2); }
+  float* op = a.out + (long)b * a.out_bs + (long)i * n + j;
+  const float r = 0.5f * f1 + 0.5f * f2;
+  *op = a.accumulate ? (*op + r) : r;
+}
+
+// strand merge (orca_predict.py:514-523): out = 0.5*fwd + 0.5*rev[::-1, ::-1]
+__global__ void strand_merge_kernel(const float* __restrict__ fwd, const float* __restrict__ rev, float* __restrict__ out, int n) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n * n) return;
+  out[idx] = fwd[idx] * 0.5f + rev[n * n - 1 - idx] * 0.5f;
+}
+
+// [B,C,n,n] contiguous <-> padded [B,C,n,256] (single-layer conv2d entry point only)
+__global__ void pad_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int n, int to_padded) {
+  const int j = threadIdx.x;
+  const long row = blockIdx.x;  // over B*C*n
+  if (to_padded) dst[row * ORCA_LDW + j] = (j < n) ? src[row * n + j] : 0.f;
+  else if (j < n) dst[row * n + j] = src[row * ORCA_LDW + j];
+}

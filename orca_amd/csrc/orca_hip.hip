@@ -1,0 +1,659 @@
+// orca_hip.hip - C-ABI implementation (include/orca_hip.h) and network-level
+// orchestration of the HIP kernels for gfx950.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -I../../include orca_hip.hip -o liborca_hip.so
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "conv_kernels.h"
+#include "misc_kernels.h"
+#include "orca_hip.h"
+
+// ---------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+static int fail(int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIPCHECK(expr)                                                                          \
+  do {                                                                                          \
+    hipError_t _e = (expr);                                                                     \
+    if (_e != hipSuccess) return fail(ORCA_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+  } while (0)
+
+#define LAUNCHCHECK(name)                                                                        \
+  do {                                                                                          \
+    hipError_t _e = hipGetLastError();                                                          \
+    if (_e != hipSuccess) return fail(ORCA_EHIP, "launch of %s failed: %s", name, hipGetErrorString(_e)); \
+  } while (0)
+
+#define ORCA_TRY(expr)        \
+  do {                        \
+    int _rc = (expr);         \
+    if (_rc != ORCA_OK) return _rc; \
+  } while (0)
+
+static inline long ru4(long v) { return (v + 3) & ~3L; }
+static inline size_t ru256(size_t v) { return (v + 255) & ~size_t(255); }
+
+// ---------------------------------------------------------------------------
+// context + workspace arena
+// ---------------------------------------------------------------------------
+struct orca_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  char* ws = nullptr;
+  size_t ws_bytes = 0;
+  size_t ws_off = 0;
+};
+
+static int ws_ensure(orca_ctx* ctx, size_t bytes) {
+  ctx->ws_off = 0;
+  if (bytes <= ctx->ws_bytes) return ORCA_OK;
+  if (ctx->ws) {
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    HIPCHECK(hipFree(ctx->ws));
+    ctx->ws = nullptr;
+    ctx->ws_bytes = 0;
+  }
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, bytes);
+  if (e != hipSuccess) return fail(ORCA_ENOMEM, "hipMalloc of %zu workspace bytes failed: %s", bytes, hipGetErrorString(e));
+  ctx->ws = static_cast<char*>(p);
+  ctx->ws_bytes = bytes;
+  return ORCA_OK;
+}
+
+static float* ws_take(orca_ctx* ctx, size_t nfloats) {
+  size_t bytes = ru256(nfloats * sizeof(float));
+  if (ctx->ws_off + bytes > ctx->ws_bytes) return nullptr;
+  float* p = reinterpret_cast<float*>(ctx->ws + ctx->ws_off);
+  ctx->ws_off += bytes;
+  return p;
+}
+
+// ---------------------------------------------------------------------------
+// layers / nets
+// ---------------------------------------------------------------------------
+struct ConvLayer {
+  int cin = 0, cout = 0, ksize = 0, dil = 1;
+  int kc = 8, nchunks = 0;
+  float* d_w = nullptr;     // packed (k=9 / k=3) or raw [cout][cin] (k=1)
+  float* d_bias = nullptr;
+};
+
+struct orca_net {
+  orca_ctx* ctx = nullptr;
+  int kind = 0;
+  int upsample_mode = ORCA_UPSAMPLE_BILINEAR;
+  std::vector<ConvLayer> convs;
+};
+
+static int upload(const std::vector<float>& h, float** d) {
+  HIPCHECK(hipMalloc(reinterpret_cast<void**>(d), h.size() * sizeof(float)));
+  HIPCHECK(hipMemcpy(*d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+  return ORCA_OK;
+}
+
+static void free_layer(ConvLayer& L) {
+  if (L.d_w) (void)hipFree(L.d_w);
+  if (L.d_bias) (void)hipFree(L.d_bias);
+  L.d_w = L.d_bias = nullptr;
+}
+
+// Re-layout of reference-format weights for the MFMA kernels:
+//   conv1d  [cout][cin][9]     -> [cin/KC][9][KC][cout]
+//   conv2d  [cout][cin][3][3]  -> [cin_pad/8][9][8][cout]  (pad channels = 0)
+//   1x1     kept as [cout][cin]
+static int make_layer(const orca_conv_desc& d, ConvLayer* out) {
+  ConvLayer L;
+  L.cin = d.cin; L.cout = d.cout; L.ksize = d.ksize; L.dil = d.dilation > 0 ? d.dilation : 1;
+  if (!d.weight_host || !d.bias_host) return fail(ORCA_EINVAL, "conv desc with NULL weight/bias");
+  std::vector<float> w;
+  if (d.ksize == 9) {
+    if (!(d.cout == 64 || d.cout == 96 || d.cout == 128)) return fail(ORCA_EINVAL, "conv1d cout %d unsupported", d.cout);
+    L.kc = (d.cin % 8 == 0) ? 8 : 4;
+    if (d.cin % L.kc) return fail(ORCA_EINVAL, "conv1d cin %d not a multiple of %d", d.cin, L.kc);
+    if (L.kc == 4 && d.cout != 64) return fail(ORCA_EINVAL, "conv1d cin %d only supported with cout 64", d.cin);
+    L.nchunks = d.cin / L.kc;
+    w.assign((size_t)L.nchunks * 9 * L.kc * d.cout, 0.f);
+    for (int co = 0; co < d.cout; ++co)
+      for (int ci = 0; ci < d.cin; ++ci)
+        for (int t = 0; t < 9; ++t) {
+          const int c = ci / L.kc, k = ci % L.kc;
+          w[(((size_t)c * 9 + t) * L.kc + k) * d.cout + co] = d.weight_host[((size_t)co * d.cin + ci) * 9 + t];
+        }
+  } else if (d.ksize == 3) {
+    if (!(d.cout == 32 || d.cout == 64)) return fail(ORCA_EINVAL, "conv2d cout %d unsupported", d.cout);
+    L.kc = 8;
+    const int cpad = (d.cin + 7) / 8 * 8;
+    L.nchunks = cpad / 8;
+    w.assign((size_t)L.nchunks * 9 * 8 * d.cout, 0.f);
+    for (int co = 0; co < d.cout; ++co)
+      for (int ci = 0; ci < d.cin; ++ci)
+        for (int t = 0; t < 9; ++t) {
+          const int c = ci / 8, k = ci % 8;
+          w[(((size_t)c * 9 + t) * 8 + k) * d.cout + co] = d.weight_host[((size_t)co * d.cin + ci) * 9 + t];
+        }
+  } else if (d.ksize == 1) {
+    w.assign(d.weight_host, d.weight_host + (size_t)d.cout * d.cin);
+  } else {
+    return fail(ORCA_EINVAL, "unsupported kernel size %d", d.ksize);
+  }
+  std::vector<float> bias(d.bias_host, d.bias_host + d.cout);
+  ORCA_TRY(upload(w, &L.d_w));
+  int rc = upload(bias, &L.d_bias);
+  if (rc != ORCA_OK) { free_layer(L); return rc; }
+  *out = L;
+  return ORCA_OK;
+}
+
+// ---------------------------------------------------------------------------
+// kernel launch helpers
+// ---------------------------------------------------------------------------
+static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// position tile used for long 128-channel convs: 128 (2 waves/SIMD, 4 accumulators/wave)
+// or 256 (1 wave/SIMD, 8 accumulators/wave); ORCA_CONV1D_TILE128 overrides for A/B runs.
+static int g_big_tile128 = [] { const char* e = getenv("ORCA_CONV1D_TILE128"); int v = e ? atoi(e) : 128; return (v == 256) ? 256 : 128; }();
+
+template <int COUT, int MW, int NW, int WM, int WN, int KC>
+static void launch_conv1d_t(hipStream_t s, const Conv1dArgs& a, int B) {
+  constexpr int MT = WM * MW * 32;
+  dim3 grid((unsigned)((a.n + MT - 1) / MT), (unsigned)B);
+  hipLaunchKernelGGL((conv1d_k9_kernel<COUT, MW, NW, WM, WN, KC>), grid, dim3(WM * WN * 64), 0, s, a);
+}
+
+static int launch_conv1d(orca_ctx* ctx, const ConvLayer& L, const float* x, long x_bs, long ldx, float* y, long y_bs,
+                         long ldy, const float* r1, const float* r2, int B, long n, int relu, int tile) {
+  if (L.ksize != 9) return fail(ORCA_EINVAL, "launch_conv1d on a non-1d layer");
+  if (n <= 0 || B <= 0) return ORCA_OK;
+  Conv1dArgs a;
+  a.x = x; a.w = L.d_w; a.bias = L.d_bias; a.y = y; a.r1 = r1; a.r2 = r2;
+  a.x_bs = x_bs; a.y_bs = y_bs; a.ldx = ldx; a.ldy = ldy; a.n = n; a.nchunks = L.nchunks; a.relu = relu;
+  a.x_vec_ok = al16(x) && (ldx % 4 == 0) && (x_bs % 4 == 0);
+  a.y_vec_ok = al16(y) && (ldy % 4 == 0) && (y_bs % 4 == 0) && (!r1 || al16(r1)) && (!r2 || al16(r2));
+  hipStream_t s = ctx->stream;
+  if (L.cout == 64) {
+    if (L.kc == 4) launch_conv1d_t<64, 2, 2, 4, 1, 4>(s, a, B);
+    else launch_conv1d_t<64, 2, 2, 4, 1, 8>(s, a, B);
+  } else if (L.cout == 96) {
+    launch_conv1d_t<96, 2, 3, 4, 1, 8>(s, a, B);
+  } else {
+    if (tile == 0) tile = (n >= 65536) ? g_big_tile128 : (n >= 8192 ? 64 : 32);
+    if (tile == 256) launch_conv1d_t<128, 4, 2, 2, 2, 8>(s, a, B);
+    else if (tile == 128) launch_conv1d_t<128, 2, 2, 2, 2, 8>(s, a, B);
+    else if (tile == 64) launch_conv1d_t<128, 1, 2, 2, 2, 8>(s, a, B);
+    else if (tile == 32) launch_conv1d_t<128, 1, 1, 1, 4, 8>(s, a, B);
+    else return fail(ORCA_EINVAL, "conv1d tile %d unsupported", tile);
+  }
+  LAUNCHCHECK("conv1d_k9_kernel");
+  return ORCA_OK;
+}
+
+static int launch_conv2d(orca_ctx* ctx, const ConvLayer& L, const float* x, long x_bs, float* y, long y_bs,
+                         const float* r, long r_bs, int B, int n, int relu) {
+  if (L.ksize != 3) return fail(ORCA_EINVAL, "launch_conv2d on a non-3x3 layer");
+  Conv2dArgs a;
+  a.x = x; a.w = L.d_w; a.bias = L.d_bias; a.y = y; a.r = r;
+  a.x_bs = x_bs; a.y_bs = y_bs; a.r_bs = r_bs; a.H = n; a.W = n; a.dil = L.dil; a.nchunks = L.nchunks; a.relu = relu;
+  dim3 grid((unsigned)n, (unsigned)B);
+  if (L.cout == 64) hipLaunchKernelGGL((conv2d_3x3_kernel<64>), grid, dim3(512), 0, ctx->stream, a);
+  else hipLaunchKernelGGL((conv2d_3x3_kernel<32>), grid, dim3(512), 0, ctx->stream, a);
+  LAUNCHCHECK("conv2d_3x3_kernel");
+  return ORCA_OK;
+}
+
+static int launch_pool(orca_ctx* ctx, const float* x, long ldx, float* y, long ldy, long rows, long n_out, int k) {
+  if (n_out <= 0 || rows <= 0) return ORCA_OK;
+  dim3 grid((unsigned)((n_out + 255) / 256), (unsigned)rows);
+  switch (k) {
+    case 2: hipLaunchKernelGGL((maxpool1d_kernel<2>), grid, dim3(256), 0, ctx->stream, x, ldx, y, ldy, n_out); break;
+    case 4: hipLaunchKernelGGL((maxpool1d_kernel<4>), grid, dim3(256), 0, ctx->stream, x, ldx, y, ldy, n_out); break;
+    case 5: hipLaunchKernelGGL((maxpool1d_kernel<5>), grid, dim3(256), 0, ctx->stream, x, ldx, y, ldy, n_out); break;
+    default: return fail(ORCA_EINVAL, "maxpool k=%d unsupported", k);
+  }
+  LAUNCHCHECK("maxpool1d_kernel");
+  return ORCA_OK;
+}
+
+static int launch_copy2d(orca_ctx* ctx, const float* src, long lds_, long scol, float* dst, long ldd, long rows, long cols) {
+  if (rows <= 0 || cols <= 0) return ORCA_OK;
+  dim3 grid((unsigned)((cols + 255) / 256), (unsigned)rows);
+  hipLaunchKernelGGL(copy2d_kernel, grid, dim3(256), 0, ctx->stream, src, lds_, scol, dst, ldd, cols);
+  LAUNCHCHECK("copy2d_kernel");
+  return ORCA_OK;
+}
+
+// ---------------------------------------------------------------------------
+// C ABI: library / context
+// ---------------------------------------------------------------------------
+extern "C" int orca_abi_version(void) { return ORCA_ABI_VERSION; }
+extern "C" const char* orca_last_error(void) { return g_err.c_str(); }
+
+extern "C" int orca_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return n;
+}
+
+extern "C" int orca_ctx_create(int device, void* hip_stream, orca_ctx** out) {
+  if (!out) return fail(ORCA_EINVAL, "orca_ctx_create: out is NULL");
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { (void)hipGetLastError(); return fail(ORCA_ENODEV, "no HIP device visible"); }
+  if (device < 0 || device >= n) return fail(ORCA_EINVAL, "device %d out of range (have %d)", device, n);
+  HIPCHECK(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIPCHECK(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(ORCA_ENODEV, "device %d is %s; liborca_hip is built for gfx950 only", device, prop.gcnArchName);
+  orca_ctx* c = new orca_ctx();
+  c->device = device;
+  c->stream = static_cast<hipStream_t>(hip_stream);
+  *out = c;
+  return ORCA_OK;
+}
+
+extern "C" int orca_ctx_destroy(orca_ctx* ctx) {
+  if (!ctx) return ORCA_OK;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->ws) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(ctx->ws); }
+  delete ctx;
+  return ORCA_OK;
+}
+
+extern "C" int orca_ctx_set_stream(orca_ctx* ctx, void* hip_stream) {
+  if (!ctx) return fail(ORCA_EINVAL, "ctx is NULL");
+  ctx->stream = static_cast<hipStream_t>(hip_stream);
+  return ORCA_OK;
+}
+
+extern "C" int orca_ctx_workspace_bytes(orca_ctx* ctx, size_t* out) {
+  if (!ctx || !out) return fail(ORCA_EINVAL, "NULL argument");
+  *out = ctx->ws_bytes;
+  return ORCA_OK;
+}
+
+extern "C" int orca_ctx_release_workspace(orca_ctx* ctx) {
+  if (!ctx) return fail(ORCA_EINVAL, "ctx is NULL");
+  HIPCHECK(hipSetDevice(ctx->device));
+  if (ctx->ws) {
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    HIPCHECK(hipFree(ctx->ws));
+  }
+  ctx->ws = nullptr; ctx->ws_bytes = 0; ctx->ws_off = 0;
+  return ORCA_OK;
+}
+
+// ---------------------------------------------------------------------------
+// C ABI: weights
+// ---------------------------------------------------------------------------
+struct Shape { int cout, cin, k; };
+
+static void expected_shapes(int kind, std::vector<Shape>* s) {
+  s->clear();
+  auto c1 = [&](int co, int ci) { s->push_back({co, ci, 9}); };
+  auto c2 = [&](int co, int ci) { s->push_back({co, ci, 3}); };
+  if (kind == ORCA_NET_ENCODER) {
+    const int ch[7] = {64, 96, 128, 128, 128, 128, 128};
+    int prev = 4;
+    for (int i = 0; i < 7; ++i) { c1(ch[i], prev); c1(ch[i], ch[i]); c1(ch[i], ch[i]); c1(ch[i], ch[i]); prev = ch[i]; }
+  } else if (kind == ORCA_NET_ENCODER2 || kind == ORCA_NET_ENCODER3) {
+    const int nlev = kind == ORCA_NET_ENCODER2 ? 5 : 3;
+    for (int i = 0; i < 8 * nlev; ++i) c1(128, 128);
+  } else if (kind == ORCA_NET_DECODER) {
+    c2(64, 129); c2(64, 64); c2(64, 64); c2(64, 64);  // lcombinerD, combinerD
+    c2(64, 65); c2(64, 64); c2(64, 64); c2(64, 64);   // lcombiner, combiner
+    for (int i = 0; i < 28; ++i) { c2(32, 64); c2(64, 32); c2(32, 64); c2(64, 32); }
+    s->push_back({5, 64, 1}); s->push_back({1, 5, 1});
+  } else if (kind == ORCA_NET_DECODER_1M) {
+    for (int i = 0; i < 19; ++i) { c2(32, i == 0 ? 128 : 64); c2(64, 32); c2(32, 64); c2(64, 32); }
+    s->push_back({5, 64, 1}); s->push_back({1, 5, 1});
+  }
+}
+
+extern "C" int orca_net_create(orca_ctx* ctx, int kind, const orca_conv_desc* convs, int n_convs, int upsample_mode, orca_net** out) {
+  if (!ctx || !convs || !out) return fail(ORCA_EINVAL, "orca_net_create: NULL argument");
+  HIPCHECK(hipSetDevice(ctx->device));
+  std::vector<Shape> exp;
+  expected_shapes(kind, &exp);
+  if (exp.empty()) return fail(ORCA_EINVAL, "unknown net kind %d", kind);
+  if ((int)exp.size() != n_convs) return fail(ORCA_EINVAL, "net kind %d expects %zu convs, got %d", kind, exp.size(), n_convs);
+  for (int i = 0; i < n_convs; ++i)
+    if (convs[i].cout != exp[i].cout || convs[i].cin != exp[i].cin || convs[i].ksize != exp[i].k)
+      return fail(ORCA_EINVAL, "net kind %d conv %d: expected cout=%d cin=%d k=%d, got cout=%d cin=%d k=%d", kind, i,
+                  exp[i].cout, exp[i].cin, exp[i].k, convs[i].cout, convs[i].cin, convs[i].ksize);
+  orca_net* net = new orca_net();
+  net->ctx = ctx; net->kind = kind; net->upsample_mode = upsample_mode;
+  net->convs.resize(n_convs);
+  for (int i = 0; i < n_convs; ++i) {
+    int rc = make_layer(convs[i], &net->convs[i]);
+    if (rc != ORCA_OK) { orca_net_free(net); return rc; }
+  }
+  *out = net;
+  return ORCA_OK;
+}
+
+extern "C" int orca_net_free(orca_net* net) {
+  if (!net) return ORCA_OK;
+  if (net->ctx) (void)hipSetDevice(net->ctx->device);
+  for (auto& L : net->convs) free_layer(L);
+  delete net;
+  return ORCA_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Encoder (orca_modules.py:929-980)
+// ---------------------------------------------------------------------------
+static const int kEncPools[7] = {1, 4, 4, 5, 5, 5, 2};
+static const long kHaloBp = 112000;  // x_padding, orca_modules.py:932
+static const long kBinBp = 4000;
+
+extern "C" int64_t orca_encoder_num_bins(int64_t L) {
+  long n = L;
+  for (int i = 1; i < 7; ++i) n /= kEncPools[i];
+  return n;
+}
+
+// One chunk: x (strided [4][n1]) -> 128 x n7 in the returned buffer.
+static int encoder_chunk(orca_ctx* ctx, orca_net* net, const float* x, long sx_c, long sx_l, long n1, float* const buf[3],
+                         long ld1, float** out, long* out_ld, long* out_n) {
+  hipStream_t s = ctx->stream;
+  int P = 0;
+  long n = n1, ld = ld1;
+  hipLaunchKernelGGL(seq_to_channel_major_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, s, x, sx_c, sx_l, n1, buf[P], ld1);
+  LAUNCHCHECK("seq_to_channel_major_kernel");
+  int cprev = 4;
+  for (int st = 0; st < 7; ++st) {
+    const ConvLayer* L = &net->convs[4 * st];
+    if (kEncPools[st] > 1) {
+      const long n2 = n / kEncPools[st], ld2 = ru4(n2);
+      const int Q = (P + 1) % 3;
+      ORCA_TRY(launch_pool(ctx, buf[P], ld, buf[Q], ld2, cprev, n2, kEncPools[st]));
+      P = Q; n = n2; ld = ld2;
+    }
+    const int T = (P + 1) % 3, LO = (P + 2) % 3;
+    ORCA_TRY(launch_conv1d(ctx, L[0], buf[P], 0, ld, buf[T], 0, ld, nullptr, nullptr, 1, n, 0, 0));
+    ORCA_TRY(launch_conv1d(ctx, L[1], buf[T], 0, ld, buf[LO], 0, ld, nullptr, nullptr, 1, n, 0, 0));
+    ORCA_TRY(launch_conv1d(ctx, L[2], buf[LO], 0, ld, buf[T], 0, ld, nullptr, nullptr, 1, n, 1, 0));
+    ORCA_TRY(launch_conv1d(ctx, L[3], buf[T], 0, ld, buf[P], 0, ld, st < 6 ? buf[LO] : nullptr, nullptr, 1, n, 1, 0));
+    cprev = L[3].cout;
+  }
+  *out = buf[P]; *out_ld = ld; *out_n = n;
+  return ORCA_OK;
+}
+
+extern "C" int orca_encoder_forward(orca_ctx* ctx, orca_net* net, const float* x, int64_t sx_b, int64_t sx_c, int64_t sx_l,
+                                    int B, int64_t L, int64_t bin_lo, int64_t bin_hi, float* out, int64_t so_b,
+                                    int64_t so_c, int64_t chunk_bp) {
+  if (!ctx || !net || !x || !out) return fail(ORCA_EINVAL, "orca_encoder_forward: NULL argument");
+  if (net->kind != ORCA_NET_ENCODER) return fail(ORCA_EINVAL, "orca_encoder_forward: net is not an Encoder");
+  HIPCHECK(hipSetDevice(ctx->device));
+  const long total = orca_encoder_num_bins(L);
+  if (bin_hi <= 0) bin_hi = total;
+  if (bin_lo < 0 || bin_lo > bin_hi || bin_hi > total) return fail(ORCA_EINVAL, "bin range [%ld,%ld) outside [0,%ld)", (long)bin_lo, (long)bin_hi, total);
+  if (bin_lo == bin_hi || B <= 0) return ORCA_OK;
+  if (chunk_bp <= 0) {
+    const char* e = getenv("ORCA_ENCODER_CHUNK_BP");
+    chunk_bp = e ? atol(e) : 32000000L;
+  }
+  if (chunk_bp % kBinBp) return fail(ORCA_EINVAL, "chunk_bp must be a multiple of 4000");
+  const long chunk_bins = chunk_bp / kBinBp;
+  long max_n1 = 0;
+  for (long cb0 = bin_lo; cb0 < bin_hi; cb0 += chunk_bins) {
+    const long cb1 = cb0 + chunk_bins < bin_hi ? cb0 + chunk_bins : bin_hi;
+    const long lo = cb0 * kBinBp - kHaloBp > 0 ? cb0 * kBinBp - kHaloBp : 0;
+    const long hi = (cb1 == total) ? L : (cb1 * kBinBp + kHaloBp < L ? cb1 * kBinBp + kHaloBp : L);
+    if (hi - lo > max_n1) max_n1 = hi - lo;
+  }
+  const long ld1 = ru4(max_n1);
+  const size_t per = ru256((size_t)64 * ld1 * sizeof(float));
+  ORCA_TRY(ws_ensure(ctx, 3 * per));
+  float* buf[3];
+  for (int i = 0; i < 3; ++i) buf[i] = ws_take(ctx, (size_t)64 * ld1);
+  for (int b = 0; b < B; ++b) {
+    for (long cb0 = bin_lo; cb0 < bin_hi; cb0 += chunk_bins) {
+      const long cb1 = cb0 + chunk_bins < bin_hi ? cb0 + chunk_bins : bin_hi;
+      const long lo = cb0 * kBinBp - kHaloBp > 0 ? cb0 * kBinBp - kHaloBp : 0;
+      const long hi = (cb1 == total) ? L : (cb1 * kBinBp + kHaloBp < L ? cb1 * kBinBp + kHaloBp : L);
+      float* res; long rld, rn;
+      ORCA_TRY(encoder_chunk(ctx, net, x + (long)b * sx_b + lo * sx_l, sx_c, sx_l, hi - lo, buf, ru4(hi - lo), &res, &rld, &rn));
+      const long keep = cb0 - lo / kBinBp;
+      if (keep + (cb1 - cb0) > rn) return fail(ORCA_EINVAL, "internal: chunk produced %ld bins, need %ld", rn, keep + (cb1 - cb0));
+      ORCA_TRY(launch_copy2d(ctx, res + keep, rld, 1, out + (long)b * so_b + (cb0 - bin_lo), so_c, 128, cb1 - cb0));
+    }
+  }
+  return ORCA_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Encoder2 / Encoder3 (orca_modules.py:1151-1169, :1388-1406)
+// ---------------------------------------------------------------------------
+extern "C" int orca_unet_forward(orca_ctx* ctx, orca_net* net, const float* x, int64_t sx_b, int64_t sx_c, int64_t sx_l, int B,
+                                 int n, float* const* outs, int n_outs) {
+  if (!ctx || !net || !x || !outs) return fail(ORCA_EINVAL, "orca_unet_forward: NULL argument");
+  if (net->kind != ORCA_NET_ENCODER2 && net->kind != ORCA_NET_ENCODER3) return fail(ORCA_EINVAL, "orca_unet_forward: wrong net kind");
+  HIPCHECK(hipSetDevice(ctx->device));
+  const int nlev = net->kind == ORCA_NET_ENCODER2 ? 5 : 3;
+  if (n_outs != nlev + 1) return fail(ORCA_EINVAL, "expected %d output pointers, got %d", nlev + 1, n_outs);
+  if (n <= 0 || (n % (1 << nlev))) return fail(ORCA_EINVAL, "length %d not divisible by %d", n, 1 << nlev);
+  if (B <= 0) return ORCA_OK;
+  const size_t full = (size_t)B * 128 * n;
+  size_t need = 0;
+  for (int i = 0; i < nlev; ++i) need += ru256((full >> i) * sizeof(float));  // encs[0..nlev-1]
+  need += 3 * ru256(full * sizeof(float));
+  ORCA_TRY(ws_ensure(ctx, need));
+  std::vector<float*> encs(nlev + 1);
+  for (int i = 0; i < nlev; ++i) encs[i] = ws_take(ctx, full >> i);
+  encs[nlev] = outs[nlev];
+  float* t0 = ws_take(ctx, full);
+  float* t1 = ws_take(ctx, full);
+  float* t2 = ws_take(ctx, full);
+  hipStream_t s = ctx->stream;
+  // stage the (possibly strided) input as contiguous [B][128][n]
+  for (int b = 0; b < B; ++b)
+    ORCA_TRY(launch_copy2d(ctx, x + (long)b * sx_b, sx_c, sx_l, encs[0] + (size_t)b * 128 * n, n, 128, n));
+  const ConvLayer* L = net->convs.data();
+  // contracting path
+  for (int i = 0; i < nlev; ++i) {
+    const long ni = n >> i, no = n >> (i + 1);
+    ORCA_TRY(launch_pool(ctx, encs[i], ni, t0, no, (long)B * 128, no, 2));
+    const long bs = 128 * no;
+    ORCA_TRY(launch_conv1d(ctx, L[4 * i + 0], t0, bs, no, t1, bs, no, nullptr, nullptr, B, no, 0, 0));
+    ORCA_TRY(launch_conv1d(ctx, L[4 * i + 1], t1, bs, no, t2, bs, no, nullptr, nullptr, B, no, 0, 0));  // lout
+    ORCA_TRY(launch_conv1d(ctx, L[4 * i + 2], t2, bs, no, t1, bs, no, nullptr, nullptr, B, no, 1, 0));
+    ORCA_TRY(launch_conv1d(ctx, L[4 * i + 3], t1, bs, no, encs[i + 1], bs, no, t2, nullptr, B, no, 1, 0));
+  }
+  // expanding path
+  const float* cur = encs[nlev];
+  for (int i = 0; i < nlev; ++i) {
+    const int lev = nlev - 1 - i;
+    const long ni = n >> (lev + 1), no = n >> lev;
+    dim3 grid((unsigned)((no + 255) / 256), (unsigned)(B * 128));
+    hipLaunchKernelGGL(upsample1d_x2_kernel, grid, dim3(256), 0, s, cur, ni, t0, no, no);
+    LAUNCHCHECK("upsample1d_x2_kernel");
+    const long bs = 128 * no;
+    const ConvLayer* D = L + 4 * nlev + 4 * i;
+    ORCA_TRY(launch_conv1d(ctx, D[0], t0, bs, no, t1, bs, no, nullptr, nullptr, B, no, 0, 0));
+    ORCA_TRY(launch_conv1d(ctx, D[1], t1, bs, no, t2, bs, no, nullptr, nullptr, B, no, 0, 0));  // lout
+    ORCA_TRY(launch_conv1d(ctx, D[2], t2, bs, no, t1, bs, no, nullptr, nullptr, B, no, 1, 0));
+    ORCA_TRY(launch_conv1d(ctx, D[3], t1, bs, no, outs[lev], bs, no, t2, encs[lev], B, no, 1, 0));
+    cur = outs[lev];
+  }
+  return ORCA_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Decoder / Decoder_1m (orca_modules.py:461-488, :782-800)
+// ---------------------------------------------------------------------------
+static int launch_final(orca_ctx* ctx, orca_net* net, const float* cur, long cur_bs, float* out, int B, int n, int accumulate) {
+  const ConvLayer& fa = net->convs[net->convs.size() - 2];
+  const ConvLayer& fb = net->convs[net->convs.size() - 1];
+  FinalArgs a;
+  a.cur = cur; a.w1 = fa.d_w; a.b1 = fa.d_bias; a.w2 = fb.d_w; a.b2 = fb.d_bias; a.out = out;
+  a.cur_bs = cur_bs; a.out_bs = (long)n * n; a.n = n; a.accumulate = accumulate;
+  hipLaunchKernelGGL(final_sym_kernel, dim3((unsigned)n, (unsigned)B), dim3(256), 0, ctx->stream, a);
+  LAUNCHCHECK("final_sym_kernel");
+  return ORCA_OK;
+}
+
+static int decoder_common(orca_ctx* ctx, orca_net* net, const float* x, long sx_b, long sx_c, long sx_l, const float* de,
+                          long sd_b, long sd_h, long sd_w, const float* y, long sy_b, long sy_h, long sy_w, int B, int n,
+                          float* out, int accumulate) {
+  if (n <= 0 || n > ORCA_LDW || (n & 1)) return fail(ORCA_EINVAL, "map size %d unsupported (even, <=256)", n);
+  if (B <= 0) return ORCA_OK;
+  HIPCHECK(hipSetDevice(ctx->device));
+  const bool is1m = net->kind == ORCA_NET_DECODER_1M;
+  const size_t plane = (size_t)n * ORCA_LDW;
+  const int cin0 = is1m ? 128 : 136;
+  const size_t szIN = plane * cin0, szA = plane * 72, sz64 = plane * 64, sz32 = plane * 32;
+  const size_t need = ru256(B * szIN * 4) + ru256(B * szA * 4) + 3 * ru256(B * sz64 * 4) + ru256(B * sz32 * 4);
+  ORCA_TRY(ws_ensure(ctx, need));
+  float* IN = ws_take(ctx, B * szIN);
+  float* A = ws_take(ctx, B * szA);
+  float* Bf = ws_take(ctx, B * sz64);
+  float* Cf = ws_take(ctx, B * sz64);
+  float* Df = ws_take(ctx, B * sz64);
+  float* T = ws_take(ctx, B * sz32);
+  hipStream_t s = ctx->stream;
+  for (int b = 0; b < B; ++b) {
+    hipLaunchKernelGGL(outer_sum_kernel, dim3((unsigned)n, (unsigned)cin0), dim3(64), 0, s, x + (long)b * sx_b, sx_c, sx_l,
+                       de ? de + (long)b * sd_b : nullptr, sd_h, sd_w, IN + b * szIN, n, cin0);
+    LAUNCHCHECK("outer_sum_kernel");
+  }
+  const ConvLayer* L = net->convs.data();
+  const ConvLayer* pairs;
+  int npairs;
+  if (!is1m) {
+    ORCA_TRY(launch_conv2d(ctx, L[0], IN, szIN, Bf, sz64, nullptr, 0, B, n, 0));
+    ORCA_TRY(launch_conv2d(ctx, L[1], Bf, sz64, Cf, sz64, nullptr, 0, B, n, 0));     // Cf = lcombinerD(mat)
+    ORCA_TRY(launch_conv2d(ctx, L[2], Cf, sz64, Bf, sz64, nullptr, 0, B, n, 1));
+    ORCA_TRY(launch_conv2d(ctx, L[3], Bf, sz64, A, szA, Cf, sz64, B, n, 1));         // A[0:64] = combinerD(.)+.
+    pairs = L + 8; npairs = 28;
+    if (y) {
+      for (int b = 0; b < B; ++b) {
+        hipLaunchKernelGGL(upsample2d_x2_kernel, dim3((unsigned)n, 8), dim3(ORCA_LDW), 0, s, y + (long)b * sy_b, sy_h, sy_w,
+                           A + b * szA + 64 * plane, n, net->upsample_mode == ORCA_UPSAMPLE_BILINEAR ? 1 : 0, 8);
+        LAUNCHCHECK("upsample2d_x2_kernel");
+      }
+      ORCA_TRY(launch_conv2d(ctx, L[4], A, szA, Bf, sz64, nullptr, 0, B, n, 0));
+      ORCA_TRY(launch_conv2d(ctx, L[5], Bf, sz64, Cf, sz64, nullptr, 0, B, n, 0));   // Cf = lcombiner(cat)
+      ORCA_TRY(launch_conv2d(ctx, L[6], Cf, sz64, Bf, sz64, nullptr, 0, B, n, 1));
+      ORCA_TRY(launch_conv2d(ctx, L[7], Bf, sz64, Df, sz64, Cf, sz64, B, n, 1));     // Df = combiner(.)+.
+    } else {
+      ORCA_TRY(launch_conv2d(ctx, pairs[0], A, szA, T, sz32, nullptr, 0, B, n, 0));
+      ORCA_TRY(launch_conv2d(ctx, pairs[1], T, sz32, Cf, sz64, nullptr, 0, B, n, 0));  // Cf = lm0(mat) (no residual, :477)
+      ORCA_TRY(launch_conv2d(ctx, pairs[2], Cf, sz64, T, sz32, nullptr, 0, B, n, 1));
+      ORCA_TRY(launch_conv2d(ctx, pairs[3], T, sz32, Df, sz64, Cf, sz64, B, n, 1));
+    }
+  } else {
+    pairs = L; npairs = 19;
+    ORCA_TRY(launch_conv2d(ctx, pairs[0], IN, szIN, T, sz32, nullptr, 0, B, n, 0));
+    ORCA_TRY(launch_conv2d(ctx, pairs[1], T, sz32, Cf, sz64, nullptr, 0, B, n, 0));
+    ORCA_TRY(launch_conv2d(ctx, pairs[2], Cf, sz64, T, sz32, nullptr, 0, B, n, 1));
+    ORCA_TRY(launch_conv2d(ctx, pairs[3], T, sz32, Df, sz64, Cf, sz64, B, n, 1));
+  }
+  float* cur = Df;
+  float* oth = Cf;
+  for (int i = 1; i < npairs; ++i) {
+    const ConvLayer* p = pairs + 4 * i;
+    ORCA_TRY(launch_conv2d(ctx, p[0], cur, sz64, T, sz32, nullptr, 0, B, n, 0));
+    ORCA_TRY(launch_conv2d(ctx, p[1], T, sz32, oth, sz64, cur, sz64, B, n, 0));   // oth = lm(cur)+cur
+    ORCA_TRY(launch_conv2d(ctx, p[2], oth, sz64, T, sz32, nullptr, 0, B, n, 1));
+    ORCA_TRY(launch_conv2d(ctx, p[3], T, sz32, cur, sz64, oth, sz64, B, n, 1));   // cur = m(oth)+oth
+  }
+  return launch_final(ctx, net, cur, sz64, out, B, n, accumulate);
+}
+
+extern "C" int orca_decoder_forward(orca_ctx* ctx, orca_net* net, const float* x, int64_t sx_b, int64_t sx_c, int64_t sx_l,
+                                    const float* distenc, int64_t sd_b, int64_t sd_h, int64_t sd_w, const float* y,
+                                    int64_t sy_b, int64_t sy_h, int64_t sy_w, int B, int n, float* out, int accumulate) {
+  if (!ctx || !net || !x || !distenc || !out) return fail(ORCA_EINVAL, "orca_decoder_forward: NULL argument");
+  if (net->kind != ORCA_NET_DECODER) return fail(ORCA_EINVAL, "orca_decoder_forward: net is not a Decoder");
+  return decoder_common(ctx, net, x, sx_b, sx_c, sx_l, distenc, sd_b, sd_h, sd_w, y, sy_b, sy_h, sy_w, B, n, out, accumulate);
+}
+
+extern "C" int orca_decoder1m_forward(orca_ctx* ctx, orca_net* net, const float* x, int64_t sx_b, int64_t sx_c, int64_t sx_l,
+                                      int B, int n, float* out, int accumulate) {
+  if (!ctx || !net || !x || !out) return fail(ORCA_EINVAL, "orca_decoder1m_forward: NULL argument");
+  if (net->kind != ORCA_NET_DECODER_1M) return fail(ORCA_EINVAL, "orca_decoder1m_forward: net is not a Decoder_1m");
+  return decoder_common(ctx, net, x, sx_b, sx_c, sx_l, nullptr, 0, 0, 0, nullptr, 0, 0, 0, B, n, out, accumulate);
+}
+
+extern "C" int orca_strand_merge(orca_ctx* ctx, const float* fwd, const float* rev, float* out, int n) {
+  if (!ctx || !fwd || !rev || !out || n <= 0) return fail(ORCA_EINVAL, "orca_strand_merge: bad argument");
+  HIPCHECK(hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(strand_merge_kernel, dim3((unsigned)((n * n + 255) / 256)), dim3(256), 0, ctx->stream, fwd, rev, out, n);
+  LAUNCHCHECK("strand_merge_kernel");
+  return ORCA_OK;
+}
+
+// ---------------------------------------------------------------------------
+// single-layer entry points
+// ---------------------------------------------------------------------------
+extern "C" int orca_conv1d_forward(orca_ctx* ctx, const orca_conv_desc* conv, const float* x, int64_t x_bs, int64_t ldx, float* y,
+                                   int64_t y_bs, int64_t ldy, const float* r1, const float* r2, int B, int64_t n, int relu,
+                                   int tile) {
+  if (!ctx || !conv || !x || !y) return fail(ORCA_EINVAL, "orca_conv1d_forward: NULL argument");
+  HIPCHECK(hipSetDevice(ctx->device));
+  ConvLayer L;
+  ORCA_TRY(make_layer(*conv, &L));
+  int rc = launch_conv1d(ctx, L, x, x_bs, ldx, y, y_bs, ldy, r1, r2, B, n, relu, tile);
+  (void)hipStreamSynchronize(ctx->stream);
+  free_layer(L);
+  return rc;
+}
+
+extern "C" int orca_conv2d_forward(orca_ctx* ctx, const orca_conv_desc* conv, const float* x, float* y, const float* r, int B,
+                                   int n, int relu) {
+  if (!ctx || !conv || !x || !y) return fail(ORCA_EINVAL, "orca_conv2d_forward: NULL argument");
+  if (n <= 0 || n > ORCA_LDW) return fail(ORCA_EINVAL, "map size %d unsupported", n);
+  HIPCHECK(hipSetDevice(ctx->device));
+  ConvLayer L;
+  ORCA_TRY(make_layer(*conv, &L));
+  const int cpad = L.nchunks * 8;
+  const size_t plane = (size_t)n * ORCA_LDW;
+  int rc = ws_ensure(ctx, ru256(B * plane * cpad * 4) + 2 * ru256(B * plane * L.cout * 4));
+  if (rc == ORCA_OK) {
+    float* xp = ws_take(ctx, B * plane * cpad);
+    float* yp = ws_take(ctx, B * plane * L.cout);
+    float* rp = ws_take(ctx, B * plane * L.cout);
+    hipStream_t s = ctx->stream;
+    (void)hipMemsetAsync(xp, 0, B * plane * cpad * 4, s);
+    for (int b = 0; b < B; ++b)
+      hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)(conv->cin * n)), dim3(ORCA_LDW), 0, s, x + (size_t)b * conv->cin * n * n,
+                         xp + b * plane * cpad, n, 1);
+    if (r) hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)(B * L.cout * n)), dim3(ORCA_LDW), 0, s, r, rp, n, 1);
+    rc = launch_conv2d(ctx, L, xp, plane * cpad, yp, plane * L.cout, r ? rp : nullptr, plane * L.cout, B, n, relu);
+    if (rc == ORCA_OK) {
+      hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)(B * L.cout * n)), dim3(ORCA_LDW), 0, s, yp, y, n, 0);
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess) rc = fail(ORCA_EHIP, "pad_rows_kernel: %s", hipGetErrorString(e));
+    }
+  }
+  (void)hipStreamSynchronize(ctx->stream);
+  free_layer(L);
+  return rc;
+}
+
+extern "C" int orca_maxpool1d_forward(orca_ctx* ctx, const float* x, int64_t ldx, float* y, int64_t ldy, int64_t rows,
+                                      int64_t n_out, int k) {
+  if (!ctx || !x || !y) return fail(ORCA_EINVAL, "orca_maxpool1d_forward: NULL argument");
+  HIPCHECK(hipSetDevice(ctx->device));
+  return launch_pool(ctx, x, ldx, y, ldy, rows, n_out, k);
+}

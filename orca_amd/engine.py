@@ -1,0 +1,247 @@
+"""Thin host layer over the C ABI: contexts, BatchNorm folding, net handles and
+forward wrappers that take torch ROCm tensors purely as device containers
+(``data_ptr()`` + strides).  No arithmetic on the data path happens in torch.
+"""
+import ctypes
+import threading
+import weakref
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, OrcaHipError, check
+
+BN_EPS = 1e-5  # nn.BatchNorm1d/2d default used throughout orca_modules.py
+
+
+# ---------------------------------------------------------------------------
+# contexts: one per (host thread, device)
+# ---------------------------------------------------------------------------
+_tls = threading.local()
+
+
+class Context:
+    def __init__(self, device_index):
+        lib = _lib.load()
+        self.device_index = device_index
+        self.handle = ctypes.c_void_p()
+        stream = torch.cuda.current_stream(device_index).cuda_stream
+        check(lib.orca_ctx_create(device_index, ctypes.c_void_p(stream), ctypes.byref(self.handle)), "orca_ctx_create")
+        self._finalizer = weakref.finalize(self, lib.orca_ctx_destroy, self.handle)
+
+    def sync_stream(self):
+        """Point the context at torch's current stream for this device."""
+        stream = torch.cuda.current_stream(self.device_index).cuda_stream
+        check(_lib.load().orca_ctx_set_stream(self.handle, ctypes.c_void_p(stream)), "orca_ctx_set_stream")
+
+    def workspace_bytes(self):
+        n = ctypes.c_size_t()
+        check(_lib.load().orca_ctx_workspace_bytes(self.handle, ctypes.byref(n)))
+        return n.value
+
+    def release_workspace(self):
+        check(_lib.load().orca_ctx_release_workspace(self.handle))
+
+
+def get_context(device):
+    if isinstance(device, torch.device):
+        if device.type != "cuda":
+            raise OrcaHipError(f"orca_amd runs on MI355X only; got a tensor on '{device}'. There is no CPU path.")
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+    else:
+        idx = int(device)
+    ctxs = getattr(_tls, "ctxs", None)
+    if ctxs is None:
+        ctxs = _tls.ctxs = {}
+    if idx not in ctxs:
+        ctxs[idx] = Context(idx)
+    ctx = ctxs[idx]
+    ctx.sync_stream()
+    return ctx
+
+
+# ---------------------------------------------------------------------------
+# BatchNorm folding (host, float64) - checkpoint format of orca_models.py:53-123
+# ---------------------------------------------------------------------------
+def _np64(v):
+    if isinstance(v, torch.Tensor):
+        return v.detach().cpu().double().numpy()
+    return np.asarray(v, dtype=np.float64)
+
+
+def fold_conv(sd, conv, bn=None, dilation=1):
+    """(weight, bias[, BN running stats]) -> folded fp32 (w, b) + shape info.
+    Eval-mode BN is the per-channel affine y = (x-mean)/sqrt(var+eps)*gamma+beta."""
+    w = _np64(sd[conv + ".weight"])
+    b = _np64(sd[conv + ".bias"])
+    if bn is not None:
+        s = _np64(sd[bn + ".weight"]) / np.sqrt(_np64(sd[bn + ".running_var"]) + BN_EPS)
+        w = w * s.reshape((-1,) + (1,) * (w.ndim - 1))
+        b = (b - _np64(sd[bn + ".running_mean"])) * s + _np64(sd[bn + ".bias"])
+    return {"w": np.ascontiguousarray(w, dtype=np.float32), "b": np.ascontiguousarray(b, dtype=np.float32),
+            "cout": w.shape[0], "cin": w.shape[1], "k": w.shape[2], "dil": int(dilation)}
+
+
+def make_descs(convs):
+    arr = (ConvDesc * len(convs))()
+    for i, c in enumerate(convs):
+        arr[i].weight_host = c["w"].ctypes.data
+        arr[i].bias_host = c["b"].ctypes.data
+        arr[i].cout, arr[i].cin, arr[i].ksize, arr[i].dilation = c["cout"], c["cin"], c["k"], c["dil"]
+    return arr
+
+
+class Net:
+    """Device-resident weights of one reference module (orca_net)."""
+
+    def __init__(self, ctx, kind, convs, upsample_mode=_lib.ORCA_UPSAMPLE_BILINEAR):
+        lib = _lib.load()
+        self.ctx, self.kind = ctx, kind
+        self.handle = ctypes.c_void_p()
+        descs = make_descs(convs)  # `convs` keeps the numpy arrays alive during the call
+        check(lib.orca_net_create(ctx.handle, kind, descs, len(convs), upsample_mode, ctypes.byref(self.handle)), "orca_net_create")
+        self._finalizer = weakref.finalize(self, lib.orca_net_free, self.handle)
+
+
+# ---------------------------------------------------------------------------
+# forward wrappers
+# ---------------------------------------------------------------------------
+def _f32_cuda(t, name):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if not t.is_cuda:
+        raise OrcaHipError(f"{name} is on '{t.device}': orca_amd has no CPU path (move it to the MI355X with .cuda())")
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def encoder_num_bins(L):
+    return int(_lib.load().orca_encoder_num_bins(int(L)))
+
+
+def encoder_forward(net, x, bin_lo=0, bin_hi=0, chunk_bp=0, out=None):
+    x = _f32_cuda(x, "x")
+    if x.dim() != 3 or x.shape[1] != 4:
+        raise ValueError(f"Encoder input must be [B,4,L], got {tuple(x.shape)}")
+    B, _, L = x.shape
+    total = encoder_num_bins(L)
+    hi = total if bin_hi <= 0 else bin_hi
+    if out is None:
+        out = torch.empty((B, 128, hi - bin_lo), dtype=torch.float32, device=x.device)
+    net.ctx.sync_stream()
+    check(_lib.load().orca_encoder_forward(net.ctx.handle, net.handle, _p(x), x.stride(0), x.stride(1), x.stride(2), B, L,
+                                           bin_lo, hi, _p(out), out.stride(0), out.stride(1), chunk_bp), "orca_encoder_forward")
+    return out
+
+
+def unet_forward(net, x, nlev):
+    x = _f32_cuda(x, "x")
+    if x.dim() != 3 or x.shape[1] != 128:
+        raise ValueError(f"Encoder2/3 input must be [B,128,n], got {tuple(x.shape)}")
+    B, _, n = x.shape
+    outs = [torch.empty((B, 128, n >> i), dtype=torch.float32, device=x.device) for i in range(nlev + 1)]
+    ptrs = (ctypes.c_void_p * (nlev + 1))(*[o.data_ptr() for o in outs])
+    net.ctx.sync_stream()
+    check(_lib.load().orca_unet_forward(net.ctx.handle, net.handle, _p(x), x.stride(0), x.stride(1), x.stride(2), B, n, ptrs,
+                                        nlev + 1), "orca_unet_forward")
+    return outs
+
+
+def decoder_forward(net, x, distenc, y=None, out=None, accumulate=False):
+    x = _f32_cuda(x, "x")
+    distenc = _f32_cuda(distenc, "distenc")
+    B, C, n = x.shape
+    if C != 128:
+        raise ValueError(f"Decoder input must be [B,128,n], got {tuple(x.shape)}")
+    if distenc.dim() != 4 or distenc.shape[1] != 1 or distenc.shape[2] != n or distenc.shape[3] != n:
+        raise ValueError(f"distenc must be [B,1,{n},{n}], got {tuple(distenc.shape)}")
+    if distenc.shape[0] not in (1, B):
+        raise ValueError("distenc batch mismatch")
+    sd_b = distenc.stride(0) if distenc.shape[0] == B else 0
+    yp, sy = ctypes.c_void_p(0), (0, 0, 0)
+    if y is not None:
+        y = _f32_cuda(y, "y")
+        if tuple(y.shape) != (B, 1, n // 2, n // 2):
+            raise ValueError(f"coarse prediction must be [{B},1,{n // 2},{n // 2}], got {tuple(y.shape)}")
+        yp, sy = _p(y), (y.stride(0), y.stride(2), y.stride(3))
+    if out is None:
+        out = torch.empty((B, 1, n, n), dtype=torch.float32, device=x.device)
+        accumulate = False
+    net.ctx.sync_stream()
+    check(_lib.load().orca_decoder_forward(net.ctx.handle, net.handle, _p(x), x.stride(0), x.stride(1), x.stride(2), _p(distenc),
+                                           sd_b, distenc.stride(2), distenc.stride(3), yp, sy[0], sy[1], sy[2], B, n, _p(out),
+                                           1 if accumulate else 0), "orca_decoder_forward")
+    return out
+
+
+def decoder1m_forward(net, x, out=None, accumulate=False):
+    x = _f32_cuda(x, "x")
+    B, C, n = x.shape
+    if C != 128:
+        raise ValueError(f"Decoder_1m input must be [B,128,n], got {tuple(x.shape)}")
+    if out is None:
+        out = torch.empty((B, 1, n, n), dtype=torch.float32, device=x.device)
+        accumulate = False
+    net.ctx.sync_stream()
+    check(_lib.load().orca_decoder1m_forward(net.ctx.handle, net.handle, _p(x), x.stride(0), x.stride(1), x.stride(2), B, n,
+                                             _p(out), 1 if accumulate else 0), "orca_decoder1m_forward")
+    return out
+
+
+def strand_merge(fwd, rev):
+    """0.5*fwd + 0.5*rev[::-1, ::-1] for contiguous [n,n] maps (orca_predict.py:514-523)."""
+    fwd, rev = _f32_cuda(fwd, "fwd").contiguous(), _f32_cuda(rev, "rev").contiguous()
+    n = fwd.shape[-1]
+    out = torch.empty_like(fwd)
+    ctx = get_context(fwd.device)
+    check(_lib.load().orca_strand_merge(ctx.handle, _p(fwd), _p(rev), _p(out), n), "orca_strand_merge")
+    return out
+
+
+# ---- single layers (kernel unit tests) -------------------------------------
+def conv1d(x, w, b, relu=False, r1=None, r2=None, tile=0):
+    """y = [relu](conv1d_k9(x, w) + b) [+ r1] [+ r2]; x [B,cin,n] contiguous cuda."""
+    x = _f32_cuda(x, "x").contiguous()
+    B, cin, n = x.shape
+    w = np.ascontiguousarray(w, dtype=np.float32)
+    b = np.ascontiguousarray(b, dtype=np.float32)
+    cout = w.shape[0]
+    d = make_descs([{"w": w, "b": b, "cout": cout, "cin": cin, "k": 9, "dil": 1}])
+    y = torch.empty((B, cout, n), dtype=torch.float32, device=x.device)
+    ctx = get_context(x.device)
+    r1 = r1.contiguous() if r1 is not None else None
+    r2 = r2.contiguous() if r2 is not None else None
+    check(_lib.load().orca_conv1d_forward(ctx.handle, d, _p(x), cin * n, n, _p(y), cout * n, n,
+                                          _p(r1) if r1 is not None else None, _p(r2) if r2 is not None else None, B, n,
+                                          1 if relu else 0, tile), "orca_conv1d_forward")
+    return y
+
+
+def conv2d(x, w, b, dilation=1, relu=False, r=None):
+    x = _f32_cuda(x, "x").contiguous()
+    B, cin, n, _ = x.shape
+    w = np.ascontiguousarray(w, dtype=np.float32)
+    b = np.ascontiguousarray(b, dtype=np.float32)
+    cout = w.shape[0]
+    d = make_descs([{"w": w, "b": b, "cout": cout, "cin": cin, "k": 3, "dil": dilation}])
+    y = torch.empty((B, cout, n, n), dtype=torch.float32, device=x.device)
+    ctx = get_context(x.device)
+    r = r.contiguous() if r is not None else None
+    check(_lib.load().orca_conv2d_forward(ctx.handle, d, _p(x), _p(y), _p(r) if r is not None else None, B, n,
+                                          1 if relu else 0), "orca_conv2d_forward")
+    return y
+
+
+def maxpool1d(x, k):
+    x = _f32_cuda(x, "x").contiguous()
+    B, C, n = x.shape
+    y = torch.empty((B, C, n // k), dtype=torch.float32, device=x.device)
+    ctx = get_context(x.device)
+    check(_lib.load().orca_maxpool1d_forward(ctx.handle, _p(x), n, _p(y), n // k, B * C, n // k, k), "orca_maxpool1d_forward")
+    return y

@@ -1,0 +1,150 @@
+"""Deterministic synthetic weights / sequences / backgrounds (pure numpy).
+
+The real Orca checkpoints (``models/orca_<cell>.<part>.statedict``) and
+``resources/*.npy`` are a 1.3 GB download that is not available offline, so
+parity tests, golden fixtures and ``bench.py`` all use tensors produced here.
+Every tensor depends only on (key name, shape, seed), so the GPU box can
+regenerate bit-identical weights without any reference file.
+
+The value distributions keep activations O(1) through the 28-conv Encoder and
+the 118-conv Decoder (checked in tools/make_golden.py against the reference
+modules), with non-trivial BatchNorm running statistics so that BN folding is
+really exercised.
+"""
+import zlib
+
+import numpy as np
+
+
+CONV2D_GAIN = 0.6
+
+
+def _rs(key, seed):
+    return np.random.RandomState((zlib.crc32(key.encode("utf8")) ^ (seed * 0x9E3779B1)) & 0x7FFFFFFF)
+
+
+def synth_state_dict(shapes, seed=0, relu_gain=1.0):
+    """shapes: ordered mapping key -> tuple(shape), as given by
+    ``module.state_dict()`` of a reference-format module. Returns
+    ``{key: np.ndarray}`` (float32; int64 for num_batches_tracked)."""
+    keys = list(shapes.keys())
+    bn_prefixes = {k[: -len("running_mean")] for k in keys if k.endswith("running_mean")}
+    out = {}
+    for k in keys:
+        shp = tuple(shapes[k])
+        rs = _rs(k, seed)
+        prefix = k[: k.rfind(".") + 1]
+        leaf = k[k.rfind(".") + 1:]
+        if leaf == "num_batches_tracked":
+            out[k] = np.array(1000, dtype=np.int64)
+        elif prefix in bn_prefixes:
+            if leaf == "weight":
+                v = rs.uniform(0.6, 1.2, shp)
+            elif leaf == "bias":
+                v = rs.normal(0.0, 0.1, shp)
+            elif leaf == "running_mean":
+                v = rs.normal(0.0, 0.1, shp)
+            elif leaf == "running_var":
+                v = rs.uniform(0.6, 1.4, shp)
+            else:
+                raise KeyError(k)
+            out[k] = v.astype(np.float32)
+        elif leaf == "weight":
+            fan_in = int(np.prod(shp[1:]))
+            # 3x3 Conv2d branches sit inside 56 residual adds per Decoder
+            # (orca_modules.py:471-486); a smaller gain keeps the map O(1).
+            gain = relu_gain * (CONV2D_GAIN if (len(shp) == 4 and shp[-1] == 3) else 1.0)
+            v = rs.normal(0.0, gain / np.sqrt(fan_in), shp)
+            out[k] = v.astype(np.float32)
+        elif leaf == "bias":
+            out[k] = rs.normal(0.0, 0.05, shp).astype(np.float32)
+        else:
+            raise KeyError(k)
+    return out
+
+
+def synth_sequence(length, seed=1, n_frac=0.0, batch=1):
+    """One-hot float32 [batch, length, 4] (channel order A,C,G,T as in
+    selene_utils2.py:216-222); a fraction ``n_frac`` of positions, in runs,
+    are 'N' = 0.25 x 4 (selene_utils2.py:272)."""
+    rs = np.random.RandomState(seed)
+    out = np.zeros((batch, length, 4), dtype=np.float32)
+    for b in range(batch):
+        base = rs.randint(0, 4, length)
+        out[b, np.arange(length), base] = 1.0
+        if n_frac > 0:
+            nrun = max(1, int(length * n_frac / 200))
+            for s in rs.randint(0, max(1, length - 200), nrun):
+                out[b, s: s + 200, :] = 0.25
+    return out
+
+
+def synth_base_codes(length, seed=1):
+    """uint8 base codes 0..3 (A,C,G,T); 4 = N. Cheap stand-in for a packed genome."""
+    return np.random.RandomState(seed).randint(0, 4, length).astype(np.uint8)
+
+
+def synth_expected_log(n=8000, seed=0):
+    """Stand-in for resources/*.expected.res4000.npy (orca_models.py:135-137):
+    a smooth, monotonically decaying log expected-contact curve."""
+    d = np.arange(n, dtype=np.float64)
+    return (-0.9 * np.log1p(d) - 1.5 + 0.02 * np.sin(d / 37.0 + seed)).astype(np.float64)
+
+
+def synth_normmats_32m(seed=0):
+    """normmats/epss pyramid exactly as orca_models.py:139-156 builds it."""
+    e = synth_expected_log(8000, seed)
+    idx = np.abs(np.arange(8000)[None, :] - np.arange(8000)[:, None])
+    normmat = np.exp(e[idx])
+    normmats, epss = {}, {}
+    for lv in (1, 2, 4, 8, 16, 32):
+        m = np.reshape(normmat[: 250 * lv, : 250 * lv], (250, lv, 250, lv)).mean(axis=1).mean(axis=2)
+        normmats[lv] = m
+        epss[lv] = np.min(m)
+    return normmats, epss
+
+
+def synth_normmat_256m(chrlen, seed=0, nbins=8000, binsize=32000):
+    """8000x8000 background for genomepredict_256Mb, assembled the way
+    orca_predict.py:944-972 does it: cis Toeplitz blocks for the chromosome and
+    for the padding chromosome, a scalar trans background elsewhere."""
+    n1 = int(chrlen // binsize)
+    n2 = nbins - n1
+    d = np.arange(nbins + 2000, dtype=np.float64)
+    cis = np.exp(-1.1 * np.log1p(d) - 2.0 + 0.02 * np.cos(d / 53.0 + seed))
+    trans = float(np.exp(-12.5))
+
+    def blk(n):
+        i = np.arange(n)
+        return cis[np.abs(i[:, None] - i[None, :])]
+
+    top = np.hstack([blk(n1), np.full((n1, n2), trans)])
+    bot = np.hstack([np.full((n2, n1), trans), blk(n2)])
+    return np.vstack([top, bot])
+
+
+try:  # torch is only needed for the scaffolding module below
+    import torch as _torch
+
+    class FakeNet0(_torch.nn.Module):
+        """Cheap stand-in for Encoder used by cascade (host-logic) tests and
+        fixtures: bins the [B,4,L] input into ``nbins`` windows, projects 4->128
+        with a seeded matrix and adds a positional term so bins differ.  Pure
+        torch ops; NOT part of the product path."""
+
+        def __init__(self, nbins, seed=0):
+            super().__init__()
+            rs = np.random.RandomState(1000 + seed)
+            self.nbins = nbins
+            self.register_buffer("proj", _torch.from_numpy(rs.normal(0, 1.0, (128, 4)).astype(np.float32)))
+            t = np.arange(nbins, dtype=np.float64)[None, :]
+            c = (np.arange(128, dtype=np.float64)[:, None] % 7 + 1)
+            self.register_buffer("posterm", _torch.from_numpy((0.3 * np.sin(0.01 * t * c)).astype(np.float32)))
+
+        def forward(self, x):
+            B, C, L = x.shape
+            k = L // self.nbins
+            pooled = x[:, :, : k * self.nbins].reshape(B, C, self.nbins, k).mean(dim=3)
+            return _torch.einsum("oc,bct->bot", self.proj, pooled) + self.posterm[None]
+except ImportError:  # pragma: no cover
+    pass

@@ -1,0 +1,82 @@
+"""Pin the CPU oracle (oracle/orca_oracle.py) against fixtures generated from the
+REAL reference modules by tools/make_golden.py (the reference has no tests of its
+own).  CPU only."""
+import numpy as np
+import torch
+
+from oracle import orca_oracle as O
+from orca_amd import synth
+from tests.util import golden, maxabs, stats, synth_sd
+
+TOL = 2e-5  # same ATen CPU kernels as the reference; only op grouping may differ
+
+
+def test_manifest_matches_product_modules():
+    from orca_amd import orca_modules as pm
+    man = golden("G0_manifest.npz")
+    for cls in ("Encoder", "Encoder2", "Encoder3", "Decoder", "Decoder_1m"):
+        m = getattr(pm, cls)()
+        mine = [f"{k}|{','.join(map(str, v.shape))}" for k, v in m.state_dict().items()]
+        assert mine == list(man[cls]), cls
+
+
+def test_encoder_blocks_and_edges():
+    g = golden("G1_encoder.npz")
+    sd = synth_sd("Encoder", 0)
+    x = torch.from_numpy(synth.synth_sequence(1712000, seed=11, n_frac=0.01)).transpose(1, 2)
+    y = O.encoder_forward(sd, x)[0].numpy()
+    assert y.shape == (128, 428)
+    assert maxabs(y, g["y"]) < TOL
+    # block-size invariance (G2): 200 kb blocks give the same bins
+    y200 = O.encoder_forward(sd, x, blocksize=4000 * 50)[0].numpy()
+    assert maxabs(y200, g["y_block200k"]) < TOL
+    assert maxabs(y200, y) < 1e-4
+    x2 = torch.from_numpy(synth.synth_sequence(4000 * 37, seed=12)).transpose(1, 2)
+    assert maxabs(O.encoder_forward(sd, x2)[0].numpy(), g["y_single"]) < TOL
+    x3 = torch.from_numpy(np.random.RandomState(13).rand(1, 4, 4000 * 12).astype(np.float32))
+    assert maxabs(O.encoder_forward(sd, x3)[0].numpy(), g["y_float"]) < TOL
+
+
+def test_encoder2_encoder3():
+    g = golden("G3_encoder23.npz")
+    sd2 = synth_sd("Encoder2", 0)
+    x = torch.from_numpy((np.random.RandomState(21).rand(1, 128, 800) * 0.5).astype(np.float32))
+    ys = O.encoder2_forward(sd2, x)
+    assert [y.shape[2] for y in ys] == [800, 400, 200, 100, 50, 25]
+    for i, y in enumerate(ys):
+        assert maxabs(y[0].numpy(), g[f"e2_{i}"]) < TOL
+    xl = torch.from_numpy((np.random.RandomState(22).rand(1, 128, 8000) * 0.5).astype(np.float32))
+    for i, y in enumerate(O.encoder2_forward(sd2, xl)):
+        assert maxabs(y[0, :, :16].numpy(), g[f"e2L_head_{i}"]) < TOL
+        np.testing.assert_allclose(stats(y.numpy()), g[f"e2L_stats_{i}"], rtol=1e-4)
+    sd3 = synth_sd("Encoder3", 0)
+    x3 = torch.from_numpy((np.random.RandomState(23).rand(1, 128, 2000) * 0.5).astype(np.float32))
+    for i, y in enumerate(O.encoder3_forward(sd3, x3)):
+        assert maxabs(y[0, :, ::5].numpy(), g[f"e3_{i}"]) < TOL
+
+
+def test_decoders():
+    g = golden("G5_decoder.npz")
+    nm, _ = synth.synth_normmats_32m()
+    x = torch.from_numpy((np.random.RandomState(31).rand(1, 128, 250) * 0.5).astype(np.float32))
+    de = torch.log(torch.from_numpy(nm[8][None, None].astype(np.float32)))
+    sd = synth_sd("Decoder", 0)
+    p0 = O.decoder_forward(sd, x, de)
+    assert maxabs(p0[0, 0].numpy(), g["noy"]) < TOL
+    assert float((p0 - p0.transpose(2, 3)).abs().max()) == 0.0  # exact symmetry, orca_modules.py:488
+    yc = torch.from_numpy(g["noy"][None, None, 37:162, 37:162].copy())
+    assert maxabs(O.decoder_forward(sd, x, de, yc, "bilinear")[0, 0].numpy(), g["y_bilinear"]) < TOL
+    assert maxabs(O.decoder_forward(sd, x, de, yc, "nearest")[0, 0].numpy(), g["y_nearest"]) < TOL
+    assert maxabs(O.decoder_1m_forward(synth_sd("Decoder_1m", 0), x)[0, 0].numpy(), g["dec1m"]) < TOL
+
+
+def test_zoom_index_arithmetic_matches_reference_cascade():
+    g = golden("G7_cascade32.npz")
+    for ci in range(4):
+        mpos, wpos = (int(v) for v in g[f"c{ci}_args"])
+        for reverse in (False,):
+            starts = [0]
+            for j, level in enumerate([32, 16, 8, 4, 2, 1]):
+                starts.append(starts[j] + O.zoom_index_32m(level, starts[j], mpos, wpos, reverse) * level)
+            coords = [wpos - 16000000 + s * 4000 for s in starts[:-1]]
+            assert coords == list(g[f"c{ci}_start"])

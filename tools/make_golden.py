@@ -1,0 +1,267 @@
+#!/usr/bin/env python
+"""Generate golden fixtures under tests/golden/ from the REAL reference.
+
+Runs only in the build container (needs /root/reference).  Imports
+/root/reference/orca_modules.py and orca_predict.py read-only (third-party
+modules that are not installed - selene_sdk, cooler, cooltools, pyfaidx,
+pyranges, tabix, pygenometracks - are stubbed in sys.modules; none of them is
+touched by the functions exercised here), loads deterministic synthetic weights
+from orca_amd/synth.py into the reference nn.Modules, runs seeded inputs and
+stores the outputs as small .npz fixtures.  The reference source itself never
+travels: fixtures are data only (inputs are regenerated from seeds).
+
+Usage:  python tools/make_golden.py [--full32m]   (--full32m adds the ~8 min
+full 32 Mb two-strand forward, G8)
+"""
+import argparse
+import os
+import sys
+import time
+import types
+import warnings
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+sys.path.insert(0, REPO)
+sys.path.insert(0, REF)
+warnings.filterwarnings("ignore")
+
+from orca_amd import synth  # noqa: E402
+
+GOLD = os.path.join(REPO, "tests", "golden")
+
+
+def _stub_third_party():
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    class _Dummy:
+        def __init__(self, *a, **k):
+            pass
+
+    mod("selene_sdk")
+    mod("selene_sdk.sequences", Genome=_Dummy)
+    mod("selene_sdk.samplers", OnlineSampler=_Dummy)
+    mod("selene_sdk.utils", get_indices_and_probabilities=lambda *a, **k: None)
+    mod("selene_sdk.targets", Target=_Dummy)
+    mod("cooltools")
+    mod("cooltools.lib")
+    mod("cooltools.lib.numutils", adaptive_coarsegrain=lambda *a, **k: None)
+    for n in ("cooler", "pyranges", "pyfaidx", "tabix", "pkg_resources"):
+        if n not in sys.modules:
+            try:
+                __import__(n)
+            except Exception:
+                mod(n)
+    mod("pygenometracks")
+    mod("pygenometracks.plotTracks")
+    import matplotlib
+    matplotlib.use("Agg")
+
+
+def load_synth(module, seed):
+    shapes = {k: tuple(v.shape) for k, v in module.state_dict().items()}
+    sd = synth.synth_state_dict(shapes, seed=seed)
+    module.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    module.eval()
+    return module
+
+
+def stats(a):
+    a = np.asarray(a, dtype=np.float64)
+    return np.array([a.sum(), (a * a).sum(), np.abs(a).max()])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--full32m", action="store_true")
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    os.makedirs(GOLD, exist_ok=True)
+    _stub_third_party()
+    import orca_modules as om
+
+    torch.set_num_threads(os.cpu_count())
+    only = set(args.only.split(",")) if args.only else None
+
+    def want(name):
+        return only is None or name in only
+
+    with torch.no_grad():
+        # ---- G0: state-dict key/shape manifest of every hot-path module -----------
+        if want("G0"):
+            man = {}
+            for cls in ("Encoder", "Encoder2", "Encoder3", "Decoder", "Decoder_1m"):
+                m = getattr(om, cls)()
+                man[cls] = np.array([f"{k}|{','.join(map(str, v.shape))}" for k, v in m.state_dict().items()])
+            np.savez_compressed(os.path.join(GOLD, "G0_manifest.npz"), **man)
+            print("G0 done")
+
+        # ---- G1: Encoder, 3 blocks (first / interior / last), with N runs ---------
+        if want("G1"):
+            t = time.time()
+            enc = load_synth(om.Encoder(), seed=0)
+            L = 1712000
+            x = torch.from_numpy(synth.synth_sequence(L, seed=11, n_frac=0.01)).transpose(1, 2)
+            y = enc(x)[0].numpy()
+            # G2: block-size invariance pair
+            om.Blocksize = 4000 * 50
+            y200 = enc(x)[0].numpy()
+            om.Blocksize = 4000 * 200
+            # single block, length not a multiple of anything big
+            L2 = 4000 * 37
+            x2 = torch.from_numpy(synth.synth_sequence(L2, seed=12)).transpose(1, 2)
+            y2 = enc(x2)[0].numpy()
+            # arbitrary float (non one-hot) input
+            rs = np.random.RandomState(13)
+            x3 = torch.from_numpy(rs.rand(1, 4, 4000 * 12).astype(np.float32))
+            y3 = enc(x3)[0].numpy()
+            np.savez_compressed(os.path.join(GOLD, "G1_encoder.npz"), y=y, y_block200k=y200, y_single=y2, y_float=y3)
+            print("G1 done %.1fs  max|y-y200|=%.3g  |y|max=%.3g" % (time.time() - t, np.abs(y - y200).max(), np.abs(y).max()))
+
+        # ---- G3/G4: Encoder2 / Encoder3 ------------------------------------------
+        if want("G3"):
+            e2 = load_synth(om.Encoder2(), seed=0)
+            rs = np.random.RandomState(21)
+            x = torch.from_numpy((rs.rand(1, 128, 800) * 0.5).astype(np.float32))
+            ys = e2(x)
+            xl = torch.from_numpy((np.random.RandomState(22).rand(1, 128, 8000) * 0.5).astype(np.float32))
+            yl = e2(xl)
+            e3 = load_synth(om.Encoder3(), seed=0)
+            x3 = torch.from_numpy((np.random.RandomState(23).rand(1, 128, 2000) * 0.5).astype(np.float32))
+            y3 = e3(x3)
+            d = {f"e2_{i}": y[0].numpy() for i, y in enumerate(ys)}
+            d.update({f"e2L_stats_{i}": stats(y.numpy()) for i, y in enumerate(yl)})
+            d.update({f"e2L_head_{i}": y[0, :, :16].numpy() for i, y in enumerate(yl)})
+            d.update({f"e3_{i}": y[0, :, ::5].numpy() for i, y in enumerate(y3)})
+            d.update({f"e3_stats_{i}": stats(y.numpy()) for i, y in enumerate(y3)})
+            np.savez_compressed(os.path.join(GOLD, "G3_encoder23.npz"), **d)
+            print("G3/G4 done")
+
+        # ---- G5/G6: Decoder (no y / y bilinear / y nearest), Decoder_1m ----------
+        if want("G5"):
+            nm, _ = synth.synth_normmats_32m()
+            x = torch.from_numpy((np.random.RandomState(31).rand(1, 128, 250) * 0.5).astype(np.float32))
+            de = torch.log(torch.from_numpy(nm[8][None, None].astype(np.float32)))
+            dec = load_synth(om.Decoder(upsample_mode="bilinear"), seed=0)
+            p0 = dec(x, de)
+            yc = p0[:, :, 37:162, 37:162]
+            p1 = dec(x, de, yc)
+            decn = load_synth(om.Decoder(upsample_mode="nearest"), seed=0)
+            p2 = decn(x, de, yc)
+            d1m = load_synth(om.Decoder_1m(), seed=0)
+            p3 = d1m(x)
+            np.savez_compressed(os.path.join(GOLD, "G5_decoder.npz"), noy=p0[0, 0].numpy(), y_bilinear=p1[0, 0].numpy(),
+                                y_nearest=p2[0, 0].numpy(), dec1m=p3[0, 0].numpy())
+            print("G5/G6 done; sym err", float((p1 - p1.transpose(2, 3)).abs().max()))
+
+        # ---- G7: genomepredict cascade through the REAL orca_predict -------------
+        if want("G7"):
+            import orca_predict as op
+
+            class Container(torch.nn.Module):
+                def __init__(self, seed):
+                    super().__init__()
+                    self.net0 = synth.FakeNet0(nbins=8000, seed=seed)
+                    self.net = load_synth(om.Encoder2(), seed=seed)
+                    self.denets = {lv: load_synth(om.Decoder(upsample_mode="bilinear"), seed=seed + lv)
+                                   for lv in (1, 2, 4, 8, 16, 32)}
+                    self.denet_1_pt = load_synth(om.Decoder_1m(), seed=seed)
+                    self.normmats, self.epss = synth.synth_normmats_32m()
+
+            model = Container(0)
+            seq = synth.synth_sequence(320000, seed=41)
+            cases = [(16000000 + 1234567, 16000000), (3000000, 16000000), (31500000, 16000000),
+                     (50000000 + 9876543, 50000000 + 1)]
+            d = {}
+            for ci, (mpos, wpos) in enumerate(cases):
+                t = time.time()
+                out = op.genomepredict(seq, "chrS", mpos, wpos, models=[model], use_cuda=False)
+                d[f"c{ci}_args"] = np.array([mpos, wpos], dtype=np.int64)
+                d[f"c{ci}_start"] = np.array(out["start_coords"], dtype=np.int64)
+                d[f"c{ci}_end"] = np.array(out["end_coords"], dtype=np.int64)
+                for j, p in enumerate(out["predictions"][0]):
+                    d[f"c{ci}_stats_{j}"] = stats(p)
+                    d[f"c{ci}_sub_{j}"] = (p if ci == 0 else p[::5, ::5]).astype(np.float32)
+                print("G7 case", ci, "%.1fs" % (time.time() - t), out["start_coords"])
+            # targets + annotation bookkeeping on case 0
+            tgt = np.abs(np.random.RandomState(42).randn(1, 8000, 8000).astype(np.float32)) * 1e-3
+            tgt[0, 100:140, :] = np.nan
+            anno = [(0.1, 0.3, "a"), (0.52, "b"), (0.9, 0.95, "c")]
+            out = op.genomepredict(seq, "chrS", cases[0][0], cases[0][1], models=[model],
+                                   targets=[torch.from_numpy(tgt)], annotation=anno, use_cuda=False)
+            for j, e in enumerate(out["experiments"][0]):
+                d[f"tgt_sub_{j}"] = np.asarray(e)[::5, ::5].astype(np.float32)
+            d["annos_repr"] = np.array([repr([[tuple(float(v) if not isinstance(v, str) else v for v in r) for r in lv]
+                                              for lv in out["annos"]])])
+            np.savez_compressed(os.path.join(GOLD, "G7_cascade32.npz"), **d)
+            print("G7 done")
+
+        # ---- G9: genomepredict_256Mb cascade -------------------------------------
+        if want("G9"):
+            import orca_predict as op
+
+            class Container256(torch.nn.Module):
+                def __init__(self, seed):
+                    super().__init__()
+                    self.net0 = synth.FakeNet0(nbins=64000, seed=seed)
+                    self.net1 = load_synth(om.Encoder2(), seed=seed)
+                    self.net = load_synth(om.Encoder3(), seed=seed)
+                    self.denets = {lv: load_synth(om.Decoder(upsample_mode="bilinear"), seed=seed + lv)
+                                   for lv in (32, 64, 128, 256)}
+
+            model = Container256(0)
+            seq = synth.synth_sequence(512000, seed=51)
+            chrlen = 138368000
+            d = {}
+            for ci, (mpos, wpos) in enumerate([(70000000, 128000000), (130000000, 128000000), (5000000, 128000000)]):
+                nm = synth.synth_normmat_256m(chrlen, seed=0)
+                out = op.genomepredict_256Mb(seq, "chrS", [nm], chrlen, mpos, wpos, models=[model],
+                                             padding_chr="chrP", use_cuda=False)
+                d[f"c{ci}_args"] = np.array([mpos, wpos, chrlen], dtype=np.int64)
+                d[f"c{ci}_start"] = np.array(out["start_coords"], dtype=np.int64)
+                d[f"c{ci}_end"] = np.array([int(v) for v in out["end_coords"]], dtype=np.int64)
+                for j, p in enumerate(out["predictions"][0]):
+                    d[f"c{ci}_stats_{j}"] = stats(p)
+                    d[f"c{ci}_sub_{j}"] = (p if ci == 0 else p[::5, ::5]).astype(np.float32)
+                print("G9 case", ci, out["start_coords"])
+            np.savez_compressed(os.path.join(GOLD, "G9_cascade256.npz"), **d)
+            print("G9 done")
+
+        # ---- G8: one full 32 Mb H1-ESC-shaped forward, both strands ---------------
+        if args.full32m and want("G8"):
+            import orca_predict as op
+
+            class Full(torch.nn.Module):
+                def __init__(self, seed):
+                    super().__init__()
+                    self.net0 = load_synth(om.Encoder(), seed=seed)
+                    self.net = load_synth(om.Encoder2(), seed=seed)
+                    self.denets = {lv: load_synth(om.Decoder(upsample_mode="bilinear"), seed=seed + lv)
+                                   for lv in (1, 2, 4, 8, 16, 32)}
+                    self.denet_1_pt = load_synth(om.Decoder_1m(), seed=seed)
+                    self.normmats, self.epss = synth.synth_normmats_32m()
+
+            model = Full(0)
+            seq = synth.synth_sequence(32000000, seed=1)
+            t = time.time()
+            enc_f = model.net0(torch.from_numpy(seq).transpose(1, 2))
+            t_enc = time.time() - t
+            out = op.genomepredict(seq, "chrS", 16000000 + 1234567, 16000000, models=[model], use_cuda=False)
+            d = {"enc_fwd": enc_f[0].numpy(), "t_encoder_cpu_s": np.array([t_enc]),
+                 "t_total_cpu_s": np.array([time.time() - t]), "ncores": np.array([os.cpu_count()]),
+                 "start": np.array(out["start_coords"], dtype=np.int64)}
+            for j, p in enumerate(out["predictions"][0]):
+                d[f"pred_{j}"] = p.astype(np.float32)
+            np.savez_compressed(os.path.join(GOLD, "G8_full32m.npz"), **d)
+            print("G8 done: encoder %.1fs, total %.1fs" % (t_enc, time.time() - t))
+
+
+if __name__ == "__main__":
+    main()
