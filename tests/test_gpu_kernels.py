@@ -1,0 +1,83 @@
+"""-m gpu: single HIP kernels (through the C ABI) vs the torch fp32 CPU reference of
+the same op.  fp32 MFMA is an exact fmaf chain, so the only difference is summation
+order: tolerance 2e-5 abs on O(1) outputs (observed ~1e-6)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from orca_amd import engine
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+
+
+def _ref_conv1d(x, w, b, relu, r1=None, r2=None):
+    y = F.conv1d(x, torch.from_numpy(w), torch.from_numpy(b), padding=4)
+    if relu:
+        y = F.relu(y)
+    if r1 is not None:
+        y = y + r1
+    if r2 is not None:
+        y = y + r2
+    return y
+
+
+@pytest.mark.parametrize("cin,cout,n,tile", [
+    (4, 64, 1000, 0), (64, 64, 777, 0), (64, 96, 1024, 0), (96, 96, 515, 0), (96, 128, 300, 32),
+    (128, 128, 250, 32), (128, 128, 250, 64), (128, 128, 1000, 128), (128, 128, 1001, 256), (128, 128, 4096, 0),
+])
+def test_conv1d_k9(cuda, cin, cout, n, tile):
+    rs = np.random.RandomState(cin * 1000 + cout + n)
+    B = 2
+    x = torch.from_numpy(rs.randn(B, cin, n).astype(np.float32))
+    w = (rs.randn(cout, cin, 9) / np.sqrt(cin * 9)).astype(np.float32)
+    b = rs.randn(cout).astype(np.float32) * 0.1
+    r1 = torch.from_numpy(rs.randn(B, cout, n).astype(np.float32))
+    r2 = torch.from_numpy(rs.randn(B, cout, n).astype(np.float32))
+    for relu, ra, rb in [(False, None, None), (True, r1, None), (True, r1, r2)]:
+        y = engine.conv1d(x.to(cuda), w, b, relu, None if ra is None else ra.to(cuda), None if rb is None else rb.to(cuda), tile)
+        ref = _ref_conv1d(x, w, b, relu, ra, rb)
+        err = float((y.cpu() - ref).abs().max())
+        assert err < TOL, (cin, cout, n, tile, relu, err)
+
+
+def test_conv1d_is_transpose_sensitive(cuda):
+    """asymmetric weights / identity-like input catch swapped operands or cout/pos maps."""
+    n, cin, cout = 256, 64, 64
+    x = torch.zeros(1, cin, n)
+    x[0, 3, 100] = 1.0
+    w = np.zeros((cout, cin, 9), dtype=np.float32)
+    w[7, 3, 2] = 5.0  # tap 2 -> output position 100 + (4 - 2) = 102
+    y = engine.conv1d(x.to(cuda), w, np.zeros(cout, dtype=np.float32)).cpu()
+    assert float(y[0, 7, 102]) == 5.0
+    assert float(y.abs().sum()) == 5.0
+
+
+@pytest.mark.parametrize("cin,cout,dil,n", [
+    (64, 32, 1, 250), (32, 64, 2, 250), (64, 64, 1, 250), (64, 32, 64, 250), (32, 64, 32, 250), (129, 64, 1, 250),
+    (65, 64, 1, 250), (128, 32, 1, 250), (64, 32, 16, 126), (32, 64, 8, 64),
+])
+def test_conv2d_3x3_dilated(cuda, cin, cout, dil, n):
+    rs = np.random.RandomState(cin * 100 + cout + dil)
+    B = 2 if n < 250 else 1
+    x = torch.from_numpy(rs.randn(B, cin, n, n).astype(np.float32))
+    w = (rs.randn(cout, cin, 3, 3) / np.sqrt(cin * 9)).astype(np.float32)
+    b = rs.randn(cout).astype(np.float32) * 0.1
+    r = torch.from_numpy(rs.randn(B, cout, n, n).astype(np.float32))
+    for relu, rr in [(False, None), (True, r)]:
+        y = engine.conv2d(x.to(cuda), w, b, dil, relu, None if rr is None else rr.to(cuda)).cpu()
+        ref = F.conv2d(x, torch.from_numpy(w), torch.from_numpy(b), padding=dil, dilation=dil)
+        if relu:
+            ref = F.relu(ref)
+        if rr is not None:
+            ref = ref + rr
+        err = float((y - ref).abs().max())
+        assert err < TOL, (cin, cout, dil, n, relu, err)
+
+
+@pytest.mark.parametrize("k", [2, 4, 5])
+def test_maxpool(cuda, k):
+    x = torch.from_numpy(np.random.RandomState(k).randn(2, 7, 1003).astype(np.float32))
+    y = engine.maxpool1d(x.to(cuda), k).cpu()
+    assert torch.equal(y, F.max_pool1d(x, k, k))

@@ -1,0 +1,108 @@
+"""-m gpu: whole modules on the MI355X (HIP path through the C ABI) vs (a) the golden
+fixtures generated from the real reference and (b) the CPU oracle on the same inputs.
+Tolerance from BASELINE.json north_star: 1e-4 max-abs on O(1) fp32 outputs, plus
+Pearson r per output."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import orca_oracle as O
+from orca_amd import synth
+from tests.util import golden, maxabs, pearson, product_module, stats, synth_sd
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def test_encoder_vs_golden_and_chunking(cuda):
+    g = golden("G1_encoder.npz")
+    enc = product_module("Encoder", 0)
+    x = torch.from_numpy(synth.synth_sequence(1712000, seed=11, n_frac=0.01)).to(cuda).transpose(1, 2)
+    y = enc(x)[0].cpu().numpy()
+    assert y.shape == (128, 428)
+    assert maxabs(y, g["y"]) < TOL and pearson(y, g["y"]) > 0.99999
+    # internal chunking (halo 112 kb) must not change the result: 400 kb chunks vs one chunk
+    y2 = enc(x, chunk_bp=400000)[0].cpu().numpy()
+    assert maxabs(y2, y) < 2e-5
+    # bin sub-range (multi-GPU shard) equals the slice of the full result
+    y3 = enc(x, bin_lo=100, bin_hi=300)[0].cpu().numpy()
+    assert maxabs(y3, y[:, 100:300]) < 2e-5
+    x2 = torch.from_numpy(synth.synth_sequence(4000 * 37, seed=12)).to(cuda).transpose(1, 2)
+    assert maxabs(enc(x2)[0].cpu().numpy(), g["y_single"]) < TOL
+    x3 = torch.from_numpy(np.random.RandomState(13).rand(1, 4, 4000 * 12).astype(np.float32)).to(cuda)
+    assert maxabs(enc(x3)[0].cpu().numpy(), g["y_float"]) < TOL
+
+
+def test_encoder_ragged_length_and_batch_vs_oracle(cuda):
+    enc = product_module("Encoder", 3)
+    sd = synth_sd("Encoder", 3)
+    L = 4000 * 9 + 1234  # not a multiple of the bin size
+    x = torch.from_numpy(synth.synth_sequence(L, seed=5, batch=2, n_frac=0.02)).transpose(1, 2)
+    ref = O.encoder_forward(sd, x).numpy()
+    y = enc(x.to(cuda)).cpu().numpy()
+    assert y.shape == ref.shape == (2, 128, 9)
+    assert maxabs(y, ref) < TOL
+
+
+def test_encoder2_encoder3_vs_golden(cuda):
+    g = golden("G3_encoder23.npz")
+    e2 = product_module("Encoder2", 0)
+    x = torch.from_numpy((np.random.RandomState(21).rand(1, 128, 800) * 0.5).astype(np.float32)).to(cuda)
+    ys = e2(x)
+    for i, y in enumerate(ys):
+        assert maxabs(y[0].cpu().numpy(), g[f"e2_{i}"]) < TOL
+    xl = torch.from_numpy((np.random.RandomState(22).rand(1, 128, 8000) * 0.5).astype(np.float32)).to(cuda)
+    for i, y in enumerate(e2(xl)):
+        assert maxabs(y[0, :, :16].cpu().numpy(), g[f"e2L_head_{i}"]) < TOL
+        np.testing.assert_allclose(stats(y.cpu().numpy()), g[f"e2L_stats_{i}"], rtol=1e-4)
+    e3 = product_module("Encoder3", 0)
+    x3 = torch.from_numpy((np.random.RandomState(23).rand(1, 128, 2000) * 0.5).astype(np.float32)).to(cuda)
+    for i, y in enumerate(e3(x3)):
+        assert maxabs(y[0, :, ::5].cpu().numpy(), g[f"e3_{i}"]) < TOL
+
+
+def test_encoder2_batch_and_strided_input_vs_oracle(cuda):
+    e2 = product_module("Encoder2", 1)
+    sd = synth_sd("Encoder2", 1)
+    big = torch.from_numpy((np.random.RandomState(7).rand(2, 128, 700) * 0.5).astype(np.float32))
+    x = big[:, :, 30:670]  # non-contiguous, 640 bins
+    ref = O.encoder2_forward(sd, x)
+    ys = e2(big.to(cuda)[:, :, 30:670])
+    for a, b in zip(ys, ref):
+        assert maxabs(a.cpu().numpy(), b.numpy()) < TOL
+
+
+def test_decoders_vs_golden(cuda):
+    g = golden("G5_decoder.npz")
+    nm, _ = synth.synth_normmats_32m()
+    x = torch.from_numpy((np.random.RandomState(31).rand(1, 128, 250) * 0.5).astype(np.float32)).to(cuda)
+    de = torch.log(torch.from_numpy(nm[8][None, None].astype(np.float32))).to(cuda)
+    dec = product_module("Decoder", 0, upsample_mode="bilinear")
+    p0 = dec(x, de)
+    assert maxabs(p0[0, 0].cpu().numpy(), g["noy"]) < TOL
+    assert float((p0 - p0.transpose(2, 3)).abs().max()) == 0.0  # exactly symmetric
+    yc = torch.from_numpy(g["noy"][None, None]).to(cuda)[:, :, 37:162, 37:162]  # strided crop, as in the cascade
+    p1 = dec(x, de, yc)
+    assert maxabs(p1[0, 0].cpu().numpy(), g["y_bilinear"]) < TOL
+    assert pearson(p1[0, 0].cpu().numpy(), g["y_bilinear"]) > 0.99999
+    decn = product_module("Decoder", 0, upsample_mode="nearest")
+    assert maxabs(decn(x, de, yc)[0, 0].cpu().numpy(), g["y_nearest"]) < TOL
+    d1m = product_module("Decoder_1m", 0)
+    p3 = d1m(x)
+    assert maxabs(p3[0, 0].cpu().numpy(), g["dec1m"]) < TOL
+    # accumulate form used for `+ denet_1_pt(...)` (orca_predict.py:362-366)
+    acc = p1.clone()
+    d1m.forward_into(acc, x, accumulate=True)
+    assert maxabs(acc.cpu().numpy(), (p1 + p3).cpu().numpy()) < 1e-6
+
+
+def test_decoder_batch_sliced_input_vs_oracle(cuda):
+    nm, _ = synth.synth_normmats_32m()
+    sd = synth_sd("Decoder", 2, upsample_mode="bilinear")
+    dec = product_module("Decoder", 2, upsample_mode="bilinear")
+    enc = torch.from_numpy((np.random.RandomState(9).rand(2, 128, 400) * 0.5).astype(np.float32))
+    de = torch.log(torch.from_numpy(nm[2][None, None].astype(np.float32))).expand(2, -1, -1, -1)
+    yc = torch.from_numpy(np.random.RandomState(10).randn(2, 1, 125, 125).astype(np.float32))
+    ref = O.decoder_forward(sd, enc[:, :, 77:327], de, yc, "bilinear").numpy()
+    out = dec(enc.to(cuda)[:, :, 77:327], de.to(cuda), yc.to(cuda)).cpu().numpy()
+    assert maxabs(out, ref) < TOL
