@@ -1,0 +1,203 @@
+#!/usr/bin/env python
+"""bench.py - headline benchmark of the Orca hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): H1-ESC-shaped 32 Mb model (Encoder + Encoder2 +
+six Decoders + Decoder_1m), ONE random 32 Mb sequence, fp32.  One "step" is what the
+reference's `genomepredict` does on the device for one model: both strands through
+net0 -> net -> the 6-level decoder cascade (+ denet_1_pt at 4 kb) and the strand merge.
+Inputs (forward strand and its reverse complement, float32 [1,32e6,4]) are resident in
+HBM before the timed region; weights are deterministic synthetic tensors of the
+reference architecture (the real checkpoints are a 1.3 GB download, unavailable offline).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+N>1: every rank runs the same workload on its own sequence (independent 32 Mb windows,
+the reference's structural-variant-screen pattern): weak scaling, no data-path collective.
+
+Prints ONE JSON line (rank 0).  value = strand-Mb of sequence encoded AND decoded per
+second over the whole job (2 strands x 32 Mb per step per rank).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+L_BP = 32_000_000
+ENC_FLOP_PER_BP = 465555.5
+DEC_TFLOP = {"first": 0.2812, "withy": 0.2905, "dec1m": 0.1774, "enc2": 0.0274}
+
+
+def step_flops():
+    per_strand = ENC_FLOP_PER_BP * L_BP / 1e12 + DEC_TFLOP["enc2"] + DEC_TFLOP["first"] + 5 * DEC_TFLOP["withy"] + DEC_TFLOP["dec1m"]
+    return 2 * per_strand
+
+
+def cpu_baseline(seed):
+    """Reference-architecture PyTorch-CPU fp32 forward (oracle/orca_oracle.py = the torch ops the
+    reference dispatches with use_cuda=False) on a bounded sample of the same workload."""
+    from oracle import orca_oracle as O
+    from orca_amd import synth
+    from tests.util import synth_sd
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    sample_bp = 4_000_000
+    x = torch.from_numpy(synth.synth_sequence(sample_bp, seed=1)).transpose(1, 2)
+    sd0 = synth_sd("Encoder", seed)
+    O.encoder_forward(sd0, x[:, :, :912000])  # warm-up
+    t = time.perf_counter()
+    enc = O.encoder_forward(sd0, x)
+    t_enc = time.perf_counter() - t
+    nm, _ = synth.synth_normmats_32m()
+    sd2 = synth_sd("Encoder2", seed)
+    encfull = torch.from_numpy((np.random.RandomState(3).rand(1, 128, 8000) * 0.5).astype(np.float32))
+    t = time.perf_counter()
+    encs = O.encoder2_forward(sd2, encfull)
+    pred = None
+    for j, lv in enumerate([32, 16, 8, 4, 2, 1]):
+        de = torch.log(torch.from_numpy(nm[lv][None, None].astype(np.float32)))
+        sdd = synth_sd("Decoder", seed + lv, upsample_mode="bilinear")
+        pred = O.decoder_forward(sdd, encs[5 - j][:, :, :250], de, None if pred is None else pred[:, :, 60:185, 60:185], "bilinear")
+    O.decoder_1m_forward(synth_sd("Decoder_1m", seed), encs[0][:, :, :250])
+    t_rest = time.perf_counter() - t
+    t_strand = t_enc * (L_BP / sample_bp) + t_rest
+    return {"value": round(L_BP / 1e6 / t_strand, 4), "unit": "Mb/s", "cores": ncores, "kind": "port",
+            "sample": f"Encoder on {sample_bp // 1000000} Mb (5 reference blocks, {t_enc:.1f}s, scaled x{L_BP // sample_bp}) + "
+                      f"Encoder2(8000 bins) + 6 Decoder + Decoder_1m ({t_rest:.1f}s), torch CPU fp32, {ncores} threads",
+            "t_encoder_sample_s": round(t_enc, 2), "t_decoders_s": round(t_rest, 2)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--seq-mb", type=int, default=32, help="debug only: shorter sequence (invalidates the metric)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from orca_amd import engine, orca_models, orca_predict, synth
+
+    Lbp = args.seq_mb * 1_000_000
+    model = orca_models.H1esc(synthetic_seed=0)
+    # device-resident inputs: forward strand and reverse complement as [1,4,L] views of [1,L,4] storage
+    seq = synth.synth_sequence(Lbp, seed=1 + rank)
+    x_fwd = torch.from_numpy(seq).to(dev).transpose(1, 2)
+    x_rev = torch.from_numpy(np.ascontiguousarray(seq[:, ::-1, ::-1])).to(dev).transpose(1, 2)
+    del seq
+    distencs = {lv: torch.log(torch.from_numpy(model.normmats[lv][None, None].astype(np.float32))).to(dev)
+                for lv in model.levels}
+    mpos, wpos = Lbp // 2 + 1234567 * Lbp // 32_000_000, Lbp // 2
+    ctx = engine.get_context(dev)
+
+    def step():
+        pf, _ = orca_predict.cascade_32m(model, x_fwd, mpos, wpos, False, distencs)
+        pr, _ = orca_predict.cascade_32m(model, x_rev, mpos, wpos, True, distencs)
+        return [engine.strand_merge(a[0, 0], b[0, 0]) for a, b in zip(pf, pr)]
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    ctx.set_timing(True)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ev[0].record()
+        pf, _ = orca_predict.cascade_32m(model, x_fwd, mpos, wpos, False, distencs)
+        pr, _ = orca_predict.cascade_32m(model, x_rev, mpos, wpos, True, distencs)
+        outs = [engine.strand_merge(a[0, 0], b[0, 0]) for a, b in zip(pf, pr)]
+    sync()
+    elapsed = time.perf_counter() - t0
+    ctx.set_timing(False)
+    recs = ctx.get_timing()
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- dominant kernel: per-instantiation HIP-event timings collected in the timed region
+    groups = {}
+    for cout, cin, tile, batch, n, ms in recs:
+        g = groups.setdefault((cout, cin, tile), {"ms": 0.0, "launches": 0, "flop": 0.0})
+        g["ms"] += ms
+        g["launches"] += 1
+        g["flop"] += 2.0 * 9 * cin * cout * n * batch
+    inst = {}
+    for (cout, cin, tile), g in groups.items():   # instantiation = (cout, KC) ; cin in {64,96,128} share KC=8
+        key = f"conv1d_k9<cout={cout},kc={4 if cin == 4 else 8},tile={tile}>"
+        d = inst.setdefault(key, {"ms": 0.0, "launches": 0, "flop": 0.0})
+        for k in d:
+            d[k] += g[k]
+    roofline = None
+    if inst:
+        name, d = max(inst.items(), key=lambda kv: kv[1]["ms"])
+        achieved = d["flop"] / (d["ms"] * 1e-3) / 1e12
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tp):
+            try:
+                traffic = json.load(open(tp)).get(name)
+            except Exception:
+                traffic = None
+        roofline = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                    "avg_launch_ms": round(d["ms"] / d["launches"], 4), "launches": d["launches"],
+                    "flop_per_launch": d["flop"] / d["launches"],
+                    "conv1d_time_share_of_step": round(sum(v["ms"] for v in inst.values()) / (elapsed * 1e3), 4),
+                    "all_conv1d_tflops": round(sum(v["flop"] for v in inst.values()) / (sum(v["ms"] for v in inst.values()) * 1e-3) / 1e12, 2)}
+
+    ms_per_step = elapsed / args.steps * 1e3
+    mb_per_s = world * 2 * (Lbp / 1e6) * args.steps / elapsed
+    res = {
+        "metric": "Mb of sequence encoded+decoded per second (32Mb H1-ESC-shaped model, both strands, 6 levels)",
+        "value": round(mb_per_s, 3), "unit": "Mb/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"H1-ESC 32Mb model forward, single random {args.seq_mb}Mb sequence, fp32, both strands "
+                               "(genomepredict-equivalent, 1 model): Encoder+Encoder2+6 Decoder+Decoder_1m per strand",
+                   "sequence_bp": Lbp, "strands": 2, "levels": 6, "weights": "synthetic seed 0",
+                   "parallelism": f"replicas x{world}" if world > 1 else "single GPU"},
+        "contact_map_pixels_per_s": round(world * 2 * 6 * 62500 * args.steps / elapsed, 1),
+        "step_tflop_algorithmic": round(step_flops() * Lbp / L_BP, 3) if Lbp == L_BP else None,
+        "whole_step_tflops": round(world * step_flops() * args.steps / elapsed, 2) if Lbp == L_BP else None,
+        "roofline": roofline,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(0)
+        res["speedup_vs_cpu"] = round(res["value"] / world / res["cpu_baseline"]["value"], 1)
+    if rank == 0:
+        print(json.dumps(res))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -92,6 +92,21 @@ int orca_ctx_workspace_bytes(orca_ctx* ctx, size_t* out);
 /* Free the workspace (it is re-grown on demand). */
 int orca_ctx_release_workspace(orca_ctx* ctx);
 
+/* ---- per-kernel timing (bench.py roofline) ---------------------------------
+ * When enabled, every conv1d launch over >= 65536 positions (the Encoder's
+ * stage 1-4 convolutions, >96 % of the path's FLOPs) is bracketed by HIP events
+ * on the context's stream.  orca_ctx_get_timing synchronises the stream, fills
+ * up to `max` records (oldest first), stores the number available in *n and
+ * clears the log. */
+typedef struct orca_kernel_time {
+  int32_t cout, cin, tile, batch;
+  int64_t n;      /* positions per batch row            */
+  float ms;       /* elapsed between the two HIP events */
+  int32_t pad_;
+} orca_kernel_time;
+int orca_ctx_set_timing(orca_ctx* ctx, int enable);
+int orca_ctx_get_timing(orca_ctx* ctx, orca_kernel_time* out, int max, int* n);
+
 /* ---- weights -------------------------------------------------------------
  * Replaces: nn.Module.load_state_dict + .cuda() of the reference containers
  * (orca_models.py:53-133).  `convs` lists the folded convolutions of the module

@@ -24,6 +24,11 @@ class ConvDesc(ctypes.Structure):
                 ("ksize", c_int32), ("dilation", c_int32)]
 
 
+class KernelTime(ctypes.Structure):
+    _fields_ = [("cout", c_int32), ("cin", c_int32), ("tile", c_int32), ("batch", c_int32), ("n", c_int64),
+                ("ms", ctypes.c_float), ("pad_", c_int32)]
+
+
 # name -> (restype, argtypes); every symbol declared in include/orca_hip.h
 SIGNATURES = {
     "orca_abi_version": (c_int, []),
@@ -34,6 +39,8 @@ SIGNATURES = {
     "orca_ctx_set_stream": (c_int, [c_void_p, c_void_p]),
     "orca_ctx_workspace_bytes": (c_int, [c_void_p, POINTER(c_size_t)]),
     "orca_ctx_release_workspace": (c_int, [c_void_p]),
+    "orca_ctx_set_timing": (c_int, [c_void_p, c_int]),
+    "orca_ctx_get_timing": (c_int, [c_void_p, POINTER(KernelTime), c_int, POINTER(c_int)]),
     "orca_net_create": (c_int, [c_void_p, c_int, POINTER(ConvDesc), c_int, c_int, POINTER(c_void_p)]),
     "orca_net_free": (c_int, [c_void_p]),
     "orca_encoder_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_int64, c_int64,

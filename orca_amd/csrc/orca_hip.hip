@@ -54,12 +54,19 @@ static inline size_t ru256(size_t v) { return (v + 255) & ~size_t(255); }
 // ---------------------------------------------------------------------------
 // context + workspace arena
 // ---------------------------------------------------------------------------
+struct TimedLaunch {
+  orca_kernel_time rec;
+  hipEvent_t e0, e1;
+};
+
 struct orca_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   char* ws = nullptr;
   size_t ws_bytes = 0;
   size_t ws_off = 0;
+  bool timing = false;
+  std::vector<TimedLaunch> timed;
 };
 
 static int ws_ensure(orca_ctx* ctx, size_t bytes) {
@@ -189,6 +196,14 @@ static int launch_conv1d(orca_ctx* ctx, const ConvLayer& L, const float* x, long
   a.x_vec_ok = al16(x) && (ldx % 4 == 0) && (x_bs % 4 == 0);
   a.y_vec_ok = al16(y) && (ldy % 4 == 0) && (y_bs % 4 == 0) && (!r1 || al16(r1)) && (!r2 || al16(r2));
   hipStream_t s = ctx->stream;
+  const bool timed = ctx->timing && n >= 65536;
+  TimedLaunch tl;
+  if (timed) {
+    HIPCHECK(hipEventCreate(&tl.e0));
+    HIPCHECK(hipEventCreate(&tl.e1));
+    HIPCHECK(hipEventRecord(tl.e0, s));
+  }
+  int used_tile = 256;
   if (L.cout == 64) {
     if (L.kc == 4) launch_conv1d_t<64, 2, 2, 4, 1, 4>(s, a, B);
     else launch_conv1d_t<64, 2, 2, 4, 1, 8>(s, a, B);
@@ -201,8 +216,14 @@ static int launch_conv1d(orca_ctx* ctx, const ConvLayer& L, const float* x, long
     else if (tile == 64) launch_conv1d_t<128, 1, 2, 2, 2, 8>(s, a, B);
     else if (tile == 32) launch_conv1d_t<128, 1, 1, 1, 4, 8>(s, a, B);
     else return fail(ORCA_EINVAL, "conv1d tile %d unsupported", tile);
+    used_tile = tile;
   }
   LAUNCHCHECK("conv1d_k9_kernel");
+  if (timed) {
+    HIPCHECK(hipEventRecord(tl.e1, s));
+    tl.rec.cout = L.cout; tl.rec.cin = L.cin; tl.rec.tile = used_tile; tl.rec.batch = B; tl.rec.n = n; tl.rec.ms = 0.f; tl.rec.pad_ = 0;
+    ctx->timed.push_back(tl);
+  }
   return ORCA_OK;
 }
 
@@ -280,6 +301,30 @@ extern "C" int orca_ctx_destroy(orca_ctx* ctx) {
 extern "C" int orca_ctx_set_stream(orca_ctx* ctx, void* hip_stream) {
   if (!ctx) return fail(ORCA_EINVAL, "ctx is NULL");
   ctx->stream = static_cast<hipStream_t>(hip_stream);
+  return ORCA_OK;
+}
+
+extern "C" int orca_ctx_set_timing(orca_ctx* ctx, int enable) {
+  if (!ctx) return fail(ORCA_EINVAL, "ctx is NULL");
+  ctx->timing = enable != 0;
+  return ORCA_OK;
+}
+
+extern "C" int orca_ctx_get_timing(orca_ctx* ctx, orca_kernel_time* out, int max, int* n) {
+  if (!ctx || !n) return fail(ORCA_EINVAL, "NULL argument");
+  HIPCHECK(hipSetDevice(ctx->device));
+  HIPCHECK(hipStreamSynchronize(ctx->stream));
+  *n = (int)ctx->timed.size();
+  for (size_t i = 0; i < ctx->timed.size(); ++i) {
+    TimedLaunch& t = ctx->timed[i];
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, t.e0, t.e1);
+    t.rec.ms = ms;
+    if (out && (int)i < max) out[i] = t.rec;
+    (void)hipEventDestroy(t.e0);
+    (void)hipEventDestroy(t.e1);
+  }
+  ctx->timed.clear();
   return ORCA_OK;
 }
 

@@ -1,0 +1,65 @@
+"""-m gpu: end-to-end genomepredict on the MI355X against (a) the fixture produced by the
+real reference's genomepredict on CPU for one full 32 Mb H1-ESC-shaped forward (G8,
+both strands, ~3 min of CPU in the build container) and (b) the cascade fixtures G7.
+North-star tolerance: 1e-4 max-abs per level, plus Pearson r."""
+import numpy as np
+import pytest
+import torch
+
+from orca_amd import orca_models as M
+from orca_amd import orca_predict as P
+from orca_amd import synth
+from tests.util import golden, maxabs, pearson
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def test_full_32mb_genomepredict_vs_reference(cuda):
+    g = golden("G8_full32m.npz")
+    model = M.H1esc(synthetic_seed=0)
+    seq = synth.synth_sequence(32000000, seed=1)
+    # encoder alone (forward strand) against the reference Encoder output
+    x = torch.from_numpy(seq).to(cuda).transpose(1, 2)
+    enc = model.net0(x)[0].cpu().numpy()
+    assert enc.shape == (128, 8000)
+    assert maxabs(enc, g["enc_fwd"]) < TOL and pearson(enc, g["enc_fwd"]) > 0.999999
+    del x
+    out = P.genomepredict(seq, "chrS", 16000000 + 1234567, 16000000, models=[model], use_cuda=True)
+    assert out["start_coords"] == list(g["start"])
+    for j, p in enumerate(out["predictions"][0]):
+        ref = g[f"pred_{j}"]
+        assert p.shape == (250, 250) and p.dtype == np.float32
+        assert maxabs(p, ref) < TOL, (j, maxabs(p, ref))
+        assert pearson(p, ref) > 0.999999
+    # invariant: a strand-averaged map of a reverse-palindromic input is flip-symmetric
+    half = synth.synth_sequence(160000, seed=3)
+    pal = np.concatenate([half, half[:, ::-1, ::-1]], axis=1)
+    fake = _FakeEncoderModel(model)
+    o2 = P.genomepredict(pal, "chrS", 16000000, 16000000, models=[fake], use_cuda=True)
+    for p in o2["predictions"][0][:1]:
+        assert maxabs(p, p[::-1, ::-1]) < 1e-5
+
+
+class _FakeEncoderModel(torch.nn.Module):
+    """real HIP Encoder2/decoders behind a cheap binned-projection net0 (short input)."""
+
+    def __init__(self, full):
+        super().__init__()
+        self.net0 = synth.FakeNet0(nbins=8000, seed=0).cuda()
+        self.net, self.denets, self.denet_1_pt = full.net, full.denets, full.denet_1_pt
+        self.normmats, self.epss = full.normmats, full.epss
+
+
+def test_cascade_fixture_on_gpu(cuda):
+    g = golden("G7_cascade32.npz")
+    full = M.H1esc(synthetic_seed=0)
+    model = _FakeEncoderModel(full)
+    seq = synth.synth_sequence(320000, seed=41)
+    for ci in range(4):
+        mpos, wpos = (int(v) for v in g[f"c{ci}_args"])
+        out = P.genomepredict(seq, "chrS", mpos, wpos, models=[model], use_cuda=True)
+        assert out["start_coords"] == list(g[f"c{ci}_start"])
+        for j, p in enumerate(out["predictions"][0]):
+            ref = g[f"c{ci}_sub_{j}"]
+            assert maxabs(p if ci == 0 else p[::5, ::5], ref) < TOL, (ci, j)
