@@ -70,6 +70,10 @@ def load():
         raise OrcaHipError(
             f"{LIB_PATH} not found: the HIP extension is not built. Run `make -C orca_amd/csrc` "
             "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+    # torch bundles its own HIP runtime (torch/lib/libamdhip64.so, soname libamdhip64.so.7).  It must be
+    # in the process BEFORE liborca_hip.so so that our NEEDED libamdhip64.so.7 binds to the same runtime
+    # instance that owns torch's tensors and streams (two runtimes in one process do not share devices).
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
