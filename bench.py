@@ -41,13 +41,27 @@ def step_flops():
     return 2 * per_strand
 
 
+def usable_cores():
+    """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota
+    (the GPU box exposes 256 logical CPUs but grants a 16-core quota; oversubscribing torch's
+    intra-op pool beyond the quota makes the CPU path several times SLOWER)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(seed):
     """Reference-architecture PyTorch-CPU fp32 forward (oracle/orca_oracle.py = the torch ops the
     reference dispatches with use_cuda=False) on a bounded sample of the same workload."""
     from oracle import orca_oracle as O
     from orca_amd import synth
     from tests.util import synth_sd
-    ncores = os.cpu_count() or 1
+    ncores = usable_cores()
     torch.set_num_threads(ncores)
     sample_bp = 4_000_000
     x = torch.from_numpy(synth.synth_sequence(sample_bp, seed=1)).transpose(1, 2)
@@ -126,10 +140,8 @@ def main():
         step()
     sync()
     ctx.set_timing(True)
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        ev[0].record()
         pf, _ = orca_predict.cascade_32m(model, x_fwd, mpos, wpos, False, distencs)
         pr, _ = orca_predict.cascade_32m(model, x_rev, mpos, wpos, True, distencs)
         outs = [engine.strand_merge(a[0, 0], b[0, 0]) for a, b in zip(pf, pr)]

@@ -1,0 +1,95 @@
+"""Multi-GPU execution: one process per GPU, torch.distributed over RCCL/xGMI
+(backend "nccl" on ROCm; "gloo" in the CPU tests).
+
+The reference's only multi-GPU mechanism is nn.DataParallel's batch split
+(orca_models.py:44-50).  What actually shards on this path:
+
+* the Encoder's sequence blocks are independent given a 112 kb input halo
+  (orca_modules.py:955-977), so rank r computes a contiguous range of 4 kb bins
+  via the C ABI's bin_lo/bin_hi and ONE all-gather per strand assembles the
+  [B,128,n_bins] encoding (32.8 MB for 256 Mb on 8 ranks - latency-bound on
+  xGMI, ~0.2 % of the encoder time).  Everything after it (Encoder2/Encoder3 +
+  decoder cascade, ~1 % of the FLOPs) runs replicated on every rank.
+* independent 32 Mb windows (structural-variant screens, batches) are plain
+  replicas: `shard_indices` deals them out, no data-path collective.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise the default process group from torchrun's env (RANK, WORLD_SIZE,
+    LOCAL_RANK, MASTER_ADDR/PORT).  Returns (rank, world, device)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    use_gpu = torch.cuda.is_available()
+    device = torch.device("cuda", local) if use_gpu else torch.device("cpu")
+    if use_gpu:
+        torch.cuda.set_device(local)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend is None:
+            backend = "nccl" if use_gpu else "gloo"
+        kw = {"device_id": device} if (backend == "nccl") else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return rank, world, device
+
+
+def bin_range(total_bins, rank, world):
+    """Contiguous, balanced partition of [0,total_bins) (first `rem` ranks get one more)."""
+    q, rem = divmod(total_bins, world)
+    lo = rank * q + min(rank, rem)
+    return lo, lo + q + (1 if rank < rem else 0)
+
+
+def shard_indices(n_items, rank, world):
+    """Round-robin deal of independent work items (replica mode)."""
+    return list(range(rank, n_items, world))
+
+
+def sharded_encode(encode_range, x, total_bins, group=None):
+    """encode_range(x, bin_lo, bin_hi) -> [B,128,bin_hi-bin_lo] on this rank's device.
+    Every rank computes its bin range, then one all-gather assembles [B,128,total_bins]
+    on every rank.  With a single process this is just encode_range(x, 0, total_bins)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return encode_range(x, 0, total_bins)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    lo, hi = bin_range(total_bins, rank, world)
+    part = encode_range(x, lo, hi)
+    B = part.shape[0]
+    width = -(-total_bins // world)  # ceil: every rank contributes an equal-size slab
+    slab = torch.zeros((B, 128, width), dtype=part.dtype, device=part.device)
+    slab[:, :, : hi - lo] = part
+    gathered = torch.empty((world * B, 128, width), dtype=part.dtype, device=part.device)
+    dist.all_gather_into_tensor(gathered, slab.contiguous(), group=group)  # rank-major along dim 0
+    gathered = gathered.view(world, B, 128, width)
+    pieces = []
+    for r in range(world):
+        rlo, rhi = bin_range(total_bins, r, world)
+        pieces.append(gathered[r, :, :, : rhi - rlo])
+    return torch.cat(pieces, dim=2)
+
+
+class ShardedEncoder(torch.nn.Module):
+    """Drop-in for ``model.net0``: same call signature as Encoder.forward, but the bins
+    are computed cooperatively by all ranks of ``group`` (input replicated on every rank)."""
+
+    def __init__(self, encoder, group=None):
+        super().__init__()
+        self.encoder, self.group = encoder, group
+
+    def forward(self, x):
+        from . import engine
+        total = engine.encoder_num_bins(x.shape[2])
+        return sharded_encode(lambda t, lo, hi: self.encoder(t, bin_lo=lo, bin_hi=hi), x, total, self.group)
+
+
+def max_over_ranks(value, device):
+    if not dist.is_initialized():
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

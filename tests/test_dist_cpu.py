@@ -1,0 +1,76 @@
+"""world_size-2 gloo test (CPU) of the sharded-encoder path: two processes each compute half
+of the bins (with the reference's 112 kb input halo) and all-gather; the result must equal
+the single-process encoding.  The per-rank encode function here is the CPU oracle, so what
+is tested is orca_amd.dist (partition, padding, all-gather, reassembly)."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _oracle_range(sd):
+    from oracle import orca_oracle as O
+
+    def enc(x, lo, hi):
+        L = x.shape[2]
+        a = max(0, lo * 4000 - 112000)
+        total = L // 4000
+        b = L if hi == total else min(L, hi * 4000 + 112000)
+        y = O.encoder_forward(sd, x[:, :, a:b])
+        k = lo - a // 4000
+        return y[:, :, k: k + (hi - lo)].contiguous()
+    return enc
+
+
+def _worker(rank, world, port, L, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    from orca_amd import dist as D
+    from orca_amd import synth
+    from tests.util import synth_sd
+    try:
+        r, w, dev = D.init_from_env("gloo")
+        assert (r, w) == (rank, world) and dev.type == "cpu"
+        x = torch.from_numpy(synth.synth_sequence(L, seed=5)).transpose(1, 2)
+        out = D.sharded_encode(_oracle_range(synth_sd("Encoder", 0)), x, L // 4000)
+        t = D.max_over_ranks(float(rank + 1), dev)
+        q.put((rank, out.numpy(), t))
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+    except Exception as e:  # surface the failure instead of letting the parent time out
+        q.put((rank, repr(e), -1.0))
+
+
+def test_sharded_encoder_allgather_gloo_world2():
+    from oracle import orca_oracle as O
+    from orca_amd import dist as D
+    from orca_amd import synth
+    from tests.util import synth_sd
+    L = 4000 * 75  # 75 bins: uneven split 38 / 37
+    assert D.bin_range(75, 0, 2) == (0, 38) and D.bin_range(75, 1, 2) == (38, 75)
+    assert D.shard_indices(5, 1, 2) == [1, 3]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, L, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict()
+    for _ in range(2):
+        rank, arr, t = q.get(timeout=300)
+        assert not isinstance(arr, str), arr
+        res[rank] = arr
+        assert t == 2.0
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    x = torch.from_numpy(synth.synth_sequence(L, seed=5)).transpose(1, 2)
+    ref = O.encoder_forward(synth_sd("Encoder", 0), x).numpy()
+    assert res[0].shape == ref.shape == (1, 128, 75)
+    assert np.abs(res[0] - ref).max() < 1e-5 and np.abs(res[1] - ref).max() < 1e-5
+    assert np.array_equal(res[0], res[1])

@@ -63,3 +63,51 @@ def test_cascade_fixture_on_gpu(cuda):
         for j, p in enumerate(out["predictions"][0]):
             ref = g[f"c{ci}_sub_{j}"]
             assert maxabs(p if ci == 0 else p[::5, ::5], ref) < TOL, (ci, j)
+
+
+class _Fake256(torch.nn.Module):
+    def __init__(self, full):
+        super().__init__()
+        self.net0 = synth.FakeNet0(nbins=64000, seed=0).cuda()
+        self.net1, self.net, self.denets = full.net1, full.net, full.denets
+
+
+def test_256mb_cascade_fixture_on_gpu(cuda):
+    """genomepredict_256Mb with the HIP Encoder2 (64 000 bins) / Encoder3 / four Decoders vs the
+    fixture produced by the real reference function (G9)."""
+    g = golden("G9_cascade256.npz")
+    model = _Fake256(M.H1esc_256M(synthetic_seed=0))
+    seq = synth.synth_sequence(512000, seed=51)
+    for ci in range(3):
+        mpos, wpos, chrlen = (int(v) for v in g[f"c{ci}_args"])
+        nm = synth.synth_normmat_256m(chrlen, seed=0)
+        out = P.genomepredict_256Mb(seq, "chrS", [nm], chrlen, mpos, wpos, models=[model], padding_chr="chrP", use_cuda=True)
+        assert out["start_coords"] == list(g[f"c{ci}_start"])
+        assert [int(v) for v in out["end_coords"]] == list(g[f"c{ci}_end"])
+        for j, p in enumerate(out["predictions"][0]):
+            ref = g[f"c{ci}_sub_{j}"]
+            assert maxabs(p if ci == 0 else p[::5, ::5], ref) < TOL, (ci, j)
+
+
+def test_encoder_256mb_full_size_properties(cuda):
+    """Config-4 size (256 Mb, 64 000 bins): size-independent properties instead of an oracle run -
+    (i) a bin sub-range (one GPU's shard) equals the slice of the full encoding, (ii) internal
+    chunk size does not matter, (iii) the single-process ShardedEncoder is the identity wrapper."""
+    from orca_amd import dist as D
+    model = M.H1esc_256M(synthetic_seed=0)
+    L = 256_000_000
+    gen = torch.Generator(device=cuda).manual_seed(2)
+    base = torch.randint(0, 4, (L,), device=cuda, generator=gen)
+    x = torch.zeros((1, L, 4), dtype=torch.float32, device=cuda)
+    x[0, torch.arange(L, device=cuda), base] = 1.0
+    del base
+    xt = x.transpose(1, 2)
+    full = model.net0(xt)
+    assert full.shape == (1, 128, 64000)
+    assert bool(torch.isfinite(full).all())
+    shard = model.net0(xt, bin_lo=24000, bin_hi=32000)          # rank 3 of 8
+    assert float((shard - full[:, :, 24000:32000]).abs().max()) < 2e-5
+    part = model.net0(xt, bin_lo=100, bin_hi=2100, chunk_bp=4_000_000)
+    assert float((part - full[:, :, 100:2100]).abs().max()) < 2e-5
+    same = D.ShardedEncoder(model.net0)(xt)
+    assert torch.equal(same, full)
