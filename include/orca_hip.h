@@ -118,6 +118,23 @@ int orca_net_create(orca_ctx* ctx, int kind, const orca_conv_desc* convs, int n_
                     int upsample_mode, orca_net** out);
 int orca_net_free(orca_net* net);
 
+/* Arithmetic used for the Conv1d stacks of an Encoder net.
+ *  ORCA_PRECISION_F32   : v_mfma_f32_32x32x2_f32, exact fp32 products (default)
+ *  ORCA_PRECISION_BF16X3: operands split into 3 bf16 parts, 6 bf16-MFMA products per fp32
+ *                         product, fp32 accumulate - fp32-class error
+ *                         at 2.67x the fp32-MFMA rate
+ *  ORCA_PRECISION_BF16X2: 2-way split, 3 products (~2^-17 relative per product)
+ *  ORCA_PRECISION_BF16  : plain bf16 operands (throughput mode) */
+#define ORCA_PRECISION_F32 0
+#define ORCA_PRECISION_BF16 1
+#define ORCA_PRECISION_BF16X2 2
+#define ORCA_PRECISION_BF16X3 3
+/*  ORCA_PRECISION_F16X2 : operands split into 2 fp16 parts (22 significant bits), 3 fp16-MFMA products,
+ *                         fp32 accumulate: ~2^-22 relative error (fp32-class end to end) at 5.3x the
+ *                         fp32-MFMA rate; requires |activation|, |weight| < 65504 (fp16 range). */
+#define ORCA_PRECISION_F16X2 4
+int orca_net_set_precision(orca_net* net, int precision);
+
 /* ---- forward passes -------------------------------------------------------- */
 
 /* Replaces: model.net0(x) = Encoder.forward (orca_modules.py:929-980).
@@ -172,6 +189,10 @@ int orca_strand_merge(orca_ctx* ctx, const float* fwd, const float* rev, float* 
 int orca_conv1d_forward(orca_ctx* ctx, const orca_conv_desc* conv, const float* x, int64_t x_bs, int64_t ldx,
                         float* y, int64_t y_bs, int64_t ldy, const float* r1, const float* r2, int B, int64_t n,
                         int relu, int tile);
+/* Channel-last variant on the bf16 matrix cores with split operands (precision = ORCA_PRECISION_BF16 /
+ * _BF16X2 / _BF16X3): x [B][n][cin], y and r1 [B][n][cout], all contiguous; cin % 16 == 0. */
+int orca_conv1d_nlc_forward(orca_ctx* ctx, const orca_conv_desc* conv, int precision, const float* x, float* y,
+                            const float* r1, int B, int64_t n, int relu);
 /* y = [relu](conv2d_3x3_dilated(x) + b) [+ r]; x: contiguous [B,cin,n,n], y/r: [B,cout,n,n]. */
 int orca_conv2d_forward(orca_ctx* ctx, const orca_conv_desc* conv, const float* x, float* y, const float* r,
                         int B, int n, int relu);

@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "liborca_hip.so")
 
 ORCA_NET_ENCODER, ORCA_NET_ENCODER2, ORCA_NET_ENCODER3, ORCA_NET_DECODER, ORCA_NET_DECODER_1M = 1, 2, 3, 4, 5
 ORCA_UPSAMPLE_NEAREST, ORCA_UPSAMPLE_BILINEAR = 0, 1
+PRECISIONS = {"f32": 0, "bf16": 1, "bf16x2": 2, "bf16x3": 3, "f16x2": 4}
 
 
 class OrcaHipError(RuntimeError):
@@ -43,6 +44,7 @@ SIGNATURES = {
     "orca_ctx_get_timing": (c_int, [c_void_p, POINTER(KernelTime), c_int, POINTER(c_int)]),
     "orca_net_create": (c_int, [c_void_p, c_int, POINTER(ConvDesc), c_int, c_int, POINTER(c_void_p)]),
     "orca_net_free": (c_int, [c_void_p]),
+    "orca_net_set_precision": (c_int, [c_void_p, c_int]),
     "orca_encoder_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_int64, c_int64,
                                      c_int64, c_void_p, c_int64, c_int64, c_int64]),
     "orca_encoder_num_bins": (c_int64, [c_int64]),
@@ -54,6 +56,7 @@ SIGNATURES = {
     "orca_strand_merge": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int]),
     "orca_conv1d_forward": (c_int, [c_void_p, POINTER(ConvDesc), c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
                                     c_void_p, c_void_p, c_int, c_int64, c_int, c_int]),
+    "orca_conv1d_nlc_forward": (c_int, [c_void_p, POINTER(ConvDesc), c_int, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int]),
     "orca_conv2d_forward": (c_int, [c_void_p, POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_int, c_int, c_int]),
     "orca_maxpool1d_forward": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int]),
 }

@@ -52,6 +52,7 @@ struct Conv1dArgs {
   int relu;
   int x_vec_ok;     // x rows are 16-byte aligned at multiples of 4 positions
   int y_vec_ok;     // same for y / r1 / r2
+  int y_nlc;        // write y (and read r1/r2) channel-LAST: y[pos*COUT + cout] (feeds conv_bf16s.h)
 };
 
 template <int COUT, int MW, int NW, int WM, int WN, int KC>
@@ -184,7 +185,19 @@ __global__ __launch_bounds__(WM* WN * 64) void conv1d_k9_kernel(Conv1dArgs a) {
         if (a.relu) {
           v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
         }
-        if (a.y_vec_ok && pos + 3 < a.n) {
+        if (a.y_nlc) {
+          const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (pos + e < a.n) {
+              const long o = (pos + e) * COUT + co;
+              float t = vv[e];
+              if (r1b) t += r1b[o];
+              if (r2b) t += r2b[o];
+              yb[o] = t;
+            }
+          }
+        } else if (a.y_vec_ok && pos + 3 < a.n) {
           if (r1b) { const float4 q = *reinterpret_cast<const float4*>(r1b + rowoff + pos); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
           if (r2b) { const float4 q = *reinterpret_cast<const float4*>(r2b + rowoff + pos); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
           *reinterpret_cast<float4*>(yb + rowoff + pos) = v;

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "conv_kernels.h"
+#include "conv_bf16s.h"
 #include "misc_kernels.h"
 #include "orca_hip.h"
 
@@ -102,11 +103,14 @@ struct ConvLayer {
   int kc = 8, nchunks = 0;
   float* d_w = nullptr;     // packed (k=9 / k=3) or raw [cout][cin] (k=1)
   float* d_bias = nullptr;
+  void* d_wb16 = nullptr;   // k=9, cin%16==0: bf16 3-way split pack [cin/16][3][9][2][cout][8]
+  void* d_wf16 = nullptr;   // same, fp16 2-way split pack [cin/16][2][9][2][cout][8]
 };
 
 struct orca_net {
   orca_ctx* ctx = nullptr;
   int kind = 0;
+  int precision = ORCA_PRECISION_F32;
   int upsample_mode = ORCA_UPSAMPLE_BILINEAR;
   std::vector<ConvLayer> convs;
 };
@@ -117,7 +121,24 @@ static int upload(const std::vector<float>& h, float** d) {
   return ORCA_OK;
 }
 
+static inline uint16_t bf16_rne(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7f800000u) == 0x7f800000u) return (uint16_t)(u >> 16);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+static inline float bf16_f32(uint16_t h) {
+  uint32_t u = (uint32_t)h << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
 static void free_layer(ConvLayer& L) {
+  if (L.d_wb16) (void)hipFree(L.d_wb16);
+  if (L.d_wf16) (void)hipFree(L.d_wf16);
+  L.d_wb16 = L.d_wf16 = nullptr;
   if (L.d_w) (void)hipFree(L.d_w);
   if (L.d_bias) (void)hipFree(L.d_bias);
   L.d_w = L.d_bias = nullptr;
@@ -166,6 +187,43 @@ static int make_layer(const orca_conv_desc& d, ConvLayer* out) {
   ORCA_TRY(upload(w, &L.d_w));
   int rc = upload(bias, &L.d_bias);
   if (rc != ORCA_OK) { free_layer(L); return rc; }
+  if (d.ksize == 9 && d.cin % 16 == 0) {
+    // bf16 split pack for conv_bf16s.h: w = w1 + w2 + w3 (successive RNE residuals)
+    const int nc = d.cin / 16;
+    std::vector<uint16_t> pk((size_t)nc * 3 * 9 * 2 * d.cout * 8);
+    for (int co = 0; co < d.cout; ++co)
+      for (int ci = 0; ci < d.cin; ++ci)
+        for (int t = 0; t < 9; ++t) {
+          float v = d.weight_host[((size_t)co * d.cin + ci) * 9 + t];
+          const int c = ci / 16, gg = (ci % 16) / 8, e = ci % 8;
+          for (int sp = 0; sp < 3; ++sp) {
+            const uint16_t h = bf16_rne(v);
+            v -= bf16_f32(h);
+            pk[(((((size_t)c * 3 + sp) * 9 + t) * 2 + gg) * d.cout + co) * 8 + e] = h;
+          }
+        }
+    hipError_t e1 = hipMalloc(&L.d_wb16, pk.size() * 2);
+    if (e1 == hipSuccess) e1 = hipMemcpy(L.d_wb16, pk.data(), pk.size() * 2, hipMemcpyHostToDevice);
+    if (e1 != hipSuccess) { free_layer(L); return fail(ORCA_EHIP, "bf16 weight upload failed: %s", hipGetErrorString(e1)); }
+    // fp16 2-way split pack: w = h1 + h2 (RNE residuals)
+    std::vector<uint16_t> pf((size_t)nc * 2 * 9 * 2 * d.cout * 8);
+    for (int co = 0; co < d.cout; ++co)
+      for (int ci = 0; ci < d.cin; ++ci)
+        for (int t = 0; t < 9; ++t) {
+          float v = d.weight_host[((size_t)co * d.cin + ci) * 9 + t];
+          const int c = ci / 16, gg = (ci % 16) / 8, e = ci % 8;
+          for (int sp = 0; sp < 2; ++sp) {
+            const _Float16 h = (_Float16)v;
+            v -= (float)h;
+            uint16_t bits;
+            memcpy(&bits, &h, 2);
+            pf[(((((size_t)c * 2 + sp) * 9 + t) * 2 + gg) * d.cout + co) * 8 + e] = bits;
+          }
+        }
+    e1 = hipMalloc(&L.d_wf16, pf.size() * 2);
+    if (e1 == hipSuccess) e1 = hipMemcpy(L.d_wf16, pf.data(), pf.size() * 2, hipMemcpyHostToDevice);
+    if (e1 != hipSuccess) { free_layer(L); return fail(ORCA_EHIP, "fp16 weight upload failed: %s", hipGetErrorString(e1)); }
+  }
   *out = L;
   return ORCA_OK;
 }
@@ -187,12 +245,12 @@ static void launch_conv1d_t(hipStream_t s, const Conv1dArgs& a, int B) {
 }
 
 static int launch_conv1d(orca_ctx* ctx, const ConvLayer& L, const float* x, long x_bs, long ldx, float* y, long y_bs,
-                         long ldy, const float* r1, const float* r2, int B, long n, int relu, int tile) {
+                         long ldy, const float* r1, const float* r2, int B, long n, int relu, int tile, int y_nlc = 0) {
   if (L.ksize != 9) return fail(ORCA_EINVAL, "launch_conv1d on a non-1d layer");
   if (n <= 0 || B <= 0) return ORCA_OK;
   Conv1dArgs a;
   a.x = x; a.w = L.d_w; a.bias = L.d_bias; a.y = y; a.r1 = r1; a.r2 = r2;
-  a.x_bs = x_bs; a.y_bs = y_bs; a.ldx = ldx; a.ldy = ldy; a.n = n; a.nchunks = L.nchunks; a.relu = relu;
+  a.x_bs = x_bs; a.y_bs = y_bs; a.ldx = ldx; a.ldy = ldy; a.n = n; a.nchunks = L.nchunks; a.relu = relu; a.y_nlc = y_nlc;
   a.x_vec_ok = al16(x) && (ldx % 4 == 0) && (x_bs % 4 == 0);
   a.y_vec_ok = al16(y) && (ldy % 4 == 0) && (y_bs % 4 == 0) && (!r1 || al16(r1)) && (!r2 || al16(r2));
   hipStream_t s = ctx->stream;
@@ -250,6 +308,83 @@ static int launch_pool(orca_ctx* ctx, const float* x, long ldx, float* y, long l
     default: return fail(ORCA_EINVAL, "maxpool k=%d unsupported", k);
   }
   LAUNCHCHECK("maxpool1d_kernel");
+  return ORCA_OK;
+}
+
+// ---- bf16 split-operand conv1d (channel-last activations) --------------------------------
+template <int COUT, int MW, int NW, int WM, int WN, int NS, int DT>
+static void launch_b16_t(hipStream_t s, ConvB16Args a, int B) {
+  constexpr int MT = WM * MW * 32;
+  // persistent grid: CUs x resident workgroups per CU (queried once per instantiation)
+  static int resident = [] {
+    int dev = 0, ncu = 256, per_cu = 1;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv1d_k9_bf16s_kernel<COUT, MW, NW, WM, WN, NS, DT>, WM * WN * 64, 0) != hipSuccess || per_cu < 1) {
+      (void)hipGetLastError();
+      per_cu = 1;
+    }
+    return ncu * per_cu;
+  }();
+  a.tiles_per_row = (a.n + MT - 1) / MT;
+  a.batch = B;
+  const long ntiles = a.tiles_per_row * B;
+  dim3 grid((unsigned)(ntiles < resident ? ntiles : resident));
+  hipLaunchKernelGGL((conv1d_k9_bf16s_kernel<COUT, MW, NW, WM, WN, NS, DT>), grid, dim3(WM * WN * 64), 0, s, a);
+}
+
+template <int NS, int DT>
+static int launch_conv1d_b16_ns(orca_ctx* ctx, const ConvLayer& L, const ConvB16Args& a, int B) {
+  hipStream_t s = ctx->stream;
+  if (L.cout == 64) launch_b16_t<64, 2, 2, 4, 1, NS, DT>(s, a, B);
+  else if (L.cout == 96) launch_b16_t<96, 1, 3, 8, 1, NS, DT>(s, a, B);
+  else if (L.cout == 128) launch_b16_t<128, 2, 2, 4, 2, NS, DT>(s, a, B);
+  else return fail(ORCA_EINVAL, "bf16s conv1d cout %d unsupported", L.cout);
+  return ORCA_OK;
+}
+
+// x [B][n][cin], y/r1 [B][n][cout] channel-last.  precision: ORCA_PRECISION_BF16 / _BF16X2 / _BF16X3
+static int launch_conv1d_b16(orca_ctx* ctx, const ConvLayer& L, int precision, const float* x, long x_bs, float* y, long y_bs,
+                             const float* r1, int B, long n, int relu) {
+  if (!L.d_wb16) return fail(ORCA_EINVAL, "layer has no bf16 split pack (cin %d)", L.cin);
+  if (n <= 0 || B <= 0) return ORCA_OK;
+  ConvB16Args a;
+  a.x = x; a.w = L.d_wb16; a.bias = L.d_bias; a.y = y; a.r1 = r1; a.x_bs = x_bs; a.y_bs = y_bs; a.n = n;
+  a.cin = L.cin; a.nchunks = L.cin / 16; a.relu = relu; a.stagger = 2;
+  if (precision == ORCA_PRECISION_F16X2) a.w = L.d_wf16;
+  const bool timed = ctx->timing && n >= 65536;
+  TimedLaunch tl;
+  if (timed) {
+    HIPCHECK(hipEventCreate(&tl.e0));
+    HIPCHECK(hipEventCreate(&tl.e1));
+    HIPCHECK(hipEventRecord(tl.e0, ctx->stream));
+  }
+  int rc;
+  if (precision == ORCA_PRECISION_BF16X3) rc = launch_conv1d_b16_ns<3, 0>(ctx, L, a, B);
+  else if (precision == ORCA_PRECISION_BF16X2) rc = launch_conv1d_b16_ns<2, 0>(ctx, L, a, B);
+  else if (precision == ORCA_PRECISION_F16X2) rc = launch_conv1d_b16_ns<2, 1>(ctx, L, a, B);
+  else rc = launch_conv1d_b16_ns<1, 0>(ctx, L, a, B);
+  if (rc != ORCA_OK) return rc;
+  LAUNCHCHECK("conv1d_k9_bf16s_kernel");
+  if (timed) {
+    HIPCHECK(hipEventRecord(tl.e1, ctx->stream));
+    tl.rec.cout = L.cout; tl.rec.cin = L.cin; tl.rec.tile = -precision; tl.rec.batch = B; tl.rec.n = n; tl.rec.ms = 0.f; tl.rec.pad_ = 0;
+    ctx->timed.push_back(tl);
+  }
+  return ORCA_OK;
+}
+
+static int launch_pool_nlc(orca_ctx* ctx, const float* x, float* y, long n_out, int C, int k) {
+  if (n_out <= 0) return ORCA_OK;
+  const long total = n_out * (C / 4);
+  dim3 grid((unsigned)((total + 255) / 256));
+  switch (k) {
+    case 2: hipLaunchKernelGGL((maxpool1d_nlc_kernel<2>), grid, dim3(256), 0, ctx->stream, x, y, n_out, C); break;
+    case 4: hipLaunchKernelGGL((maxpool1d_nlc_kernel<4>), grid, dim3(256), 0, ctx->stream, x, y, n_out, C); break;
+    case 5: hipLaunchKernelGGL((maxpool1d_nlc_kernel<5>), grid, dim3(256), 0, ctx->stream, x, y, n_out, C); break;
+    default: return fail(ORCA_EINVAL, "maxpool k=%d unsupported", k);
+  }
+  LAUNCHCHECK("maxpool1d_nlc_kernel");
   return ORCA_OK;
 }
 
@@ -394,6 +529,15 @@ extern "C" int orca_net_create(orca_ctx* ctx, int kind, const orca_conv_desc* co
   return ORCA_OK;
 }
 
+extern "C" int orca_net_set_precision(orca_net* net, int precision) {
+  if (!net) return fail(ORCA_EINVAL, "net is NULL");
+  if (precision < ORCA_PRECISION_F32 || precision > ORCA_PRECISION_F16X2) return fail(ORCA_EINVAL, "unknown precision %d", precision);
+  if (precision != ORCA_PRECISION_F32 && net->kind != ORCA_NET_ENCODER)
+    return fail(ORCA_EINVAL, "split-bf16 precision is implemented for the Encoder only");
+  net->precision = precision;
+  return ORCA_OK;
+}
+
 extern "C" int orca_net_free(orca_net* net) {
   if (!net) return ORCA_OK;
   if (net->ctx) (void)hipSetDevice(net->ctx->device);
@@ -423,6 +567,28 @@ static int encoder_chunk(orca_ctx* ctx, orca_net* net, const float* x, long sx_c
   long n = n1, ld = ld1;
   hipLaunchKernelGGL(seq_to_channel_major_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, s, x, sx_c, sx_l, n1, buf[P], ld1);
   LAUNCHCHECK("seq_to_channel_major_kernel");
+  if (net->precision != ORCA_PRECISION_F32) {
+    // channel-last pipeline on the bf16 matrix cores (conv_bf16s.h); the 4-channel first layer stays on
+    // the fp32 kernel (K = 36, 1 % of the FLOPs) and writes channel-last.
+    const int prec = net->precision;
+    for (int st = 0; st < 7; ++st) {
+      const ConvLayer* L = &net->convs[4 * st];
+      if (kEncPools[st] > 1) {
+        const long n2 = n / kEncPools[st];
+        const int Q = (P + 1) % 3;
+        ORCA_TRY(launch_pool_nlc(ctx, buf[P], buf[Q], n2, L[0].cin, kEncPools[st]));
+        P = Q; n = n2;
+      }
+      const int T = (P + 1) % 3, LO = (P + 2) % 3;
+      if (st == 0) ORCA_TRY(launch_conv1d(ctx, L[0], buf[P], 0, ld1, buf[T], 0, 0, nullptr, nullptr, 1, n, 0, 0, 1));
+      else ORCA_TRY(launch_conv1d_b16(ctx, L[0], prec, buf[P], 0, buf[T], 0, nullptr, 1, n, 0));
+      ORCA_TRY(launch_conv1d_b16(ctx, L[1], prec, buf[T], 0, buf[LO], 0, nullptr, 1, n, 0));
+      ORCA_TRY(launch_conv1d_b16(ctx, L[2], prec, buf[LO], 0, buf[T], 0, nullptr, 1, n, 1));
+      ORCA_TRY(launch_conv1d_b16(ctx, L[3], prec, buf[T], 0, buf[P], 0, st < 6 ? buf[LO] : nullptr, 1, n, 1));
+    }
+    *out = buf[P]; *out_ld = -128; *out_n = n;   // negative ld: result is channel-last [n][128]
+    return ORCA_OK;
+  }
   int cprev = 4;
   for (int st = 0; st < 7; ++st) {
     const ConvLayer* L = &net->convs[4 * st];
@@ -480,7 +646,10 @@ extern "C" int orca_encoder_forward(orca_ctx* ctx, orca_net* net, const float* x
       ORCA_TRY(encoder_chunk(ctx, net, x + (long)b * sx_b + lo * sx_l, sx_c, sx_l, hi - lo, buf, ru4(hi - lo), &res, &rld, &rn));
       const long keep = cb0 - lo / kBinBp;
       if (keep + (cb1 - cb0) > rn) return fail(ORCA_EINVAL, "internal: chunk produced %ld bins, need %ld", rn, keep + (cb1 - cb0));
-      ORCA_TRY(launch_copy2d(ctx, res + keep, rld, 1, out + (long)b * so_b + (cb0 - bin_lo), so_c, 128, cb1 - cb0));
+      if (rld < 0)  // channel-last result [bins][128] -> out[c][bin]
+        ORCA_TRY(launch_copy2d(ctx, res + keep * 128, 1, 128, out + (long)b * so_b + (cb0 - bin_lo), so_c, 128, cb1 - cb0));
+      else
+        ORCA_TRY(launch_copy2d(ctx, res + keep, rld, 1, out + (long)b * so_b + (cb0 - bin_lo), so_c, 128, cb1 - cb0));
     }
   }
   return ORCA_OK;
@@ -659,6 +828,19 @@ extern "C" int orca_conv1d_forward(orca_ctx* ctx, const orca_conv_desc* conv, co
   ConvLayer L;
   ORCA_TRY(make_layer(*conv, &L));
   int rc = launch_conv1d(ctx, L, x, x_bs, ldx, y, y_bs, ldy, r1, r2, B, n, relu, tile);
+  (void)hipStreamSynchronize(ctx->stream);
+  free_layer(L);
+  return rc;
+}
+
+extern "C" int orca_conv1d_nlc_forward(orca_ctx* ctx, const orca_conv_desc* conv, int precision, const float* x, float* y,
+                                       const float* r1, int B, int64_t n, int relu) {
+  if (!ctx || !conv || !x || !y) return fail(ORCA_EINVAL, "orca_conv1d_nlc_forward: NULL argument");
+  if (precision < ORCA_PRECISION_BF16 || precision > ORCA_PRECISION_F16X2) return fail(ORCA_EINVAL, "precision %d unsupported here", precision);
+  HIPCHECK(hipSetDevice(ctx->device));
+  ConvLayer L;
+  ORCA_TRY(make_layer(*conv, &L));
+  int rc = launch_conv1d_b16(ctx, L, precision, x, (long)n * conv->cin, y, (long)n * conv->cout, r1, B, n, relu);
   (void)hipStreamSynchronize(ctx->stream);
   free_layer(L);
   return rc;

@@ -113,6 +113,11 @@ class Net:
         check(lib.orca_net_create(ctx.handle, kind, descs, len(convs), upsample_mode, ctypes.byref(self.handle)), "orca_net_create")
         self._finalizer = weakref.finalize(self, lib.orca_net_free, self.handle)
 
+    def set_precision(self, name):
+        if name not in _lib.PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(_lib.PRECISIONS)}, got {name!r}")
+        check(_lib.load().orca_net_set_precision(self.handle, _lib.PRECISIONS[name]), "orca_net_set_precision")
+
 
 # ---------------------------------------------------------------------------
 # forward wrappers
@@ -230,6 +235,22 @@ def conv1d(x, w, b, relu=False, r1=None, r2=None, tile=0):
     check(_lib.load().orca_conv1d_forward(ctx.handle, d, _p(x), cin * n, n, _p(y), cout * n, n,
                                           _p(r1) if r1 is not None else None, _p(r2) if r2 is not None else None, B, n,
                                           1 if relu else 0, tile), "orca_conv1d_forward")
+    return y
+
+
+def conv1d_nlc(x, w, b, precision="bf16x3", relu=False, r1=None):
+    """channel-last split-bf16 conv: x [B,n,cin] -> [B,n,cout]."""
+    x = _f32_cuda(x, "x").contiguous()
+    B, n, cin = x.shape
+    w = np.ascontiguousarray(w, dtype=np.float32)
+    b = np.ascontiguousarray(b, dtype=np.float32)
+    cout = w.shape[0]
+    d = make_descs([{"w": w, "b": b, "cout": cout, "cin": cin, "k": 9, "dil": 1}])
+    y = torch.empty((B, n, cout), dtype=torch.float32, device=x.device)
+    ctx = get_context(x.device)
+    r1 = r1.contiguous() if r1 is not None else None
+    check(_lib.load().orca_conv1d_nlc_forward(ctx.handle, d, _lib.PRECISIONS[precision], _p(x), _p(y),
+                                              _p(r1) if r1 is not None else None, B, n, 1 if relu else 0), "orca_conv1d_nlc_forward")
     return y
 
 

@@ -13,6 +13,8 @@ arithmetic on the data path and no CPU fallback - inputs must be ROCm tensors.
 Inference engine only: BatchNorm always uses running statistics and Dropout is
 the identity, i.e. the reference's ``.eval()`` behaviour (orca_models.py:125-133).
 """
+import os
+
 import torch
 from torch import nn
 
@@ -108,8 +110,14 @@ class Encoder(_HipModule):
 
     _kind = _lib.ORCA_NET_ENCODER
 
-    def __init__(self):
+    def __init__(self, precision=None):
+        """precision: arithmetic of the Conv1d stacks - "f32" (fp32 MFMA, exact products),
+        "bf16x3" (3-way split operands on the bf16 matrix cores, fp32-class error, 2.67x the
+        fp32 MFMA rate), "bf16x2", "bf16".  Default: $ORCA_ENCODER_PRECISION or "bf16x3"."""
         super().__init__()
+        self.precision = precision or os.environ.get("ORCA_ENCODER_PRECISION", "bf16x3")
+        if self.precision not in _lib.PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(_lib.PRECISIONS)}")
         prev = 4
         for i, (ch, pool) in enumerate(zip(ENCODER_CHANNELS, ENCODER_POOLS), start=1):
             lead = nn.MaxPool1d(kernel_size=pool, stride=pool) if pool > 1 else None
@@ -127,7 +135,11 @@ class Encoder(_HipModule):
         """x: [B,4,L] float32 ROCm tensor (any strides).  Returns [B,128,L//4000].
         ``bin_lo/bin_hi`` restrict the output to a bin range (multi-GPU sharding of
         the independent sequence blocks, orca_modules.py:955-977)."""
-        return engine.encoder_forward(self._net(x.device), x, bin_lo, bin_hi, chunk_bp)
+        net = self._net(x.device)
+        if getattr(net, "_precision", None) != self.precision:
+            net.set_precision(self.precision)
+            net._precision = self.precision
+        return engine.encoder_forward(net, x, bin_lo, bin_hi, chunk_bp)
 
 
 class _UNetEncoder(_HipModule):

@@ -81,3 +81,32 @@ def test_maxpool(cuda, k):
     x = torch.from_numpy(np.random.RandomState(k).randn(2, 7, 1003).astype(np.float32))
     y = engine.maxpool1d(x.to(cuda), k).cpu()
     assert torch.equal(y, F.max_pool1d(x, k, k))
+
+
+@pytest.mark.parametrize("cin,cout,n", [(64, 64, 1000), (64, 96, 515), (96, 96, 777), (96, 128, 300), (128, 128, 2049), (128, 128, 250)])
+@pytest.mark.parametrize("precision,tol", [("bf16x3", 2e-5), ("f16x2", 2e-5), ("bf16x2", 3e-4), ("bf16", 5e-2)])
+def test_conv1d_split_bf16_channel_last(cuda, cin, cout, n, precision, tol):
+    """conv_bf16s.h: bf16 MFMA with split fp32 operands; bf16x3 (6 products) must be fp32-class."""
+    rs = np.random.RandomState(cin + cout + n)
+    B = 2
+    x = torch.from_numpy(rs.randn(B, cin, n).astype(np.float32))
+    w = (rs.randn(cout, cin, 9) / np.sqrt(cin * 9)).astype(np.float32)
+    b = rs.randn(cout).astype(np.float32) * 0.1
+    r1 = torch.from_numpy(rs.randn(B, cout, n).astype(np.float32))
+    for relu, ra in [(False, None), (True, r1)]:
+        y = engine.conv1d_nlc(x.transpose(1, 2).contiguous().to(cuda), w, b, precision, relu,
+                              None if ra is None else ra.transpose(1, 2).contiguous().to(cuda))
+        ref = _ref_conv1d(x, w, b, relu, ra, None)
+        err = float((y.cpu().transpose(1, 2) - ref).abs().max())
+        assert err < tol, (cin, cout, n, precision, relu, err)
+
+
+def test_conv1d_split_bf16_wide_dynamic_range(cuda):
+    """3-way split keeps fp32 exponent range: inputs spanning 1e-6..1e4 stay fp32-accurate (relative)."""
+    rs = np.random.RandomState(0)
+    x = torch.from_numpy((rs.randn(1, 64, 512) * np.exp(rs.uniform(-14, 9, (1, 64, 512)))).astype(np.float32))
+    w = (rs.randn(64, 64, 9) / 24).astype(np.float32)
+    y = engine.conv1d_nlc(x.transpose(1, 2).contiguous().to(cuda), w, np.zeros(64, np.float32), "bf16x3").cpu().transpose(1, 2)
+    ref = F.conv1d(x.double(), torch.from_numpy(w).double(), None, padding=4)
+    scale = F.conv1d(x.double().abs(), torch.from_numpy(w).double().abs(), None, padding=4)
+    assert float(((y.double() - ref).abs() / scale).max()) < 1e-6

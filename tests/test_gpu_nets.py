@@ -14,9 +14,12 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 
-def test_encoder_vs_golden_and_chunking(cuda):
+@pytest.mark.parametrize("precision,tol", [("f32", 1e-4), ("bf16x3", 1e-4), ("f16x2", 1e-4), ("bf16x2", 1e-3)])
+def test_encoder_vs_golden_and_chunking(cuda, precision, tol):
+    TOL = tol
     g = golden("G1_encoder.npz")
     enc = product_module("Encoder", 0)
+    enc.precision = precision
     x = torch.from_numpy(synth.synth_sequence(1712000, seed=11, n_frac=0.01)).to(cuda).transpose(1, 2)
     y = enc(x)[0].cpu().numpy()
     assert y.shape == (128, 428)
