@@ -31,6 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_16BIT_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16/f16 MFMA dense peak (v_mfma_f32_32x32x16_{bf16,f16})
 L_BP = 32_000_000
 ENC_FLOP_PER_BP = 465555.5
 DEC_TFLOP = {"first": 0.2812, "withy": 0.2905, "dec1m": 0.1774, "enc2": 0.0274}
@@ -161,11 +162,17 @@ def main():
         g["ms"] += ms
         g["launches"] += 1
         g["flop"] += 2.0 * 9 * cin * cout * n * batch
+    # kernel instantiation = (cout, arithmetic); records of the 16-bit split kernels carry tile = -precision
+    PREC = {0: ("f32", "conv1d_k9_kernel", PEAK_F32_MFMA_TFLOPS, 1), 1: ("bf16", "conv1d_k9_bf16s_kernel", PEAK_16BIT_MFMA_TFLOPS, 1),
+            2: ("bf16x2", "conv1d_k9_bf16s_kernel", PEAK_16BIT_MFMA_TFLOPS, 3), 3: ("bf16x3", "conv1d_k9_bf16s_kernel", PEAK_16BIT_MFMA_TFLOPS, 6),
+            4: ("f16x2", "conv1d_k9_bf16s_kernel", PEAK_16BIT_MFMA_TFLOPS, 3)}
     inst = {}
-    for (cout, cin, tile), g in groups.items():   # instantiation = (cout, KC) ; cin in {64,96,128} share KC=8
-        key = f"conv1d_k9<cout={cout},kc={4 if cin == 4 else 8},tile={tile}>"
-        d = inst.setdefault(key, {"ms": 0.0, "launches": 0, "flop": 0.0})
-        for k in d:
+    for (cout, cin, tile), g in groups.items():
+        prec = -tile if tile < 0 else 0
+        pname, kname, peak, nprod = PREC[prec]
+        key = f"{kname}<cout={cout},{pname}>" if prec else f"{kname}<cout={cout},kc={4 if cin == 4 else 8},tile={tile}>"
+        d = inst.setdefault(key, {"ms": 0.0, "launches": 0, "flop": 0.0, "peak": peak, "nprod": nprod, "arith": pname})
+        for k in ("ms", "launches", "flop"):
             d[k] += g[k]
     roofline = None
     if inst:
@@ -178,12 +185,16 @@ def main():
                 traffic = json.load(open(tp)).get(name)
             except Exception:
                 traffic = None
-        roofline = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+        tot_ms = sum(v["ms"] for v in inst.values())
+        roofline = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": d["peak"],
+                    "unit": "TFLOP/s", "frac": round(achieved / d["peak"], 4), "traffic": traffic,
+                    "arithmetic": d["arith"], "mfma_products_per_algorithmic_mac": d["nprod"],
+                    "mfma_pipe_frac": round(achieved * d["nprod"] / d["peak"], 4),
+                    "frac_of_f32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
                     "avg_launch_ms": round(d["ms"] / d["launches"], 4), "launches": d["launches"],
                     "flop_per_launch": d["flop"] / d["launches"],
-                    "conv1d_time_share_of_step": round(sum(v["ms"] for v in inst.values()) / (elapsed * 1e3), 4),
-                    "all_conv1d_tflops": round(sum(v["flop"] for v in inst.values()) / (sum(v["ms"] for v in inst.values()) * 1e-3) / 1e12, 2)}
+                    "conv1d_time_share_of_step": round(tot_ms / (elapsed * 1e3), 4),
+                    "all_conv1d_tflops": round(sum(v["flop"] for v in inst.values()) / (tot_ms * 1e-3) / 1e12, 2)}
 
     ms_per_step = elapsed / args.steps * 1e3
     mb_per_s = world * 2 * (Lbp / 1e6) * args.steps / elapsed
@@ -191,7 +202,9 @@ def main():
         "metric": "Mb of sequence encoded+decoded per second (32Mb H1-ESC-shaped model, both strands, 6 levels)",
         "value": round(mb_per_s, 3), "unit": "Mb/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": {"f32": "f32", "f16x2": "f32 emulated as 2xf16 split operands, 3 MFMA products, f32 accumulate (encoder convs); f32 (rest)",
+                  "bf16x3": "f32 emulated as 3xbf16 split operands, 6 MFMA products, f32 accumulate (encoder convs); f32 (rest)"}.get(model.net0.precision, model.net0.precision),
+        "data": "synthetic",
         "config": {"workload": f"H1-ESC 32Mb model forward, single random {args.seq_mb}Mb sequence, fp32, both strands "
                                "(genomepredict-equivalent, 1 model): Encoder+Encoder2+6 Decoder+Decoder_1m per strand",
                    "sequence_bp": Lbp, "strands": 2, "levels": 6, "weights": "synthetic seed 0",

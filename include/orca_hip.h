@@ -134,6 +134,10 @@ int orca_net_free(orca_net* net);
  *                         fp32-MFMA rate; requires |activation|, |weight| < 65504 (fp16 range). */
 #define ORCA_PRECISION_F16X2 4
 int orca_net_set_precision(orca_net* net, int precision);
+/* ORCA_PRECISION_F16X2 only: the kernels raise a device flag when an activation leaves the fp16
+ * range (the result of that forward is then invalid).  This call waits for the context's stream,
+ * returns the flag in *flag and clears it - the host falls back to ORCA_PRECISION_BF16X3. */
+int orca_ctx_take_overflow(orca_ctx* ctx, int* flag);
 
 /* ---- forward passes -------------------------------------------------------- */
 

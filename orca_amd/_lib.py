@@ -40,6 +40,7 @@ SIGNATURES = {
     "orca_ctx_set_stream": (c_int, [c_void_p, c_void_p]),
     "orca_ctx_workspace_bytes": (c_int, [c_void_p, POINTER(c_size_t)]),
     "orca_ctx_release_workspace": (c_int, [c_void_p]),
+    "orca_ctx_take_overflow": (c_int, [c_void_p, POINTER(c_int)]),
     "orca_ctx_set_timing": (c_int, [c_void_p, c_int]),
     "orca_ctx_get_timing": (c_int, [c_void_p, POINTER(KernelTime), c_int, POINTER(c_int)]),
     "orca_net_create": (c_int, [c_void_p, c_int, POINTER(ConvDesc), c_int, c_int, POINTER(c_void_p)]),

@@ -58,6 +58,7 @@ struct ConvB16Args {
   int nchunks;      // cin / 16
   int relu;
   int stagger;      // units of 4096 cycles by which half of the resident workgroups start late
+  unsigned* flag;   // fp16 mode: set to 1 if an activation exceeds the fp16 range (result then invalid)
 };
 
 __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
@@ -70,8 +71,9 @@ __device__ __forceinline__ float bf16hi_f32(unsigned pk) { return __uint_as_floa
 
 // 4 fp32 -> NS x (4 halves packed in 8 bytes): successive round-to-nearest residual splits
 template <int NS, int DT>
-__device__ __forceinline__ void split4(f32x4 v, u32x2 (&out)[NS]) {
+__device__ __forceinline__ void split4(f32x4 v, u32x2 (&out)[NS], bool& overflow) {
   if (DT == 1) {
+    overflow |= (fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))) > 65504.f);
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       const f16x2 h0 = {(_Float16)v.x, (_Float16)v.y}, h1 = {(_Float16)v.z, (_Float16)v.w};
@@ -142,6 +144,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv1d_k9_bf16s_kernel(ConvB16
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  bool overflow = false;
   // ---- staging registers (thread-constant geometry: which float4 of the X window, where it lands) ----
   f32x4 xr[XIT], wr[WIT];
   int xprel[XIT], xq4[XIT], xdst[XIT];
@@ -181,7 +184,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv1d_k9_bf16s_kernel(ConvB16
     _Pragma("unroll") for (int it = 0; it < XIT; ++it) {                                     \
       if (tid + it * NT < XF4) {                                                             \
         u32x2 sp[NS];                                                                        \
-        split4<NS, DT>(xr[it], sp);                                                              \
+        split4<NS, DT>(xr[it], sp, overflow);                                                              \
         _Pragma("unroll") for (int s = 0; s < NS; ++s)                                       \
             *reinterpret_cast<u32x2*>(xs + s * (2 * XROW * 16) + xdst[it]) = sp[s];          \
       }                                                                                      \
@@ -288,6 +291,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv1d_k9_bf16s_kernel(ConvB16
   }
 #undef B16_LOAD_CHUNK
 #undef B16_STORE_CHUNK
+  if (DT == 1 && overflow && a.flag) *a.flag = 1u;
 }
 
 // nn.MaxPool1d(k,k) on channel-last data: y[m][c] = max_j x[k*m+j][c]; one thread = 4 channels

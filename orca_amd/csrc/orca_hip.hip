@@ -68,6 +68,7 @@ struct orca_ctx {
   size_t ws_off = 0;
   bool timing = false;
   std::vector<TimedLaunch> timed;
+  unsigned* d_flag = nullptr;   // fp16-range overflow flag written by the f16x2 kernels
 };
 
 static int ws_ensure(orca_ctx* ctx, size_t bytes) {
@@ -105,6 +106,7 @@ struct ConvLayer {
   float* d_bias = nullptr;
   void* d_wb16 = nullptr;   // k=9, cin%16==0: bf16 3-way split pack [cin/16][3][9][2][cout][8]
   void* d_wf16 = nullptr;   // same, fp16 2-way split pack [cin/16][2][9][2][cout][8]
+  bool f16_ok = true;       // all |w| < 65504
 };
 
 struct orca_net {
@@ -211,6 +213,7 @@ static int make_layer(const orca_conv_desc& d, ConvLayer* out) {
       for (int ci = 0; ci < d.cin; ++ci)
         for (int t = 0; t < 9; ++t) {
           float v = d.weight_host[((size_t)co * d.cin + ci) * 9 + t];
+          if (!(v > -65504.f && v < 65504.f)) L.f16_ok = false;
           const int c = ci / 16, gg = (ci % 16) / 8, e = ci % 8;
           for (int sp = 0; sp < 2; ++sp) {
             const _Float16 h = (_Float16)v;
@@ -351,7 +354,11 @@ static int launch_conv1d_b16(orca_ctx* ctx, const ConvLayer& L, int precision, c
   ConvB16Args a;
   a.x = x; a.w = L.d_wb16; a.bias = L.d_bias; a.y = y; a.r1 = r1; a.x_bs = x_bs; a.y_bs = y_bs; a.n = n;
   a.cin = L.cin; a.nchunks = L.cin / 16; a.relu = relu; a.stagger = 2;
-  if (precision == ORCA_PRECISION_F16X2) a.w = L.d_wf16;
+  a.flag = ctx->d_flag;
+  if (precision == ORCA_PRECISION_F16X2) {
+    if (!L.f16_ok) return fail(ORCA_EINVAL, "layer weights exceed the fp16 range: use ORCA_PRECISION_BF16X3");
+    a.w = L.d_wf16;
+  }
   const bool timed = ctx->timing && n >= 65536;
   TimedLaunch tl;
   if (timed) {
@@ -421,6 +428,10 @@ extern "C" int orca_ctx_create(int device, void* hip_stream, orca_ctx** out) {
   orca_ctx* c = new orca_ctx();
   c->device = device;
   c->stream = static_cast<hipStream_t>(hip_stream);
+  if (hipMalloc(reinterpret_cast<void**>(&c->d_flag), sizeof(unsigned)) != hipSuccess || hipMemset(c->d_flag, 0, sizeof(unsigned)) != hipSuccess) {
+    delete c;
+    return fail(ORCA_ENOMEM, "could not allocate the context flag word");
+  }
   *out = c;
   return ORCA_OK;
 }
@@ -429,6 +440,7 @@ extern "C" int orca_ctx_destroy(orca_ctx* ctx) {
   if (!ctx) return ORCA_OK;
   (void)hipSetDevice(ctx->device);
   if (ctx->ws) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(ctx->ws); }
+  if (ctx->d_flag) (void)hipFree(ctx->d_flag);
   delete ctx;
   return ORCA_OK;
 }
@@ -460,6 +472,17 @@ extern "C" int orca_ctx_get_timing(orca_ctx* ctx, orca_kernel_time* out, int max
     (void)hipEventDestroy(t.e1);
   }
   ctx->timed.clear();
+  return ORCA_OK;
+}
+
+extern "C" int orca_ctx_take_overflow(orca_ctx* ctx, int* flag) {
+  if (!ctx || !flag) return fail(ORCA_EINVAL, "NULL argument");
+  HIPCHECK(hipSetDevice(ctx->device));
+  unsigned h = 0;
+  HIPCHECK(hipMemcpyAsync(&h, ctx->d_flag, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHECK(hipMemsetAsync(ctx->d_flag, 0, sizeof h, ctx->stream));
+  HIPCHECK(hipStreamSynchronize(ctx->stream));
+  *flag = (int)h;
   return ORCA_OK;
 }
 

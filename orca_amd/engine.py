@@ -40,6 +40,12 @@ class Context:
         check(_lib.load().orca_ctx_workspace_bytes(self.handle, ctypes.byref(n)))
         return n.value
 
+    def take_overflow(self):
+        """f16x2 mode: True if an activation left the fp16 range since the last call (syncs the stream)."""
+        f = ctypes.c_int()
+        check(_lib.load().orca_ctx_take_overflow(self.handle, ctypes.byref(f)), "orca_ctx_take_overflow")
+        return bool(f.value)
+
     def set_timing(self, enable):
         check(_lib.load().orca_ctx_set_timing(self.handle, 1 if enable else 0))
 

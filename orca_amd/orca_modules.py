@@ -111,11 +111,16 @@ class Encoder(_HipModule):
     _kind = _lib.ORCA_NET_ENCODER
 
     def __init__(self, precision=None):
-        """precision: arithmetic of the Conv1d stacks - "f32" (fp32 MFMA, exact products),
-        "bf16x3" (3-way split operands on the bf16 matrix cores, fp32-class error, 2.67x the
-        fp32 MFMA rate), "bf16x2", "bf16".  Default: $ORCA_ENCODER_PRECISION or "bf16x3"."""
+        """precision: arithmetic of the Conv1d stacks (all accumulate in fp32)
+          "f32"    fp32 MFMA, exact fp32 products (157 TFLOP/s class)
+          "f16x2"  operands split into 2 fp16 parts, 3 MFMA products: ~2^-22 relative error, 5.3x the
+                   fp32-MFMA rate; needs |activations| < 65504 - checked on the device, and the forward
+                   is transparently redone in "bf16x3" if the check fires (default)
+          "bf16x3" 3 bf16 parts, 6 products: fp32-class error for ANY finite fp32 input, 2.67x
+          "bf16x2" / "bf16"  reduced-precision throughput modes
+        Default: $ORCA_ENCODER_PRECISION or "f16x2"."""
         super().__init__()
-        self.precision = precision or os.environ.get("ORCA_ENCODER_PRECISION", "bf16x3")
+        self.precision = precision or os.environ.get("ORCA_ENCODER_PRECISION", "f16x2")
         if self.precision not in _lib.PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(_lib.PRECISIONS)}")
         prev = 4
@@ -136,10 +141,21 @@ class Encoder(_HipModule):
         ``bin_lo/bin_hi`` restrict the output to a bin range (multi-GPU sharding of
         the independent sequence blocks, orca_modules.py:955-977)."""
         net = self._net(x.device)
-        if getattr(net, "_precision", None) != self.precision:
-            net.set_precision(self.precision)
-            net._precision = self.precision
-        return engine.encoder_forward(net, x, bin_lo, bin_hi, chunk_bp)
+        self._apply_precision(net, self.precision)
+        out = engine.encoder_forward(net, x, bin_lo, bin_hi, chunk_bp)
+        if self.precision == "f16x2" and net.ctx.take_overflow():
+            import warnings
+            warnings.warn("orca_amd.Encoder: an activation left the fp16 range; recomputing this forward with "
+                          "precision='bf16x3' (set Encoder.precision='bf16x3' to avoid the retry)")
+            self._apply_precision(net, "bf16x3")
+            out = engine.encoder_forward(net, x, bin_lo, bin_hi, chunk_bp)
+        return out
+
+    @staticmethod
+    def _apply_precision(net, name):
+        if getattr(net, "_precision", None) != name:
+            net.set_precision(name)
+            net._precision = name
 
 
 class _UNetEncoder(_HipModule):

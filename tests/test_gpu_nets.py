@@ -109,3 +109,21 @@ def test_decoder_batch_sliced_input_vs_oracle(cuda):
     ref = O.decoder_forward(sd, enc[:, :, 77:327], de, yc, "bilinear").numpy()
     out = dec(enc.to(cuda)[:, :, 77:327], de.to(cuda), yc.to(cuda)).cpu().numpy()
     assert maxabs(out, ref) < TOL
+
+
+def test_f16x2_overflow_guard_falls_back(cuda):
+    """|activation| beyond the fp16 range must not produce a silent wrong result: the device flag
+    fires and the forward is redone with the range-safe bf16x3 split."""
+    import warnings
+    enc = product_module("Encoder", 0)
+    sd = synth_sd("Encoder", 0)
+    L = 4000 * 8
+    x = torch.from_numpy(synth.synth_sequence(L, seed=3)).transpose(1, 2) * 3.0e6   # first-layer output ~1e6
+    ref = O.encoder_forward(sd, x).numpy()
+    enc.precision = "f16x2"
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        y = enc(x.to(cuda)).cpu().numpy()
+    assert any("fp16 range" in str(m.message) for m in w)
+    assert np.isfinite(y).all()
+    assert maxabs(y / np.abs(ref).max(), ref / np.abs(ref).max()) < 1e-4
