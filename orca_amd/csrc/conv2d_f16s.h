@@ -1,0 +1,255 @@
+// conv2d_f16s.h - dilated 3x3 Conv2d of the Decoders on the fp16 matrix cores with 2-way split fp32
+// operands (3 MFMA products per fp32 product, ~2^-22 relative error; see conv_bf16s.h).
+//
+// Feature maps are channel-LAST: [row][256 px][C] fp32 (row pitch padded 250 -> 256 px; pad pixels are
+// kept at ZERO by every producer so that reads past the right edge need no mask).  One workgroup = one
+// output row; wave w owns pixels [32w, 32w+32) and all COUT channels.  K walks chunks of 16 input
+// channels x 9 taps; per chunk the LDS holds
+//   X image [split][g][3 source rows][256 px][8 ch] fp16     (split while staging)
+//   W image [split][tap][g][COUT][8 ch]             fp16     (pre-split on the host)
+// MFMA is issued as D = W-frag x X-frag, so a lane owns ONE pixel and 4 consecutive couts per register
+// group: the epilogue (bias, ReLU, residual) is float4 along the channel axis.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "conv_bf16s.h"
+#include "misc_kernels.h"
+
+struct Conv2dF16Args {
+  const float* x;    // [B][H][256][xc]
+  const void* w;     // packed fp16 [nchunks][2][9][2][COUT][8]
+  const float* bias;
+  float* y;          // [B][H][256][yc]   (channels 0..COUT-1 written)
+  const float* r;    // optional residual [B][H][256][rc]
+  long x_bs, y_bs, r_bs;
+  int xc, yc, rc;    // channels per pixel (pixel stride) of x / y / r
+  int H, W, dil, nchunks, relu;
+  unsigned* flag;
+};
+
+template <int COUT>
+__global__ __launch_bounds__(512) void conv2d_3x3_f16s_kernel(Conv2dF16Args a) {
+  constexpr int NS = 2, NT = 512, NW = COUT / 32, PX = 256;
+  constexpr int XU = NS * 2 * 3 * PX;     // 16-byte units of the X image (6144)
+  constexpr int WU = NS * 9 * 2 * COUT;   // 16-byte units of the W image
+  constexpr int XF4 = 3 * PX * 4;         // float4 loads per chunk (3 rows x 256 px x 4 channel quads)
+  constexpr int XIT = XF4 / NT;           // 6
+  constexpr int WIT = (WU + NT - 1) / NT;
+  __shared__ f32x4 smem[XU + WU];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, g = lane >> 5;
+  const int y0 = blockIdx.x, b = blockIdx.y, H = a.H, W = a.W, d = a.dil;
+  const float* xb = a.x + (long)b * a.x_bs;
+  const f32x4* wg = reinterpret_cast<const f32x4*>(a.w);
+  const long rowpitch = (long)PX * a.xc;
+
+  bool rowok[3];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int ys = y0 + (ky - 1) * d;
+    rowok[ky] = (ys >= 0 && ys < H);
+  }
+  // this lane's source pixel per kx (pad pixels [W,256) are zero in memory; only <0 / >=256 need a mask)
+  int xsrc[3];
+  bool xok[3], wskip[3];
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx) {
+    const int x0 = wave * 32 + (kx - 1) * d, xs = x0 + l31;
+    xok[kx] = (xs >= 0 && xs < PX);
+    xsrc[kx] = xs < 0 ? 0 : (xs > PX - 1 ? PX - 1 : xs);
+    wskip[kx] = (x0 + 31 < 0) || (x0 >= W);
+  }
+
+  f32x16 acc[NW];
+#pragma unroll
+  for (int j = 0; j < NW; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  bool overflow = false;
+  f32x4 xr[XIT], wr[WIT];
+  long xoff[XIT];
+  int xdst[XIT];
+  bool xvalid[XIT];
+#pragma unroll
+  for (int it = 0; it < XIT; ++it) {
+    const int u = tid + it * NT;            // u = (ky*256 + px)*4 + q
+    const int q = u & 3, px = (u >> 2) & (PX - 1), ky = u >> 10;
+    const int ys = y0 + (ky - 1) * d;
+    xvalid[it] = (ys >= 0 && ys < H);
+    xoff[it] = (long)(xvalid[it] ? ys : y0) * rowpitch + (long)px * a.xc + 4 * q;
+    xdst[it] = ((((q >> 1) * 3 + ky) * PX) + px) * 16 + (q & 1) * 8;
+  }
+#define C2_LOAD_CHUNK(c)                                                                     \
+  {                                                                                          \
+    _Pragma("unroll") for (int it = 0; it < XIT; ++it) {                                     \
+      f32x4 v = *reinterpret_cast<const f32x4*>(xb + xoff[it] + 16 * (c));                   \
+      if (!xvalid[it]) v = (f32x4)(0.f);                                                     \
+      xr[it] = v;                                                                            \
+    }                                                                                        \
+    const f32x4* wc = wg + (long)(c) * WU;                                                   \
+    _Pragma("unroll") for (int it = 0; it < WIT; ++it) {                                     \
+      int idx = tid + it * NT;                                                               \
+      idx = idx < WU ? idx : WU - 1;                                                         \
+      wr[it] = wc[idx];                                                                      \
+    }                                                                                        \
+  }
+#define C2_STORE_CHUNK()                                                                     \
+  {                                                                                          \
+    char* xs_ = reinterpret_cast<char*>(smem);                                               \
+    _Pragma("unroll") for (int it = 0; it < XIT; ++it) {                                     \
+      u32x2 sp[NS];                                                                          \
+      split4<NS, 1>(xr[it], sp, overflow);                                                   \
+      _Pragma("unroll") for (int s = 0; s < NS; ++s)                                         \
+          *reinterpret_cast<u32x2*>(xs_ + s * (2 * 3 * PX * 16) + xdst[it]) = sp[s];         \
+    }                                                                                        \
+    _Pragma("unroll") for (int it = 0; it < WIT; ++it) {                                     \
+      const int idx = tid + it * NT;                                                         \
+      if (idx < WU) smem[XU + idx] = wr[it];                                                 \
+    }                                                                                        \
+  }
+
+  C2_LOAD_CHUNK(0);
+  C2_STORE_CHUNK();
+  __syncthreads();
+
+  const f32x4* xa0 = smem + g * (3 * PX);                  // + s*2*3*PX + ky*PX + px
+  const f32x4* wb0 = smem + XU + g * COUT + l31;           // + ((s*9+tap)*2)*COUT + j*32
+
+  for (int c = 0; c < a.nchunks; ++c) {
+    const bool more = (c + 1 < a.nchunks);
+    if (more) C2_LOAD_CHUNK(c + 1);
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      if (!rowok[ky]) continue;   // workgroup-uniform: the whole source row is zero padding
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        if (wskip[kx]) continue;  // wave-uniform: all 32 source pixels of this wave are padding
+        const int tap = ky * 3 + kx;
+        f16x8 xv[NS], wv[NS][NW];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+          f32x4 t = xa0[s * (2 * 3 * PX) + ky * PX + xsrc[kx]];
+          if (!xok[kx]) t = (f32x4)(0.f);
+          xv[s] = __builtin_bit_cast(f16x8, t);
+#pragma unroll
+          for (int j = 0; j < NW; ++j) wv[s][j] = __builtin_bit_cast(f16x8, wb0[((s * 9 + tap) * 2) * COUT + j * 32]);
+        }
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wv[0][j], xv[1], acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wv[1][j], xv[0], acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wv[0][j], xv[0], acc[j], 0, 0, 0);
+        }
+      }
+    }
+    if (!more) break;
+    __syncthreads();
+    C2_STORE_CHUNK();
+    __syncthreads();
+  }
+#undef C2_LOAD_CHUNK
+#undef C2_STORE_CHUNK
+
+  const int px = wave * 32 + l31;
+  float* yp = a.y + (long)b * a.y_bs + ((long)y0 * PX + px) * a.yc;
+  const float* rp = a.r ? a.r + (long)b * a.r_bs + ((long)y0 * PX + px) * a.rc : nullptr;
+#pragma unroll
+  for (int j = 0; j < NW; ++j) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int co = j * 32 + 8 * q + 4 * g;
+      const f32x4 bias = *reinterpret_cast<const f32x4*>(a.bias + co);
+      f32x4 v;
+      v.x = acc[j][4 * q + 0] + bias.x;
+      v.y = acc[j][4 * q + 1] + bias.y;
+      v.z = acc[j][4 * q + 2] + bias.z;
+      v.w = acc[j][4 * q + 3] + bias.w;
+      if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      if (rp) v += *reinterpret_cast<const f32x4*>(rp + co);
+      if (px >= W) v = (f32x4)(0.f);   // keep the pad pixels of every feature map at zero
+      *reinterpret_cast<f32x4*>(yp + co) = v;
+    }
+  }
+  if (overflow && a.flag) *a.flag = 1u;
+}
+
+// ---- channel-last helpers of the Decoder --------------------------------------------------------------
+// mat[i][j][c] = x[c][i] + x[c][j] (c<128); channel 128 = distenc[i][j] (if given); other pad channels and
+// pad pixels = 0.  out [n][256][cp].  block = (cp/4 threads x 8 pixels), grid = (32, n)
+__global__ void outer_sum_nhwc_kernel(const float* __restrict__ x, long sx_c, long sx_l, const float* __restrict__ de, long sd_h,
+                                      long sd_w, float* __restrict__ out, int n, int cp) {
+  const int c4 = threadIdx.x, j = blockIdx.x * blockDim.y + threadIdx.y, i = blockIdx.y;
+  f32x4 v = (f32x4)(0.f);
+  if (j < n) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = 4 * c4 + e;
+      float t = 0.f;
+      if (c < 128) t = x[c * sx_c + i * sx_l] + x[c * sx_c + j * sx_l];
+      else if (c == 128 && de) t = de[i * sd_h + j * sd_w];
+      v[e] = t;
+    }
+  }
+  *reinterpret_cast<f32x4*>(out + ((long)i * 256 + j) * cp + 4 * c4) = v;
+}
+
+// bilinear / nearest x2 upsample of y [n/2][n/2] into channels [c0, c0+16) of an [n][256][cp] map
+// (channel c0 = value, c0+1.. = 0; pad pixels 0).  block 256 (pixels), grid n
+__global__ void upsample2d_nhwc_kernel(const float* __restrict__ y, long sy_h, long sy_w, float* __restrict__ out, int n, int cp, int c0,
+                                       int bilinear) {
+  const int j = threadIdx.x, i = blockIdx.x, h = n / 2;
+  float v = 0.f;
+  if (j < n) {
+    if (!bilinear) {
+      v = y[(i >> 1) * sy_h + (j >> 1) * sy_w];
+    } else {
+      const float fy = fmaxf(0.5f * (i + 0.5f) - 0.5f, 0.f), fx = fmaxf(0.5f * (j + 0.5f) - 0.5f, 0.f);
+      const int y0 = (int)fy, x0 = (int)fx;
+      const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < h - 1 ? 1 : 0);
+      const float ly = fy - y0, lx = fx - x0, hy = 1.f - ly, hx = 1.f - lx;
+      v = hy * (hx * y[y0 * sy_h + x0 * sy_w] + lx * y[y0 * sy_h + x1 * sy_w]) +
+          ly * (hx * y[y1 * sy_h + x0 * sy_w] + lx * y[y1 * sy_h + x1 * sy_w]);
+    }
+  }
+  float* o = out + ((long)i * 256 + j) * cp + c0;
+  f32x4 z = (f32x4)(0.f), f = z;
+  f.x = v;
+  reinterpret_cast<f32x4*>(o)[0] = f;
+  reinterpret_cast<f32x4*>(o)[1] = z;
+  reinterpret_cast<f32x4*>(o)[2] = z;
+  reinterpret_cast<f32x4*>(o)[3] = z;
+}
+
+// `final` head + symmetrisation on a channel-last [n][256][64] map (see final_sym_kernel)
+__global__ void final_sym_nhwc_kernel(FinalArgs a) {
+  __shared__ float w1s[5 * 64], b1s[5], w2s[5], b2s;
+  for (int t = threadIdx.x; t < 320; t += blockDim.x) w1s[t] = a.w1[t];
+  if (threadIdx.x < 5) { b1s[threadIdx.x] = a.b1[threadIdx.x]; w2s[threadIdx.x] = a.w2[threadIdx.x]; }
+  if (threadIdx.x == 0) b2s = a.b2[0];
+  __syncthreads();
+  const int j = threadIdx.x, i = blockIdx.x, b = blockIdx.y, n = a.n;
+  if (j >= n) return;
+  const float* cur = a.cur + (long)b * a.cur_bs;
+  const f32x4* pu = reinterpret_cast<const f32x4*>(cur + ((long)i * 256 + j) * 64);
+  const f32x4* pv = reinterpret_cast<const f32x4*>(cur + ((long)j * 256 + i) * 64);
+  float h1[5], h2[5];
+#pragma unroll
+  for (int o = 0; o < 5; ++o) { h1[o] = b1s[o]; h2[o] = b1s[o]; }
+  for (int c4 = 0; c4 < 16; ++c4) {
+    const f32x4 u = pu[c4], v = pv[c4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int o = 0; o < 5; ++o) { h1[o] = fmaf(w1s[o * 64 + 4 * c4 + e], u[e], h1[o]); h2[o] = fmaf(w1s[o * 64 + 4 * c4 + e], v[e], h2[o]); }
+  }
+  float f1 = b2s, f2 = b2s;
+#pragma unroll
+  for (int o = 0; o < 5; ++o) { f1 = fmaf(w2s[o], fmaxf(h1[o], 0.f), f1); f2 = fmaf(w2s[o], fmaxf(h2[o], 0.f), f2); }
+  float* op = a.out + (long)b * a.out_bs + (long)i * n + j;
+  const float r = 0.5f * f1 + 0.5f * f2;
+  *op = a.accumulate ? (*op + r) : r;
+}

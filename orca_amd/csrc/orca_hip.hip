@@ -13,6 +13,7 @@
 
 #include "conv_kernels.h"
 #include "conv_bf16s.h"
+#include "conv2d_f16s.h"
 #include "misc_kernels.h"
 #include "orca_hip.h"
 
@@ -227,6 +228,28 @@ static int make_layer(const orca_conv_desc& d, ConvLayer* out) {
     if (e1 == hipSuccess) e1 = hipMemcpy(L.d_wf16, pf.data(), pf.size() * 2, hipMemcpyHostToDevice);
     if (e1 != hipSuccess) { free_layer(L); return fail(ORCA_EHIP, "fp16 weight upload failed: %s", hipGetErrorString(e1)); }
   }
+  if (d.ksize == 3) {
+    // fp16 2-way split pack for conv2d_f16s.h: [cin_pad16/16][2][9][2][cout][8], pad channels = 0
+    const int nc = (d.cin + 15) / 16;
+    std::vector<uint16_t> pf((size_t)nc * 2 * 9 * 2 * d.cout * 8, 0);
+    for (int co = 0; co < d.cout; ++co)
+      for (int ci = 0; ci < d.cin; ++ci)
+        for (int t = 0; t < 9; ++t) {
+          float v = d.weight_host[((size_t)co * d.cin + ci) * 9 + t];
+          if (!(v > -65504.f && v < 65504.f)) L.f16_ok = false;
+          const int c = ci / 16, gg = (ci % 16) / 8, e = ci % 8;
+          for (int sp = 0; sp < 2; ++sp) {
+            const _Float16 h = (_Float16)v;
+            v -= (float)h;
+            uint16_t bits;
+            memcpy(&bits, &h, 2);
+            pf[(((((size_t)c * 2 + sp) * 9 + t) * 2 + gg) * d.cout + co) * 8 + e] = bits;
+          }
+        }
+    hipError_t e1 = hipMalloc(&L.d_wf16, pf.size() * 2);
+    if (e1 == hipSuccess) e1 = hipMemcpy(L.d_wf16, pf.data(), pf.size() * 2, hipMemcpyHostToDevice);
+    if (e1 != hipSuccess) { free_layer(L); return fail(ORCA_EHIP, "fp16 conv2d weight upload failed: %s", hipGetErrorString(e1)); }
+  }
   *out = L;
   return ORCA_OK;
 }
@@ -298,6 +321,22 @@ static int launch_conv2d(orca_ctx* ctx, const ConvLayer& L, const float* x, long
   if (L.cout == 64) hipLaunchKernelGGL((conv2d_3x3_kernel<64>), grid, dim3(512), 0, ctx->stream, a);
   else hipLaunchKernelGGL((conv2d_3x3_kernel<32>), grid, dim3(512), 0, ctx->stream, a);
   LAUNCHCHECK("conv2d_3x3_kernel");
+  return ORCA_OK;
+}
+
+// channel-last fp16-split conv2d (conv2d_f16s.h): x [B][n][256][xc], y [B][n][256][yc], r [B][n][256][rc]
+static int launch_conv2d_f16(orca_ctx* ctx, const ConvLayer& L, const float* x, long x_bs, int xc, float* y, long y_bs, int yc,
+                             const float* r, long r_bs, int rc, int B, int n, int relu) {
+  if (L.ksize != 3 || !L.d_wf16) return fail(ORCA_EINVAL, "launch_conv2d_f16 on a layer without an fp16 pack");
+  if (!L.f16_ok) return fail(ORCA_EINVAL, "layer weights exceed the fp16 range");
+  Conv2dF16Args a;
+  a.x = x; a.w = L.d_wf16; a.bias = L.d_bias; a.y = y; a.r = r; a.x_bs = x_bs; a.y_bs = y_bs; a.r_bs = r_bs;
+  a.xc = xc; a.yc = yc; a.rc = rc; a.H = n; a.W = n; a.dil = L.dil; a.nchunks = (L.cin + 15) / 16; a.relu = relu; a.flag = ctx->d_flag;
+  if (a.nchunks * 16 > xc) return fail(ORCA_EINVAL, "conv2d_f16: input has %d channels per pixel, layer needs %d", xc, a.nchunks * 16);
+  dim3 grid((unsigned)n, (unsigned)B);
+  if (L.cout == 64) hipLaunchKernelGGL((conv2d_3x3_f16s_kernel<64>), grid, dim3(512), 0, ctx->stream, a);
+  else hipLaunchKernelGGL((conv2d_3x3_f16s_kernel<32>), grid, dim3(512), 0, ctx->stream, a);
+  LAUNCHCHECK("conv2d_3x3_f16s_kernel");
   return ORCA_OK;
 }
 
@@ -555,8 +594,9 @@ extern "C" int orca_net_create(orca_ctx* ctx, int kind, const orca_conv_desc* co
 extern "C" int orca_net_set_precision(orca_net* net, int precision) {
   if (!net) return fail(ORCA_EINVAL, "net is NULL");
   if (precision < ORCA_PRECISION_F32 || precision > ORCA_PRECISION_F16X2) return fail(ORCA_EINVAL, "unknown precision %d", precision);
-  if (precision != ORCA_PRECISION_F32 && net->kind != ORCA_NET_ENCODER)
-    return fail(ORCA_EINVAL, "split-bf16 precision is implemented for the Encoder only");
+  const bool dec = net->kind == ORCA_NET_DECODER || net->kind == ORCA_NET_DECODER_1M;
+  if (precision != ORCA_PRECISION_F32 && !(net->kind == ORCA_NET_ENCODER || (dec && precision == ORCA_PRECISION_F16X2)))
+    return fail(ORCA_EINVAL, "precision %d is not implemented for net kind %d", precision, net->kind);
   net->precision = precision;
   return ORCA_OK;
 }
@@ -749,12 +789,90 @@ static int launch_final(orca_ctx* ctx, orca_net* net, const float* cur, long cur
   return ORCA_OK;
 }
 
+// Decoder / Decoder_1m on the fp16 matrix cores, channel-last feature maps [n][256 px][C]
+static int decoder_nhwc(orca_ctx* ctx, orca_net* net, const float* x, long sx_b, long sx_c, long sx_l, const float* de, long sd_b,
+                        long sd_h, long sd_w, const float* y, long sy_b, long sy_h, long sy_w, int B, int n, float* out,
+                        int accumulate) {
+  const bool is1m = net->kind == ORCA_NET_DECODER_1M;
+  const size_t px = (size_t)n * 256;
+  const int cIN = is1m ? 128 : 144, cA = 80;
+  const size_t szIN = px * cIN, szA = px * cA, sz64 = px * 64, sz32 = px * 32;
+  const size_t need = ru256(B * szIN * 4) + ru256(B * szA * 4) + 3 * ru256(B * sz64 * 4) + ru256(B * sz32 * 4);
+  ORCA_TRY(ws_ensure(ctx, need));
+  float* IN = ws_take(ctx, B * szIN);
+  float* A = ws_take(ctx, B * szA);
+  float* Bf = ws_take(ctx, B * sz64);
+  float* Cf = ws_take(ctx, B * sz64);
+  float* Df = ws_take(ctx, B * sz64);
+  float* T = ws_take(ctx, B * sz32);
+  hipStream_t s = ctx->stream;
+  for (int b = 0; b < B; ++b) {
+    hipLaunchKernelGGL(outer_sum_nhwc_kernel, dim3(32, (unsigned)n), dim3(cIN / 4, 8), 0, s, x + (long)b * sx_b, sx_c, sx_l,
+                       de ? de + (long)b * sd_b : nullptr, sd_h, sd_w, IN + b * szIN, n, cIN);
+    LAUNCHCHECK("outer_sum_nhwc_kernel");
+  }
+  const ConvLayer* L = net->convs.data();
+  const ConvLayer* pairs;
+  int npairs;
+#define C2(layer, src, sbs, sc, dst, dbs, dc, res, rbs, rc, relu) \
+  ORCA_TRY(launch_conv2d_f16(ctx, layer, src, sbs, sc, dst, dbs, dc, res, rbs, rc, B, n, relu))
+  if (!is1m) {
+    C2(L[0], IN, szIN, cIN, Bf, sz64, 64, nullptr, 0, 0, 0);
+    C2(L[1], Bf, sz64, 64, Cf, sz64, 64, nullptr, 0, 0, 0);
+    C2(L[2], Cf, sz64, 64, Bf, sz64, 64, nullptr, 0, 0, 1);
+    C2(L[3], Bf, sz64, 64, A, szA, cA, Cf, sz64, 64, 1);           // A[..., 0:64] = combinerD(.) + .
+    pairs = L + 8; npairs = 28;
+    if (y) {
+      for (int b = 0; b < B; ++b) {
+        hipLaunchKernelGGL(upsample2d_nhwc_kernel, dim3((unsigned)n), dim3(256), 0, s, y + (long)b * sy_b, sy_h, sy_w, A + b * szA, n,
+                           cA, 64, net->upsample_mode == ORCA_UPSAMPLE_BILINEAR ? 1 : 0);
+        LAUNCHCHECK("upsample2d_nhwc_kernel");
+      }
+      C2(L[4], A, szA, cA, Bf, sz64, 64, nullptr, 0, 0, 0);
+      C2(L[5], Bf, sz64, 64, Cf, sz64, 64, nullptr, 0, 0, 0);
+      C2(L[6], Cf, sz64, 64, Bf, sz64, 64, nullptr, 0, 0, 1);
+      C2(L[7], Bf, sz64, 64, Df, sz64, 64, Cf, sz64, 64, 1);
+    } else {
+      C2(pairs[0], A, szA, cA, T, sz32, 32, nullptr, 0, 0, 0);
+      C2(pairs[1], T, sz32, 32, Cf, sz64, 64, nullptr, 0, 0, 0);
+      C2(pairs[2], Cf, sz64, 64, T, sz32, 32, nullptr, 0, 0, 1);
+      C2(pairs[3], T, sz32, 32, Df, sz64, 64, Cf, sz64, 64, 1);
+    }
+  } else {
+    pairs = L; npairs = 19;
+    C2(pairs[0], IN, szIN, cIN, T, sz32, 32, nullptr, 0, 0, 0);
+    C2(pairs[1], T, sz32, 32, Cf, sz64, 64, nullptr, 0, 0, 0);
+    C2(pairs[2], Cf, sz64, 64, T, sz32, 32, nullptr, 0, 0, 1);
+    C2(pairs[3], T, sz32, 32, Df, sz64, 64, Cf, sz64, 64, 1);
+  }
+  float* cur = Df;
+  float* oth = Cf;
+  for (int i = 1; i < npairs; ++i) {
+    const ConvLayer* p = pairs + 4 * i;
+    C2(p[0], cur, sz64, 64, T, sz32, 32, nullptr, 0, 0, 0);
+    C2(p[1], T, sz32, 32, oth, sz64, 64, cur, sz64, 64, 0);
+    C2(p[2], oth, sz64, 64, T, sz32, 32, nullptr, 0, 0, 1);
+    C2(p[3], T, sz32, 32, cur, sz64, 64, oth, sz64, 64, 1);
+  }
+#undef C2
+  const ConvLayer& fa = net->convs[net->convs.size() - 2];
+  const ConvLayer& fb = net->convs[net->convs.size() - 1];
+  FinalArgs fa_;
+  fa_.cur = cur; fa_.w1 = fa.d_w; fa_.b1 = fa.d_bias; fa_.w2 = fb.d_w; fa_.b2 = fb.d_bias; fa_.out = out;
+  fa_.cur_bs = sz64; fa_.out_bs = (long)n * n; fa_.n = n; fa_.accumulate = accumulate;
+  hipLaunchKernelGGL(final_sym_nhwc_kernel, dim3((unsigned)n, (unsigned)B), dim3(256), 0, s, fa_);
+  LAUNCHCHECK("final_sym_nhwc_kernel");
+  return ORCA_OK;
+}
+
 static int decoder_common(orca_ctx* ctx, orca_net* net, const float* x, long sx_b, long sx_c, long sx_l, const float* de,
                           long sd_b, long sd_h, long sd_w, const float* y, long sy_b, long sy_h, long sy_w, int B, int n,
                           float* out, int accumulate) {
   if (n <= 0 || n > ORCA_LDW || (n & 1)) return fail(ORCA_EINVAL, "map size %d unsupported (even, <=256)", n);
   if (B <= 0) return ORCA_OK;
   HIPCHECK(hipSetDevice(ctx->device));
+  if (net->precision == ORCA_PRECISION_F16X2)
+    return decoder_nhwc(ctx, net, x, sx_b, sx_c, sx_l, de, sd_b, sd_h, sd_w, y, sy_b, sy_h, sy_w, B, n, out, accumulate);
   const bool is1m = net->kind == ORCA_NET_DECODER_1M;
   const size_t plane = (size_t)n * ORCA_LDW;
   const int cin0 = is1m ? 128 : 136;

@@ -104,6 +104,25 @@ class _HipModule(nn.Module):
             self._nets[key] = net
         return net
 
+    @staticmethod
+    def _apply_precision(net, name):
+        if getattr(net, "_precision", None) != name:
+            net.set_precision(name)
+            net._precision = name
+
+    def _run_guarded(self, net, fn, fallback):
+        """Run fn() in self.precision; in the fp16-split mode check the device range flag and redo the
+        forward in the range-safe ``fallback`` arithmetic if an activation left the fp16 range."""
+        self._apply_precision(net, self.precision)
+        out = fn()
+        if self.precision == "f16x2" and net.ctx.take_overflow():
+            import warnings
+            warnings.warn(f"orca_amd.{type(self).__name__}: an activation left the fp16 range; recomputing this forward "
+                          f"with precision='{fallback}' (set .precision='{fallback}' to avoid the retry)")
+            self._apply_precision(net, fallback)
+            out = fn()
+        return out
+
 
 class Encoder(_HipModule):
     """bp-resolution sequence -> 4 kb bins (orca_modules.py:803-980)."""
@@ -141,21 +160,7 @@ class Encoder(_HipModule):
         ``bin_lo/bin_hi`` restrict the output to a bin range (multi-GPU sharding of
         the independent sequence blocks, orca_modules.py:955-977)."""
         net = self._net(x.device)
-        self._apply_precision(net, self.precision)
-        out = engine.encoder_forward(net, x, bin_lo, bin_hi, chunk_bp)
-        if self.precision == "f16x2" and net.ctx.take_overflow():
-            import warnings
-            warnings.warn("orca_amd.Encoder: an activation left the fp16 range; recomputing this forward with "
-                          "precision='bf16x3' (set Encoder.precision='bf16x3' to avoid the retry)")
-            self._apply_precision(net, "bf16x3")
-            out = engine.encoder_forward(net, x, bin_lo, bin_hi, chunk_bp)
-        return out
-
-    @staticmethod
-    def _apply_precision(net, name):
-        if getattr(net, "_precision", None) != name:
-            net.set_precision(name)
-            net._precision = name
+        return self._run_guarded(net, lambda: engine.encoder_forward(net, x, bin_lo, bin_hi, chunk_bp), "bf16x3")
 
 
 class _UNetEncoder(_HipModule):
@@ -212,8 +217,14 @@ class Decoder(_HipModule):
 
     _kind = _lib.ORCA_NET_DECODER
 
-    def __init__(self, upsample_mode="nearest"):
+    def __init__(self, upsample_mode="nearest", precision=None):
+        """precision: "f16x2" (dilated 3x3 convs on the fp16 matrix cores with 2-way split fp32 operands,
+        ~2^-22 relative error, device range guard with automatic "f32" retry; default) or "f32" (fp32 MFMA).
+        Default: $ORCA_DECODER_PRECISION or "f16x2"."""
         super().__init__()
+        self.precision = precision or os.environ.get("ORCA_DECODER_PRECISION", "f16x2")
+        if self.precision not in ("f16x2", "f32"):
+            raise ValueError("Decoder precision must be 'f16x2' or 'f32'")
         if upsample_mode not in ("nearest", "bilinear"):
             raise ValueError("upsample_mode must be 'nearest' or 'bilinear'")
         self._upsample = _lib.ORCA_UPSAMPLE_BILINEAR if upsample_mode == "bilinear" else _lib.ORCA_UPSAMPLE_NEAREST
@@ -238,10 +249,15 @@ class Decoder(_HipModule):
 
     def forward(self, x, distenc, y=None):
         """x [B,128,n], distenc [B,1,n,n] (log background), y None or [B,1,n/2,n/2]."""
-        return engine.decoder_forward(self._net(x.device), x, distenc, y)
+        net = self._net(x.device)
+        return self._run_guarded(net, lambda: engine.decoder_forward(net, x, distenc, y), "f32")
 
     def forward_into(self, out, x, distenc, y=None, accumulate=False):
-        return engine.decoder_forward(self._net(x.device), x, distenc, y, out=out, accumulate=accumulate)
+        net = self._net(x.device)
+        if accumulate and self.precision == "f16x2":
+            base = out.clone()   # a retry must not accumulate twice
+            return self._run_guarded(net, lambda: engine.decoder_forward(net, x, distenc, y, out=out.copy_(base), accumulate=True), "f32")
+        return self._run_guarded(net, lambda: engine.decoder_forward(net, x, distenc, y, out=out, accumulate=accumulate), "f32")
 
 
 class Decoder_1m(_HipModule):
@@ -249,8 +265,11 @@ class Decoder_1m(_HipModule):
 
     _kind = _lib.ORCA_NET_DECODER_1M
 
-    def __init__(self):
+    def __init__(self, precision=None):
         super().__init__()
+        self.precision = precision or os.environ.get("ORCA_DECODER_PRECISION", "f16x2")
+        if self.precision not in ("f16x2", "f32"):
+            raise ValueError("Decoder_1m precision must be 'f16x2' or 'f32'")
         self.lconvtwos = nn.ModuleList([
             _linear_pair(nn.Conv2d, nn.BatchNorm2d, 128 if i == 0 else 64, 32, 64, nn.Dropout(p=0.1) if i == 0 else None, **_c2(d))
             for i, d in enumerate(DECODER1M_DILATIONS)])
@@ -265,7 +284,12 @@ class Decoder_1m(_HipModule):
         return items
 
     def forward(self, x):
-        return engine.decoder1m_forward(self._net(x.device), x)
+        net = self._net(x.device)
+        return self._run_guarded(net, lambda: engine.decoder1m_forward(net, x), "f32")
 
     def forward_into(self, out, x, accumulate=False):
-        return engine.decoder1m_forward(self._net(x.device), x, out=out, accumulate=accumulate)
+        net = self._net(x.device)
+        if accumulate and self.precision == "f16x2":
+            base = out.clone()   # a retry must not accumulate twice
+            return self._run_guarded(net, lambda: engine.decoder1m_forward(net, x, out=out.copy_(base), accumulate=True), "f32")
+        return self._run_guarded(net, lambda: engine.decoder1m_forward(net, x, out=out, accumulate=accumulate), "f32")

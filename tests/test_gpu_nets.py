@@ -75,7 +75,9 @@ def test_encoder2_batch_and_strided_input_vs_oracle(cuda):
         assert maxabs(a.cpu().numpy(), b.numpy()) < TOL
 
 
-def test_decoders_vs_golden(cuda):
+@pytest.mark.parametrize("precision", ["f16x2", "f32"])
+def test_decoders_vs_golden(cuda, precision, monkeypatch):
+    monkeypatch.setenv("ORCA_DECODER_PRECISION", precision)
     g = golden("G5_decoder.npz")
     nm, _ = synth.synth_normmats_32m()
     x = torch.from_numpy((np.random.RandomState(31).rand(1, 128, 250) * 0.5).astype(np.float32)).to(cuda)
@@ -99,7 +101,9 @@ def test_decoders_vs_golden(cuda):
     assert maxabs(acc.cpu().numpy(), (p1 + p3).cpu().numpy()) < 1e-6
 
 
-def test_decoder_batch_sliced_input_vs_oracle(cuda):
+@pytest.mark.parametrize("precision", ["f16x2", "f32"])
+def test_decoder_batch_sliced_input_vs_oracle(cuda, precision, monkeypatch):
+    monkeypatch.setenv("ORCA_DECODER_PRECISION", precision)
     nm, _ = synth.synth_normmats_32m()
     sd = synth_sd("Decoder", 2, upsample_mode="bilinear")
     dec = product_module("Decoder", 2, upsample_mode="bilinear")
@@ -127,3 +131,20 @@ def test_f16x2_overflow_guard_falls_back(cuda):
     assert any("fp16 range" in str(m.message) for m in w)
     assert np.isfinite(y).all()
     assert maxabs(y / np.abs(ref).max(), ref / np.abs(ref).max()) < 1e-4
+
+
+def test_decoder_f16x2_overflow_guard_falls_back(cuda):
+    import warnings
+    nm, _ = synth.synth_normmats_32m()
+    sd = synth_sd("Decoder", 0, upsample_mode="bilinear")
+    dec = product_module("Decoder", 0, upsample_mode="bilinear")
+    dec.precision = "f16x2"
+    x = torch.from_numpy((np.random.RandomState(5).rand(1, 128, 250) * 1.0e5).astype(np.float32))   # x_i + x_j > 65504
+    de = torch.log(torch.from_numpy(nm[8][None, None].astype(np.float32)))
+    ref = O.decoder_forward(sd, x, de, None, "bilinear").numpy()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        out = dec(x.to(cuda), de.to(cuda)).cpu().numpy()
+    assert any("fp16 range" in str(m.message) for m in w)
+    s = np.abs(ref).max()
+    assert maxabs(out / s, ref / s) < 1e-4
