@@ -127,9 +127,8 @@ def main():
     ctx = engine.get_context(dev)
 
     def step():
-        pf, _ = orca_predict.cascade_32m(model, x_fwd, mpos, wpos, False, distencs)
-        pr, _ = orca_predict.cascade_32m(model, x_rev, mpos, wpos, True, distencs)
-        return [engine.strand_merge(a[0, 0], b[0, 0]) for a, b in zip(pf, pr)]
+        preds, _ = orca_predict.cascade_32m(model, [x_fwd, x_rev], mpos, wpos, [False, True], distencs)
+        return [engine.strand_merge(p[0, 0], p[1, 0]) for p in preds]
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -143,9 +142,7 @@ def main():
     ctx.set_timing(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        pf, _ = orca_predict.cascade_32m(model, x_fwd, mpos, wpos, False, distencs)
-        pr, _ = orca_predict.cascade_32m(model, x_rev, mpos, wpos, True, distencs)
-        outs = [engine.strand_merge(a[0, 0], b[0, 0]) for a, b in zip(pf, pr)]
+        outs = step()
     sync()
     elapsed = time.perf_counter() - t0
     ctx.set_timing(False)

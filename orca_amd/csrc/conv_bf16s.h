@@ -51,6 +51,7 @@ struct ConvB16Args {
   float* y;         // [B][n][COUT]
   const float* r1;  // optional residual, layout of y
   long x_bs, y_bs;  // batch strides (elements)
+  long r_bs;        // batch stride of r1
   long n;
   long tiles_per_row;  // ceil(n / MT)
   int batch;
@@ -59,6 +60,7 @@ struct ConvB16Args {
   int relu;
   int stagger;      // units of 4096 cycles by which half of the resident workgroups start late
   unsigned* flag;   // fp16 mode: set to 1 if an activation exceeds the fp16 range (result then invalid)
+  int pool4;        // fuse nn.MaxPool1d(4,4) into the epilogue: y is [n/4][COUT], y_bs its batch stride
 };
 
 __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
@@ -253,7 +255,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv1d_k9_bf16s_kernel(ConvB16
       const long tb = tile / a.tiles_per_row;
       const long m0 = (tile - tb * a.tiles_per_row) * MT;
       float* yb = a.y + tb * a.y_bs;
-      const float* rb = a.r1 ? a.r1 + tb * a.y_bs : nullptr;
+      const float* rb = a.r1 ? a.r1 + tb * a.r_bs : nullptr;
 #pragma unroll
       for (int i = 0; i < MW; ++i) {
         const long pos = m0 + wm * (MW * 32) + i * 32 + l31;
@@ -270,10 +272,24 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv1d_k9_bf16s_kernel(ConvB16
             v.w = acc[i][j][4 * q + 3] + bias.w;
             acc[i][j][4 * q + 0] = 0.f; acc[i][j][4 * q + 1] = 0.f; acc[i][j][4 * q + 2] = 0.f; acc[i][j][4 * q + 3] = 0.f;
             if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            if (pos < a.n) {
-              const long o = pos * COUT + co;
-              if (rb) v += *reinterpret_cast<const f32x4*>(rb + o);
-              if (!(ABL & 16) || v.x == 12345.678f) *reinterpret_cast<f32x4*>(yb + o) = v;
+            if (!a.pool4) {
+              if (pos < a.n) {
+                const long o = pos * COUT + co;
+                if (rb) v += *reinterpret_cast<const f32x4*>(rb + o);
+                if (!(ABL & 16) || v.x == 12345.678f) *reinterpret_cast<f32x4*>(yb + o) = v;
+              }
+            } else {
+              // residual add, then max over the 4 consecutive positions held by lanes 4k..4k+3 (quad
+              // butterflies), lane 4k stores the pooled row: the next stage's MaxPool1d(4) never runs.
+              if (rb && pos < a.n) v += *reinterpret_cast<const f32x4*>(rb + pos * COUT + co);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                float t = v[e];
+                t = fmaxf(t, __shfl_xor(t, 1));
+                t = fmaxf(t, __shfl_xor(t, 2));
+                v[e] = t;
+              }
+              if ((l31 & 3) == 0 && pos + 3 < a.n) *reinterpret_cast<f32x4*>(yb + (pos >> 2) * COUT + co) = v;
             }
           }
         }

@@ -387,11 +387,12 @@ static int launch_conv1d_b16_ns(orca_ctx* ctx, const ConvLayer& L, const ConvB16
 
 // x [B][n][cin], y/r1 [B][n][cout] channel-last.  precision: ORCA_PRECISION_BF16 / _BF16X2 / _BF16X3
 static int launch_conv1d_b16(orca_ctx* ctx, const ConvLayer& L, int precision, const float* x, long x_bs, float* y, long y_bs,
-                             const float* r1, int B, long n, int relu) {
+                             const float* r1, int B, long n, int relu, int pool4 = 0) {
   if (!L.d_wb16) return fail(ORCA_EINVAL, "layer has no bf16 split pack (cin %d)", L.cin);
   if (n <= 0 || B <= 0) return ORCA_OK;
   ConvB16Args a;
   a.x = x; a.w = L.d_wb16; a.bias = L.d_bias; a.y = y; a.r1 = r1; a.x_bs = x_bs; a.y_bs = y_bs; a.n = n;
+  a.pool4 = pool4; a.r_bs = (long)n * L.cout;
   a.cin = L.cin; a.nchunks = L.cin / 16; a.relu = relu; a.stagger = 2;
   a.flag = ctx->d_flag;
   if (precision == ORCA_PRECISION_F16X2) {
@@ -636,7 +637,9 @@ static int encoder_chunk(orca_ctx* ctx, orca_net* net, const float* x, long sx_c
     const int prec = net->precision;
     for (int st = 0; st < 7; ++st) {
       const ConvLayer* L = &net->convs[4 * st];
-      if (kEncPools[st] > 1) {
+      if (kEncPools[st] == 4) {
+        n = n / 4;  // MaxPool1d(4) was fused into the epilogue of the previous stage's last conv
+      } else if (kEncPools[st] > 1) {
         const long n2 = n / kEncPools[st];
         const int Q = (P + 1) % 3;
         ORCA_TRY(launch_pool_nlc(ctx, buf[P], buf[Q], n2, L[0].cin, kEncPools[st]));
@@ -647,7 +650,8 @@ static int encoder_chunk(orca_ctx* ctx, orca_net* net, const float* x, long sx_c
       else ORCA_TRY(launch_conv1d_b16(ctx, L[0], prec, buf[P], 0, buf[T], 0, nullptr, 1, n, 0));
       ORCA_TRY(launch_conv1d_b16(ctx, L[1], prec, buf[T], 0, buf[LO], 0, nullptr, 1, n, 0));
       ORCA_TRY(launch_conv1d_b16(ctx, L[2], prec, buf[LO], 0, buf[T], 0, nullptr, 1, n, 1));
-      ORCA_TRY(launch_conv1d_b16(ctx, L[3], prec, buf[T], 0, buf[P], 0, st < 6 ? buf[LO] : nullptr, 1, n, 1));
+      ORCA_TRY(launch_conv1d_b16(ctx, L[3], prec, buf[T], 0, buf[P], 0, st < 6 ? buf[LO] : nullptr, 1, n, 1,
+                                 (st < 6 && kEncPools[st + 1] == 4) ? 1 : 0));
     }
     *out = buf[P]; *out_ld = -128; *out_n = n;   // negative ld: result is channel-last [n][128]
     return ORCA_OK;

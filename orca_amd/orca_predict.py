@@ -126,39 +126,84 @@ def zoom_index_32m(level, start, mpos, wpos, reverse):
     return int(np.clip(v, 0, 125))
 
 
-def cascade_32m(model, x, mpos, wpos, reverse, distencs=None):
-    """One strand, one model, tensors already on the device: net0 -> net -> six decoders
-    (+ denet_1_pt at 4 kb).  Returns (preds[6] each [B,1,250,250], starts[6] in 4 kb bins).
-    ``distencs``: optional {level: [B,1,250,250] log-background tensor} to skip the upload."""
-    batch = x.shape[0]
-    encs = model.net(model.net0(x))
-    encodings = dict(zip([1, 2, 4, 8, 16, 32], encs))
-    preds, starts, start_index = [], [0], 0
-    for j, level in enumerate([32, 16, 8, 4, 2, 1]):
-        s = int(starts[j] / level)
-        coarse = None
-        if j > 0:
-            coarse = preds[j - 1][:, :, start_index: start_index + 125, start_index: start_index + 125]
-        de = distencs[level] if distencs is not None else _log_background(model.normmats[level], batch, x.is_cuda)
-        preds.append(_decode(model, level, encodings[level][:, :, s: s + 250], de, coarse, level == 1))
-        start_index = zoom_index_32m(level, starts[j], mpos, wpos, reverse)
-        starts.append(starts[j] + start_index * level)
-    return preds, starts[:-1]
+def _gather(t, B, idx, width, dims):
+    """Per-strand crops of a [nstrands*B, ...] tensor (strand k uses offset idx[k]) restacked along the batch axis."""
+    parts = []
+    for k, i in enumerate(idx):
+        sl = t[k * B:(k + 1) * B]
+        for d in dims:
+            sl = sl.narrow(d, i, width)
+        parts.append(sl)
+    return parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)
 
 
-def _merge(allpreds, n_models):
-    """0.5*fwd + 0.5*rev[::-1,::-1], batch row 0 only (orca_predict.py:510-523)."""
-    merged = [[] for _ in range(n_models)]
-    for i in range(n_models):
-        for fwd, rev in zip(allpreds[i], allpreds[i + n_models]):
-            if fwd.is_cuda and fwd.shape[1] == 1:
-                merged[i].append(engine.strand_merge(fwd[0, 0], rev[0, 0]).cpu().numpy())
-                continue
-            f, r = fwd.cpu().detach().numpy(), rev.cpu().detach().numpy()
-            if f.shape[1] == 1:
-                merged[i].append(f[0, 0, :, :] * 0.5 + r[0, 0, ::-1, ::-1] * 0.5)
-            else:
-                merged[i].append(f[0, :, :, :] * 0.5 + r[0, :, ::-1, ::-1] * 0.5)
+def run_cascade(model, encodings, levels, unit, B, reverse_flags, background, zoom, add_1m_level=None, on_level=None):
+    """Coarse-to-fine decoder cascade for several strands AT ONCE: the strands are stacked along the batch axis
+    (strand k = rows k*B..(k+1)*B-1 of every tensor) so each decoder level is ONE batched call - the maps are
+    only 250x250, so batching the two strands fills the GPU twice as well.  Per strand the bookkeeping is exactly
+    the reference's (orca_predict.py:389-500 / :723-838): slice the level's encoding at the strand's current
+    start, crop the previous map at the strand's zoom offset, advance ``starts``.
+
+    encodings: {level: [S*B,128,n]};  unit(level): encoding bins per map pixel at that level;
+    background(level, k, start): [S... ] -> log-background tensor [B or 1,1,250,250] for strand k;
+    zoom(level, start, reverse) -> 0..125.  Returns (preds[level_idx] [S*B,1,250,250], starts[k][level_idx])."""
+    S = len(reverse_flags)
+    starts = [[0] for _ in range(S)]
+    zoom_idx = [0] * S
+    preds = []
+    for j, level in enumerate(levels):
+        u = unit(level)
+        sl = [int(starts[k][j] / u) for k in range(S)]
+        enc = _gather(encodings[level], B, sl, 250, (2,))
+        bgs = [background(level, k, starts[k][j]) for k in range(S)]
+        if all(b is bgs[0] for b in bgs):
+            distenc = bgs[0].expand(S * B, -1, -1, -1)
+        else:
+            distenc = torch.cat([b.expand(B, -1, -1, -1) for b in bgs], dim=0)
+        coarse = _gather(preds[j - 1], B, zoom_idx, 125, (2, 3)) if j > 0 else None
+        preds.append(_decode(model, level, enc, distenc, coarse, level == add_1m_level))
+        if on_level is not None:
+            on_level(j, level, [starts[k][j] for k in range(S)])
+        for k in range(S):
+            zoom_idx[k] = zoom(level, starts[k][j], reverse_flags[k])
+            starts[k].append(starts[k][j] + zoom_idx[k] * u)
+    return preds, [st[:-1] for st in starts]
+
+
+def cascade_32m(model, xs, mpos, wpos, reverse_flags, distencs=None):
+    """32 Mb model on device-resident strands: ``xs`` = list of [B,4,L] tensors (e.g. forward strand and reverse
+    complement), ``reverse_flags`` the matching booleans.  net0 per strand, then Encoder2 and the six decoder
+    levels batched over the strands.  Returns (preds[6] each [S*B,1,250,250], starts[k][6] in 4 kb bins)."""
+    B = xs[0].shape[0]
+    enc0 = torch.cat([model.net0(x) for x in xs], dim=0) if len(xs) > 1 else model.net0(xs[0])
+    encodings = dict(zip([1, 2, 4, 8, 16, 32], model.net(enc0)))
+    cache = {}
+
+    def background(level, k, start):
+        if distencs is not None:
+            return distencs[level]
+        if level not in cache:
+            cache[level] = _log_background(model.normmats[level], 1, enc0.is_cuda)
+        return cache[level]
+
+    return run_cascade(model, encodings, [32, 16, 8, 4, 2, 1], lambda lv: lv, B, list(reverse_flags), background,
+                       lambda lv, st, rev: zoom_index_32m(lv, st, mpos, wpos, rev), add_1m_level=1)
+
+
+def _merge(preds, B):
+    """0.5*fwd + 0.5*rev[::-1,::-1], batch row 0 only (orca_predict.py:510-523).  ``preds``: per level a
+    [2B,C,250,250] tensor, forward strand in rows 0..B-1 and reverse strand in rows B..2B-1."""
+    merged = []
+    for p in preds:
+        fwd, rev = p[0], p[B]
+        if p.is_cuda and p.shape[1] == 1:
+            merged.append(engine.strand_merge(fwd[0], rev[0]).cpu().numpy())
+            continue
+        f, r = fwd.cpu().detach().numpy(), rev.cpu().detach().numpy()
+        if f.shape[0] == 1:
+            merged.append(f[0, :, :] * 0.5 + r[0, ::-1, ::-1] * 0.5)
+        else:
+            merged.append(f[:, :, :] * 0.5 + r[:, ::-1, ::-1] * 0.5)
     return merged
 
 
@@ -168,44 +213,45 @@ def genomepredict(sequence, mchr, mpos=-1, wpos=-1, models=["h1esc", "hff"], tar
     (32, 16, 8, 4, 2, 1 Mb windows, 250x250 each) zooming into ``mpos``.
     ``sequence``: float array [1, 32000000, 4]; ``wpos``: window centre coordinate."""
     models = _resolve_models(models, "32M", use_cuda)
-    n_models = len(models)
     levels = [32, 16, 8, 4, 2, 1]
     batch = sequence.shape[0]
-    allpreds, allstarts, alltargets, allannos = [], [], [], []
+    predictions, allstarts, alltargets, allannos = [], [], [], []
     with torch.no_grad():
-        for iii, x in enumerate(_strands(sequence, use_cuda)):
-            for ii, model in enumerate(models):
-                encs = model.net(model.net0(x))
-                encodings = dict(zip([1, 2, 4, 8, 16, 32], encs))
-                preds, starts, ts, annos = [], [0], [], []
-                start_index = 0
-                for j, level in enumerate(levels):
-                    s = int(starts[j] / level)
-                    coarse = None
-                    if j > 0:
-                        coarse = preds[j - 1][:, :, start_index: start_index + 125, start_index: start_index + 125]
-                    pred = _decode(model, level, encodings[level][:, :, s: s + 250],
-                                   _log_background(model.normmats[level], batch, use_cuda), coarse, level == 1)
-                    if targets and iii == 0:
-                        tgt = targets[ii]
-                        tgt = tgt.numpy() if isinstance(tgt, torch.Tensor) else np.asarray(tgt)
-                        w = 250 * level
-                        tr = _coarse_grain(tgt[:, starts[j]: starts[j] + w, starts[j]: starts[j] + w], level, nan_thresh)
-                        lf = np.log((tr + model.epss[level]) / (model.normmats[level] + model.epss[level]))
-                        ts.append(lf[0, :, :] if tr.shape[0] == 1 else lf)
-                    if annotation is not None and iii == 0:
-                        annos.append(_scale_annotation(annotation, starts[j] / 8000.0, (starts[j] + 250 * level) / 8000.0))
-                    start_index = zoom_index_32m(level, starts[j], mpos, wpos, reverse=(iii != 0))
-                    starts.append(starts[j] + start_index * level)
-                    preds.append(pred)
-                allpreds.append(preds)
-                if iii == 0:
-                    allstarts.append(starts[:-1])
-                    if targets:
-                        alltargets.append(ts)
-                    if annotation is not None:
-                        allannos.append(annos)
-    output = {"predictions": _merge(allpreds, n_models)}
+        xs = list(_strands(sequence, use_cuda))        # forward strand, reverse complement
+        for ii, model in enumerate(models):
+            ts, annos = [], []
+
+            def on_level(j, level, starts_now, model=model, ii=ii, ts=ts, annos=annos):
+                s0 = starts_now[0]                      # bookkeeping follows the forward strand only
+                if targets:
+                    tgt = targets[ii]
+                    tgt = tgt.numpy() if isinstance(tgt, torch.Tensor) else np.asarray(tgt)
+                    w = 250 * level
+                    tr = _coarse_grain(tgt[:, s0: s0 + w, s0: s0 + w], level, nan_thresh)
+                    lf = np.log((tr + model.epss[level]) / (model.normmats[level] + model.epss[level]))
+                    ts.append(lf[0, :, :] if tr.shape[0] == 1 else lf)
+                if annotation is not None:
+                    annos.append(_scale_annotation(annotation, s0 / 8000.0, (s0 + 250 * level) / 8000.0))
+
+            enc0 = torch.cat([model.net0(x) for x in xs], dim=0)
+            encodings = dict(zip([1, 2, 4, 8, 16, 32], model.net(enc0)))
+            bg_cache = {}
+
+            def background(level, k, start, model=model, bg_cache=bg_cache):
+                if level not in bg_cache:
+                    bg_cache[level] = _log_background(model.normmats[level], 1, use_cuda)
+                return bg_cache[level]
+
+            preds, starts = run_cascade(model, encodings, levels, lambda lv: lv, batch, [False, True], background,
+                                        lambda lv, st, rev: zoom_index_32m(lv, st, mpos, wpos, rev), add_1m_level=1,
+                                        on_level=on_level)
+            predictions.append(_merge(preds, batch))
+            allstarts.append(starts[0])
+            if targets:
+                alltargets.append(ts)
+            if annotation is not None:
+                allannos.append(annos)
+    output = {"predictions": predictions}
     output["experiments"] = alltargets if targets else None
     output["start_coords"] = [wpos - 16000000 + s * 4000 for s in allstarts[0]]
     output["end_coords"] = [int(output["start_coords"][ii] + 32000000 / 2 ** (ii)) for ii in range(6)]
@@ -221,69 +267,69 @@ def genomepredict_256Mb(sequence, mchr, normmats, chrlen, mpos=-1, wpos=-1, mode
     (256, 128, 64, 32 Mb).  ``normmats``: one 8000x8000 (32 kb bins) background per model;
     ``chrlen``: length of the (first) chromosome, bounding the zoom."""
     models = _resolve_models(models, "256M", use_cuda)
-    n_models = len(models)
     levels = [256, 128, 64, 32]
     batch = sequence.shape[0]
-    allpreds, allstarts, allnormmats, alltargets, allannos = [], [], [], [], []
+    predictions, allstarts, allnormmats, allnormmats_rev, alltargets, allannos = [], [], [], [], [], []
+
+    def zoom(level, start, reverse):
+        """window offset with chromosome-end bounds (orca_predict.py:813-835)"""
+        half = level * 1000000 / 4
+        if not reverse:
+            proposed = (mpos - half) - (wpos - 128000000 + start * 32000)
+        else:
+            proposed = (mpos - half) - (wpos + 128000000 - start * 32000 - level * 1000000)
+        if chrlen is not None:
+            lo = 0 - (wpos - 128000000)
+            hi = chrlen - level * 1000000 / 2 - (wpos - 128000000)
+            proposed = np.clip(proposed, lo, hi) if lo < hi else lo
+        i = int(np.clip(np.floor(proposed / (4000 * level)), 0, 125))
+        return 250 - (i + 125) if reverse else i
+
     with torch.no_grad():
-        for iii, x in enumerate(_strands(sequence, use_cuda)):
-            for ii, model in enumerate(models):
-                normmat = normmats[ii]
-                isnan = np.isnan(normmat)
-                if np.any(isnan):
-                    normmat[isnan] = np.nanmin(normmat[~isnan])   # in place, as the reference (:664-667)
-                encs = model.net(model.net1(model.net0(x))[-1])
-                encodings = dict(zip([32, 64, 128, 256], encs))
-                preds, starts, ns, ts, annos = [], [0], {}, [], []
-                start_index = 0
-                for j, level in enumerate(levels):
-                    unit = level // 8                      # 32 kb bins per map pixel
-                    w = 250 * unit
-                    ns[level] = _coarse_grain(normmat[None, starts[j]: starts[j] + w, starts[j]: starts[j] + w], unit, 1)
-                    s = int(starts[j] / unit)
-                    coarse = None
-                    if j > 0:
-                        coarse = preds[j - 1][:, :, start_index: start_index + 125, start_index: start_index + 125]
-                    pred = _decode(model, level, encodings[level][:, :, s: s + 250],
-                                   _log_background(ns[level], batch, use_cuda, flip=(iii != 0)), coarse, False)
-                    if targets and iii == 0:
-                        tgt = targets[ii]
-                        tgt = tgt.numpy() if isinstance(tgt, torch.Tensor) else np.asarray(tgt)
-                        tr = _coarse_grain(tgt[:, starts[j]: starts[j] + w, starts[j]: starts[j] + w], unit, nan_thresh)
-                        eps = np.nanmin(ns[level])
-                        lf = np.log((tr + eps) / (ns[level] + eps))
-                        ts.append(lf[0, :, :] if tr.shape[0] == 1 else lf)
-                    if annotation is not None and iii == 0:
-                        annos.append(_scale_annotation(annotation, starts[j] / 8000.0, (starts[j] + w) / 8000.0))
-                    # zoom with chromosome-end bounds (orca_predict.py:813-835)
-                    half = level * 1000000 / 4
-                    if iii == 0:
-                        proposed = (mpos - half) - (wpos - 128000000 + starts[j] * 32000)
-                    else:
-                        proposed = (mpos - half) - (wpos + 128000000 - starts[j] * 32000 - level * 1000000)
-                    if chrlen is not None:
-                        lo = 0 - (wpos - 128000000)
-                        hi = chrlen - level * 1000000 / 2 - (wpos - 128000000)
-                        proposed = np.clip(proposed, lo, hi) if lo < hi else lo
-                    start_index = int(np.clip(np.floor(proposed / (4000 * level)), 0, 125))
-                    if iii != 0:
-                        start_index = 250 - (start_index + 125)
-                    starts.append(starts[j] + start_index * unit)
-                    preds.append(pred)
-                allpreds.append(preds)
-                allnormmats.append(ns)
-                if iii == 0:
-                    allstarts.append(starts[:-1])
-                    if targets:
-                        alltargets.append(ts)
-                    if annotation is not None:
-                        allannos.append(annos)
-    output = {"predictions": _merge(allpreds, n_models)}
+        xs = list(_strands(sequence, use_cuda))
+        for ii, model in enumerate(models):
+            normmat = normmats[ii]
+            isnan = np.isnan(normmat)
+            if np.any(isnan):
+                normmat[isnan] = np.nanmin(normmat[~isnan])   # in place, as the reference (:664-667)
+            ns = [{}, {}]                                     # per strand: {level: coarse-grained background}
+            ts, annos = [], []
+
+            def background(level, k, start, normmat=normmat, ns=ns):
+                w = 250 * (level // 8)
+                ns[k][level] = _coarse_grain(normmat[None, start: start + w, start: start + w], level // 8, 1)
+                return _log_background(ns[k][level], 1, use_cuda, flip=(k != 0))   # flipped on the reverse strand (:703)
+
+            def on_level(j, level, starts_now, ii=ii, ns=ns, ts=ts, annos=annos):
+                s0, w = starts_now[0], 250 * (level // 8)
+                if targets:
+                    tgt = targets[ii]
+                    tgt = tgt.numpy() if isinstance(tgt, torch.Tensor) else np.asarray(tgt)
+                    tr = _coarse_grain(tgt[:, s0: s0 + w, s0: s0 + w], level // 8, nan_thresh)
+                    eps = np.nanmin(ns[0][level])
+                    lf = np.log((tr + eps) / (ns[0][level] + eps))
+                    ts.append(lf[0, :, :] if tr.shape[0] == 1 else lf)
+                if annotation is not None:
+                    annos.append(_scale_annotation(annotation, s0 / 8000.0, (s0 + w) / 8000.0))
+
+            enc0 = torch.cat([model.net0(x) for x in xs], dim=0)
+            encodings = dict(zip([32, 64, 128, 256], model.net(model.net1(enc0)[-1])))
+            preds, starts = run_cascade(model, encodings, levels, lambda lv: lv // 8, batch, [False, True], background, zoom,
+                                        add_1m_level=None, on_level=on_level)
+            predictions.append(_merge(preds, batch))
+            allstarts.append(starts[0])
+            allnormmats.append(ns[0])
+            allnormmats_rev.append(ns[1])
+            if targets:
+                alltargets.append(ts)
+            if annotation is not None:
+                allannos.append(annos)
+    output = {"predictions": predictions}
     output["experiments"] = alltargets if targets else None
     output["start_coords"] = [wpos - 128000000 + s * 32000 for s in allstarts[0]]
     output["end_coords"] = [np.fmin(int(output["start_coords"][ii] + 256000000 / 2 ** (ii)), chrlen) for ii in range(4)]
     output["annos"] = allannos[0] if annotation is not None else None
     output["chr"] = mchr
     output["padding_chr"] = padding_chr
-    output["normmats"] = allnormmats
+    output["normmats"] = allnormmats + allnormmats_rev   # reference order: forward-strand dicts, then reverse-strand
     return output
