@@ -162,7 +162,8 @@ def main():
     # kernel instantiation = (cout, arithmetic); records of the 16-bit split kernels carry tile = -precision
     PREC = {0: ("f32", "conv1d_k9_kernel", PEAK_F32_MFMA_TFLOPS, 1), 1: ("bf16", "conv1d_k9_bf16s_kernel", PEAK_16BIT_MFMA_TFLOPS, 1),
             2: ("bf16x2", "conv1d_k9_bf16s_kernel", PEAK_16BIT_MFMA_TFLOPS, 3), 3: ("bf16x3", "conv1d_k9_bf16s_kernel", PEAK_16BIT_MFMA_TFLOPS, 6),
-            4: ("f16x2", "conv1d_k9_bf16s_kernel", PEAK_16BIT_MFMA_TFLOPS, 3)}
+            4: ("f16x2", "conv1d_k9_bf16s_kernel", PEAK_16BIT_MFMA_TFLOPS, 3),
+            5: ("f16x2", "conv1d_k9_p16_kernel", PEAK_16BIT_MFMA_TFLOPS, 3)}
     inst = {}
     for (cout, cin, tile), g in groups.items():
         prec = -tile if tile < 0 else 0

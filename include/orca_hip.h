@@ -197,6 +197,11 @@ int orca_conv1d_forward(orca_ctx* ctx, const orca_conv_desc* conv, const float* 
  * _BF16X2 / _BF16X3): x [B][n][cin], y and r1 [B][n][cout], all contiguous; cin % 16 == 0. */
 int orca_conv1d_nlc_forward(orca_ctx* ctx, const orca_conv_desc* conv, int precision, const float* x, float* y,
                             const float* r1, int B, int64_t n, int relu);
+/* The P16 / LDS-DMA conv1d of the Encoder's stages 1-3 (conv_p16.h), wrapped for tests: channel-last fp32
+ * in/out (x [n][cin], r1 [n][cout], y [n][cout] or, with out_mode 1 = fused MaxPool1d(4), [n/4][cout]);
+ * out_mode 0/1 round-trip through the planar split-fp16 storage, out_mode 2 writes fp32 directly. */
+int orca_conv1d_p16_forward(orca_ctx* ctx, const orca_conv_desc* conv, const float* x, float* y, const float* r1,
+                            int64_t n, int relu, int out_mode);
 /* y = [relu](conv2d_3x3_dilated(x) + b) [+ r]; x: contiguous [B,cin,n,n], y/r: [B,cout,n,n]. */
 int orca_conv2d_forward(orca_ctx* ctx, const orca_conv_desc* conv, const float* x, float* y, const float* r,
                         int B, int n, int relu);

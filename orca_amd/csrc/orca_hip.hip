@@ -14,6 +14,7 @@
 #include "conv_kernels.h"
 #include "conv_bf16s.h"
 #include "conv2d_f16s.h"
+#include "conv_p16.h"
 #include "misc_kernels.h"
 #include "orca_hip.h"
 
@@ -114,6 +115,7 @@ struct orca_net {
   orca_ctx* ctx = nullptr;
   int kind = 0;
   int precision = ORCA_PRECISION_F32;
+  float* d_first_w = nullptr;   // Encoder: folded [64][4][9] weights of the first layer, unpacked (conv1d_first_p16_kernel)
   int upsample_mode = ORCA_UPSAMPLE_BILINEAR;
   std::vector<ConvLayer> convs;
 };
@@ -421,6 +423,64 @@ static int launch_conv1d_b16(orca_ctx* ctx, const ConvLayer& L, int precision, c
   return ORCA_OK;
 }
 
+// ---- P16 (planar split fp16) conv1d with LDS-DMA staging (conv_p16.h) -------------------------------------
+static inline long p16_plen(long n) { return ((n + 511) / 512) * 512 + 2 * P16_GUARD; }
+
+static int launch_p16_zero_pads(orca_ctx* ctx, float* base, int C, long n_valid) {
+  hipLaunchKernelGGL(p16_zero_pads_kernel, dim3((unsigned)(C / 8 * 2)), dim3(256), 0, ctx->stream, reinterpret_cast<f32x4*>(base),
+                     p16_plen(n_valid), n_valid);
+  LAUNCHCHECK("p16_zero_pads_kernel");
+  return ORCA_OK;
+}
+
+template <int CT, int MW, int NW, int WM>
+static void launch_p16_t(hipStream_t s, ConvP16Args a) {
+  constexpr int MT = WM * MW * 32;
+  static int resident = [] {
+    int dev = 0, ncu = 256, per_cu = 1;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv1d_k9_p16_kernel<CT, MW, NW, WM>, WM * 64, 0) != hipSuccess || per_cu < 1) {
+      (void)hipGetLastError();
+      per_cu = 1;
+    }
+    return ncu * per_cu;
+  }();
+  a.tiles_per_row = (a.n + MT - 1) / MT;
+  const long ntiles = a.tiles_per_row * (a.cout / CT);
+  dim3 grid((unsigned)(ntiles < resident ? ntiles : resident));
+  hipLaunchKernelGGL((conv1d_k9_p16_kernel<CT, MW, NW, WM>), grid, dim3(WM * 64), 0, s, a);
+}
+
+// x: P16 [cin] of n positions; y: P16 (out_mode 0: n positions, 1: n/4 pooled) or fp32 [n][cout] (2); r1: P16 [cout], n
+static int launch_conv1d_p16(orca_ctx* ctx, const ConvLayer& L, const float* x, void* y, const float* r1, long n, int relu,
+                             int out_mode) {
+  if (!L.d_wf16 || L.ksize != 9) return fail(ORCA_EINVAL, "layer has no fp16 split pack");
+  if (!L.f16_ok) return fail(ORCA_EINVAL, "layer weights exceed the fp16 range: use ORCA_PRECISION_BF16X3");
+  if (n <= 0) return ORCA_OK;
+  ConvP16Args a;
+  a.x = reinterpret_cast<const f32x4*>(x); a.w = reinterpret_cast<const f32x4*>(L.d_wf16); a.bias = L.d_bias; a.y = y;
+  a.r1 = reinterpret_cast<const f32x4*>(r1); a.x_plen = p16_plen(n); a.y_plen = p16_plen(out_mode == 1 ? n / 4 : n); a.n = n;
+  a.nchunks = L.cin / 16; a.cout = L.cout; a.relu = relu; a.out_mode = out_mode; a.flag = ctx->d_flag;
+  const bool timed = ctx->timing && n >= 65536;
+  TimedLaunch tl;
+  if (timed) {
+    HIPCHECK(hipEventCreate(&tl.e0));
+    HIPCHECK(hipEventCreate(&tl.e1));
+    HIPCHECK(hipEventRecord(tl.e0, ctx->stream));
+  }
+  if (L.cout == 96) launch_p16_t<96, 1, 3, 8>(ctx->stream, a);
+  else if (L.cout % 64 == 0) launch_p16_t<64, 2, 2, 8>(ctx->stream, a);
+  else return fail(ORCA_EINVAL, "p16 conv1d cout %d unsupported", L.cout);
+  LAUNCHCHECK("conv1d_k9_p16_kernel");
+  if (timed) {
+    HIPCHECK(hipEventRecord(tl.e1, ctx->stream));
+    tl.rec.cout = L.cout; tl.rec.cin = L.cin; tl.rec.tile = -5; tl.rec.batch = 1; tl.rec.n = n; tl.rec.ms = 0.f; tl.rec.pad_ = 0;
+    ctx->timed.push_back(tl);
+  }
+  return ORCA_OK;
+}
+
 static int launch_pool_nlc(orca_ctx* ctx, const float* x, float* y, long n_out, int C, int k) {
   if (n_out <= 0) return ORCA_OK;
   const long total = n_out * (C / 4);
@@ -588,6 +648,11 @@ extern "C" int orca_net_create(orca_ctx* ctx, int kind, const orca_conv_desc* co
     int rc = make_layer(convs[i], &net->convs[i]);
     if (rc != ORCA_OK) { orca_net_free(net); return rc; }
   }
+  if (kind == ORCA_NET_ENCODER) {
+    std::vector<float> w0(convs[0].weight_host, convs[0].weight_host + 64 * 4 * 9);
+    int rc = upload(w0, &net->d_first_w);
+    if (rc != ORCA_OK) { orca_net_free(net); return rc; }
+  }
   *out = net;
   return ORCA_OK;
 }
@@ -606,6 +671,7 @@ extern "C" int orca_net_free(orca_net* net) {
   if (!net) return ORCA_OK;
   if (net->ctx) (void)hipSetDevice(net->ctx->device);
   for (auto& L : net->convs) free_layer(L);
+  if (net->d_first_w) (void)hipFree(net->d_first_w);
   delete net;
   return ORCA_OK;
 }
@@ -629,15 +695,52 @@ static int encoder_chunk(orca_ctx* ctx, orca_net* net, const float* x, long sx_c
   hipStream_t s = ctx->stream;
   int P = 0;
   long n = n1, ld = ld1;
-  hipLaunchKernelGGL(seq_to_channel_major_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, s, x, sx_c, sx_l, n1, buf[P], ld1);
-  LAUNCHCHECK("seq_to_channel_major_kernel");
+  const bool use_p16 = net->precision == ORCA_PRECISION_F16X2 && !getenv("ORCA_NO_P16");
+  if (!use_p16) {
+    hipLaunchKernelGGL(seq_to_channel_major_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, s, x, sx_c, sx_l, n1, buf[P], ld1);
+    LAUNCHCHECK("seq_to_channel_major_kernel");
+  }
   if (net->precision != ORCA_PRECISION_F32) {
     // channel-last pipeline on the bf16 matrix cores (conv_bf16s.h); the 4-channel first layer stays on
     // the fp32 kernel (K = 36, 1 % of the FLOPs) and writes channel-last.
     const int prec = net->precision;
-    for (int st = 0; st < 7; ++st) {
+    int st0 = 0;
+    if (use_p16) {
+      // stages 1-3 (96 % of the FLOPs) on P16 activations with LDS-DMA staging (conv_p16.h)
+      const ConvLayer* L = net->convs.data();
+      FirstP16Args fa;
+      fa.x = x; fa.sc = sx_c; fa.sl = sx_l; fa.n = n1; fa.w = nullptr; fa.bias = L[0].d_bias; fa.y = reinterpret_cast<f32x4*>(buf[1]);
+      fa.y_plen = p16_plen(n1); fa.flag = ctx->d_flag;
+      fa.w = net->d_first_w;
+      ORCA_TRY(launch_p16_zero_pads(ctx, buf[1], 64, n1));
+      hipLaunchKernelGGL(conv1d_first_p16_kernel, dim3((unsigned)((n1 + 255) / 256), 8), dim3(256), 0, s, fa);
+      LAUNCHCHECK("conv1d_first_p16_kernel");
+      int T = 1, LO = 2, S = 0;   // buffer roles: T holds the current input
+      n = n1;
+      for (st0 = 0; st0 < 3; ++st0) {
+        const ConvLayer* Ls = L + 4 * st0;
+        const int C = Ls[3].cout;
+        if (st0 > 0) {  // first conv of the stage: previous (pooled) output in buf[S] -> buf[T]
+          ORCA_TRY(launch_p16_zero_pads(ctx, buf[T], C, n));
+          ORCA_TRY(launch_conv1d_p16(ctx, Ls[0], buf[S], buf[T], nullptr, n, 0, 0));
+        }
+        ORCA_TRY(launch_p16_zero_pads(ctx, buf[LO], C, n));
+        ORCA_TRY(launch_conv1d_p16(ctx, Ls[1], buf[T], buf[LO], nullptr, n, 0, 0));           // lout
+        ORCA_TRY(launch_p16_zero_pads(ctx, buf[T], C, n));
+        ORCA_TRY(launch_conv1d_p16(ctx, Ls[2], buf[LO], buf[T], nullptr, n, 1, 0));
+        if (st0 < 2) {
+          ORCA_TRY(launch_p16_zero_pads(ctx, buf[S], C, n / 4));
+          ORCA_TRY(launch_conv1d_p16(ctx, Ls[3], buf[T], buf[S], buf[LO], n, 1, 1));          // relu(.)+lout, MaxPool1d(4)
+          n /= 4;
+        } else {
+          ORCA_TRY(launch_conv1d_p16(ctx, Ls[3], buf[T], buf[S], buf[LO], n, 1, 2));          // fp32 channel-last hand-over
+        }
+      }
+      P = S;
+    }
+    for (int st = st0; st < 7; ++st) {
       const ConvLayer* L = &net->convs[4 * st];
-      if (kEncPools[st] == 4) {
+      if (kEncPools[st] == 4 && st0 == 0) {
         n = n / 4;  // MaxPool1d(4) was fused into the epilogue of the previous stage's last conv
       } else if (kEncPools[st] > 1) {
         const long n2 = n / kEncPools[st];
@@ -699,7 +802,7 @@ extern "C" int orca_encoder_forward(orca_ctx* ctx, orca_net* net, const float* x
     const long hi = (cb1 == total) ? L : (cb1 * kBinBp + kHaloBp < L ? cb1 * kBinBp + kHaloBp : L);
     if (hi - lo > max_n1) max_n1 = hi - lo;
   }
-  const long ld1 = ru4(max_n1);
+  const long ld1 = ru4(max_n1) + 1024;   // slack: P16 planes are padded to 512 positions + guards
   const size_t per = ru256((size_t)64 * ld1 * sizeof(float));
   ORCA_TRY(ws_ensure(ctx, 3 * per));
   float* buf[3];
@@ -986,6 +1089,39 @@ extern "C" int orca_conv1d_nlc_forward(orca_ctx* ctx, const orca_conv_desc* conv
   ConvLayer L;
   ORCA_TRY(make_layer(*conv, &L));
   int rc = launch_conv1d_b16(ctx, L, precision, x, (long)n * conv->cin, y, (long)n * conv->cout, r1, B, n, relu);
+  (void)hipStreamSynchronize(ctx->stream);
+  free_layer(L);
+  return rc;
+}
+
+extern "C" int orca_conv1d_p16_forward(orca_ctx* ctx, const orca_conv_desc* conv, const float* x, float* y, const float* r1, int64_t n,
+                                       int relu, int out_mode) {
+  if (!ctx || !conv || !x || !y) return fail(ORCA_EINVAL, "orca_conv1d_p16_forward: NULL argument");
+  HIPCHECK(hipSetDevice(ctx->device));
+  ConvLayer L;
+  ORCA_TRY(make_layer(*conv, &L));
+  const long nout = out_mode == 1 ? n / 4 : n;
+  const size_t sx = (size_t)conv->cin * p16_plen(n), sy = (size_t)conv->cout * p16_plen(nout), sr = (size_t)conv->cout * p16_plen(n);
+  int rc = ws_ensure(ctx, ru256(sx * 4) + ru256(sy * 4) + ru256(sr * 4));
+  if (rc == ORCA_OK) {
+    float* xp = ws_take(ctx, sx);
+    float* yp = ws_take(ctx, sy);
+    float* rp = ws_take(ctx, sr);
+    hipStream_t s = ctx->stream;
+    auto blocks = [](long n_, int C) { return dim3((unsigned)((n_ * (C / 4) + 255) / 256)); };
+    (void)launch_p16_zero_pads(ctx, xp, conv->cin, n);
+    hipLaunchKernelGGL(nlc_to_p16_kernel, blocks(n, conv->cin), dim3(256), 0, s, x, reinterpret_cast<f32x4*>(xp), (long)n, conv->cin, p16_plen(n));
+    if (r1) {
+      (void)launch_p16_zero_pads(ctx, rp, conv->cout, n);
+      hipLaunchKernelGGL(nlc_to_p16_kernel, blocks(n, conv->cout), dim3(256), 0, s, r1, reinterpret_cast<f32x4*>(rp), (long)n, conv->cout, p16_plen(n));
+    }
+    if (out_mode != 2) (void)launch_p16_zero_pads(ctx, yp, conv->cout, nout);
+    rc = launch_conv1d_p16(ctx, L, xp, out_mode == 2 ? (void*)y : (void*)yp, r1 ? rp : nullptr, n, relu, out_mode);
+    if (rc == ORCA_OK && out_mode != 2)
+      hipLaunchKernelGGL(p16_to_nlc_kernel, blocks(nout, conv->cout), dim3(256), 0, s, reinterpret_cast<const f32x4*>(yp), y, nout, conv->cout, p16_plen(nout));
+    hipError_t e = hipGetLastError();
+    if (rc == ORCA_OK && e != hipSuccess) rc = fail(ORCA_EHIP, "p16 test path: %s", hipGetErrorString(e));
+  }
   (void)hipStreamSynchronize(ctx->stream);
   free_layer(L);
   return rc;

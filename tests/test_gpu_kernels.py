@@ -110,3 +110,22 @@ def test_conv1d_split_bf16_wide_dynamic_range(cuda):
     ref = F.conv1d(x.double(), torch.from_numpy(w).double(), None, padding=4)
     scale = F.conv1d(x.double().abs(), torch.from_numpy(w).double().abs(), None, padding=4)
     assert float(((y.double() - ref).abs() / scale).max()) < 1e-6
+
+
+@pytest.mark.parametrize("cin,cout,n", [(64, 64, 2000), (64, 64, 513), (64, 96, 1500), (96, 96, 777), (96, 128, 1030), (128, 128, 3000)])
+@pytest.mark.parametrize("out_mode", [0, 1, 2])
+def test_conv1d_p16_dma(cuda, cin, cout, n, out_mode):
+    """conv_p16.h: planar split-fp16 activations + LDS-DMA staging; optional fused MaxPool1d(4); vs torch fp32."""
+    rs = np.random.RandomState(cin + cout + n + out_mode)
+    x = torch.from_numpy(rs.randn(1, cin, n).astype(np.float32))
+    w = (rs.randn(cout, cin, 9) / np.sqrt(cin * 9)).astype(np.float32)
+    b = rs.randn(cout).astype(np.float32) * 0.1
+    r1 = torch.from_numpy(rs.randn(1, cout, n).astype(np.float32))
+    for relu, ra in [(False, None), (True, r1)]:
+        y = engine.conv1d_p16(x[0].t().contiguous().to(cuda), w, b, relu, None if ra is None else ra[0].t().contiguous().to(cuda), out_mode)
+        ref = _ref_conv1d(x, w, b, relu, ra, None)
+        if out_mode == 1:
+            ref = F.max_pool1d(ref, 4, 4)
+        err = float((y.cpu().t()[None] - ref).abs().max())
+        assert y.shape[0] == ref.shape[2]
+        assert err < 2e-5, (cin, cout, n, out_mode, relu, err)

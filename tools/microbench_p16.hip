@@ -1,0 +1,43 @@
+// Ablation micro-benchmark of conv1d_k9_p16_kernel.  hipcc --offload-arch=gfx950 -O3 -std=c++17 -I orca_amd/csrc ...
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#include "conv_p16.h"
+template <int CT, int MW, int NW, int WM, int ABL>
+static void run(ConvP16Args a, const char* what) {
+  constexpr int MT = WM * MW * 32;
+  int per_cu = 1;
+  (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv1d_k9_p16_kernel<CT, MW, NW, WM, ABL>, WM * 64, 0);
+  a.tiles_per_row = (a.n + MT - 1) / MT;
+  long ntiles = a.tiles_per_row * (a.cout / CT), grid = 256L * per_cu; if (grid > ntiles) grid = ntiles;
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  float best = 1e9;
+  for (int r = 0; r < 4; ++r) {
+    hipEventRecord(e0, 0);
+    hipLaunchKernelGGL((conv1d_k9_p16_kernel<CT, MW, NW, WM, ABL>), dim3((unsigned)grid), dim3(WM * 64), 0, 0, a);
+    hipEventRecord(e1, 0); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); if (r > 0 && ms < best) best = ms;
+  }
+  double fl = 2.0 * 9 * a.nchunks * 16 * a.cout * (double)a.n;
+  printf("CT=%d MT=%d cin=%d cout=%d n=%ld ABL=%2d (%s) occ=%d: %.3f ms  %.1f TFLOP/s-eq  [%s]\n", CT, MT, a.nchunks * 16, a.cout, a.n, ABL, what, per_cu, best, fl / best / 1e9, hipGetErrorString(hipGetLastError()));
+}
+int main(int argc, char** argv) {
+  long n = argc > 1 ? atol(argv[1]) : 8000000;
+  const long plen = ((n + 511) / 512) * 512 + 8;
+  f32x4 *x, *y, *w; float* bias;
+  hipMalloc(&x, (size_t)128 * plen * 4); hipMalloc(&y, (size_t)128 * plen * 4); hipMalloc(&w, (size_t)8 * 2 * 9 * 2 * 128 * 16); hipMalloc(&bias, 512);
+  hipMemset(x, 0x2c, (size_t)128 * plen * 4); hipMemset(w, 0x2c, (size_t)8 * 2 * 9 * 2 * 128 * 16); hipMemset(bias, 0, 512);
+  ConvP16Args a{}; a.x = x; a.w = w; a.bias = bias; a.y = y; a.r1 = nullptr; a.x_plen = plen; a.y_plen = plen; a.n = n; a.nchunks = 4; a.cout = 64; a.relu = 1; a.out_mode = 0; a.flag = nullptr;
+  run<64, 2, 2, 8, 0>(a, "full");
+  run<64, 2, 2, 8, 16>(a, "no epilogue stores");
+  run<64, 2, 2, 8, 32>(a, "no epilogue");
+  run<64, 2, 2, 8, 1>(a, "no DMA");
+  run<64, 2, 2, 8, 33>(a, "no DMA, no epilogue");
+  run<64, 2, 2, 8, 41>(a, "MFMA only");
+  run<64, 2, 2, 8, 4>(a, "no MFMA");
+  run<64, 2, 2, 8, 36>(a, "DMA + LDS reads only");
+  run<64, 2, 2, 8, 44>(a, "DMA only");
+  a.out_mode = 2; run<64, 2, 2, 8, 0>(a, "full, fp32 out");
+  a.out_mode = 1; run<64, 2, 2, 8, 0>(a, "full, pooled out");
+  return 0;
+}
