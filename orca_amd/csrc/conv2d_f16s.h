@@ -36,7 +36,7 @@ __global__ __launch_bounds__(512) void conv2d_3x3_f16s_kernel(Conv2dF16Args a) {
   constexpr int XF4 = 3 * PX * 4;         // float4 loads per chunk (3 rows x 256 px x 4 channel quads)
   constexpr int XIT = XF4 / NT;           // 6
   constexpr int WIT = (WU + NT - 1) / NT;
-  __shared__ f32x4 smem[XU + WU];
+  __shared__ f32x4 smem[XU + WU + COUT / 4];   // + bias
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -44,6 +44,8 @@ __global__ __launch_bounds__(512) void conv2d_3x3_f16s_kernel(Conv2dF16Args a) {
   const int y0 = blockIdx.x, b = blockIdx.y, H = a.H, W = a.W, d = a.dil;
   const float* xb = a.x + (long)b * a.x_bs;
   const f32x4* wg = reinterpret_cast<const f32x4*>(a.w);
+  float* bias_s = reinterpret_cast<float*>(smem + XU + WU);
+  if (tid < COUT) bias_s[tid] = a.bias[tid];   // visible after the first barrier
   const long rowpitch = (long)PX * a.xc;
 
   bool rowok[3];
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(512) void conv2d_3x3_f16s_kernel(Conv2dF16Args a) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int co = j * 32 + 8 * q + 4 * g;
-      const f32x4 bias = *reinterpret_cast<const f32x4*>(a.bias + co);
+      const f32x4 bias = *reinterpret_cast<const f32x4*>(bias_s + co);
       f32x4 v;
       v.x = acc[j][4 * q + 0] + bias.x;
       v.y = acc[j][4 * q + 1] + bias.y;

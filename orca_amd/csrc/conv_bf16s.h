@@ -120,13 +120,16 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv1d_k9_bf16s_kernel(ConvB16
   constexpr int WIT = (WU + NT - 1) / NT;
   constexpr int NPROD = NS == 3 ? 6 : (NS == 2 ? 3 : 1);
 
-  __shared__ f32x4 smem[XU + WU];
+  __shared__ f32x4 smem[XU + WU + COUT / 4];   // + bias (read with ds_read in the epilogue: a global load there
+                                               // would make the epilogue wait for the whole in-flight prefetch)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, g = lane >> 5;
+  float* bias_s = reinterpret_cast<float*>(smem + XU + WU);
+  if (tid < COUT) bias_s[tid] = a.bias[tid];   // visible after the first barrier
   const f32x4* wg = reinterpret_cast<const f32x4*>(a.w);
   const long ntiles = a.tiles_per_row * a.batch;
 
@@ -264,7 +267,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv1d_k9_bf16s_kernel(ConvB16
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int co = wn * (NW * 32) + j * 32 + 8 * q + 4 * g;
-            const f32x4 bias = *reinterpret_cast<const f32x4*>(a.bias + co);
+            const f32x4 bias = *reinterpret_cast<const f32x4*>(bias_s + co);
             f32x4 v;
             v.x = acc[i][j][4 * q + 0] + bias.x;
             v.y = acc[i][j][4 * q + 1] + bias.y;

@@ -12,6 +12,9 @@
 //
 // Kernel: persistent workgroups, 8 waves, (tile, chunk) stream as in conv_bf16s.h, but with TWO LDS buffers:
 // the DMA of step s+1 is issued before the MFMA block of step s and lands underneath it; one barrier per step.
+// (Tried and dropped: a de-phased two-group variant - waves 0-3 / 4-7 on different tiles, group B walking its
+// K-chunks in rotated order so both share the W chunk - was correct but 15 % slower: with one barrier per step
+// the step time becomes max(group in epilogue, group in MFMA) twice per tile instead of once.)
 // Arithmetic: 3 fp16 MFMA products per fp32 product (hi*hi + hi*lo + lo*hi), fp32 accumulate.
 #pragma once
 #include <hip/hip_runtime.h>
