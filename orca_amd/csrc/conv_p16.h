@@ -50,6 +50,7 @@ __device__ __forceinline__ void p16_split_store(char* plane_hi, long plen_bytes,
 }
 
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4 p16_load4(const char* plane_hi, long plen_bytes) {
   const f16x4 h = *reinterpret_cast<const f16x4*>(plane_hi), l = *reinterpret_cast<const f16x4*>(plane_hi + plen_bytes);
   f32x4 v;
@@ -319,6 +320,112 @@ __global__ __launch_bounds__(256) void conv1d_first_p16_kernel(FirstP16Args a) {
   p16_split_store(pl, a.y_plen * 16, lo4, true, ovf);
   p16_split_store(pl + 8, a.y_plen * 16, hi4, true, ovf);
   if (ovf && a.flag) *a.flag = 1u;
+}
+
+// ---- first layer on the matrix cores ----------------------------------------------------------------------
+// With the sequence stored [L][4] the 9-tap x 4-channel window of a position is 36 CONTIGUOUS floats, so
+// Conv1d(4,64,k9) is a GEMM with K = tap*4+ci = 36 (padded to 48 = three k16 steps; the pad weights are zero).
+// X operand of lane (pos, g) for k-step kk = the 8 halves at flat index 4*(pos-4) + 16*kk + 8*g of the split
+// window image (8-byte aligned: two ds_read_b64).  Persistent; W stays in LDS; the next tile's window is
+// prefetched to registers under the current tile's MFMAs + epilogue.  HBM-write bound (8 GB P16 output).
+struct FirstMfmaArgs {
+  const float* x;     // [n][4] contiguous fp32
+  long n;
+  const f32x4* w;     // fp16 pack [2 splits][3 ksteps][2 g][64 couts][8]  (units of 16 B), k >= 36 zero
+  const float* bias;
+  f32x4* y;           // P16, 64 channels
+  long y_plen;
+  unsigned* flag;
+};
+
+__global__ __launch_bounds__(256, 2) void conv1d_first_mfma_p16_kernel(FirstMfmaArgs a) {
+  constexpr int MT = 256, WIN = MT + 12;          // positions m0-4 .. m0+MT+7 (9-tap window + k padding overrun)
+  constexpr int WU = 2 * 3 * 2 * 64;              // 768 units
+  __shared__ f32x4 wsm[WU];
+  __shared__ u32x2 xsm[2][WIN];                   // [split][position] -> 4 halves (the 4 channels)
+  __shared__ float bias_s[64];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, g = lane >> 5;
+  const long ntiles = (a.n + MT - 1) / MT;
+  for (int i = tid; i < WU; i += 256) wsm[i] = a.w[i];
+  if (tid < 64) bias_s[tid] = a.bias[tid];
+  bool overflow = false;
+
+  f32x4 xr[2];
+  auto load_win = [&](long t, f32x4& r0, f32x4& r1) {
+    const long p0 = t * MT - 4 + tid, p1 = p0 + 256;
+    r0 = (p0 >= 0 && p0 < a.n) ? *reinterpret_cast<const f32x4*>(a.x + p0 * 4) : (f32x4)(0.f);
+    r1 = (tid < WIN - 256 && p1 < a.n) ? *reinterpret_cast<const f32x4*>(a.x + p1 * 4) : (f32x4)(0.f);
+  };
+  long tile = blockIdx.x;
+  if (tile >= ntiles) return;
+  load_win(tile, xr[0], xr[1]);
+  for (; tile < ntiles; tile += gridDim.x) {
+    __syncthreads();   // previous tile's LDS reads are done
+    {
+      u32x2 sp[2];
+      split4<2, 1>(xr[0], sp, overflow);
+      xsm[0][tid] = sp[0]; xsm[1][tid] = sp[1];
+      if (tid < WIN - 256) {
+        split4<2, 1>(xr[1], sp, overflow);
+        xsm[0][256 + tid] = sp[0]; xsm[1][256 + tid] = sp[1];
+      }
+    }
+    __syncthreads();
+    if (tile + gridDim.x < ntiles) load_win(tile + gridDim.x, xr[0], xr[1]);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 3; ++kk) {
+      f16x8 xv[2][2], wv[2][2];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int pr = wave * 64 + i * 32 + l31 + 4 * kk + 2 * g;   // window position holding k = 16kk + 8g
+          const u32x2 lo = xsm[s][pr], hi = xsm[s][pr + 1];
+          u32x4_t q = {lo.x, lo.y, hi.x, hi.y};
+          xv[s][i] = __builtin_bit_cast(f16x8, q);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) wv[s][j] = __builtin_bit_cast(f16x8, wsm[((s * 3 + kk) * 2 + g) * 64 + j * 32 + l31]);
+      }
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wv[PB[p]][j], xv[PA[p]][i], acc[i][j], 0, 0, 0);
+      }
+    }
+    const long ypl = a.y_plen * 16;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const long pos = tile * MT + wave * 64 + i * 32 + l31;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int co = j * 32 + 8 * q + 4 * g;
+          const f32x4 bias = *reinterpret_cast<const f32x4*>(bias_s + co);
+          f32x4 v;
+          v.x = acc[i][j][4 * q + 0] + bias.x; v.y = acc[i][j][4 * q + 1] + bias.y;
+          v.z = acc[i][j][4 * q + 2] + bias.z; v.w = acc[i][j][4 * q + 3] + bias.w;
+          if (pos < a.n)
+            p16_split_store(reinterpret_cast<char*>(a.y) + (long)(co >> 3) * 2 * ypl + (P16_GUARD + pos) * 16 + g * 8, ypl, v, true, overflow);
+        }
+    }
+  }
+  if (overflow && a.flag) *a.flag = 1u;
 }
 
 // ---- converters (tests, and the stage 3 -> 4 hand-over) -------------------------------------------------

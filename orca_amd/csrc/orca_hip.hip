@@ -116,6 +116,7 @@ struct orca_net {
   int kind = 0;
   int precision = ORCA_PRECISION_F32;
   float* d_first_w = nullptr;   // Encoder: folded [64][4][9] weights of the first layer, unpacked (conv1d_first_p16_kernel)
+  void* d_first_w16 = nullptr;  // same as a K=48 fp16 split pack [2][3][2][64][8] (conv1d_first_mfma_p16_kernel)
   int upsample_mode = ORCA_UPSAMPLE_BILINEAR;
   std::vector<ConvLayer> convs;
 };
@@ -652,6 +653,24 @@ extern "C" int orca_net_create(orca_ctx* ctx, int kind, const orca_conv_desc* co
     std::vector<float> w0(convs[0].weight_host, convs[0].weight_host + 64 * 4 * 9);
     int rc = upload(w0, &net->d_first_w);
     if (rc != ORCA_OK) { orca_net_free(net); return rc; }
+    std::vector<uint16_t> pk((size_t)2 * 3 * 2 * 64 * 8, 0);   // k = tap*4 + ci; k16 step kk, half g, element e
+    for (int co = 0; co < 64; ++co)
+      for (int k = 0; k < 36; ++k) {
+        float v = w0[((size_t)co * 4 + (k & 3)) * 9 + (k >> 2)];
+        const int kk = k / 16, gg = (k % 16) / 8, e = k % 8;
+        for (int sp = 0; sp < 2; ++sp) {
+          const _Float16 hh = (_Float16)v;
+          v -= (float)hh;
+          uint16_t bits;
+          memcpy(&bits, &hh, 2);
+          pk[((((size_t)sp * 3 + kk) * 2 + gg) * 64 + co) * 8 + e] = bits;
+        }
+      }
+    if (hipMalloc(&net->d_first_w16, pk.size() * 2) != hipSuccess ||
+        hipMemcpy(net->d_first_w16, pk.data(), pk.size() * 2, hipMemcpyHostToDevice) != hipSuccess) {
+      orca_net_free(net);
+      return fail(ORCA_EHIP, "first-layer fp16 pack upload failed");
+    }
   }
   *out = net;
   return ORCA_OK;
@@ -672,6 +691,7 @@ extern "C" int orca_net_free(orca_net* net) {
   if (net->ctx) (void)hipSetDevice(net->ctx->device);
   for (auto& L : net->convs) free_layer(L);
   if (net->d_first_w) (void)hipFree(net->d_first_w);
+  if (net->d_first_w16) (void)hipFree(net->d_first_w16);
   delete net;
   return ORCA_OK;
 }
@@ -713,8 +733,17 @@ static int encoder_chunk(orca_ctx* ctx, orca_net* net, const float* x, long sx_c
       fa.y_plen = p16_plen(n1); fa.flag = ctx->d_flag;
       fa.w = net->d_first_w;
       ORCA_TRY(launch_p16_zero_pads(ctx, buf[1], 64, n1));
-      hipLaunchKernelGGL(conv1d_first_p16_kernel, dim3((unsigned)((n1 + 255) / 256), 8), dim3(256), 0, s, fa);
-      LAUNCHCHECK("conv1d_first_p16_kernel");
+      if (sx_c == 1 && sx_l == 4 && al16(x) && !getenv("ORCA_FIRST_VALU")) {
+        FirstMfmaArgs fm;   // K=48 GEMM on the flat [L][4] window
+        fm.x = x; fm.n = n1; fm.w = reinterpret_cast<const f32x4*>(net->d_first_w16); fm.bias = L[0].d_bias;
+        fm.y = reinterpret_cast<f32x4*>(buf[1]); fm.y_plen = p16_plen(n1); fm.flag = ctx->d_flag;
+        const long nt = (n1 + 255) / 256;
+        hipLaunchKernelGGL(conv1d_first_mfma_p16_kernel, dim3((unsigned)(nt < 2048 ? nt : 2048)), dim3(256), 0, s, fm);
+        LAUNCHCHECK("conv1d_first_mfma_p16_kernel");
+      } else {
+        hipLaunchKernelGGL(conv1d_first_p16_kernel, dim3((unsigned)((n1 + 255) / 256), 8), dim3(256), 0, s, fa);
+        LAUNCHCHECK("conv1d_first_p16_kernel");
+      }
       int T = 1, LO = 2, S = 0;   // buffer roles: T holds the current input
       n = n1;
       for (st0 = 0; st0 < 3; ++st0) {

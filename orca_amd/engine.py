@@ -78,6 +78,52 @@ def get_context(device):
 
 
 # ---------------------------------------------------------------------------
+# fp16-range guard policy (see orca_modules._HipModule._run_guarded)
+#   immediate (default): every module forward in "f16x2" checks the device flag right away (one stream sync)
+#   deferred: a caller that runs a whole cascade checks ONCE at the end and reruns it under force_safe()
+# ---------------------------------------------------------------------------
+import contextlib
+
+_guard = {"defer": False, "force_safe": False}
+
+
+@contextlib.contextmanager
+def defer_overflow_guard():
+    old = _guard["defer"]
+    _guard["defer"] = True
+    try:
+        yield
+    finally:
+        _guard["defer"] = old
+
+
+@contextlib.contextmanager
+def force_safe_precision():
+    old = _guard["force_safe"]
+    _guard["force_safe"] = True
+    try:
+        yield
+    finally:
+        _guard["force_safe"] = old
+
+
+def run_with_overflow_retry(fn, device):
+    """Run fn() (a chain of module forwards on ``device``) with ONE fp16-range check at the end instead of one
+    per module; if an activation left the fp16 range anywhere, redo the whole chain in the range-safe arithmetic."""
+    if not (isinstance(device, torch.device) and device.type == "cuda"):
+        return fn()
+    ctx = get_context(device)
+    with defer_overflow_guard():
+        out = fn()
+    if ctx.take_overflow():
+        import warnings
+        warnings.warn("orca_amd: an activation left the fp16 range; recomputing with range-safe arithmetic (bf16x3 / f32)")
+        with force_safe_precision():
+            out = fn()
+    return out
+
+
+# ---------------------------------------------------------------------------
 # BatchNorm folding (host, float64) - checkpoint format of orca_models.py:53-123
 # ---------------------------------------------------------------------------
 def _np64(v):

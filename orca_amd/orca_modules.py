@@ -113,9 +113,10 @@ class _HipModule(nn.Module):
     def _run_guarded(self, net, fn, fallback):
         """Run fn() in self.precision; in the fp16-split mode check the device range flag and redo the
         forward in the range-safe ``fallback`` arithmetic if an activation left the fp16 range."""
-        self._apply_precision(net, self.precision)
+        prec = fallback if (engine._guard["force_safe"] and self.precision == "f16x2") else self.precision
+        self._apply_precision(net, prec)
         out = fn()
-        if self.precision == "f16x2" and net.ctx.take_overflow():
+        if prec == "f16x2" and not engine._guard["defer"] and net.ctx.take_overflow():
             import warnings
             warnings.warn(f"orca_amd.{type(self).__name__}: an activation left the fp16 range; recomputing this forward "
                           f"with precision='{fallback}' (set .precision='{fallback}' to avoid the retry)")

@@ -175,19 +175,22 @@ def cascade_32m(model, xs, mpos, wpos, reverse_flags, distencs=None):
     complement), ``reverse_flags`` the matching booleans.  net0 per strand, then Encoder2 and the six decoder
     levels batched over the strands.  Returns (preds[6] each [S*B,1,250,250], starts[k][6] in 4 kb bins)."""
     B = xs[0].shape[0]
-    enc0 = torch.cat([model.net0(x) for x in xs], dim=0) if len(xs) > 1 else model.net0(xs[0])
-    encodings = dict(zip([1, 2, 4, 8, 16, 32], model.net(enc0)))
     cache = {}
 
     def background(level, k, start):
         if distencs is not None:
             return distencs[level]
         if level not in cache:
-            cache[level] = _log_background(model.normmats[level], 1, enc0.is_cuda)
+            cache[level] = _log_background(model.normmats[level], 1, xs[0].is_cuda)
         return cache[level]
 
-    return run_cascade(model, encodings, [32, 16, 8, 4, 2, 1], lambda lv: lv, B, list(reverse_flags), background,
-                       lambda lv, st, rev: zoom_index_32m(lv, st, mpos, wpos, rev), add_1m_level=1)
+    def forward():
+        enc0 = torch.cat([model.net0(x) for x in xs], dim=0) if len(xs) > 1 else model.net0(xs[0])
+        encodings = dict(zip([1, 2, 4, 8, 16, 32], model.net(enc0)))
+        return run_cascade(model, encodings, [32, 16, 8, 4, 2, 1], lambda lv: lv, B, list(reverse_flags), background,
+                           lambda lv, st, rev: zoom_index_32m(lv, st, mpos, wpos, rev), add_1m_level=1)
+
+    return engine.run_with_overflow_retry(forward, xs[0].device)
 
 
 def _merge(preds, B):
@@ -233,8 +236,6 @@ def genomepredict(sequence, mchr, mpos=-1, wpos=-1, models=["h1esc", "hff"], tar
                 if annotation is not None:
                     annos.append(_scale_annotation(annotation, s0 / 8000.0, (s0 + 250 * level) / 8000.0))
 
-            enc0 = torch.cat([model.net0(x) for x in xs], dim=0)
-            encodings = dict(zip([1, 2, 4, 8, 16, 32], model.net(enc0)))
             bg_cache = {}
 
             def background(level, k, start, model=model, bg_cache=bg_cache):
@@ -242,9 +243,15 @@ def genomepredict(sequence, mchr, mpos=-1, wpos=-1, models=["h1esc", "hff"], tar
                     bg_cache[level] = _log_background(model.normmats[level], 1, use_cuda)
                 return bg_cache[level]
 
-            preds, starts = run_cascade(model, encodings, levels, lambda lv: lv, batch, [False, True], background,
-                                        lambda lv, st, rev: zoom_index_32m(lv, st, mpos, wpos, rev), add_1m_level=1,
-                                        on_level=on_level)
+            def forward(model=model, background=background, on_level=on_level, ts=ts, annos=annos):
+                del ts[:], annos[:]
+                enc0 = torch.cat([model.net0(x) for x in xs], dim=0)
+                encodings = dict(zip([1, 2, 4, 8, 16, 32], model.net(enc0)))
+                return run_cascade(model, encodings, levels, lambda lv: lv, batch, [False, True], background,
+                                   lambda lv, st, rev: zoom_index_32m(lv, st, mpos, wpos, rev), add_1m_level=1,
+                                   on_level=on_level)
+
+            preds, starts = engine.run_with_overflow_retry(forward, xs[0].device)
             predictions.append(_merge(preds, batch))
             allstarts.append(starts[0])
             if targets:
@@ -312,10 +319,14 @@ def genomepredict_256Mb(sequence, mchr, normmats, chrlen, mpos=-1, wpos=-1, mode
                 if annotation is not None:
                     annos.append(_scale_annotation(annotation, s0 / 8000.0, (s0 + w) / 8000.0))
 
-            enc0 = torch.cat([model.net0(x) for x in xs], dim=0)
-            encodings = dict(zip([32, 64, 128, 256], model.net(model.net1(enc0)[-1])))
-            preds, starts = run_cascade(model, encodings, levels, lambda lv: lv // 8, batch, [False, True], background, zoom,
-                                        add_1m_level=None, on_level=on_level)
+            def forward(model=model, background=background, on_level=on_level, ts=ts, annos=annos):
+                del ts[:], annos[:]
+                enc0 = torch.cat([model.net0(x) for x in xs], dim=0)
+                encodings = dict(zip([32, 64, 128, 256], model.net(model.net1(enc0)[-1])))
+                return run_cascade(model, encodings, levels, lambda lv: lv // 8, batch, [False, True], background, zoom,
+                                   add_1m_level=None, on_level=on_level)
+
+            preds, starts = engine.run_with_overflow_retry(forward, xs[0].device)
             predictions.append(_merge(preds, batch))
             allstarts.append(starts[0])
             allnormmats.append(ns[0])

@@ -28,16 +28,14 @@ int main(int argc, char** argv) {
   hipMalloc(&x, (size_t)128 * plen * 4); hipMalloc(&y, (size_t)128 * plen * 4); hipMalloc(&w, (size_t)8 * 2 * 9 * 2 * 128 * 16); hipMalloc(&bias, 512);
   hipMemset(x, 0x2c, (size_t)128 * plen * 4); hipMemset(w, 0x2c, (size_t)8 * 2 * 9 * 2 * 128 * 16); hipMemset(bias, 0, 512);
   ConvP16Args a{}; a.x = x; a.w = w; a.bias = bias; a.y = y; a.r1 = nullptr; a.x_plen = plen; a.y_plen = plen; a.n = n; a.nchunks = 4; a.cout = 64; a.relu = 1; a.out_mode = 0; a.flag = nullptr;
-  run<64, 2, 2, 8, 0>(a, "full");
-  run<64, 2, 2, 8, 16>(a, "no epilogue stores");
-  run<64, 2, 2, 8, 32>(a, "no epilogue");
-  run<64, 2, 2, 8, 1>(a, "no DMA");
-  run<64, 2, 2, 8, 33>(a, "no DMA, no epilogue");
-  run<64, 2, 2, 8, 41>(a, "MFMA only");
-  run<64, 2, 2, 8, 4>(a, "no MFMA");
-  run<64, 2, 2, 8, 36>(a, "DMA + LDS reads only");
-  run<64, 2, 2, 8, 44>(a, "DMA only");
-  a.out_mode = 2; run<64, 2, 2, 8, 0>(a, "full, fp32 out");
-  a.out_mode = 1; run<64, 2, 2, 8, 0>(a, "full, pooled out");
+  for (int round = 0; round < 4; ++round) {
+    printf("-- round %d\n", round);
+    a.out_mode = 0;
+    run<64, 2, 2, 8, 0>(a, "full, sched_barrier");
+    run<64, 2, 2, 8, 64>(a, "full, no sched_barrier");
+    run<64, 2, 2, 8, 16>(a, "no stores, sched_barrier");
+    run<64, 2, 2, 8, 80>(a, "no stores, no sched_barrier");
+    run<64, 2, 2, 8, 4>(a, "no MFMA");
+  }
   return 0;
 }
