@@ -26,6 +26,13 @@ int main(int argc, char** argv) {
   const long plen = ((n + 511) / 512) * 512 + 8;
   f32x4 *x, *y, *w; float* bias;
   hipMalloc(&x, (size_t)128 * plen * 4); hipMalloc(&y, (size_t)128 * plen * 4); hipMalloc(&w, (size_t)8 * 2 * 9 * 2 * 128 * 16); hipMalloc(&bias, 512);
+  if (argc > 2) {   // random fp16 content (hi ~ U(-1,1), lo tiny) instead of a constant fill: realistic switching activity
+    std::vector<unsigned short> hx((size_t)64 * plen * 2);
+    unsigned s = 1234567u;
+    for (auto& v : hx) { s = s * 1664525u + 1013904223u; v = (unsigned short)(((s >> 9) & 0x8fff) | 0x3000); }
+    hipMemcpy(x, hx.data(), hx.size() * 2, hipMemcpyHostToDevice);
+    printf("random activations\n");
+  } else
   hipMemset(x, 0x2c, (size_t)128 * plen * 4); hipMemset(w, 0x2c, (size_t)8 * 2 * 9 * 2 * 128 * 16); hipMemset(bias, 0, 512);
   ConvP16Args a{}; a.x = x; a.w = w; a.bias = bias; a.y = y; a.r1 = nullptr; a.x_plen = plen; a.y_plen = plen; a.n = n; a.nchunks = 4; a.cout = 64; a.relu = 1; a.out_mode = 0; a.flag = nullptr;
   for (int round = 0; round < 4; ++round) {
