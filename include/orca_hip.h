@@ -154,6 +154,18 @@ int orca_encoder_forward(orca_ctx* ctx, orca_net* net, const float* x, int64_t s
                          int64_t sx_l, int B, int64_t L, int64_t bin_lo, int64_t bin_hi, float* out,
                          int64_t so_b, int64_t so_c, int64_t chunk_bp);
 
+/* Packed-sequence input.  The reference materialises every window as a 512 MB float [L,4] array per strand
+ * (selene_utils2.py:216-272) and a second, flipped copy for the reverse complement (orca_predict.py:324-329).
+ * orca_pack_sequence turns a float view (device) into 1 byte per base - 0..3 = A,C,G,T one-hot rows, 4 = the
+ * 0.25 x 4 'N' row - and reports *packable = 0 if some row is neither (the float path must then be used; it
+ * synchronises the stream to return that flag).  orca_encoder_forward_codes runs the Encoder straight from the
+ * codes ([B][L] bytes, batch stride sc_b); reverse != 0 encodes the REVERSE COMPLEMENT of the same buffer
+ * (index L-1-i, code 3-c), so no second sequence copy ever exists.  The one-hot expansion happens in LDS inside
+ * the first-layer kernel. */
+int orca_pack_sequence(orca_ctx* ctx, const float* x, int64_t sx_c, int64_t sx_l, int64_t L, uint8_t* codes_out, int* packable);
+int orca_encoder_forward_codes(orca_ctx* ctx, orca_net* net, const uint8_t* codes, int64_t sc_b, int reverse, int B, int64_t L,
+                               int64_t bin_lo, int64_t bin_hi, float* out, int64_t so_b, int64_t so_c, int64_t chunk_bp);
+
 /* Number of 4 kb bins Encoder emits for an L-bp input (floor through the
  * 4,4,5,5,5,2 pooling chain). */
 int64_t orca_encoder_num_bins(int64_t L);

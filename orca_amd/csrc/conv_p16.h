@@ -329,7 +329,12 @@ __global__ __launch_bounds__(256) void conv1d_first_p16_kernel(FirstP16Args a) {
 // window image (8-byte aligned: two ds_read_b64).  Persistent; W stays in LDS; the next tile's window is
 // prefetched to registers under the current tile's MFMAs + epilogue.  HBM-write bound (8 GB P16 output).
 struct FirstMfmaArgs {
-  const float* x;     // [n][4] contiguous fp32
+  const float* x;     // [n][4] contiguous fp32, or NULL when `codes` is given
+  // packed input: 1 byte per base (0..3 = A,C,G,T one-hot rows, 4 = N = 0.25 x 4, other = zero row).  The chunk's
+  // position p is strand position off+p; on the reverse strand that is base L-1-(off+p), complemented (3-code).
+  const unsigned char* codes;
+  long codes_L, codes_off;
+  int reverse;
   long n;
   const f32x4* w;     // fp16 pack [2 splits][3 ksteps][2 g][64 couts][8]  (units of 16 B), k >= 36 zero
   const float* bias;
@@ -353,10 +358,20 @@ __global__ __launch_bounds__(256, 2) void conv1d_first_mfma_p16_kernel(FirstMfma
   bool overflow = false;
 
   f32x4 xr[2];
+  auto fetch = [&](long p) -> f32x4 {
+    if (p < 0 || p >= a.n) return (f32x4)(0.f);
+    if (!a.codes) return *reinterpret_cast<const f32x4*>(a.x + p * 4);
+    const long P = a.codes_off + p;
+    int c = a.reverse ? a.codes[a.codes_L - 1 - P] : a.codes[P];
+    if (a.reverse && c < 4) c = 3 - c;
+    f32x4 v = (f32x4)(c == 4 ? 0.25f : 0.f);   // LDS-staged one-hot expansion of the packed base
+    if (c < 4) v[c] = 1.f;
+    return v;
+  };
   auto load_win = [&](long t, f32x4& r0, f32x4& r1) {
-    const long p0 = t * MT - 4 + tid, p1 = p0 + 256;
-    r0 = (p0 >= 0 && p0 < a.n) ? *reinterpret_cast<const f32x4*>(a.x + p0 * 4) : (f32x4)(0.f);
-    r1 = (tid < WIN - 256 && p1 < a.n) ? *reinterpret_cast<const f32x4*>(a.x + p1 * 4) : (f32x4)(0.f);
+    const long p0 = t * MT - 4 + tid;
+    r0 = fetch(p0);
+    r1 = (tid < WIN - 256) ? fetch(p0 + 256) : (f32x4)(0.f);
   };
   long tile = blockIdx.x;
   if (tile >= ntiles) return;
@@ -426,6 +441,38 @@ __global__ __launch_bounds__(256, 2) void conv1d_first_mfma_p16_kernel(FirstMfma
     }
   }
   if (overflow && a.flag) *a.flag = 1u;
+}
+
+// ---- packed sequence helpers --------------------------------------------------------------------------------
+// [L][4] float rows (element strides sc, sl) -> 1-byte codes; *bad is raised for rows that are neither one-hot nor N
+__global__ void pack_sequence_kernel(const float* __restrict__ x, long sc, long sl, long L, unsigned char* __restrict__ codes,
+                                     unsigned* __restrict__ bad) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= L) return;
+  float v[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) v[c] = x[i * sl + c * sc];
+  int code = 5;
+  if (v[0] == 0.25f && v[1] == 0.25f && v[2] == 0.25f && v[3] == 0.25f) code = 4;
+  else {
+    int ones = 0, zeros = 0, which = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { if (v[c] == 1.f) { ++ones; which = c; } else if (v[c] == 0.f) ++zeros; }
+    if (ones == 1 && zeros == 3) code = which;
+  }
+  if (code == 5) *bad = 1u;
+  codes[i] = (unsigned char)code;
+}
+// codes -> [n][4] fp32 rows of strand positions off .. off+n-1 (used by the non-P16 arithmetic modes)
+__global__ void expand_codes_kernel(const unsigned char* __restrict__ codes, long L, long off, int reverse, long n, float* __restrict__ y) {
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const long P = off + p;
+  int c = reverse ? codes[L - 1 - P] : codes[P];
+  if (reverse && c < 4) c = 3 - c;
+  f32x4 v = (f32x4)(c == 4 ? 0.25f : 0.f);
+  if (c < 4) v[c] = 1.f;
+  reinterpret_cast<f32x4*>(y)[p] = v;
 }
 
 // ---- converters (tests, and the stage 3 -> 4 hand-over) -------------------------------------------------

@@ -529,7 +529,7 @@ extern "C" int orca_ctx_create(int device, void* hip_stream, orca_ctx** out) {
   orca_ctx* c = new orca_ctx();
   c->device = device;
   c->stream = static_cast<hipStream_t>(hip_stream);
-  if (hipMalloc(reinterpret_cast<void**>(&c->d_flag), sizeof(unsigned)) != hipSuccess || hipMemset(c->d_flag, 0, sizeof(unsigned)) != hipSuccess) {
+  if (hipMalloc(reinterpret_cast<void**>(&c->d_flag), 4 * sizeof(unsigned)) != hipSuccess || hipMemset(c->d_flag, 0, 4 * sizeof(unsigned)) != hipSuccess) {
     delete c;
     return fail(ORCA_ENOMEM, "could not allocate the context flag word");
   }
@@ -710,12 +710,29 @@ extern "C" int64_t orca_encoder_num_bins(int64_t L) {
 }
 
 // One chunk: x (strided [4][n1]) -> 128 x n7 in the returned buffer.
-static int encoder_chunk(orca_ctx* ctx, orca_net* net, const float* x, long sx_c, long sx_l, long n1, float* const buf[3],
+struct SeqSource {            // where a chunk's input comes from: a float [.,4] view or packed base codes
+  const float* x = nullptr;   // already offset to the chunk start
+  long sx_c = 0, sx_l = 0;
+  const unsigned char* codes = nullptr;   // whole sequence of this batch row
+  long codes_L = 0, codes_off = 0;
+  int reverse = 0;
+};
+
+static int encoder_chunk(orca_ctx* ctx, orca_net* net, const SeqSource& src, long n1, float* const buf[3],
                          long ld1, float** out, long* out_ld, long* out_n) {
   hipStream_t s = ctx->stream;
   int P = 0;
   long n = n1, ld = ld1;
+  const float* x = src.x;
+  long sx_c = src.sx_c, sx_l = src.sx_l;
   const bool use_p16 = net->precision == ORCA_PRECISION_F16X2 && !getenv("ORCA_NO_P16");
+  if (src.codes && !use_p16) {
+    // the other arithmetic modes start from float rows: expand the packed bases into buf[2] as [n][4]
+    hipLaunchKernelGGL(expand_codes_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, s, src.codes, src.codes_L, src.codes_off,
+                       src.reverse, n1, buf[2]);
+    LAUNCHCHECK("expand_codes_kernel");
+    x = buf[2]; sx_c = 1; sx_l = 4;
+  }
   if (!use_p16) {
     hipLaunchKernelGGL(seq_to_channel_major_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, s, x, sx_c, sx_l, n1, buf[P], ld1);
     LAUNCHCHECK("seq_to_channel_major_kernel");
@@ -733,9 +750,10 @@ static int encoder_chunk(orca_ctx* ctx, orca_net* net, const float* x, long sx_c
       fa.y_plen = p16_plen(n1); fa.flag = ctx->d_flag;
       fa.w = net->d_first_w;
       ORCA_TRY(launch_p16_zero_pads(ctx, buf[1], 64, n1));
-      if (sx_c == 1 && sx_l == 4 && al16(x) && !getenv("ORCA_FIRST_VALU")) {
-        FirstMfmaArgs fm;   // K=48 GEMM on the flat [L][4] window
-        fm.x = x; fm.n = n1; fm.w = reinterpret_cast<const f32x4*>(net->d_first_w16); fm.bias = L[0].d_bias;
+      if (src.codes || (sx_c == 1 && sx_l == 4 && al16(x) && !getenv("ORCA_FIRST_VALU"))) {
+        FirstMfmaArgs fm;   // K=48 GEMM on the flat [L][4] window (or straight from the packed bases)
+        fm.x = src.codes ? nullptr : x; fm.n = n1;
+        fm.codes = src.codes; fm.codes_L = src.codes_L; fm.codes_off = src.codes_off; fm.reverse = src.reverse; fm.w = reinterpret_cast<const f32x4*>(net->d_first_w16); fm.bias = L[0].d_bias;
         fm.y = reinterpret_cast<f32x4*>(buf[1]); fm.y_plen = p16_plen(n1); fm.flag = ctx->d_flag;
         const long nt = (n1 + 255) / 256;
         hipLaunchKernelGGL(conv1d_first_mfma_p16_kernel, dim3((unsigned)(nt < 2048 ? nt : 2048)), dim3(256), 0, s, fm);
@@ -808,10 +826,11 @@ static int encoder_chunk(orca_ctx* ctx, orca_net* net, const float* x, long sx_c
   return ORCA_OK;
 }
 
-extern "C" int orca_encoder_forward(orca_ctx* ctx, orca_net* net, const float* x, int64_t sx_b, int64_t sx_c, int64_t sx_l,
-                                    int B, int64_t L, int64_t bin_lo, int64_t bin_hi, float* out, int64_t so_b,
-                                    int64_t so_c, int64_t chunk_bp) {
-  if (!ctx || !net || !x || !out) return fail(ORCA_EINVAL, "orca_encoder_forward: NULL argument");
+static int encoder_forward_impl(orca_ctx* ctx, orca_net* net, const float* x, int64_t sx_b, int64_t sx_c, int64_t sx_l,
+                                const unsigned char* codes, int64_t sc_b, int reverse,
+                                int B, int64_t L, int64_t bin_lo, int64_t bin_hi, float* out, int64_t so_b,
+                                int64_t so_c, int64_t chunk_bp) {
+  if (!ctx || !net || (!x && !codes) || !out) return fail(ORCA_EINVAL, "orca_encoder_forward: NULL argument");
   if (net->kind != ORCA_NET_ENCODER) return fail(ORCA_EINVAL, "orca_encoder_forward: net is not an Encoder");
   HIPCHECK(hipSetDevice(ctx->device));
   const long total = orca_encoder_num_bins(L);
@@ -842,7 +861,10 @@ extern "C" int orca_encoder_forward(orca_ctx* ctx, orca_net* net, const float* x
       const long lo = cb0 * kBinBp - kHaloBp > 0 ? cb0 * kBinBp - kHaloBp : 0;
       const long hi = (cb1 == total) ? L : (cb1 * kBinBp + kHaloBp < L ? cb1 * kBinBp + kHaloBp : L);
       float* res; long rld, rn;
-      ORCA_TRY(encoder_chunk(ctx, net, x + (long)b * sx_b + lo * sx_l, sx_c, sx_l, hi - lo, buf, ru4(hi - lo), &res, &rld, &rn));
+      SeqSource src;
+      if (codes) { src.codes = codes + (long)b * sc_b; src.codes_L = L; src.codes_off = lo; src.reverse = reverse; }
+      else { src.x = x + (long)b * sx_b + lo * sx_l; src.sx_c = sx_c; src.sx_l = sx_l; }
+      ORCA_TRY(encoder_chunk(ctx, net, src, hi - lo, buf, ru4(hi - lo), &res, &rld, &rn));
       const long keep = cb0 - lo / kBinBp;
       if (keep + (cb1 - cb0) > rn) return fail(ORCA_EINVAL, "internal: chunk produced %ld bins, need %ld", rn, keep + (cb1 - cb0));
       if (rld < 0)  // channel-last result [bins][128] -> out[c][bin]
@@ -851,6 +873,31 @@ extern "C" int orca_encoder_forward(orca_ctx* ctx, orca_net* net, const float* x
         ORCA_TRY(launch_copy2d(ctx, res + keep, rld, 1, out + (long)b * so_b + (cb0 - bin_lo), so_c, 128, cb1 - cb0));
     }
   }
+  return ORCA_OK;
+}
+
+extern "C" int orca_encoder_forward(orca_ctx* ctx, orca_net* net, const float* x, int64_t sx_b, int64_t sx_c, int64_t sx_l,
+                                    int B, int64_t L, int64_t bin_lo, int64_t bin_hi, float* out, int64_t so_b,
+                                    int64_t so_c, int64_t chunk_bp) {
+  return encoder_forward_impl(ctx, net, x, sx_b, sx_c, sx_l, nullptr, 0, 0, B, L, bin_lo, bin_hi, out, so_b, so_c, chunk_bp);
+}
+
+extern "C" int orca_encoder_forward_codes(orca_ctx* ctx, orca_net* net, const uint8_t* codes, int64_t sc_b, int reverse, int B,
+                                          int64_t L, int64_t bin_lo, int64_t bin_hi, float* out, int64_t so_b, int64_t so_c,
+                                          int64_t chunk_bp) {
+  return encoder_forward_impl(ctx, net, nullptr, 0, 0, 0, codes, sc_b, reverse, B, L, bin_lo, bin_hi, out, so_b, so_c, chunk_bp);
+}
+
+extern "C" int orca_pack_sequence(orca_ctx* ctx, const float* x, int64_t sx_c, int64_t sx_l, int64_t L, uint8_t* codes, int* packable) {
+  if (!ctx || !x || !codes || !packable) return fail(ORCA_EINVAL, "orca_pack_sequence: NULL argument");
+  HIPCHECK(hipSetDevice(ctx->device));
+  HIPCHECK(hipMemsetAsync(ctx->d_flag + 1, 0, sizeof(unsigned), ctx->stream));
+  hipLaunchKernelGGL(pack_sequence_kernel, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, ctx->stream, x, sx_c, sx_l, L, codes, ctx->d_flag + 1);
+  LAUNCHCHECK("pack_sequence_kernel");
+  unsigned h = 0;
+  HIPCHECK(hipMemcpyAsync(&h, ctx->d_flag + 1, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHECK(hipStreamSynchronize(ctx->stream));
+  *packable = h ? 0 : 1;
   return ORCA_OK;
 }
 

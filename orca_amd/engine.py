@@ -207,6 +207,39 @@ def encoder_forward(net, x, bin_lo=0, bin_hi=0, chunk_bp=0, out=None):
     return out
 
 
+def pack_sequence(x):
+    """x: [B,4,L] float ROCm tensor (any strides) -> (codes uint8 [B,L], packable).  ``packable`` is False if some
+    row is neither one-hot nor the 0.25 'N' row; the codes are then meaningless and the float path must be used."""
+    x = _f32_cuda(x, "x")
+    B, C, L = x.shape
+    if C != 4:
+        raise ValueError(f"sequence must be [B,4,L], got {tuple(x.shape)}")
+    codes = torch.empty((B, L), dtype=torch.uint8, device=x.device)
+    ctx = get_context(x.device)
+    ok = True
+    for b in range(B):
+        flag = ctypes.c_int()
+        check(_lib.load().orca_pack_sequence(ctx.handle, ctypes.c_void_p(x[b].data_ptr()), x.stride(1), x.stride(2), L,
+                                             ctypes.c_void_p(codes[b].data_ptr()), ctypes.byref(flag)), "orca_pack_sequence")
+        ok = ok and bool(flag.value)
+    return codes, ok
+
+
+def encoder_forward_codes(net, codes, reverse=False, bin_lo=0, bin_hi=0, chunk_bp=0):
+    if not (isinstance(codes, torch.Tensor) and codes.is_cuda and codes.dtype == torch.uint8 and codes.dim() == 2):
+        raise ValueError("codes must be a [B,L] uint8 ROCm tensor")
+    if codes.stride(1) != 1:
+        codes = codes.contiguous()
+    B, L = codes.shape
+    total = encoder_num_bins(L)
+    hi = total if bin_hi <= 0 else bin_hi
+    out = torch.empty((B, 128, hi - bin_lo), dtype=torch.float32, device=codes.device)
+    net.ctx.sync_stream()
+    check(_lib.load().orca_encoder_forward_codes(net.ctx.handle, net.handle, _p(codes), codes.stride(0), 1 if reverse else 0, B, L,
+                                                 bin_lo, hi, _p(out), out.stride(0), out.stride(1), chunk_bp), "orca_encoder_forward_codes")
+    return out
+
+
 def unet_forward(net, x, nlev):
     x = _f32_cuda(x, "x")
     if x.dim() != 3 or x.shape[1] != 128:

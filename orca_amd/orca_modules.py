@@ -164,6 +164,15 @@ class Encoder(_HipModule):
         return self._run_guarded(net, lambda: engine.encoder_forward(net, x, bin_lo, bin_hi, chunk_bp), "bf16x3")
 
 
+    def forward_codes(self, codes, reverse=False, bin_lo=0, bin_hi=0, chunk_bp=0):
+        """Encoder straight from packed bases: ``codes`` [B,L] uint8 on the MI355X (0..3 = A,C,G,T, 4 = N, see
+        engine.pack_sequence).  ``reverse=True`` encodes the reverse complement of the same buffer."""
+        net = self._net(codes.device)
+        return self._run_guarded(net, lambda: engine.encoder_forward_codes(net, codes, reverse, bin_lo, bin_hi, chunk_bp), "bf16x3")
+
+    forward_codes.__doc__ += "  (Replaces the float [B,4,L] input of orca_predict.py:334.)"
+
+
 class _UNetEncoder(_HipModule):
     _nlev = 0
 

@@ -48,15 +48,55 @@ def _resolve_models(models, group, use_cuda):
     return objs
 
 
-def _strands(sequence, use_cuda):
-    """Forward strand and reverse complement (flip of the length AND channel axes,
-    orca_predict.py:324-329) as [B,4,L] views of [B,L,4] storage."""
-    seq = np.asarray(sequence, dtype=np.float32)
-    for s in (seq, seq[:, ::-1, ::-1]):
-        t = torch.from_numpy(np.ascontiguousarray(s))
-        if use_cuda:
-            t = t.cuda()
-        yield t.transpose(1, 2)
+class _StrandInputs:
+    """The two strands of a [B,L,4] float sequence as the models want them.
+
+    Reference (orca_predict.py:324-337): the reverse complement is a second, flipped 512 MB host copy
+    (`sequence[:, ::-1, ::-1].copy()`), and each strand is uploaded per model.  Here the forward strand is
+    uploaded ONCE; if every row is one-hot or the 0.25 'N' row it is packed to 1 byte per base on the device and an
+    orca_amd Encoder encodes both strands from that one buffer (reverse complement = index/ code flip inside the
+    first-layer kernel).  Anything else (arbitrary floats, foreign models, CPU) uses float views as the reference does."""
+
+    def __init__(self, sequence, use_cuda):
+        self.seq = np.asarray(sequence, dtype=np.float32)
+        self.use_cuda = use_cuda
+        self.batch = self.seq.shape[0]
+        self._fwd = self._rev = self._codes = None
+        self._packable = None
+
+    @property
+    def device(self):
+        return self.fwd.device
+
+    @property
+    def fwd(self):
+        if self._fwd is None:
+            t = torch.from_numpy(np.ascontiguousarray(self.seq))
+            self._fwd = (t.cuda() if self.use_cuda else t).transpose(1, 2)
+        return self._fwd
+
+    @property
+    def rev(self):
+        if self._rev is None:
+            if self.use_cuda:   # flip length and channel axes on the device instead of a second host copy + upload
+                self._rev = torch.flip(self.fwd.transpose(1, 2), [1, 2]).transpose(1, 2)
+            else:
+                self._rev = torch.from_numpy(np.ascontiguousarray(self.seq[:, ::-1, ::-1])).transpose(1, 2)
+        return self._rev
+
+    def _pack(self):
+        if self._packable is None:
+            self._codes, self._packable = engine.pack_sequence(self.fwd)
+            if self._packable:
+                self._fwd = None   # the float copy is no longer needed on the device
+        return self._packable
+
+    def encode(self, net0):
+        """[2B,128,n_bins]: forward strand rows first, reverse strand rows second."""
+        from .orca_modules import Encoder
+        if self.use_cuda and isinstance(net0, Encoder) and self._pack():
+            return torch.cat([net0.forward_codes(self._codes, reverse=False), net0.forward_codes(self._codes, reverse=True)], dim=0)
+        return torch.cat([net0(self.fwd), net0(self.rev)], dim=0)
 
 
 def _log_background(bg, batch, use_cuda, flip=False):
@@ -220,7 +260,7 @@ def genomepredict(sequence, mchr, mpos=-1, wpos=-1, models=["h1esc", "hff"], tar
     batch = sequence.shape[0]
     predictions, allstarts, alltargets, allannos = [], [], [], []
     with torch.no_grad():
-        xs = list(_strands(sequence, use_cuda))        # forward strand, reverse complement
+        strands = _StrandInputs(sequence, use_cuda)     # forward strand + reverse complement
         for ii, model in enumerate(models):
             ts, annos = [], []
 
@@ -245,13 +285,13 @@ def genomepredict(sequence, mchr, mpos=-1, wpos=-1, models=["h1esc", "hff"], tar
 
             def forward(model=model, background=background, on_level=on_level, ts=ts, annos=annos):
                 del ts[:], annos[:]
-                enc0 = torch.cat([model.net0(x) for x in xs], dim=0)
+                enc0 = strands.encode(model.net0)
                 encodings = dict(zip([1, 2, 4, 8, 16, 32], model.net(enc0)))
                 return run_cascade(model, encodings, levels, lambda lv: lv, batch, [False, True], background,
                                    lambda lv, st, rev: zoom_index_32m(lv, st, mpos, wpos, rev), add_1m_level=1,
                                    on_level=on_level)
 
-            preds, starts = engine.run_with_overflow_retry(forward, xs[0].device)
+            preds, starts = engine.run_with_overflow_retry(forward, strands.device)
             predictions.append(_merge(preds, batch))
             allstarts.append(starts[0])
             if targets:
@@ -293,7 +333,7 @@ def genomepredict_256Mb(sequence, mchr, normmats, chrlen, mpos=-1, wpos=-1, mode
         return 250 - (i + 125) if reverse else i
 
     with torch.no_grad():
-        xs = list(_strands(sequence, use_cuda))
+        strands = _StrandInputs(sequence, use_cuda)
         for ii, model in enumerate(models):
             normmat = normmats[ii]
             isnan = np.isnan(normmat)
@@ -321,12 +361,12 @@ def genomepredict_256Mb(sequence, mchr, normmats, chrlen, mpos=-1, wpos=-1, mode
 
             def forward(model=model, background=background, on_level=on_level, ts=ts, annos=annos):
                 del ts[:], annos[:]
-                enc0 = torch.cat([model.net0(x) for x in xs], dim=0)
+                enc0 = strands.encode(model.net0)
                 encodings = dict(zip([32, 64, 128, 256], model.net(model.net1(enc0)[-1])))
                 return run_cascade(model, encodings, levels, lambda lv: lv // 8, batch, [False, True], background, zoom,
                                    add_1m_level=None, on_level=on_level)
 
-            preds, starts = engine.run_with_overflow_retry(forward, xs[0].device)
+            preds, starts = engine.run_with_overflow_retry(forward, strands.device)
             predictions.append(_merge(preds, batch))
             allstarts.append(starts[0])
             allnormmats.append(ns[0])

@@ -148,3 +148,30 @@ def test_decoder_f16x2_overflow_guard_falls_back(cuda):
     assert any("fp16 range" in str(m.message) for m in w)
     s = np.abs(ref).max()
     assert maxabs(out / s, ref / s) < 1e-4
+
+
+def test_encoder_from_packed_codes_and_reverse_complement(cuda):
+    """orca_pack_sequence + orca_encoder_forward_codes: 1 byte/base input, reverse complement derived on the device,
+    vs the oracle on the explicit float strands; non-packable rows are detected."""
+    from orca_amd import engine
+    enc = product_module("Encoder", 0)
+    sd = synth_sd("Encoder", 0)
+    L = 4000 * 30
+    seq = synth.synth_sequence(L, seed=21, n_frac=0.02, batch=2)          # [2, L, 4] with N runs
+    x = torch.from_numpy(seq).to(cuda).transpose(1, 2)
+    codes, ok = engine.pack_sequence(x)
+    assert ok and codes.shape == (2, L) and int(codes.max()) == 4
+    for precision in ("f16x2", "bf16x3"):
+        enc.precision = precision
+        yf = enc.forward_codes(codes).cpu().numpy()
+        yr = enc.forward_codes(codes, reverse=True).cpu().numpy()
+        ref_f = O.encoder_forward(sd, torch.from_numpy(seq).transpose(1, 2)).numpy()
+        ref_r = O.encoder_forward(sd, torch.from_numpy(np.ascontiguousarray(seq[:, ::-1, ::-1])).transpose(1, 2)).numpy()
+        assert maxabs(yf, ref_f) < TOL and maxabs(yr, ref_r) < TOL, precision
+        # a bin sub-range on the reverse strand (multi-GPU shard) and small internal chunks
+        part = enc.forward_codes(codes, reverse=True, bin_lo=7, bin_hi=19, chunk_bp=40000).cpu().numpy()
+        assert maxabs(part, yr[:, :, 7:19]) < 2e-5
+    bad = x.clone()
+    bad[0, :, 1234] = torch.tensor([0.3, 0.2, 0.4, 0.1], device=cuda)
+    _, ok2 = engine.pack_sequence(bad)
+    assert not ok2
