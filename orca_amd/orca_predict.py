@@ -58,15 +58,22 @@ class _StrandInputs:
     first-layer kernel).  Anything else (arbitrary floats, foreign models, CPU) uses float views as the reference does."""
 
     def __init__(self, sequence, use_cuda):
-        self.seq = np.asarray(sequence, dtype=np.float32)
         self.use_cuda = use_cuda
-        self.batch = self.seq.shape[0]
         self._fwd = self._rev = self._codes = None
         self._packable = None
+        if isinstance(sequence, torch.Tensor) and sequence.dtype == torch.uint8:
+            # already packed: [B,L] base codes on the MI355X (orca_amd extension, see orca_amd/sv.py)
+            if not (use_cuda and sequence.is_cuda and sequence.dim() == 2):
+                raise ValueError("packed input must be a [B,L] uint8 ROCm tensor with use_cuda=True")
+            self.seq, self._codes, self._packable = None, sequence, True
+            self.batch = sequence.shape[0]
+            return
+        self.seq = np.asarray(sequence, dtype=np.float32)
+        self.batch = self.seq.shape[0]
 
     @property
     def device(self):
-        return self.fwd.device
+        return self._codes.device if self.seq is None else self.fwd.device
 
     @property
     def fwd(self):
@@ -94,6 +101,8 @@ class _StrandInputs:
     def encode(self, net0):
         """[2B,128,n_bins]: forward strand rows first, reverse strand rows second."""
         from .orca_modules import Encoder
+        if self.seq is None and not isinstance(net0, Encoder):
+            raise TypeError("packed (uint8) input needs an orca_amd Encoder as model.net0")
         if self.use_cuda and isinstance(net0, Encoder) and self._pack():
             return torch.cat([net0.forward_codes(self._codes, reverse=False), net0.forward_codes(self._codes, reverse=True)], dim=0)
         return torch.cat([net0(self.fwd), net0(self.rev)], dim=0)
@@ -257,7 +266,7 @@ def genomepredict(sequence, mchr, mpos=-1, wpos=-1, models=["h1esc", "hff"], tar
     ``sequence``: float array [1, 32000000, 4]; ``wpos``: window centre coordinate."""
     models = _resolve_models(models, "32M", use_cuda)
     levels = [32, 16, 8, 4, 2, 1]
-    batch = sequence.shape[0]
+    batch = sequence.shape[0]   # float [B,L,4] (reference) or packed uint8 [B,L] codes on the device (extension)
     predictions, allstarts, alltargets, allannos = [], [], [], []
     with torch.no_grad():
         strands = _StrandInputs(sequence, use_cuda)     # forward strand + reverse complement

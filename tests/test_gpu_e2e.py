@@ -111,3 +111,34 @@ def test_encoder_256mb_full_size_properties(cuda):
     assert float((part - full[:, :, 100:2100]).abs().max()) < 2e-5
     same = D.ShardedEncoder(model.net0)(xt)
     assert torch.equal(same, full)
+
+
+def test_sv_screen_packed_genome(cuda):
+    """configs[4] in miniature: two synthetic SVs on a 40 Mb packed chromosome resident in HBM; windows assembled on the
+    device from pieces; the reference-allele prediction through the packed path equals the float-input path."""
+    from orca_amd import sv
+    chrlen = 40_000_000
+    model = M.H1esc(synthetic_seed=0)
+    gen = torch.Generator(device=cuda).manual_seed(5)
+    genome = torch.randint(0, 4, (chrlen,), device=cuda, generator=gen, dtype=torch.uint8)
+    genome[1_000_000:1_000_400] = 4                                 # an N run
+    svs = [sv.SV("inv", 20_000_000, 20_400_000), sv.SV("del", 12_000_000, 12_100_000)]
+    res = sv.sv_screen([model], genome, svs, chrlen)
+    assert sorted(res) == [0, 1]
+    assert sorted(sv.sv_screen([model], genome, svs, chrlen, rank=1, world=2)) == [1]
+    for i, r in res.items():
+        for allele in ("ref", "alt"):
+            maps = r[allele]["predictions"][0]
+            assert len(maps) == 6 and all(np.isfinite(m).all() and m.shape == (250, 250) for m in maps)
+        d = max(maxabs(a, b) for a, b in zip(r["ref"]["predictions"][0], r["alt"]["predictions"][0]))
+        assert d > 1e-3                                             # the variant changes the maps
+    # same reference window as an explicit one-hot float array through the reference-style entry point
+    rp, rw, rm, *_ = sv.sv_windows(svs[0], chrlen)
+    codes = sv.assemble_codes(genome, rp).cpu().numpy()
+    seq = np.zeros((1, sv.WINDOW, 4), dtype=np.float32)
+    seq[0, np.arange(sv.WINDOW), np.minimum(codes, 3)] = 1.0
+    seq[0, codes == 4] = 0.25
+    out = P.genomepredict(seq, "chrS", rm, rw, models=[model], use_cuda=True)
+    assert out["start_coords"] == res[0]["ref"]["start_coords"]
+    for a, b in zip(out["predictions"][0], res[0]["ref"]["predictions"][0]):
+        assert maxabs(a, b) < 1e-6

@@ -234,6 +234,21 @@ def main():
             np.savez_compressed(os.path.join(GOLD, "G9_cascade256.npz"), **d)
             print("G9 done")
 
+        # ---- G10: coordinate helpers of the SV drivers (orca_utils.py:1009-1060) --
+        if want("G10"):
+            import orca_utils as ou
+            rs = np.random.RandomState(7)
+            rows = []
+            for _ in range(400):
+                chrlen = int(rs.randint(33_000_000, 250_000_000))
+                pos = int(rs.randint(0, chrlen))
+                if rs.rand() < 0.2:
+                    pos = int(rs.choice([rs.randint(0, 200000), chrlen - rs.randint(0, 200000)]))
+                rows.append((pos, chrlen, int(ou.coord_clip(pos, chrlen)), int(ou.coord_round(pos)),
+                             int(ou.coord_clip(pos, max(chrlen, 260_000_000), binsize=1024000, window_radius=128000000))))
+            np.savez_compressed(os.path.join(GOLD, "G10_coords.npz"), rows=np.array(rows, dtype=np.int64))
+            print("G10 done")
+
         # ---- G8: one full 32 Mb H1-ESC-shaped forward, both strands ---------------
         if args.full32m and want("G8"):
             import orca_predict as op
