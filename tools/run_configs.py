@@ -1,0 +1,55 @@
+"""One-off measurements of BASELINE.json configs 3-5 on one MI355X (numbers quoted in DESIGN.md section 6)."""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from orca_amd import engine, orca_models as M, orca_predict as P, sv, synth
+
+dev = torch.device("cuda:0")
+def sync(): torch.cuda.synchronize(dev)
+def rand_codes(B, L, seed):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    return torch.randint(0, 4, (B, L), device=dev, generator=g, dtype=torch.uint8)
+res = {}
+
+# ---- config 3: HFF-shaped 32 Mb model, batch of 8 random 32 Mb sequences, bf16 encoder (throughput mode) --------
+hff = M.Hff(synthetic_seed=7)
+codes = rand_codes(8, 32_000_000, 10)
+de = {lv: torch.log(torch.from_numpy(hff.normmats[lv][None, None].astype(np.float32))).to(dev) for lv in hff.levels}
+def fwd8(prec):
+    hff.net0.precision = prec
+    enc0 = hff.net0.forward_codes(codes)
+    encs = dict(zip([1, 2, 4, 8, 16, 32], hff.net(enc0)))
+    return P.run_cascade(hff, encs, [32, 16, 8, 4, 2, 1], lambda lv: lv, 8, [False], lambda lv, k, st: de[lv],
+                         lambda lv, st, rev: P.zoom_index_32m(lv, st, 17_234_567, 16_000_000, rev), add_1m_level=1)[0]
+out = {}
+for prec in ("bf16", "f16x2"):
+    fwd8(prec); sync(); t = time.perf_counter(); p = fwd8(prec); sync(); dt = time.perf_counter() - t
+    out[prec] = [x.cpu().numpy() for x in p]
+    res[f"config3_{prec}_B8_single_strand"] = {"s": round(dt, 4), "Mb_per_s": round(8 * 32 / dt, 1), "maps_per_s": round(48 / dt, 1)}
+err = max(float(np.abs(a - b).max()) for a, b in zip(out["bf16"], out["f16x2"]))
+r = min(float(np.corrcoef(a.ravel(), b.ravel())[0, 1]) for a, b in zip(out["bf16"], out["f16x2"]))
+res["config3_bf16_vs_f16x2"] = {"max_abs": round(err, 4), "min_pearson_r": round(r, 6)}
+del codes, hff, out; engine.get_context(dev).release_workspace(); torch.cuda.empty_cache()
+
+# ---- config 4 (one GPU): H1esc_256M-shaped model on a random 256 Mb sequence ------------------------------------
+m256 = M.H1esc_256M(synthetic_seed=0)
+c256 = rand_codes(1, 256_000_000, 2)
+chrlen = 138_368_000
+nm = synth.synth_normmat_256m(chrlen, seed=0)
+m256.net0.forward_codes(c256); sync()
+t = time.perf_counter(); e = m256.net0.forward_codes(c256); sync(); t_enc = time.perf_counter() - t
+t = time.perf_counter(); o = P.genomepredict_256Mb(c256, "chrS", [nm], chrlen, 70_000_000, 128_000_000, models=[m256]); sync()
+t_all = time.perf_counter() - t
+res["config4_256Mb_1gpu"] = {"encoder_one_strand_s": round(t_enc, 4), "encoder_Mb_per_s": round(256 / t_enc, 1),
+                             "genomepredict_256Mb_s_incl_host_background_coarsegraining": round(t_all, 3), "start_coords": o["start_coords"]}
+del c256, m256; engine.get_context(dev).release_workspace(); torch.cuda.empty_cache()
+
+# ---- config 5 (one GPU): SV screen from a packed 40 Mb chromosome -------------------------------------------------
+h1 = M.H1esc(synthetic_seed=0)
+genome = rand_codes(1, 40_000_000, 5)[0]
+svs = sv.synth_svs(6, 40_000_000)
+sv.sv_screen([h1], genome, svs[:1], 40_000_000); sync()
+t = time.perf_counter(); r5 = sv.sv_screen([h1], genome, svs, 40_000_000); sync(); dt = time.perf_counter() - t
+res["config5_sv_screen_1gpu"] = {"svs": len(svs), "s_per_sv_ref_plus_alt": round(dt / len(svs), 4), "svs_per_s": round(len(svs) / dt, 2),
+                                 "kinds": [v.kind for v in svs]}
+print(json.dumps(res, indent=1))
