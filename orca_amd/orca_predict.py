@@ -120,6 +120,17 @@ def _log_background(bg, batch, use_cuda, flip=False):
     return t.expand(batch, -1, -1, -1)
 
 
+def _cached_log_background(model, level, use_cuda):
+    """log(normmats[level]) on the device, computed/uploaded once per model (the pageable H2D copy of the reference's
+    per-call `torch.FloatTensor(normmat).cuda()` stalls the host until the GPU queue drains)."""
+    arr = model.normmats[level]
+    cache = model.__dict__.setdefault("_orca_amd_bg_cache", {})
+    key = (level, bool(use_cuda), id(arr))
+    if key not in cache:
+        cache[key] = _log_background(arr, 1, use_cuda)
+    return cache[key]
+
+
 def _decode(model, level, enc_slice, distenc, coarse, add_1m):
     dec = model.denets[level]
     if coarse is None:
@@ -230,7 +241,7 @@ def cascade_32m(model, xs, mpos, wpos, reverse_flags, distencs=None):
         if distencs is not None:
             return distencs[level]
         if level not in cache:
-            cache[level] = _log_background(model.normmats[level], 1, xs[0].is_cuda)
+            cache[level] = _cached_log_background(model, level, xs[0].is_cuda)
         return cache[level]
 
     def forward():
@@ -289,7 +300,7 @@ def genomepredict(sequence, mchr, mpos=-1, wpos=-1, models=["h1esc", "hff"], tar
 
             def background(level, k, start, model=model, bg_cache=bg_cache):
                 if level not in bg_cache:
-                    bg_cache[level] = _log_background(model.normmats[level], 1, use_cuda)
+                    bg_cache[level] = _cached_log_background(model, level, use_cuda)
                 return bg_cache[level]
 
             def forward(model=model, background=background, on_level=on_level, ts=ts, annos=annos):
