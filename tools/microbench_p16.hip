@@ -35,14 +35,13 @@ int main(int argc, char** argv) {
   } else
   hipMemset(x, 0x2c, (size_t)128 * plen * 4); hipMemset(w, 0x2c, (size_t)8 * 2 * 9 * 2 * 128 * 16); hipMemset(bias, 0, 512);
   ConvP16Args a{}; a.x = x; a.w = w; a.bias = bias; a.y = y; a.r1 = nullptr; a.x_plen = plen; a.y_plen = plen; a.n = n; a.nchunks = 4; a.cout = 64; a.relu = 1; a.out_mode = 0; a.flag = nullptr;
-  for (int round = 0; round < 4; ++round) {
+  for (int round = 0; round < 3; ++round) {
     printf("-- round %d\n", round);
     a.out_mode = 0;
-    run<64, 2, 2, 8, 0>(a, "full, sched_barrier");
-    run<64, 2, 2, 8, 64>(a, "full, no sched_barrier");
-    run<64, 2, 2, 8, 16>(a, "no stores, sched_barrier");
-    run<64, 2, 2, 8, 80>(a, "no stores, no sched_barrier");
-    run<64, 2, 2, 8, 4>(a, "no MFMA");
+    run<64, 2, 2, 8, 0>(a, "8 waves, 64x64 wave tile (library)");
+    run<64, 1, 2, 16, 0>(a, "16 waves, 32x64 wave tile");
+    run<64, 1, 2, 8, 0>(a, "8 waves, 32x64, MT=256");
+    run<64, 4, 2, 4, 0>(a, "4 waves, 128x64 wave tile");
   }
   return 0;
 }
