@@ -255,3 +255,8 @@ __global__ void final_sym_nhwc_kernel(FinalArgs a) {
   const float r = 0.5f * f1 + 0.5f * f2;
   *op = a.accumulate ? (*op + r) : r;
 }
+
+// Tried and dropped (round 1): a tap-paired variant with 8-channel chunks (45 KB LDS, three 4-wave workgroups per CU
+// instead of one 8-wave one) was correct but 30 % slower per Decoder (5.2 vs 4.0 ms at B=2): these kernels are bound by
+// the per-row latency chain global -> registers -> split -> LDS -> MFMA over only 2-4 chunks, and halving the chunk
+// doubled the number of links.  Several rows per workgroup is slower still, so it is not dispatch-bound either.
