@@ -100,10 +100,11 @@ class _StrandInputs:
 
     def encode(self, net0):
         """[2B,128,n_bins]: forward strand rows first, reverse strand rows second."""
+        from .dist import ShardedEncoder
         from .orca_modules import Encoder
-        if self.seq is None and not isinstance(net0, Encoder):
+        if self.seq is None and not isinstance(net0, (Encoder, ShardedEncoder)):
             raise TypeError("packed (uint8) input needs an orca_amd Encoder as model.net0")
-        if self.use_cuda and isinstance(net0, Encoder) and self._pack():
+        if self.use_cuda and isinstance(net0, (Encoder, ShardedEncoder)) and self._pack():
             return torch.cat([net0.forward_codes(self._codes, reverse=False), net0.forward_codes(self._codes, reverse=True)], dim=0)
         return torch.cat([net0(self.fwd), net0(self.rev)], dim=0)
 

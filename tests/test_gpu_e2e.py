@@ -111,6 +111,15 @@ def test_encoder_256mb_full_size_properties(cuda):
     assert float((part - full[:, :, 100:2100]).abs().max()) < 2e-5
     same = D.ShardedEncoder(model.net0)(xt)
     assert torch.equal(same, full)
+    # packed input: 256 MB of codes instead of 4.1 GB of floats, reverse complement from the same buffer
+    from orca_amd import engine
+    codes, ok = engine.pack_sequence(xt)
+    assert ok
+    del xt, x
+    fc = D.ShardedEncoder(model.net0).forward_codes(codes)
+    assert float((fc - full).abs().max()) < 2e-5
+    rc = model.net0.forward_codes(codes, reverse=True, bin_lo=0, bin_hi=4000)
+    assert rc.shape == (1, 128, 4000) and bool(torch.isfinite(rc).all())
 
 
 def test_sv_screen_packed_genome(cuda):
