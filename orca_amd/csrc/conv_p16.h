@@ -11,11 +11,16 @@
 //   ragged last tile need no predication at all.
 //
 // Kernel: persistent workgroups, 8 waves, (tile, chunk) stream as in conv_bf16s.h, but with TWO LDS buffers:
-// the DMA of step s+1 is issued before the MFMA block of step s and lands underneath it; one barrier per step.
-// (Tried and dropped: a de-phased two-group variant - waves 0-3 / 4-7 on different tiles, group B walking its
-// K-chunks in rotated order so both share the W chunk - was correct but 15 % slower: with one barrier per step
-// the step time becomes max(group in epilogue, group in MFMA) twice per tile instead of once.)
+// the DMA of step s+1 is issued inside the MFMA block of step s and lands underneath it; one barrier per step.
 // Arithmetic: 3 fp16 MFMA products per fp32 product (hi*hi + hi*lo + lo*hi), fp32 accumulate.
+// Tried and dropped (tools/microbench_p16.hip has the per-wave s_memtime stamp harness that judged them):
+//   * de-phased two-group variant (waves 0-3 / 4-7 on different tiles, rotated K-chunk order): 15 % slower;
+//   * epilogue software-pipelined into the next step's MFMA block from a parked accumulator copy: 256 VGPRs are
+//     not enough (acc 64 + copy 64 + fragments 64 + ...), the spill reloads are VMEM loads whose vmcnt(0)
+//     serialises against the in-flight DMA - 40 % slower;
+//   * LDS-DMA issued by the younger wave of each SIMD only, 16 waves of 32x64 per workgroup, inter-workgroup
+//     start stagger: all within +-1 %.  The part runs this kernel at 1.70-1.82 GHz (s_memtime / s_memrealtime),
+//     rising to 1.93 GHz with DMA, stores and LDS reads ablated: it is power-limited, not issue-limited.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -38,6 +43,7 @@ struct ConvP16Args {
   int relu;
   int out_mode;        // 0: P16 same length; 1: P16 with MaxPool1d(4) fused (length n/4); 2: fp32 [n][cout]
   unsigned* flag;      // raised when a value written to P16 leaves the fp16 range
+  unsigned long long* stamps;   // micro-benchmark only (ABL & 128): s_memtime stamps of workgroup 0 / wave 0
 };
 
 __device__ __forceinline__ void p16_split_store(char* plane_hi, long plen_bytes, f32x4 v, bool valid, bool& ovf) {
@@ -71,11 +77,83 @@ __device__ __forceinline__ void p16_glds16(const f32x4* gsrc, f32x4* lds_wave_ba
 #endif
 }
 
+// 4 fp32 (one position, 4 consecutive couts) -> packed fp16 hi pair-of-pairs and lo = fp16(v - hi):
+// 2 x v_cvt_pk_f16_f32 + 4 x v_fma_mix{lo,hi}_f16 (the f16 operand is widened inside the FMA; v - hi is exact in fp32)
+__device__ __forceinline__ void p16_split_hl(const f32x4 v, unsigned& h0, unsigned& h1, unsigned& l0, unsigned& l1) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const float vx = v.x, vy = v.y, vz = v.z, vw = v.w;
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h0) : "v"(vx), "v"(vy));
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h1) : "v"(vz), "v"(vw));
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(h0), "v"(vx));
+  asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l0) : "v"(h0), "v"(vy));
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(h1), "v"(vz));
+  asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l1) : "v"(h1), "v"(vw));
+#else
+  (void)v; h0 = h1 = l0 = l1 = 0u;
+#endif
+}
+
+// v_permlane32_swap: lanes 32..63 of `a` <-> lanes 0..31 of `b`
+__device__ __forceinline__ void p16_swap32(unsigned& a, unsigned& b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const u32x2 r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+  a = r.x; b = r.y;
+#endif
+}
+
+__device__ __forceinline__ float p16_dpp_quad_max(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  float t = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+  v = fmaxf(v, t);
+  t = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));         // quad_perm [2,3,0,1]
+  v = fmaxf(v, t);
+#endif
+  return v;
+}
+
+// LDS operand reads the compiler cannot see.  While an LDS-DMA (`global_load_lds`) is in flight the compiler
+// treats it as a pending FLAT access and turns EVERY lgkmcnt wait into lgkmcnt(0) - which also waits for the
+// fragment prefetch issued a moment earlier and exposes the LDS latency once per two taps (~2 000 of a step's
+// 9 800 cycles).  These reads are therefore issued from inline asm and retired by explicit counted waits
+// (LDS returns in order): p16_lds_wait<N>() lets the N youngest reads stay in flight; the fragments it guards are
+// in/out operands so that the MFMAs consuming them cannot be scheduled above the wait.
+__device__ __forceinline__ unsigned p16_lds_addr(const void* p) {
+  return (unsigned)(unsigned long)((__attribute__((address_space(3))) const char*)p);
+}
+__device__ __forceinline__ f16x8 p16_lds_read16(unsigned addr, const int off) {   // off: constant after unrolling
+  f16x8 r;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "i"(off));
+  return r;
+}
+template <int N, int MW, int NW>
+__device__ __forceinline__ void p16_lds_wait(f16x8 (&a)[2][MW], f16x8 (&b)[2][NW]) {
+  static_assert(MW <= 2 && NW <= 3, "operand list below");
+  if constexpr (MW == 2 && NW == 2)
+    asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[1][0]), "+v"(a[1][1]), "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[1][0]), "+v"(b[1][1]) : "n"(N));
+  else if constexpr (MW == 1 && NW == 3)
+    asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(a[0][0]), "+v"(a[1][0]), "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[0][2]), "+v"(b[1][0]), "+v"(b[1][1]), "+v"(b[1][2]) : "n"(N));
+  else if constexpr (MW == 1 && NW == 2)
+    asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(a[0][0]), "+v"(a[1][0]), "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[1][0]), "+v"(b[1][1]) : "n"(N));
+  else
+    static_assert(MW == 2 && NW == 2, "add the operand list for this wave tile");
+}
+
 // CT = couts per workgroup tile (cout blocks of CT are separate tiles), wave tile = MW x NW subtiles of 32x32.
-// ABL (micro-benchmark only, 0 in the library): 1 = no DMA after the first step, 4 = no MFMA, 8 = LDS operands
-// read once, 16 = no epilogue stores, 32 = no epilogue at all.
-template <int CT, int MW, int NW, int WM, int ABL = 0>
-__global__ __launch_bounds__(WM * 64, 2) void conv1d_k9_p16_kernel(ConvP16Args a) {
+// OM = out_mode, R1 = residual present: compile-time, the epilogue is branch-free.
+// ABL (micro-benchmark only, 0 in the library): 1 = no DMA after the first step, 8 = LDS operands read once,
+// 16 = no epilogue stores, 128 = per-wave s_memtime stamps into a.stamps.
+// s_memtime stamps (ABL & 128, tools/microbench_p16.hip) of the first version of this kernel, per step of
+// ~12 000 cycles at the 1.8 GHz the part sustains here: MFMA block 6 700 (the pipe needs 6 912), epilogue 2 150
+// (8 300 per tile - VALU- and store-issue-bound), DMA issue burst 1 440, vmcnt + barrier tail 3 000.  Hence:
+//   * the accumulators start from the bias (16 ds_read_b128 per tile) instead of 0;
+//   * hi/lo split in 6 instructions per 4 values (p16_split_hl), the range guard is a running v_max3;
+//   * v_permlane32_swap pairs lanes l / l+32 (couts 4g..4g+3 of the same position) so that every lane stores - and
+//     loads, for the residual - whole 16-byte units: half the VMEM instructions, uniform base + lane offset;
+//   * MaxPool1d(4) on DPP quad permutes, the 4 lanes of a quad store one dword each of the pooled unit;
+//   * the LDS-DMA of the next buffer is issued inside taps 0..4 of the MFMA block, two pieces per tap, instead of
+//     as a burst in front of it (8 waves x 9 x 1 KB against the CU's 64 B/clk path).
+template <int CT, int MW, int NW, int WM, int OM, bool R1, int ABL = 0>
+__global__ __launch_bounds__(WM * 64, WM / 4) void conv1d_k9_p16_kernel(ConvP16Args a) {
   static_assert(NW * 32 == CT, "one wave covers all couts of the tile");
   constexpr int NT = WM * 64;
   constexpr int MT = WM * MW * 32;
@@ -84,7 +162,9 @@ __global__ __launch_bounds__(WM * 64, 2) void conv1d_k9_p16_kernel(ConvP16Args a
   constexpr int WU = 2 * 9 * 2 * CT;    // W image units  [s][tap][g][CT]
   constexpr int BU = XU + WU;           // one buffer
   constexpr int NIT = (BU + NT - 1) / NT;
-  __shared__ f32x4 smem[2 * BU + 32];   // + bias of all couts (<= 128 floats), read with ds_read in the epilogue
+  constexpr int DPT = (NIT + 4) / 5;    // DMA pieces per tap, taps 0..4
+  constexpr int NG = MW * NW * 4;       // epilogue groups per wave: 1 position x 4 couts per lane
+  __shared__ f32x4 smem[2 * BU + 32];   // + bias of all couts (<= 128 floats)
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -93,21 +173,12 @@ __global__ __launch_bounds__(WM * 64, 2) void conv1d_k9_p16_kernel(ConvP16Args a
   const long ntiles = a.tiles_per_row * ncb;
   long tile = blockIdx.x;
   if (tile >= ntiles) return;
-  bool overflow = false;
-
-  f32x16 acc[MW][NW];
-#pragma unroll
-  for (int i = 0; i < MW; ++i)
-#pragma unroll
-    for (int j = 0; j < NW; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   float* bias_s = reinterpret_cast<float*>(smem + 2 * BU);
   if (tid < a.cout) bias_s[tid] = a.bias[tid];   // visible after the first barrier
 
-  // thread-constant DMA geometry: unit i = tid + it*NT of the buffer image
-  long xrel[NIT];   // X: (g*2 + s) * x_plen + col        W: grp * cout + cc     (in 16-byte units)
+  // thread-constant DMA geometry (16-byte units): unit i = tid + it*NT of the buffer image
+  int xrel[NIT];    // X: (g*2 + s) * x_plen + col        W: grp * cout + cc
   bool isx[NIT], act[NIT];
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
@@ -117,117 +188,158 @@ __global__ __launch_bounds__(WM * 64, 2) void conv1d_k9_p16_kernel(ConvP16Args a
     if (isx[it]) {
       const int row = i / XROW, col = i - row * XROW;      // row = s*2 + g
       const int s = row >> 1, gg = row & 1;
-      xrel[it] = (long)(gg * 2 + s) * a.x_plen + col;
+      xrel[it] = (int)((gg * 2 + s) * a.x_plen) + col;
     } else {
       const int u = (i < BU ? i : BU - 1) - XU;
       const int grp = u / CT, cc = u - grp * CT;           // grp = (s*9 + tap)*2 + g
-      xrel[it] = (long)grp * a.cout + cc;
+      xrel[it] = grp * a.cout + cc;
     }
   }
   const long wchunk = (long)2 * 9 * 2 * a.cout;            // units per K-chunk in the weight pack
+  const f32x4 *xsrc = nullptr, *wsrc = nullptr;            // uniform sources of the (tile, chunk) being fetched
+#define P16_SRC(t, c)                                                                  \
+  {                                                                                    \
+    const long tcb_ = (t) / a.tiles_per_row;                                           \
+    xsrc = a.x + (long)(c) * 4 * a.x_plen + ((t) - tcb_ * a.tiles_per_row) * MT;       \
+    wsrc = a.w + (long)(c) * wchunk + tcb_ * CT;                                       \
+  }
+#define P16_DMA_ONE(it, buf) \
+  if (act[it]) p16_glds16((isx[it] ? xsrc : wsrc) + xrel[it], smem + (buf) * BU + (it) * NT + wave * 64);
 
-  // LDS-DMA of (tile t, chunk c) into buffer `buf`
-#define P16_DMA(t, c, buf)                                                                         \
-  {                                                                                                \
-    const long tcb_ = (t) / a.tiles_per_row;                                                       \
-    const long tm0_ = ((t) - tcb_ * a.tiles_per_row) * MT;                                         \
-    const f32x4* xsrc_ = a.x + (long)(c) * 4 * a.x_plen + tm0_; /* (pos - 4 + GUARD) = tm0 + col */ \
-    const f32x4* wsrc_ = a.w + (long)(c) * wchunk + tcb_ * CT;                                     \
-    _Pragma("unroll") for (int it = 0; it < NIT; ++it) {                                           \
-      if (act[it]) {                                                                               \
-        const f32x4* src_ = (isx[it] ? xsrc_ : wsrc_) + xrel[it];                                  \
-        p16_glds16(src_, smem + (buf) * BU + it * NT + wave * 64);                                 \
-      }                                                                                            \
-    }                                                                                              \
+  // accumulators start from the bias of the tile's cout block
+  f32x16 acc[MW][NW];
+#define P16_ACC_INIT(t)                                                                                       \
+  {                                                                                                           \
+    const int co0_ = (int)((t) / a.tiles_per_row) * CT + 4 * g;                                               \
+    _Pragma("unroll") for (int j = 0; j < NW; ++j) _Pragma("unroll") for (int q = 0; q < 4; ++q) {            \
+      const f32x4 b_ = *reinterpret_cast<const f32x4*>(bias_s + co0_ + j * 32 + 8 * q);                       \
+      _Pragma("unroll") for (int i = 0; i < MW; ++i) {                                                        \
+        acc[i][j][4 * q + 0] = b_.x; acc[i][j][4 * q + 1] = b_.y; acc[i][j][4 * q + 2] = b_.z; acc[i][j][4 * q + 3] = b_.w; \
+      }                                                                                                       \
+    }                                                                                                         \
   }
 
-  long epi_tile = -1;   // finished tile whose accumulators still await their epilogue (-1: none)
+  // ---- epilogue (uniform bases, thread-constant lane offsets) ----
+  const float relu_lo = a.relu ? 0.f : -3.0e38f;
+  const int quad_r = l31 & 3;
+  const long xpl16 = a.x_plen * 16, ypl16 = a.y_plen * 16;
+  const unsigned lane_unit = (unsigned)(l31 * 16) + (g ? (unsigned)ypl16 : 0u);        // OM 0: g=0 stores the hi unit, g=1 the lo unit
+  const unsigned lane_res = (unsigned)(l31 * 16) + (g ? (unsigned)xpl16 : 0u);         // residual: g=0 loads the hi unit, g=1 the lo unit
+  const unsigned lane_pool = (unsigned)((l31 >> 2) * 16 + quad_r * 4) + (g ? (unsigned)ypl16 : 0u);
+  const unsigned lane_f32 = (unsigned)(l31 * a.cout * 4 + g * 16);                     // OM 2
+  float vmax = 0.f;    // running max |value| written to P16 (fp16 range guard)
+  long epi_tile = -1;  // finished tile whose accumulators still await their epilogue (-1: none)
 
-  // Epilogue of the finished tile: a lane owns ONE position and 4 consecutive couts per register group q.
-  // It runs at the START of the next step (after the barrier that drained this step's DMA), so its stores -
-  // the output is as large as the input, this kernel sits at the HBM/MFMA ridge - drain underneath that step's
-  // DMA + MFMA block and are retired by the step's closing barrier.
+  // Runs at the START of the next step (after the barrier that drained this step's DMA): its stores drain
+  // underneath that step's MFMA block and are retired by the step's closing barrier.
 #define P16_EPILOGUE()                                                                                           \
   {                                                                                                              \
     const long tcb = epi_tile / a.tiles_per_row;                                                                 \
-    const long m0 = (epi_tile - tcb * a.tiles_per_row) * MT;                                                     \
-    const long xpl = a.x_plen * 16, ypl = a.y_plen * 16;                                                         \
-    _Pragma("unroll") for (int i = 0; i < MW; ++i) _Pragma("unroll") for (int j = 0; j < NW; ++j) {              \
-      const long pos = m0 + wave * (MW * 32) + i * 32 + l31;                                                     \
-      _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                            \
-        const int co = (int)tcb * CT + j * 32 + 8 * q + 4 * g;                                                   \
-        const f32x4 bias = *reinterpret_cast<const f32x4*>(bias_s + co);                                         \
-        f32x4 v;                                                                                                 \
-        v.x = acc[i][j][4 * q + 0] + bias.x;                                                                     \
-        v.y = acc[i][j][4 * q + 1] + bias.y;                                                                     \
-        v.z = acc[i][j][4 * q + 2] + bias.z;                                                                     \
-        v.w = acc[i][j][4 * q + 3] + bias.w;                                                                     \
-        acc[i][j][4 * q + 0] = 0.f; acc[i][j][4 * q + 1] = 0.f; acc[i][j][4 * q + 2] = 0.f; acc[i][j][4 * q + 3] = 0.f; \
-        if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); } \
-        const bool valid = pos < a.n;                                                                            \
-        const long pl = (long)(co >> 3) * 2;   /* hi plane index of this cout octet */                           \
-        if (a.r1 && valid)                                                                                       \
-          v += p16_load4(reinterpret_cast<const char*>(a.r1) + pl * xpl + (P16_GUARD + pos) * 16 + g * 8, xpl);  \
+    const long m0 = (epi_tile - tcb * a.tiles_per_row) * MT + wave * (MW * 32);                                  \
+    u32x4_t rr[R1 ? NG : 1];                                                                                     \
+    if (R1) {                                                                                                    \
+      _Pragma("unroll") for (int i = 0; i < MW; ++i) _Pragma("unroll") for (int j = 0; j < NW; ++j) _Pragma("unroll") for (int q = 0; q < 4; ++q) { \
+        const char* rb_ = reinterpret_cast<const char*>(a.r1) + (long)(((int)tcb * CT + j * 32) / 8 + q) * 2 * xpl16 + (P16_GUARD + m0 + i * 32) * 16; \
+        rr[(i * NW + j) * 4 + q] = *reinterpret_cast<const u32x4_t*>(rb_ + lane_res);                            \
+      }                                                                                                          \
+    }                                                                                                            \
+    _Pragma("unroll") for (int i = 0; i < MW; ++i) _Pragma("unroll") for (int j = 0; j < NW; ++j) _Pragma("unroll") for (int q = 0; q < 4; ++q) { \
+      const int co = (int)tcb * CT + j * 32 + 8 * q;   /* + 4*g per lane */                                      \
+      const long p0 = m0 + i * 32;                     /* + l31 per lane */                                      \
+      f32x4 v;                                                                                                   \
+      v.x = fmaxf(acc[i][j][4 * q + 0], relu_lo); v.y = fmaxf(acc[i][j][4 * q + 1], relu_lo);                    \
+      v.z = fmaxf(acc[i][j][4 * q + 2], relu_lo); v.w = fmaxf(acc[i][j][4 * q + 3], relu_lo);                    \
+      if (R1) {                                                                                                  \
+        const u32x4_t u_ = rr[(i * NW + j) * 4 + q];                                                             \
+        unsigned ux_ = u_.x, uy_ = u_.y, uz_ = u_.z, uw_ = u_.w;                                                 \
+        p16_swap32(ux_, uz_);   /* both halves: ux = hi pair 0, uz = lo pair 0 of the lane's 4 couts */          \
+        p16_swap32(uy_, uw_);                                                                                    \
+        const f16x2 h0_ = __builtin_bit_cast(f16x2, ux_), h1_ = __builtin_bit_cast(f16x2, uy_);                  \
+        const f16x2 l0_ = __builtin_bit_cast(f16x2, uz_), l1_ = __builtin_bit_cast(f16x2, uw_);                  \
+        v.x += (float)h0_.x + (float)l0_.x; v.y += (float)h0_.y + (float)l0_.y;                                  \
+        v.z += (float)h1_.x + (float)l1_.x; v.w += (float)h1_.y + (float)l1_.y;                                  \
+      }                                                                                                          \
+      if (OM == 2) {                                                                                             \
+        if (p0 + l31 < a.n) *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(a.y) + (p0 * a.cout + co) * 4 + lane_f32) = v; \
+      } else {                                                                                                   \
+        bool ok_ = p0 + l31 < a.n;                                                                               \
+        if (OM == 1) {                                                                                           \
+          v.x = p16_dpp_quad_max(v.x); v.y = p16_dpp_quad_max(v.y);                                              \
+          v.z = p16_dpp_quad_max(v.z); v.w = p16_dpp_quad_max(v.w);                                              \
+          ok_ = p0 + (l31 | 3) < a.n;                                                                            \
+        }                                                                                                        \
+        if (!ok_) v = (f32x4)(0.f);                                                                              \
+        vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));                 \
+        unsigned h0_, h1_, l0_, l1_;                                                                             \
+        p16_split_hl(v, h0_, h1_, l0_, l1_);                                                                     \
+        p16_swap32(h0_, l0_);   /* g=0: {h, l} = hi halves of couts 0-3 | 4-7;  g=1: the lo halves */            \
+        p16_swap32(h1_, l1_);                                                                                    \
+        u32x4_t unit_;                                                                                           \
+        unit_.x = h0_; unit_.y = h1_; unit_.z = l0_; unit_.w = l1_;                                              \
+        char* yb_ = reinterpret_cast<char*>(a.y) + (long)(co >> 3) * 2 * ypl16;                                  \
         if (ABL & 16) {                                                                                          \
-          asm volatile("" ::"v"(v));                                                                             \
-        } else if (a.out_mode == 0) {                                                                            \
-          p16_split_store(reinterpret_cast<char*>(a.y) + pl * ypl + (P16_GUARD + pos) * 16 + g * 8, ypl, v, valid, overflow); \
-        } else if (a.out_mode == 1) {                                                                            \
-          if (!valid) v = (f32x4)(-3.0e38f);                                                                     \
-          _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                        \
-            float t = v[e];                                                                                      \
-            t = fmaxf(t, __shfl_xor(t, 1));                                                                      \
-            t = fmaxf(t, __shfl_xor(t, 2));                                                                      \
-            v[e] = t;                                                                                            \
-          }                                                                                                      \
-          if ((l31 & 3) == 0)                                                                                    \
-            p16_split_store(reinterpret_cast<char*>(a.y) + pl * ypl + (P16_GUARD + (pos >> 2)) * 16 + g * 8, ypl, v, \
-                            pos + 3 < a.n, overflow);                                                            \
-        } else if (valid) {                                                                                      \
-          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.y) + pos * a.cout + co) = v;                      \
+          asm volatile("" ::"v"(unit_));                                                                         \
+        } else if (OM == 0) {                                                                                    \
+          *reinterpret_cast<u32x4_t*>(yb_ + (P16_GUARD + p0) * 16 + lane_unit) = unit_;                          \
+        } else {                                                                                                 \
+          const unsigned d01_ = (quad_r & 1) ? unit_.y : unit_.x, d23_ = (quad_r & 1) ? unit_.w : unit_.z;       \
+          *reinterpret_cast<unsigned*>(yb_ + (P16_GUARD + (p0 >> 2)) * 16 + lane_pool) = (quad_r & 2) ? d23_ : d01_; \
         }                                                                                                        \
       }                                                                                                          \
     }                                                                                                            \
   }
 
-  P16_DMA(tile, 0, 0);
-  __syncthreads();   // drains vmcnt (the DMA) and joins the waves
+  P16_SRC(tile, 0);
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) P16_DMA_ONE(it, 0);
+  __syncthreads();   // drains vmcnt (the DMA) and joins the waves; the bias is visible
+  P16_ACC_INIT(tile);
 
   int c = 0, cur = 0;
+  int nstamp = 0;
+  unsigned long long clk0 = 0, rt0 = 0;
+  if (ABL & 128) { clk0 = __builtin_readcyclecounter(); rt0 = __builtin_amdgcn_s_memrealtime(); }
+  // stamps[(step * 8 + wave) * 5 + k]: k = 0 step start, 1 epilogue done, 3 MFMA block done, 4 own DMA + stores retired
+#define P16_STAMP(k) if ((ABL & 128) && blockIdx.x == 0 && lane == 0 && nstamp >= 200 && nstamp < 400) a.stamps[((nstamp - 200) * 8 + wave) * 5 + (k)] = __builtin_readcyclecounter();
   while (true) {
     const bool last_chunk = (c + 1 == a.nchunks);
     const long ntile = last_chunk ? tile + gridDim.x : tile;
     const int nc = last_chunk ? 0 : c + 1;
     const bool more = ntile < ntiles;
+    P16_STAMP(0);
     if (epi_tile >= 0) {
-      if (!(ABL & 32)) P16_EPILOGUE();
+      // raised priority: the SIMD's older wave reaches its MFMA block first and would otherwise starve the
+      // younger wave's epilogue VALU work until its own block is over
+      __builtin_amdgcn_s_setprio(3);
+      P16_EPILOGUE();
+      P16_ACC_INIT(tile);
+      __builtin_amdgcn_s_setprio(0);
       epi_tile = -1;
     }
-    if (more && !(ABL & 1)) P16_DMA(ntile, nc, cur ^ 1);
+    P16_STAMP(1);
+    if (more) P16_SRC(ntile, nc);
 
-    const f32x4* xa0 = smem + cur * BU + g * XROW + wave * (MW * 32) + l31;   // + s*2*XROW + i*32 + tap
-    const f32x4* wb0 = smem + cur * BU + XU + g * CT + l31;                    // + ((s*9+tap)*2)*CT + j*32
+    const unsigned xa0 = p16_lds_addr(smem + cur * BU + g * XROW + wave * (MW * 32) + l31);   // + (s*2*XROW + i*32 + tap)*16
+    const unsigned wb0 = p16_lds_addr(smem + cur * BU + XU + g * CT + l31);                    // + (((s*9+tap)*2)*CT + j*32)*16
     // operand fragments are double-buffered across taps: tap t+1 is read from LDS while tap t feeds the MFMAs
     f16x8 av[2][2][MW], bv[2][2][NW];
 #define P16_READ_FRAGS(buf_, tap_)                                                                                 \
   _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                                  \
-    _Pragma("unroll") for (int i = 0; i < MW; ++i) av[buf_][s][i] = __builtin_bit_cast(f16x8, xa0[s * 2 * XROW + i * 32 + (tap_)]); \
-    _Pragma("unroll") for (int j = 0; j < NW; ++j) bv[buf_][s][j] = __builtin_bit_cast(f16x8, wb0[((s * 9 + (tap_)) * 2) * CT + j * 32]); \
+    _Pragma("unroll") for (int i = 0; i < MW; ++i) av[buf_][s][i] = p16_lds_read16(xa0, (s * 2 * XROW + i * 32 + (tap_)) * 16); \
+    _Pragma("unroll") for (int j = 0; j < NW; ++j) bv[buf_][s][j] = p16_lds_read16(wb0, (((s * 9 + (tap_)) * 2) * CT + j * 32) * 16); \
   }
     P16_READ_FRAGS(0, 0);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-      const int fb = tap & 1;
+      const int fb = (ABL & 8) ? 0 : (tap & 1);
       if (tap + 1 < 9 && !(ABL & 8)) P16_READ_FRAGS(fb ^ 1, tap + 1);
-      if (ABL & 4) {
+      if (more && tap < 5 && !(ABL & 1)) {   // the next buffer's DMA, spread over the first taps
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-#pragma unroll
-          for (int i = 0; i < MW; ++i) asm volatile("" ::"v"(av[fb][s][i]));
-#pragma unroll
-          for (int j = 0; j < NW; ++j) asm volatile("" ::"v"(bv[fb][s][j]));
-        }
-      } else
+        for (int d = 0; d < DPT; ++d)
+          if (tap * DPT + d < NIT) P16_DMA_ONE(tap * DPT + d, cur ^ 1);
+      }
+      if (tap + 1 < 9) p16_lds_wait<2 * (MW + NW), MW, NW>(av[fb], bv[fb]);   // this tap's fragments are in, the next tap's stay in flight
+      else p16_lds_wait<0, MW, NW>(av[fb], bv[fb]);
 #pragma unroll
       for (int p = 0; p < 3; ++p) {
         constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};   // lo*hi, hi*lo, hi*hi (largest last)
@@ -237,21 +349,30 @@ __global__ __launch_bounds__(WM * 64, 2) void conv1d_k9_p16_kernel(ConvP16Args a
           for (int j = 0; j < NW; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bv[fb][PB[p]][j], av[fb][PA[p]][i], acc[i][j], 0, 0, 0);  // D[cout][pos]
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
 #undef P16_READ_FRAGS
 
+    P16_STAMP(3);
     if (last_chunk) epi_tile = tile;
 
     if (!more) break;
+    if (ABL & 128) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); P16_STAMP(4); ++nstamp; }
     __syncthreads();   // next buffer has landed (vmcnt drained), everyone is done reading the current one
     tile = ntile;
     c = nc;
     cur ^= 1;
   }
-  if (epi_tile >= 0 && !(ABL & 32)) P16_EPILOGUE();   // the last tile
+  if (epi_tile >= 0) P16_EPILOGUE();   // the last tile
+  if ((ABL & 128) && blockIdx.x == 0 && tid == 0) {
+    a.stamps[8190] = __builtin_readcyclecounter() - clk0;
+    a.stamps[8191] = __builtin_amdgcn_s_memrealtime() - rt0;
+  }
 #undef P16_EPILOGUE
-#undef P16_DMA
-  if (overflow && a.flag) *a.flag = 1u;
+#undef P16_ACC_INIT
+#undef P16_DMA_ONE
+#undef P16_SRC
+  if (OM != 2 && vmax > 65504.f && a.flag) *a.flag = 1u;
 }
 
 // zero the guard / tail units of every plane: [0,4) and [4 + n_valid, plen)

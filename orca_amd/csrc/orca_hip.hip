@@ -425,7 +425,9 @@ static int launch_conv1d_b16(orca_ctx* ctx, const ConvLayer& L, int precision, c
 }
 
 // ---- P16 (planar split fp16) conv1d with LDS-DMA staging (conv_p16.h) -------------------------------------
-static inline long p16_plen(long n) { return ((n + 511) / 512) * 512 + 2 * P16_GUARD; }
+// plane length in 16-byte units: 4 guard units each side; the +1 keeps the zero stores of a pooled output's ragged
+// last tile (128 * ceil(4n'/512) positions) inside the plane for every n'
+static inline long p16_plen(long n) { return ((n + 512) / 512) * 512 + 2 * P16_GUARD; }
 
 static int launch_p16_zero_pads(orca_ctx* ctx, float* base, int C, long n_valid) {
   hipLaunchKernelGGL(p16_zero_pads_kernel, dim3((unsigned)(C / 8 * 2)), dim3(256), 0, ctx->stream, reinterpret_cast<f32x4*>(base),
@@ -434,14 +436,14 @@ static int launch_p16_zero_pads(orca_ctx* ctx, float* base, int C, long n_valid)
   return ORCA_OK;
 }
 
-template <int CT, int MW, int NW, int WM>
-static void launch_p16_t(hipStream_t s, ConvP16Args a) {
+template <int CT, int MW, int NW, int WM, int OM, bool R1>
+static void launch_p16_k(hipStream_t s, ConvP16Args a) {
   constexpr int MT = WM * MW * 32;
   static int resident = [] {
     int dev = 0, ncu = 256, per_cu = 1;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv1d_k9_p16_kernel<CT, MW, NW, WM>, WM * 64, 0) != hipSuccess || per_cu < 1) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv1d_k9_p16_kernel<CT, MW, NW, WM, OM, R1>, WM * 64, 0) != hipSuccess || per_cu < 1) {
       (void)hipGetLastError();
       per_cu = 1;
     }
@@ -450,7 +452,21 @@ static void launch_p16_t(hipStream_t s, ConvP16Args a) {
   a.tiles_per_row = (a.n + MT - 1) / MT;
   const long ntiles = a.tiles_per_row * (a.cout / CT);
   dim3 grid((unsigned)(ntiles < resident ? ntiles : resident));
-  hipLaunchKernelGGL((conv1d_k9_p16_kernel<CT, MW, NW, WM>), grid, dim3(WM * 64), 0, s, a);
+  hipLaunchKernelGGL((conv1d_k9_p16_kernel<CT, MW, NW, WM, OM, R1>), grid, dim3(WM * 64), 0, s, a);
+}
+
+// out_mode and the residual are compile-time in the kernel (its epilogue is branch-free)
+template <int CT, int MW, int NW, int WM>
+static void launch_p16_t(hipStream_t s, const ConvP16Args& a) {
+  const bool r1 = a.r1 != nullptr;
+  switch (a.out_mode * 2 + (r1 ? 1 : 0)) {
+    case 0: launch_p16_k<CT, MW, NW, WM, 0, false>(s, a); break;
+    case 1: launch_p16_k<CT, MW, NW, WM, 0, true>(s, a); break;
+    case 2: launch_p16_k<CT, MW, NW, WM, 1, false>(s, a); break;
+    case 3: launch_p16_k<CT, MW, NW, WM, 1, true>(s, a); break;
+    case 4: launch_p16_k<CT, MW, NW, WM, 2, false>(s, a); break;
+    default: launch_p16_k<CT, MW, NW, WM, 2, true>(s, a); break;
+  }
 }
 
 // x: P16 [cin] of n positions; y: P16 (out_mode 0: n positions, 1: n/4 pooled) or fp32 [n][cout] (2); r1: P16 [cout], n
