@@ -1,0 +1,20 @@
+"""Small driver for rocprofv3 passes over ONE Decoder forward (both strands batched, 250 x 250 maps)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from tests.util import product_module
+dev = torch.device("cuda:0")
+dec = product_module("Decoder", 0, device=dev)
+rs = np.random.RandomState(0)
+x = torch.from_numpy(rs.randn(2, 128, 250).astype(np.float32)).to(dev)
+de = torch.from_numpy(rs.randn(2, 1, 250, 250).astype(np.float32)).to(dev)
+y = torch.from_numpy(rs.randn(2, 1, 125, 125).astype(np.float32)).to(dev)
+for _ in range(2):
+    out = dec(x, de, y)
+torch.cuda.synchronize()
+ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+ev0.record()
+for _ in range(5):
+    out = dec(x, de, y)
+ev1.record(); torch.cuda.synchronize()
+print(f"decoder B=2: {ev0.elapsed_time(ev1) / 5:.3f} ms per forward")
