@@ -464,6 +464,8 @@ struct FirstMfmaArgs {
   unsigned* flag;
 };
 
+// ABL (tools/microbench_first.hip only): 1 = no MFMA, 16 = no stores, 32 = input not re-fetched per tile
+template <int ABL = 0>
 __global__ __launch_bounds__(256, 2) void conv1d_first_mfma_p16_kernel(FirstMfmaArgs a) {
   constexpr int MT = 256, WIN = MT + 12;          // positions m0-4 .. m0+MT+7 (9-tap window + k padding overrun)
   constexpr int WU = 2 * 3 * 2 * 64;              // 768 units
@@ -477,6 +479,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_first_mfma_p16_kernel(FirstMfma
   for (int i = tid; i < WU; i += 256) wsm[i] = a.w[i];
   if (tid < 64) bias_s[tid] = a.bias[tid];
   bool overflow = false;
+  float vmax = 0.f;
 
   f32x4 xr[2];
   auto fetch = [&](long p) -> f32x4 {
@@ -509,15 +512,17 @@ __global__ __launch_bounds__(256, 2) void conv1d_first_mfma_p16_kernel(FirstMfma
       }
     }
     __syncthreads();
-    if (tile + gridDim.x < ntiles) load_win(tile + gridDim.x, xr[0], xr[1]);
+    if (tile + gridDim.x < ntiles && !(ABL & 32)) load_win(tile + gridDim.x, xr[0], xr[1]);
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][2];   // start from the bias (lane: couts j*32 + 8q + 4g .. +3 in registers 4q..4q+3)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 b_ = *reinterpret_cast<const f32x4*>(bias_s + j * 32 + 8 * q + 4 * g);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int i = 0; i < 2; ++i) { acc[i][j][4 * q + 0] = b_.x; acc[i][j][4 * q + 1] = b_.y; acc[i][j][4 * q + 2] = b_.z; acc[i][j][4 * q + 3] = b_.w; }
+      }
 #pragma unroll
     for (int kk = 0; kk < 3; ++kk) {
       f16x8 xv[2][2], wv[2][2];
@@ -540,27 +545,38 @@ __global__ __launch_bounds__(256, 2) void conv1d_first_mfma_p16_kernel(FirstMfma
         for (int i = 0; i < 2; ++i)
 #pragma unroll
           for (int j = 0; j < 2; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wv[PB[p]][j], xv[PA[p]][i], acc[i][j], 0, 0, 0);
+            if (!(ABL & 1)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wv[PB[p]][j], xv[PA[p]][i], acc[i][j], 0, 0, 0);
       }
     }
+    // epilogue as in conv1d_k9_p16_kernel: lanes l / l+32 exchange halves so that each stores one 16-byte unit
+    // (g = 0: the hi unit, g = 1: the lo unit); positions >= n get zeros (they are tail guard units of the plane)
     const long ypl = a.y_plen * 16;
+    const unsigned lane_unit = (unsigned)(l31 * 16) + (g ? (unsigned)ypl : 0u);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const long pos = tile * MT + wave * 64 + i * 32 + l31;
+      const long p0 = tile * MT + wave * 64 + i * 32;
+      const bool ok = p0 + l31 < a.n;
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int co = j * 32 + 8 * q + 4 * g;
-          const f32x4 bias = *reinterpret_cast<const f32x4*>(bias_s + co);
           f32x4 v;
-          v.x = acc[i][j][4 * q + 0] + bias.x; v.y = acc[i][j][4 * q + 1] + bias.y;
-          v.z = acc[i][j][4 * q + 2] + bias.z; v.w = acc[i][j][4 * q + 3] + bias.w;
-          if (pos < a.n)
-            p16_split_store(reinterpret_cast<char*>(a.y) + (long)(co >> 3) * 2 * ypl + (P16_GUARD + pos) * 16 + g * 8, ypl, v, true, overflow);
+          v.x = acc[i][j][4 * q + 0]; v.y = acc[i][j][4 * q + 1]; v.z = acc[i][j][4 * q + 2]; v.w = acc[i][j][4 * q + 3];
+          if (!ok) v = (f32x4)(0.f);
+          vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+          unsigned h0, h1, l0, l1;
+          p16_split_hl(v, h0, h1, l0, l1);
+          p16_swap32(h0, l0);
+          p16_swap32(h1, l1);
+          u32x4_t unit;
+          unit.x = h0; unit.y = h1; unit.z = l0; unit.w = l1;
+          if (ABL & 16) asm volatile("" ::"v"(unit));
+          else if (ABL & 64) { constexpr long G = (ABL >> 8) ? (ABL >> 8) : 1; *reinterpret_cast<u32x4_t*>(reinterpret_cast<char*>(a.y) + ((((tile / G) * 16 + (j * 4 + q) * 2 + g) * G + tile % G) * 256 + wave * 64 + i * 32 + l31) * 16) = unit; }   // blocked-planar test pattern: G tiles per block
+          else *reinterpret_cast<u32x4_t*>(reinterpret_cast<char*>(a.y) + (long)(j * 4 + q) * 2 * ypl + (P16_GUARD + p0) * 16 + lane_unit) = unit;
         }
     }
   }
+  if (vmax > 65504.f) overflow = true;
   if (overflow && a.flag) *a.flag = 1u;
 }
 

@@ -774,7 +774,7 @@ static int encoder_chunk(orca_ctx* ctx, orca_net* net, const SeqSource& src, lon
         fm.codes = src.codes; fm.codes_L = src.codes_L; fm.codes_off = src.codes_off; fm.reverse = src.reverse; fm.w = reinterpret_cast<const f32x4*>(net->d_first_w16); fm.bias = L[0].d_bias;
         fm.y = reinterpret_cast<f32x4*>(buf[1]); fm.y_plen = p16_plen(n1); fm.flag = ctx->d_flag;
         const long nt = (n1 + 255) / 256;
-        hipLaunchKernelGGL(conv1d_first_mfma_p16_kernel, dim3((unsigned)(nt < 2048 ? nt : 2048)), dim3(256), 0, s, fm);
+        hipLaunchKernelGGL(conv1d_first_mfma_p16_kernel<0>, dim3((unsigned)(nt < 2048 ? nt : 2048)), dim3(256), 0, s, fm);
         LAUNCHCHECK("conv1d_first_mfma_p16_kernel");
       } else {
         hipLaunchKernelGGL(conv1d_first_p16_kernel, dim3((unsigned)((n1 + 255) / 256), 8), dim3(256), 0, s, fa);

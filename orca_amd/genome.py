@@ -1,0 +1,139 @@
+"""Packed genome store: 1 byte per base, resident on the host or in HBM.
+
+The reference keeps the genome as a float32 one-hot memmap (`selene_utils2.MemmapGenome`, ~40 GB for hg38,
+`selene_utils2.py:38-272`) and materialises a 512 MB float window per `get_encoding_from_coords` call.  Here a
+chromosome is ONE uint8 array of base codes - 0..3 = A,C,G,T (the reference's channel order), 4 = N / anything else
+(the 0.25 x 4 row) - ~3.1 GB for hg38, which fits HBM many times over.  The selene query API the SV drivers use is
+kept (`get_chr_lens`, `get_encoding_from_coords(chrom, start, end, strand="+", pad=False)` returning float32
+`[end-start, 4]`, reverse complement = both axes flipped, `pad=True` filling 0.25 beyond the chromosome ends); the
+device path adds `get_codes_from_coords`, which returns the same window as codes and feeds the Encoder's packed
+input (`orca_encoder_forward_codes`) without ever expanding to floats.
+
+One-hot encoding parity is unpinned by the reference (selene is not vendored): A,C,G,T in that channel
+order, case-insensitive, every other symbol -> 0.25 x 4, consistent with `selene_utils2.py:216-222,272`.
+"""
+import numpy as np
+import torch
+
+N_CODE = 4
+_LUT = np.full(256, N_CODE, dtype=np.uint8)
+for _i, _b in enumerate("ACGT"):
+    _LUT[ord(_b)] = _i
+    _LUT[ord(_b.lower())] = _i
+_ONEHOT = np.concatenate([np.eye(4, dtype=np.float32), np.full((1, 4), 0.25, dtype=np.float32)], axis=0)   # [5,4]
+
+
+def sequence_to_codes(seq):
+    """str / bytes -> uint8 base codes."""
+    if isinstance(seq, str):
+        seq = seq.encode("ascii")
+    return _LUT[np.frombuffer(seq, dtype=np.uint8)]
+
+
+def codes_to_encoding(codes):
+    """uint8 codes [L] -> float32 one-hot [L,4] (N -> 0.25 x 4)."""
+    return _ONEHOT[np.minimum(np.asarray(codes), N_CODE)]
+
+
+def sequence_to_encoding(seq):
+    """Counterpart of `selene_sdk.sequences.Genome.sequence_to_encoding` (call site `orca_predict.py:2299`)."""
+    return codes_to_encoding(sequence_to_codes(seq))
+
+
+def revcomp_codes(codes):
+    """Reverse complement of a code array (numpy or torch): reversed order, A<->T, C<->G, N stays N."""
+    if isinstance(codes, torch.Tensor):
+        r = torch.flip(codes, [-1])
+        return torch.where(r < 4, 3 - r, r)
+    r = np.asarray(codes)[..., ::-1]
+    return np.where(r < 4, 3 - r, r).astype(np.uint8)
+
+
+class PackedGenome:
+    """Chromosome name -> uint8 code array.  `to(device)` additionally keeps a ROCm copy for `get_codes_from_coords`."""
+
+    def __init__(self, chroms):
+        self._host = {str(k): np.ascontiguousarray(np.asarray(v, dtype=np.uint8)) for k, v in chroms.items()}
+        self._dev = {}
+        self.device = None
+
+    # ---- construction ------------------------------------------------------------------------------------
+    @classmethod
+    def from_fasta(cls, path):
+        """Plain multi-FASTA reader (the reference indexes with pyfaidx; no index is needed when every
+        chromosome is packed in memory once)."""
+        chroms, name, parts = {}, None, []
+        with open(path, "rb") as f:
+            for line in f:
+                if line.startswith(b">"):
+                    if name is not None:
+                        chroms[name] = np.concatenate(parts) if parts else np.zeros(0, np.uint8)
+                    name, parts = line[1:].split()[0].decode("ascii"), []
+                else:
+                    parts.append(sequence_to_codes(line.strip()))
+        if name is not None:
+            chroms[name] = np.concatenate(parts) if parts else np.zeros(0, np.uint8)
+        return cls(chroms)
+
+    @classmethod
+    def random(cls, lengths, seed=0, n_runs=0):
+        """Synthetic genome (tests / benchmarks): uniform bases with `n_runs` runs of N per chromosome."""
+        chroms = {}
+        for k, (name, L) in enumerate(lengths.items() if isinstance(lengths, dict) else lengths):
+            rs = np.random.RandomState(seed + 7919 * k)
+            c = rs.randint(0, 4, int(L)).astype(np.uint8)
+            for _ in range(n_runs):
+                s = int(rs.randint(0, max(1, L - 50000)))
+                c[s:s + int(rs.randint(1000, 50000))] = N_CODE
+            chroms[name] = c
+        return cls(chroms)
+
+    def to(self, device):
+        self.device = torch.device(device)
+        self._dev = {k: torch.from_numpy(v).to(self.device) for k, v in self._host.items()}
+        return self
+
+    # ---- selene Genome API used by the reference's drivers -------------------------------------------------
+    def get_chrs(self):
+        return sorted(self._host)
+
+    def get_chr_lens(self):
+        return [(c, int(self._host[c].shape[0])) for c in self.get_chrs()]
+
+    def _bounds(self, chrom, start, end, pad):
+        n = self._host[chrom].shape[0]
+        if pad:
+            qs, qe = max(start, 0), min(end, n)
+            return qs, max(qe, qs), qs - start, end - max(qe, qs)
+        assert end <= n and start >= 0, "coordinates exceed the chromosome (selene_utils2.py:257)"
+        return start, end, 0, 0
+
+    def get_codes_from_coords(self, chrom, start, end, strand="+", pad=False, device=None):
+        """The window as base codes: numpy uint8 [end-start], or a ROCm tensor when the genome lives on a device
+        (`device=False` forces the host copy)."""
+        qs, qe, pl, pr = self._bounds(chrom, start, end, pad)
+        on_dev = self._dev and device is not False
+        if on_dev:
+            c = self._dev[chrom][qs:qe]
+            if pl or pr:
+                c = torch.cat([torch.full((pl,), N_CODE, dtype=torch.uint8, device=c.device), c,
+                               torch.full((pr,), N_CODE, dtype=torch.uint8, device=c.device)])
+        else:
+            c = self._host[chrom][qs:qe]
+            if pl or pr:
+                c = np.concatenate([np.full(pl, N_CODE, np.uint8), c, np.full(pr, N_CODE, np.uint8)])
+        if strand == "-":
+            c = revcomp_codes(c)
+        assert c.shape[0] == end - start
+        return c
+
+    def get_encoding_from_coords(self, chrom, start, end, strand="+", pad=False):
+        """float32 [end-start, 4] exactly as `MemmapGenome.get_encoding_from_coords` (`selene_utils2.py:231-262`)."""
+        return codes_to_encoding(self.get_codes_from_coords(chrom, start, end, strand, pad, device=False))
+
+    def get_encoding_from_coords_check_unk(self, chrom, start, end, strand="+", pad=False):
+        """As the reference (`selene_utils2.py:264-272`): the flag looks at the FIRST position's row only."""
+        enc = self.get_encoding_from_coords(chrom, start, end, strand=strand, pad=pad)
+        return enc, bool(np.any(enc[0, :] == 0.25))
+
+    sequence_to_encoding = staticmethod(sequence_to_encoding)

@@ -1,0 +1,282 @@
+"""Structural-variant drivers with the reference's signatures: `process_region / process_dup /
+process_del / process_inv / process_ins / process_custom / process_single_breakpoint`
+(/root/reference/orca_predict.py:983-3057), 32 Mb models (`window_radius=16000000`).
+
+Each driver is a list of VIEWS of a reference or mutated chromosome: (allele, anchor position, chromosome length
+used for window clipping, annotation).  A view is materialised as the 32 Mb window sequence and handed to
+`genomepredict`; the result dictionaries are the ones `genomepredict` returns, in the reference's order.
+
+What differs from the reference is where the window sequence lives.  The reference concatenates 512 MB float one-hot
+arrays on the host (`genome.get_encoding_from_coords` per piece, `[::-1, ::-1]` for '-' pieces).  With a
+`orca_amd.genome.PackedGenome` resident on the MI355X (`genome.to("cuda")`) the pieces are gathered as 1-byte base
+codes on the device and go straight into the Encoder's packed-input path - no float window ever exists.  Any other
+genome object with the selene API (`get_chr_lens`, `get_encoding_from_coords`) takes the reference's host route.
+
+Out of scope here: plotting (`file=...` must stay None), bundled Micro-C targets (`target=True` behaves as it does in
+the reference when the resources are not loaded: no targets), the 256 Mb variants (`window_radius=128000000`,
+`_retrieve_multi`): next round.
+"""
+import numpy as np
+import torch
+
+from . import genome as _genome
+from .orca_utils import StructuralChange2, coord_clip, coord_round, process_anno
+
+_R32 = 16000000
+
+
+def _setup(custom_models, window_radius, model_labels, file):
+    if file is not None:
+        raise NotImplementedError("plotting (file=...) is not part of orca_amd; plot the returned dicts with the reference's genomeplot")
+    if window_radius == 128000000:
+        raise NotImplementedError("the 256 Mb structural-variant views (window_radius=128000000) are not built yet")
+    if window_radius != _R32:
+        raise ValueError("Only window_radius 16000000 (32Mb models) or 128000000 (256Mb models) are supported")
+    if custom_models is None:
+        return ["h1esc", "hff"], ["H1-ESC", "HFF"]
+    if model_labels is None:
+        model_labels = [f"Model {i}" for i in range(len(custom_models))]
+    return custom_models, model_labels
+
+
+def _targets(target):
+    """`target=True` asks for the bundled Micro-C datasets, which do not exist offline: as in the reference when
+    `target_dict_global` lacks them (`orca_predict.py:1232-1241`), fall back to no targets."""
+    if not target or target is True:
+        return False
+    if any(not hasattr(t, "get_feature_data") for t in target):
+        return False
+    return list(target)
+
+
+def _target_windows(target, chrom, w0, w1):
+    if not target:
+        return None
+    return [torch.FloatTensor(t.get_feature_data(chrom, coord_round(w0), coord_round(w1))[None, :]) for t in target]
+
+
+def _chrlen(genome, chrom):
+    return [l for c, l in genome.get_chr_lens() if c == chrom].pop()
+
+
+def _on_device(genome, use_cuda):
+    return use_cuda and getattr(genome, "device", None) is not None and hasattr(genome, "get_codes_from_coords")
+
+
+def _assemble(genome, pieces, use_cuda, ins_seq=None, pad_to=None):
+    """Window sequence from reference pieces `(chrom, start, end, strand)`: packed codes `[1, L]` on the device when
+    the genome lives there, else float32 `[1, L, 4]` on the host (`orca_predict.py:1428-1436`).  Pieces of an
+    inserted sequence (chromosome name 'ins...') are cut from `ins_seq`; `pad_to` appends 'N' rows."""
+    if _on_device(genome, use_cuda):
+        parts = []
+        for chrom, start, end, strand in pieces:
+            if ins_seq is not None and chrom.startswith("ins"):
+                codes = torch.from_numpy(_genome.sequence_to_codes(ins_seq[start:end])).to(genome.device)
+            else:
+                codes = genome.get_codes_from_coords(chrom, start, end)
+            parts.append(_genome.revcomp_codes(codes) if strand == "-" else codes)
+        n = sum(int(p.shape[0]) for p in parts)
+        if pad_to and n < pad_to:
+            parts.append(torch.full((pad_to - n,), _genome.N_CODE, dtype=torch.uint8, device=genome.device))
+        return torch.cat(parts)[None, :]
+    parts = []
+    for chrom, start, end, strand in pieces:
+        if ins_seq is not None and chrom.startswith("ins"):
+            seq = _genome.sequence_to_encoding(ins_seq[start:end])
+        else:
+            seq = genome.get_encoding_from_coords(chrom, start, end)
+        parts.append(seq[::-1, ::-1] if strand == "-" else seq)
+    seq = np.concatenate(parts, axis=0)
+    if pad_to and seq.shape[0] < pad_to:
+        seq = np.concatenate((seq, np.full((pad_to - seq.shape[0], 4), 0.25, dtype=seq.dtype)), axis=0)
+    return seq[None, :, :]
+
+
+def _predict(sequence, mchr, mpos, wpos, models, annotation, targets, use_cuda):
+    from .orca_predict import genomepredict
+    return genomepredict(sequence, mchr, mpos, wpos, models=models, annotation=annotation, targets=targets, use_cuda=use_cuda)
+
+
+def _ref_view(genome, chrom, anchor, anno_regions, models, target, use_cuda, chrlen=None):
+    """Reference-allele window clipped around `anchor`; `anno_regions(w0, w1)` builds the unscaled annotation."""
+    chrlen = _chrlen(genome, chrom) if chrlen is None else chrlen
+    wpos = coord_clip(anchor, chrlen)
+    w0, w1 = wpos - _R32, wpos + _R32
+    seq = _assemble(genome, [(chrom, w0, w1, "+")], use_cuda)
+    anno = process_anno(anno_regions(w0, w1), base=w0, window_radius=_R32)
+    return _predict(seq, chrom, anchor, wpos, models, anno, _target_windows(target, chrom, w0, w1), use_cuda)
+
+
+def _alt_view(genome, sc, label, anchor, chrlen_alt, anno_regions, models, use_cuda, ins_seq=None):
+    wpos = coord_clip(anchor, chrlen_alt)
+    w0, w1 = wpos - _R32, wpos + _R32
+    seq = _assemble(genome, sc[w0:w1], use_cuda, ins_seq=ins_seq)
+    anno = process_anno(anno_regions(w0, w1), base=w0, window_radius=_R32)
+    return _predict(seq, label, anchor, wpos, models, anno, None, use_cuda)
+
+
+def _left_anchored(mstart, mend, colour):
+    """Region annotation of a window anchored at the variant's LEFT end: cut at the window's right edge."""
+    return lambda w0, w1: [[mstart, mend if w1 > mend else w1, colour]]
+
+
+def _right_anchored(mstart, mend, colour):
+    return lambda w0, w1: [[mstart if w0 < mstart else w0, mend, colour]]
+
+
+def process_region(mchr, mstart, mend, genome, file=None, custom_models=None, target=True, show_genes=True, show_tracks=False,
+                   window_radius=16000000, padding_chr="chr1", model_labels=None, use_cuda=True):
+    """Multiscale prediction centred on a region (`orca_predict.py:983-1169`)."""
+    models, _ = _setup(custom_models, window_radius, model_labels, file)
+    target = _targets(target)
+    mpos = int((int(mstart) + int(mend)) / 2)
+    anno = lambda w0, w1: [[np.clip(mstart, w0, w1), np.clip(mend, w0, w1), "black"]]
+    return _ref_view(genome, mchr, mpos, anno, models, target, use_cuda)
+
+
+def _ref_pair(genome, mchr, mstart, mend, models, target, use_cuda):
+    """The two reference views every interval variant starts with: anchored at its left and at its right end."""
+    ref_l = _ref_view(genome, mchr, mstart, _left_anchored(mstart, mend, "black"), models, target, use_cuda)
+    ref_r = _ref_view(genome, mchr, mend, _right_anchored(mstart, mend, "black"), models, target, use_cuda)
+    return ref_l, ref_r
+
+
+def process_dup(mchr, mstart, mend, genome, file=None, custom_models=None, target=True, show_genes=True, show_tracks=False,
+                window_radius=16000000, padding_chr="chr1", model_labels=None, use_cuda=True):
+    """Tandem duplication of [mstart, mend) (`orca_predict.py:1172-1507`): ref.l, ref.r, alt (anchored at the
+    junction `mend` between the two copies; original copy black, new copy gray)."""
+    models, _ = _setup(custom_models, window_radius, model_labels, file)
+    target = _targets(target)
+    chrlen = _chrlen(genome, mchr)
+    ref_l, ref_r = _ref_pair(genome, mchr, mstart, mend, models, target, use_cuda)
+    sc = StructuralChange2(mchr, chrlen)
+    sc.duplicate(mstart, mend)
+    copy_end = mend + mend - mstart
+
+    def anno(w0, w1):
+        return [[mstart if w0 < mstart else w0, mend, "black"], [mend, copy_end if copy_end < w1 else w1, "gray"]]
+
+    alt = _alt_view(genome, sc, mchr, mend, chrlen + mend - mstart, anno, models, use_cuda)
+    return ref_l, ref_r, alt
+
+
+def process_del(mchr, mstart, mend, genome, cmap=None, file=None, custom_models=None, target=True, show_genes=True,
+                show_tracks=False, window_radius=16000000, padding_chr="chr1", model_labels=None, use_cuda=True):
+    """Deletion of [mstart, mend) (`orca_predict.py:1510-1817`): ref.l, ref.r, alt at the breakpoint."""
+    models, _ = _setup(custom_models, window_radius, model_labels, file)
+    target = _targets(target)
+    chrlen = _chrlen(genome, mchr)
+    ref_l, ref_r = _ref_pair(genome, mchr, mstart, mend, models, target, use_cuda)
+    sc = StructuralChange2(mchr, chrlen)
+    sc.delete(mstart, mend)
+    alt = _alt_view(genome, sc, mchr, mstart, chrlen - (mend - mstart), lambda w0, w1: [[mstart, "double"]], models, use_cuda)
+    return ref_l, ref_r, alt
+
+
+def process_inv(mchr, mstart, mend, genome, file=None, custom_models=None, target=True, show_genes=True, show_tracks=False,
+                window_radius=16000000, padding_chr="chr1", model_labels=None, use_cuda=True):
+    """Inversion of [mstart, mend) (`orca_predict.py:1820-2175`): ref.l, ref.r, alt.l, alt.r."""
+    models, _ = _setup(custom_models, window_radius, model_labels, file)
+    target = _targets(target)
+    chrlen = _chrlen(genome, mchr)
+    ref_l, ref_r = _ref_pair(genome, mchr, mstart, mend, models, target, use_cuda)
+    sc = StructuralChange2(mchr, chrlen)
+    sc.invert(mstart, mend)
+    alt_l = _alt_view(genome, sc, mchr, mstart, chrlen, lambda w0, w1: [[mstart, mend if mend < w1 else w1, "gray"]], models, use_cuda)
+    alt_r = _alt_view(genome, sc, mchr, mend, chrlen, lambda w0, w1: [[mstart if mstart > w0 else w0, mend, "gray"]], models, use_cuda)
+    return ref_l, ref_r, alt_l, alt_r
+
+
+def process_ins(mchr, mpos, ins_seq, genome, strand="+", file=None, custom_models=None, target=True, show_genes=True,
+                show_tracks=False, window_radius=16000000, padding_chr="chr1", model_labels=None, use_cuda=True):
+    """Insertion of the string `ins_seq` at `mpos` (`orca_predict.py:2178-2497`): ref, alt.l, alt.r (anchored at the
+    two ends of the insert).  The reference forgets `models=` in the alt.r call (`:2453`) and so always uses the
+    default H1-ESC + HFF pair there; here alt.r uses the same models as the other views."""
+    models, _ = _setup(custom_models, window_radius, model_labels, file)
+    target = _targets(target)
+    chrlen = _chrlen(genome, mchr)
+    n_ins = len(ins_seq)
+    ref = _ref_view(genome, mchr, mpos, lambda w0, w1: [[mpos, "single"]], models, target, use_cuda, chrlen)
+    sc = StructuralChange2(mchr, chrlen)
+    sc.insert(mpos, n_ins, strand=strand)
+    alt_l = _alt_view(genome, sc, mchr, mpos, chrlen + n_ins,
+                      lambda w0, w1: [[mpos, mpos + n_ins if mpos + n_ins < w1 else w1, "gray"]], models, use_cuda, ins_seq=ins_seq)
+    alt_r = _alt_view(genome, sc, mchr, mpos + n_ins, chrlen + n_ins,
+                      lambda w0, w1: [[mpos if mpos > w0 else w0, mpos + n_ins, "gray"]], models, use_cuda, ins_seq=ins_seq)
+    return ref, alt_l, alt_r
+
+
+def process_custom(region_list, ref_region_list, mpos, genome, ref_mpos_list=None, anno_list=None, ref_anno_list=None,
+                   custom_models=None, target=True, file=None, show_genes=True, show_tracks=False, window_radius=16000000,
+                   model_labels=None, use_cuda=True):
+    """Arbitrary rearrangement given as the list of reference pieces that make up the 32 Mb alternative window
+    (`orca_predict.py:2500-2681`).  Like the reference, returns the LAST reference view and the alternative view."""
+    models, _ = _setup(custom_models, window_radius, model_labels, file)
+    target = _targets(target)
+
+    def validate(regions, enforce_strand=None):
+        total = 0
+        for chrm, start, end, strand in regions:
+            assert start >= 0 and end <= _chrlen(genome, chrm)
+            total += end - start
+            if enforce_strand and strand != enforce_strand:
+                raise ValueError("The specified strand must be " + enforce_strand)
+        assert total == 2 * window_radius
+
+    validate(region_list)
+    outputs_ref = None
+    for i, ref_region in enumerate(ref_region_list):
+        validate([ref_region], enforce_strand="+")
+        chrm, start, end = ref_region[0], ref_region[1], ref_region[2]
+        seq = _assemble(genome, [(chrm, start, end, "+")], use_cuda)
+        anno = process_anno(ref_anno_list, base=0, window_radius=window_radius)
+        outputs_ref = _predict(seq, chrm, start + window_radius if ref_mpos_list is None else ref_mpos_list[i],
+                               start + window_radius, models, anno, _target_windows(target, chrm, start, end), use_cuda)
+    seq = _assemble(genome, region_list, use_cuda)
+    anno = process_anno(anno_list, base=0, window_radius=window_radius)
+    outputs_alt = _predict(seq, "chimeric", mpos, window_radius, models, anno, None, use_cuda)
+    return outputs_ref, outputs_alt
+
+
+def process_single_breakpoint(chr1, pos1, chr2, pos2, orientation1, orientation2, genome, custom_models=None, target=True,
+                              file=None, show_genes=True, show_tracks=False, window_radius=16000000, padding_chr="chr1",
+                              model_labels=None, use_cuda=True):
+    """Simple translocation joining `chr1:pos1` and `chr2:pos2` (`orca_predict.py:2684-3057`): the two reference
+    views and the fused chromosome around the breakpoint.  orientation1 '+' keeps chr1[0:pos1), '-' keeps
+    chr1[pos1-1:] reverse-complemented; orientation2 '-' keeps chr2[pos2-1:], '+' keeps chr2[0:pos2) reversed."""
+    models, _ = _setup(custom_models, window_radius, model_labels, file)
+    target = _targets(target)
+    len1, len2 = _chrlen(genome, chr1), _chrlen(genome, chr2)
+    ref_1 = _ref_view(genome, chr1, pos1, lambda w0, w1: [[pos1, "single"]], models, target, use_cuda, len1)
+    ref_2 = _ref_view(genome, chr2, pos2, lambda w0, w1: [[pos2, "single"]], models, target, use_cuda, len2)
+
+    s = StructuralChange2(chr1, len1)
+    if orientation1 == "+":
+        s.delete(pos1, len1)
+    else:
+        s.delete(0, pos1 - 1)
+        s.invert(0, len1 - pos1 + 1)
+    s2 = StructuralChange2(chr2, len2)
+    if orientation2 == "-":
+        s2.delete(0, pos2 - 1)
+    else:
+        s2.delete(pos2, len2)
+        s2.invert(0, pos2)
+    breakpos = s.coord_points[-1]
+    s = s + s2
+    total = s.coord_points[-1]
+    if total < 2 * window_radius + 128000:   # fused chromosome shorter than a window (+ one coord_clip bin)
+        radius = total // 2
+        wpos = radius
+    else:
+        radius = window_radius
+        wpos = coord_clip(breakpos, total, window_radius=radius)
+    pieces = s[wpos - radius: wpos + radius]
+    first_len = pieces[0].end - pieces[0].start
+    n = sum(p.end - p.start for p in pieces)
+    seq = _assemble(genome, pieces, use_cuda, pad_to=32000000)
+    if n != 32000000:
+        wpos = wpos + (32000000 - n) // 2
+    anno = process_anno([[first_len, "double"]], base=0, window_radius=window_radius)
+    alt = _predict(seq, chr1 + "|" + chr2, breakpos, wpos, models, anno, None, use_cuda)
+    return ref_1, ref_2, alt

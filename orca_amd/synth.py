@@ -146,5 +146,83 @@ try:  # torch is only needed for the scaffolding module below
             k = L // self.nbins
             pooled = x[:, :, : k * self.nbins].reshape(B, C, self.nbins, k).mean(dim=3)
             return _torch.einsum("oc,bct->bot", self.proj, pooled) + self.posterm[None]
+
+    class FakeNet(_torch.nn.Module):
+        """Stand-in for Encoder2 in driver tests: the 6-level pyramid by average pooling (fine -> coarse)."""
+
+        def forward(self, enc0):
+            return [enc0 if k == 1 else _torch.nn.functional.avg_pool1d(enc0, k, k) for k in (1, 2, 4, 8, 16, 32)]
+
+    class FakeDecoder(_torch.nn.Module):
+        """Stand-in for Decoder / Decoder_1m in driver tests: symmetric, depends on every input it is given."""
+
+        def __init__(self, seed=0):
+            super().__init__()
+            self.register_buffer("v", _torch.from_numpy(np.random.RandomState(2000 + seed).normal(0, 0.3, 128).astype(np.float32)))
+
+        def forward(self, x, distenc=None, y=None):
+            a = _torch.einsum("c,bct->bt", self.v, x)
+            out = (a[:, :, None] + a[:, None, :])[:, None]
+            if distenc is not None:
+                out = out + 0.05 * distenc
+            if y is not None:
+                out = out + 0.3 * _torch.nn.functional.interpolate(y, scale_factor=2, mode="nearest")
+            return out
+
+    class FakeModel32(_torch.nn.Module):
+        """A whole 32 Mb model container made of the cheap stand-ins above (seconds on a CPU): used to pin the
+        structural-variant DRIVERS (sequence assembly, window clipping, annotations) against the reference's, whose
+        numerics are pinned separately (G1-G9)."""
+
+        def __init__(self, seed=0):
+            super().__init__()
+            self.net0 = FakeNet0(nbins=8000, seed=seed)
+            self.net = FakeNet()
+            self.denets = {lv: FakeDecoder(seed + lv) for lv in (1, 2, 4, 8, 16, 32)}
+            self.denet_1_pt = FakeDecoder(seed + 100)
+            self.normmats, self.epss = synth_normmats_32m(seed)
+            self.levels = [1, 2, 4, 8, 16, 32]
 except ImportError:  # pragma: no cover
     pass
+
+
+def sv_driver_cases():
+    """The structural-variant driver calls pinned by tests/golden/G11 (synthetic genome: chrS 40 Mb, chrT 36 Mb)."""
+    rs = np.random.RandomState(77)
+    ins_seq = "".join("ACGTN"[i] for i in rs.choice(5, 7001, p=[0.24, 0.24, 0.24, 0.24, 0.04]))
+    return [
+        ("region", "process_region", ("chrS", 11_000_000, 11_600_000), {}),
+        ("del_mid", "process_del", ("chrS", 15_200_000, 15_850_000), {}),
+        ("del_edge", "process_del", ("chrS", 2_000_000, 2_300_000), {}),
+        ("dup", "process_dup", ("chrS", 20_000_000, 21_500_000), {}),
+        ("inv", "process_inv", ("chrS", 30_100_000, 33_000_000), {}),
+        ("ins", "process_ins", ("chrS", 18_000_123, ins_seq), {"strand": "-"}),
+        ("bp_short", "process_single_breakpoint", ("chrS", 22_000_000, "chrT", 9_000_000, "+", "+"), {}),
+        ("bp_long", "process_single_breakpoint", ("chrS", 22_000_000, "chrT", 9_000_000, "-", "-"), {}),
+        ("custom", "process_custom", ([("chrS", 1_000_000, 17_000_000, "+"), ("chrT", 4_000_000, 20_000_000, "-")],
+                                      [("chrS", 1_000_000, 33_000_000, "+")], 16_000_000),
+         {"anno_list": [[16_000_000, "double"]], "ref_anno_list": [[17_000_000, "single"]]}),
+    ]
+
+
+def sv_driver_genome():
+    from .genome import PackedGenome
+    return PackedGenome.random({"chrS": 40_000_000, "chrT": 36_000_000}, seed=5, n_runs=3)
+
+
+def summarize_outputs(outputs):
+    """Compact, comparable summary of a tuple of genomepredict dicts (fixtures keep these, not the 1.5 MB maps)."""
+    d = {}
+    outs = outputs if isinstance(outputs, (tuple, list)) else (outputs,)
+    for k, out in enumerate(outs):
+        d[f"o{k}_start"] = np.array(out["start_coords"], dtype=np.int64)
+        d[f"o{k}_end"] = np.array([int(v) for v in out["end_coords"]], dtype=np.int64)
+        d[f"o{k}_chr"] = np.array([str(out["chr"])])
+        d[f"o{k}_annos"] = np.array([repr([[[float(v) if not isinstance(v, str) else v for v in r] for r in lv]
+                                            for lv in out["annos"]]) if out["annos"] is not None else "None"])
+        for m, preds in enumerate(out["predictions"]):
+            for j, p in enumerate(preds):
+                p = np.asarray(p, dtype=np.float64)
+                d[f"o{k}_m{m}_stats_{j}"] = np.array([p.sum(), (p * p).sum(), np.abs(p).max()])
+                d[f"o{k}_m{m}_sub_{j}"] = p[::10, ::10].astype(np.float32)
+    return d

@@ -151,3 +151,26 @@ def test_sv_screen_packed_genome(cuda):
     assert out["start_coords"] == res[0]["ref"]["start_coords"]
     for a, b in zip(out["predictions"][0], res[0]["ref"]["predictions"][0]):
         assert maxabs(a, b) < 1e-6
+
+
+def test_sv_drivers_device_genome_equals_host_route(cuda):
+    """`process_*` on the MI355X with the real-architecture model: a PackedGenome resident in HBM
+    (windows gathered as 1-byte codes on the device) gives the same dictionaries as the reference's host route (float
+    one-hot pieces concatenated on the host) - covering '-' pieces, an inserted string with N, and the 'N'-padded short
+    fused chromosome of a translocation.  The drivers' agreement with the reference is pinned on CPU (G11)."""
+    model = M.H1esc(synthetic_seed=0)
+    host = synth.sv_driver_genome()
+    dev = synth.sv_driver_genome().to(cuda)
+    cases = {c[0]: c for c in synth.sv_driver_cases()}
+    for name in ("inv", "ins", "bp_short"):
+        _, fn, a, kw = cases[name]
+        outs_h = getattr(P, fn)(*a, host, custom_models=[model], target=False, use_cuda=True, **kw)
+        outs_d = getattr(P, fn)(*a, dev, custom_models=[model], target=False, use_cuda=True, **kw)
+        assert len(outs_h) == len(outs_d) >= 3
+        for oh, od in zip(outs_h, outs_d):
+            assert oh["start_coords"] == od["start_coords"] and oh["end_coords"] == od["end_coords"]
+            assert oh["chr"] == od["chr"] and oh["annos"] == od["annos"]
+            for ph, pd_ in zip(oh["predictions"][0], od["predictions"][0]):
+                assert np.isfinite(ph).all() and maxabs(ph, pd_) < 1e-6
+        # the alternative allele differs from the reference allele around the variant
+        assert max(maxabs(x, y) for x, y in zip(outs_d[0]["predictions"][0], outs_d[-1]["predictions"][0])) > 1e-3

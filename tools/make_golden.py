@@ -45,8 +45,14 @@ def _stub_third_party():
         def __init__(self, *a, **k):
             pass
 
+    class _Genome(_Dummy):
+        # selene's one-hot encoder is not vendored (encoding parity unpinned): process_ins gets the
+        # build's definition (A,C,G,T channel order, anything else 0.25 x 4)
+        from orca_amd.genome import sequence_to_encoding as _s2e
+        sequence_to_encoding = staticmethod(_s2e)
+
     mod("selene_sdk")
-    mod("selene_sdk.sequences", Genome=_Dummy)
+    mod("selene_sdk.sequences", Genome=_Genome)
     mod("selene_sdk.samplers", OnlineSampler=_Dummy)
     mod("selene_sdk.utils", get_indices_and_probabilities=lambda *a, **k: None)
     mod("selene_sdk.targets", Target=_Dummy)
@@ -248,6 +254,72 @@ def main():
                              int(ou.coord_clip(pos, max(chrlen, 260_000_000), binsize=1024000, window_radius=128000000))))
             np.savez_compressed(os.path.join(GOLD, "G10_coords.npz"), rows=np.array(rows, dtype=np.int64))
             print("G10 done")
+
+        # ---- G11: structural-variant drivers through the REAL orca_predict.process_* ---------
+        if want("G11"):
+            import orca_predict as op
+            genome = synth.sv_driver_genome()
+            op.model_dict_global["h1esc"] = synth.FakeModel32(0)
+            op.model_dict_global["hff"] = synth.FakeModel32(1)
+            d = {}
+            for name, fn, a, kw in synth.sv_driver_cases():
+                t = time.time()
+                # process_ins forgets `models=` in its alt.r call and falls back to the default pair: run that case
+                # with the default pair throughout so that every view uses the same models
+                cm = None if fn == "process_ins" else [op.model_dict_global["h1esc"]]
+                outs = getattr(op, fn)(*a, genome, custom_models=cm, target=False, use_cuda=False, **kw)
+                for k, v in synth.summarize_outputs(outs).items():
+                    d[f"{name}.{k}"] = v
+                print("G11", name, "%.1fs" % (time.time() - t))
+            np.savez_compressed(os.path.join(GOLD, "G11_sv_drivers.npz"), **d)
+            print("G11 done")
+
+        # ---- G12: StructuralChange2 edit scripts (orca_utils.py:737-965) -------------------------
+        if want("G12"):
+            import orca_utils as ou
+            rs = np.random.RandomState(12)
+            scripts = []
+            for trial in range(120):
+                L = int(rs.randint(1000, 5000))
+                sc = ou.StructuralChange2("chrA", L)
+                ops = []
+                if trial % 5 == 0:
+                    sc2 = ou.StructuralChange2("chrB", L // 2)
+                    sc2.invert(3, L // 4)
+                    sc = sc + sc2
+                    ops.append(["concat", L // 2, 3, L // 4])
+                for _ in range(rs.randint(1, 7)):
+                    n = sc.coord_points[-1]
+                    if n < 10:
+                        break
+                    s0 = int(rs.randint(0, n - 2)); e0 = int(rs.randint(s0 + 1, n + 1))
+                    kind = ["delete", "duplicate", "invert", "insert"][rs.randint(4)]
+                    if kind == "insert":
+                        st = "+-"[rs.randint(2)]
+                        sc.insert(s0, e0 - s0, strand=st)
+                        ops.append([kind, s0, e0 - s0, st])
+                    else:
+                        getattr(sc, kind)(s0, e0)
+                        ops.append([kind, s0, e0])
+                n = sc.coord_points[-1]
+                queries = []
+                for _ in range(6):
+                    if n < 3:
+                        break
+                    s0 = int(rs.randint(0, n - 1)); e0 = int(rs.randint(s0 + 1, n + 2))
+                    try:
+                        res = [list(x) for x in sc[s0:e0]]
+                    except ValueError:
+                        res = "ValueError"
+                    rc, cc = sc.query_ref("chrA", s0, e0)
+                    queries.append({"q": [s0, e0], "pieces": res, "ref": [[int(v) for v in r] for r in rc],
+                                    "cur": [[int(r[0]), int(r[1]), r[2]] for r in cc]})
+                scripts.append({"L": L, "ops": ops, "points": list(sc.coord_points),
+                                "segments": [[g.len] + list(g.ref) for g in sc.segments], "queries": queries})
+            import json
+            with open(os.path.join(GOLD, "G12_structural_change.json"), "w") as f:
+                json.dump(scripts, f)
+            print("G12 done", len(scripts))
 
         # ---- G8: one full 32 Mb H1-ESC-shaped forward, both strands ---------------
         if args.full32m and want("G8"):

@@ -52,4 +52,19 @@ sv.sv_screen([h1], genome, svs[:1], 40_000_000); sync()
 t = time.perf_counter(); r5 = sv.sv_screen([h1], genome, svs, 40_000_000); sync(); dt = time.perf_counter() - t
 res["config5_sv_screen_1gpu"] = {"svs": len(svs), "s_per_sv_ref_plus_alt": round(dt / len(svs), 4), "svs_per_s": round(len(svs) / dt, 2),
                                  "kinds": [v.kind for v in svs]}
+
+# ---- config 5 through the reference-signature drivers (orca_amd.sv_drivers): genome resident in HBM vs host route --
+from orca_amd import synth
+g_dev = synth.sv_driver_genome().to(dev)
+g_host = synth.sv_driver_genome()
+calls = [("process_del", ("chrS", 15_200_000, 15_850_000)), ("process_dup", ("chrS", 20_000_000, 21_500_000)),
+         ("process_inv", ("chrS", 30_100_000, 33_000_000))]
+P.process_del("chrS", 15_200_000, 15_850_000, g_dev, custom_models=[h1], target=False); sync()
+for label, g in (("device_genome", g_dev), ("host_route", g_host)):
+    t = time.perf_counter(); nviews = 0
+    for fn, a in calls:
+        nviews += len(getattr(P, fn)(*a, g, custom_models=[h1], target=False))
+    sync(); dt = time.perf_counter() - t
+    res["config5_drivers_" + label] = {"variants": len(calls), "views": nviews, "s_per_view": round(dt / nviews, 4),
+                                       "s_per_variant": round(dt / len(calls), 4)}
 print(json.dumps(res, indent=1))
