@@ -76,12 +76,13 @@ class PackedGenome:
         return cls(chroms)
 
     @classmethod
-    def random(cls, lengths, seed=0, n_runs=0):
-        """Synthetic genome (tests / benchmarks): uniform bases with `n_runs` runs of N per chromosome."""
+    def random(cls, lengths, seed=0, n_runs=0, fast=False):
+        """Synthetic genome (tests / benchmarks): uniform bases with `n_runs` runs of N per chromosome.
+        `fast`: bases from the generator's raw byte stream (5x quicker for 100 Mb+ chromosomes; a different genome)."""
         chroms = {}
         for k, (name, L) in enumerate(lengths.items() if isinstance(lengths, dict) else lengths):
             rs = np.random.RandomState(seed + 7919 * k)
-            c = rs.randint(0, 4, int(L)).astype(np.uint8)
+            c = (np.frombuffer(rs.bytes(int(L)), dtype=np.uint8) & 3) if fast else rs.randint(0, 4, int(L)).astype(np.uint8)
             for _ in range(n_runs):
                 s = int(rs.randint(0, max(1, L - 50000)))
                 c[s:s + int(rs.randint(1000, 50000))] = N_CODE

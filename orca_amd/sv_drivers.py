@@ -1,6 +1,6 @@
 """Structural-variant drivers with the reference's signatures: `process_region / process_dup /
 process_del / process_inv / process_ins / process_custom / process_single_breakpoint`
-(/root/reference/orca_predict.py:983-3057), 32 Mb models (`window_radius=16000000`).
+(/root/reference/orca_predict.py:983-3057), for the 32 Mb (`window_radius=16000000`) and the 256 Mb models.
 
 Each driver is a list of VIEWS of a reference or mutated chromosome: (allele, anchor position, chromosome length
 used for window clipping, annotation).  A view is materialised as the 32 Mb window sequence and handed to
@@ -12,9 +12,15 @@ arrays on the host (`genome.get_encoding_from_coords` per piece, `[::-1, ::-1]` 
 codes on the device and go straight into the Encoder's packed-input path - no float window ever exists.  Any other
 genome object with the selene API (`get_chr_lens`, `get_encoding_from_coords`) takes the reference's host route.
 
-Out of scope here: plotting (`file=...` must stay None), bundled Micro-C targets (`target=True` behaves as it does in
-the reference when the resources are not loaded: no targets), the 256 Mb variants (`window_radius=128000000`,
-`_retrieve_multi`): next round.
+`window_radius=128000000` selects the 256 Mb models: the whole (mutated) chromosome, rounded down to 32 kb and padded
+with `padding_chr` to 256 Mb, goes through `genomepredict_256Mb` together with a distance background assembled per
+region pair by `_retrieve_multi` (`orca_predict.py:881-980`).  Not offered at 256 Mb, because the reference itself
+cannot run them: `process_ins` (its alt.r view is assigned to the wrong name and inserted pieces are looked up in the
+genome, `:2412-2490`) and `process_custom` (always calls the 32 Mb `genomepredict`, `:2660`).
+
+Out of scope here: plotting (`file=...` must stay None; the reference's `process_dup` even REQUIRES a file name at
+256 Mb, `:1365-1367`) and the bundled Micro-C targets (`target=True` behaves as it does in the reference when the
+resources are not loaded: no targets).
 """
 import numpy as np
 import torch
@@ -23,17 +29,19 @@ from . import genome as _genome
 from .orca_utils import StructuralChange2, coord_clip, coord_round, process_anno
 
 _R32 = 16000000
+_R256 = 128000000
+_BIN256 = 32000
 
 
-def _setup(custom_models, window_radius, model_labels, file):
+def _setup(custom_models, window_radius, model_labels, file, allow_256=True):
     if file is not None:
         raise NotImplementedError("plotting (file=...) is not part of orca_amd; plot the returned dicts with the reference's genomeplot")
-    if window_radius == 128000000:
-        raise NotImplementedError("the 256 Mb structural-variant views (window_radius=128000000) are not built yet")
-    if window_radius != _R32:
+    if window_radius not in (_R32, _R256):
         raise ValueError("Only window_radius 16000000 (32Mb models) or 128000000 (256Mb models) are supported")
+    if window_radius == _R256 and not allow_256:
+        raise NotImplementedError("this driver has no working 256 Mb form in the reference (see orca_amd/sv_drivers.py)")
     if custom_models is None:
-        return ["h1esc", "hff"], ["H1-ESC", "HFF"]
+        return (["h1esc", "hff"] if window_radius == _R32 else ["h1esc_256m", "hff_256m"]), ["H1-ESC", "HFF"]
     if model_labels is None:
         model_labels = [f"Model {i}" for i in range(len(custom_models))]
     return custom_models, model_labels
@@ -124,6 +132,116 @@ def _right_anchored(mstart, mend, colour):
     return lambda w0, w1: [[mstart if w0 < mstart else w0, mend, colour]]
 
 
+# ---- 256 Mb models -----------------------------------------------------------------------------------------
+def _background_objects(models, normmat):
+    """Objects carrying `background_cis` / `background_trans`.  The reference always takes the module-level default
+    pair `h1esc_256m, hff_256m` (`orca_predict.py:938-941`), even next to custom models; here custom models that
+    bring their own backgrounds are used as they are, anything else falls back to the registered default pair."""
+    if isinstance(normmat, (list, tuple)):
+        return list(normmat)
+    from .orca_predict import _resolve_models
+    if models is not None and all(hasattr(m, "background_cis") for m in models if not isinstance(m, str)):
+        return _resolve_models(models, "256M", False)
+    return _resolve_models(["h1esc_256m", "hff_256m"], "256M", False)
+
+
+def _retrieve_multi(regionlist, genome, target=True, normmat=True, normmat_regionlist=None, use_cuda=False, models=None):
+    """Sequence (+ per-model distance background, + targets) of a concatenation of regions `(chrom, start, end[,
+    strand])` (`orca_predict.py:881-980`).  The background of a region pair on the same chromosome is the cis
+    expectation at the pair's 32 kb-bin distances, flipped for '-' regions; pairs on different chromosomes get the
+    scalar trans background."""
+    regions = [tuple(r) if len(r) == 4 else (r[0], r[1], r[2], "+") for r in regionlist]
+    # get_encoding_from_coords(strand='-') is already the reverse complement: regions are passed with their strand
+    sequence = _assemble(genome, regions, use_cuda)
+    out = (sequence,)
+    def block_matrix(rl, block):
+        """Square matrix over the 32 kb bins of the concatenated regions, filled block by block in place."""
+        nbins = [int((end - start) / _BIN256) for _, start, end, _ in rl]
+        offs = np.concatenate([[0], np.cumsum(nbins)])
+        out = np.empty((offs[-1], offs[-1]), dtype=np.float64)
+        for i, ra in enumerate(rl):
+            for j, rb in enumerate(rl):
+                blk = block(ra, rb, nbins[i], nbins[j])
+                if ra[3] == "-":
+                    blk = blk[::-1, :]
+                if rb[3] == "-":
+                    blk = blk[:, ::-1]
+                out[offs[i]:offs[i + 1], offs[j]:offs[j + 1]] = blk
+        return out
+
+    if normmat:
+        nrl = [tuple(r) for r in (regions if normmat_regionlist is None else normmat_regionlist)]
+        normmats = []
+        for obj in _background_objects(models, normmat):
+            def background(ra, rb, na, nb, obj=obj):
+                if ra[0] != rb[0]:
+                    return np.full((na, nb), obj.background_trans)
+                if (ra[2] - ra[1]) == na * _BIN256 and (rb[2] - rb[1]) == nb * _BIN256:
+                    # bins are exactly 32 kb apart, so the block is Toeplitz in i - j: a strided VIEW of one diagonal
+                    # profile instead of an [na, nb] gather (bit-identical to the general formula below)
+                    k = np.arange(-(nb - 1), na, dtype=np.int64)
+                    prof = np.ascontiguousarray(obj.background_cis[np.abs((ra[1] - rb[1]) + _BIN256 * k) // _BIN256])
+                    st = prof.strides[0]
+                    return np.lib.stride_tricks.as_strided(prof[nb - 1:], shape=(na, nb), strides=(st, -st), writeable=False)
+                acoor = np.linspace(ra[1], ra[2], na + 1)[:-1]
+                bcoor = np.linspace(rb[1], rb[2], nb + 1)[:-1]
+                return obj.background_cis[(np.abs(acoor[:, None] - bcoor[None, :]) / _BIN256).astype(int)]
+            normmats.append(block_matrix(nrl, background))
+        out = out + (normmats,)
+    if isinstance(target, (list, tuple)) and target:
+        targets = []
+        for t in target:
+            def observed(ra, rb, na, nb, t=t):
+                return t.get_feature_data(ra[0], ra[1], ra[2], chrom2=rb[0], start2=rb[1], end2=rb[2])
+            targets.append(torch.from_numpy(block_matrix(regions, observed).astype(np.float32)[None, :, :]))
+        out = out + (targets,)
+    return out
+
+
+def _predict256(sequence, mchr, normmats, chrlen, mpos, wpos, models, annotation, padding_chr, targets, use_cuda):
+    from .orca_predict import genomepredict_256Mb
+    return genomepredict_256Mb(sequence, mchr, normmats, chrlen, mpos, wpos, models=models, targets=targets,
+                               annotation=annotation, padding_chr=padding_chr, use_cuda=use_cuda)
+
+
+class _Chrom256:
+    """The whole reference chromosome, 32 kb-rounded and padded to 256 Mb, fetched once and viewed at several anchors
+    (the window is always the full 256 Mb: wpos = 128 000 000)."""
+
+    def __init__(self, genome, chrom, padding_chr, target, models, use_cuda):
+        self.chrom, self.padding_chr, self.models, self.use_cuda = chrom, padding_chr, models, use_cuda
+        chrlen = _chrlen(genome, chrom)
+        self.chrlen_round = chrlen - chrlen % _BIN256
+        self.regions = [[chrom, 0, self.chrlen_round, "+"], [padding_chr, 0, 2 * _R256 - self.chrlen_round, "+"]]
+        got = _retrieve_multi(self.regions, genome, target=target, use_cuda=use_cuda, models=models)
+        self.sequence, self.normmats = got[0], got[1]
+        self.targets = got[2] if len(got) > 2 else None
+
+    def view(self, anchor, anno_regions, sequence=None, targets="ref"):
+        anno = process_anno(anno_regions(0, 2 * _R256), base=0, window_radius=_R256)
+        return _predict256(self.sequence if sequence is None else sequence, self.chrom, self.normmats, self.chrlen_round,
+                           anchor, _R256, self.models, anno, self.padding_chr, self.targets if targets == "ref" else None,
+                           self.use_cuda)
+
+
+def _alt_view_256(genome, sc, mchr, anchor, chrlen_alt, anno_regions, models, padding_chr, use_cuda):
+    """Mutated chromosome at 256 Mb: whole chromosome + padding while it fits, else a clipped 256 Mb window of it
+    (`orca_predict.py:1438-1460`)."""
+    alt_round = chrlen_alt - chrlen_alt % _BIN256
+    if alt_round < 2 * _R256:
+        wpos = _R256
+        seq, normmats = _retrieve_multi(list(sc[0:alt_round]) + [[padding_chr, 0, 2 * _R256 - alt_round, "+"]], genome,
+                                        target=False, normmat=True, use_cuda=use_cuda, models=models,
+                                        normmat_regionlist=[[mchr, 0, alt_round, "+"], [padding_chr, 0, 2 * _R256 - alt_round, "+"]])
+    else:
+        wpos = coord_clip(anchor, alt_round, window_radius=_R256)
+        seq, normmats = _retrieve_multi(list(sc[wpos - _R256: wpos + _R256]), genome, target=False, normmat=True,
+                                        use_cuda=use_cuda, models=models,
+                                        normmat_regionlist=[[mchr, wpos - _R256, wpos + _R256, "+"]])
+    anno = process_anno(anno_regions(wpos - _R256, wpos + _R256), base=wpos - _R256, window_radius=_R256)
+    return _predict256(seq, mchr, normmats, alt_round, anchor, wpos, models, anno, padding_chr, None, use_cuda)
+
+
 def process_region(mchr, mstart, mend, genome, file=None, custom_models=None, target=True, show_genes=True, show_tracks=False,
                    window_radius=16000000, padding_chr="chr1", model_labels=None, use_cuda=True):
     """Multiscale prediction centred on a region (`orca_predict.py:983-1169`)."""
@@ -131,14 +249,20 @@ def process_region(mchr, mstart, mend, genome, file=None, custom_models=None, ta
     target = _targets(target)
     mpos = int((int(mstart) + int(mend)) / 2)
     anno = lambda w0, w1: [[np.clip(mstart, w0, w1), np.clip(mend, w0, w1), "black"]]
+    if window_radius == _R256:
+        return _Chrom256(genome, mchr, padding_chr, target, models, use_cuda).view(mpos, anno)
     return _ref_view(genome, mchr, mpos, anno, models, target, use_cuda)
 
 
-def _ref_pair(genome, mchr, mstart, mend, models, target, use_cuda):
-    """The two reference views every interval variant starts with: anchored at its left and at its right end."""
+def _ref_pair(genome, mchr, mstart, mend, models, target, use_cuda, window_radius=_R32, padding_chr=None):
+    """The two reference views every interval variant starts with: anchored at its left and at its right end.
+    Returns (ref_l, ref_r, whole-chromosome handle at 256 Mb or None)."""
+    if window_radius == _R256:
+        ref = _Chrom256(genome, mchr, padding_chr, target, models, use_cuda)
+        return ref.view(mstart, _left_anchored(mstart, mend, "black")), ref.view(mend, _right_anchored(mstart, mend, "black")), ref
     ref_l = _ref_view(genome, mchr, mstart, _left_anchored(mstart, mend, "black"), models, target, use_cuda)
     ref_r = _ref_view(genome, mchr, mend, _right_anchored(mstart, mend, "black"), models, target, use_cuda)
-    return ref_l, ref_r
+    return ref_l, ref_r, None
 
 
 def process_dup(mchr, mstart, mend, genome, file=None, custom_models=None, target=True, show_genes=True, show_tracks=False,
@@ -148,7 +272,7 @@ def process_dup(mchr, mstart, mend, genome, file=None, custom_models=None, targe
     models, _ = _setup(custom_models, window_radius, model_labels, file)
     target = _targets(target)
     chrlen = _chrlen(genome, mchr)
-    ref_l, ref_r = _ref_pair(genome, mchr, mstart, mend, models, target, use_cuda)
+    ref_l, ref_r, _ = _ref_pair(genome, mchr, mstart, mend, models, target, use_cuda, window_radius, padding_chr)
     sc = StructuralChange2(mchr, chrlen)
     sc.duplicate(mstart, mend)
     copy_end = mend + mend - mstart
@@ -156,7 +280,10 @@ def process_dup(mchr, mstart, mend, genome, file=None, custom_models=None, targe
     def anno(w0, w1):
         return [[mstart if w0 < mstart else w0, mend, "black"], [mend, copy_end if copy_end < w1 else w1, "gray"]]
 
-    alt = _alt_view(genome, sc, mchr, mend, chrlen + mend - mstart, anno, models, use_cuda)
+    if window_radius == _R256:
+        alt = _alt_view_256(genome, sc, mchr, mend, chrlen + mend - mstart, anno, models, padding_chr, use_cuda)
+    else:
+        alt = _alt_view(genome, sc, mchr, mend, chrlen + mend - mstart, anno, models, use_cuda)
     return ref_l, ref_r, alt
 
 
@@ -166,10 +293,14 @@ def process_del(mchr, mstart, mend, genome, cmap=None, file=None, custom_models=
     models, _ = _setup(custom_models, window_radius, model_labels, file)
     target = _targets(target)
     chrlen = _chrlen(genome, mchr)
-    ref_l, ref_r = _ref_pair(genome, mchr, mstart, mend, models, target, use_cuda)
+    ref_l, ref_r, _ = _ref_pair(genome, mchr, mstart, mend, models, target, use_cuda, window_radius, padding_chr)
     sc = StructuralChange2(mchr, chrlen)
     sc.delete(mstart, mend)
-    alt = _alt_view(genome, sc, mchr, mstart, chrlen - (mend - mstart), lambda w0, w1: [[mstart, "double"]], models, use_cuda)
+    anno = lambda w0, w1: [[mstart, "double"]]
+    if window_radius == _R256:
+        alt = _alt_view_256(genome, sc, mchr, mstart, chrlen - (mend - mstart), anno, models, padding_chr, use_cuda)
+    else:
+        alt = _alt_view(genome, sc, mchr, mstart, chrlen - (mend - mstart), anno, models, use_cuda)
     return ref_l, ref_r, alt
 
 
@@ -179,11 +310,16 @@ def process_inv(mchr, mstart, mend, genome, file=None, custom_models=None, targe
     models, _ = _setup(custom_models, window_radius, model_labels, file)
     target = _targets(target)
     chrlen = _chrlen(genome, mchr)
-    ref_l, ref_r = _ref_pair(genome, mchr, mstart, mend, models, target, use_cuda)
+    ref_l, ref_r, ref = _ref_pair(genome, mchr, mstart, mend, models, target, use_cuda, window_radius, padding_chr)
     sc = StructuralChange2(mchr, chrlen)
     sc.invert(mstart, mend)
-    alt_l = _alt_view(genome, sc, mchr, mstart, chrlen, lambda w0, w1: [[mstart, mend if mend < w1 else w1, "gray"]], models, use_cuda)
-    alt_r = _alt_view(genome, sc, mchr, mend, chrlen, lambda w0, w1: [[mstart if mstart > w0 else w0, mend, "gray"]], models, use_cuda)
+    anno_l = lambda w0, w1: [[mstart, mend if mend < w1 else w1, "gray"]]
+    anno_r = lambda w0, w1: [[mstart if mstart > w0 else w0, mend, "gray"]]
+    if window_radius == _R256:   # an inversion changes neither the length nor the distance background (`:2017-2024`)
+        (seq,) = _retrieve_multi(list(sc[0:ref.chrlen_round]) + [ref.regions[1]], genome, target=False, normmat=False, use_cuda=use_cuda)
+        return ref_l, ref_r, ref.view(mstart, anno_l, sequence=seq, targets=None), ref.view(mend, anno_r, sequence=seq, targets=None)
+    alt_l = _alt_view(genome, sc, mchr, mstart, chrlen, anno_l, models, use_cuda)
+    alt_r = _alt_view(genome, sc, mchr, mend, chrlen, anno_r, models, use_cuda)
     return ref_l, ref_r, alt_l, alt_r
 
 
@@ -192,7 +328,7 @@ def process_ins(mchr, mpos, ins_seq, genome, strand="+", file=None, custom_model
     """Insertion of the string `ins_seq` at `mpos` (`orca_predict.py:2178-2497`): ref, alt.l, alt.r (anchored at the
     two ends of the insert).  The reference forgets `models=` in the alt.r call (`:2453`) and so always uses the
     default H1-ESC + HFF pair there; here alt.r uses the same models as the other views."""
-    models, _ = _setup(custom_models, window_radius, model_labels, file)
+    models, _ = _setup(custom_models, window_radius, model_labels, file, allow_256=False)
     target = _targets(target)
     chrlen = _chrlen(genome, mchr)
     n_ins = len(ins_seq)
@@ -211,7 +347,7 @@ def process_custom(region_list, ref_region_list, mpos, genome, ref_mpos_list=Non
                    model_labels=None, use_cuda=True):
     """Arbitrary rearrangement given as the list of reference pieces that make up the 32 Mb alternative window
     (`orca_predict.py:2500-2681`).  Like the reference, returns the LAST reference view and the alternative view."""
-    models, _ = _setup(custom_models, window_radius, model_labels, file)
+    models, _ = _setup(custom_models, window_radius, model_labels, file, allow_256=False)
     target = _targets(target)
 
     def validate(regions, enforce_strand=None):
@@ -247,8 +383,12 @@ def process_single_breakpoint(chr1, pos1, chr2, pos2, orientation1, orientation2
     models, _ = _setup(custom_models, window_radius, model_labels, file)
     target = _targets(target)
     len1, len2 = _chrlen(genome, chr1), _chrlen(genome, chr2)
-    ref_1 = _ref_view(genome, chr1, pos1, lambda w0, w1: [[pos1, "single"]], models, target, use_cuda, len1)
-    ref_2 = _ref_view(genome, chr2, pos2, lambda w0, w1: [[pos2, "single"]], models, target, use_cuda, len2)
+    if window_radius == _R256:
+        ref_1 = _Chrom256(genome, chr1, padding_chr, target, models, use_cuda).view(pos1, lambda w0, w1: [[pos1, "single"]])
+        ref_2 = _Chrom256(genome, chr2, padding_chr, target, models, use_cuda).view(pos2, lambda w0, w1: [[pos2, "single"]])
+    else:
+        ref_1 = _ref_view(genome, chr1, pos1, lambda w0, w1: [[pos1, "single"]], models, target, use_cuda, len1)
+        ref_2 = _ref_view(genome, chr2, pos2, lambda w0, w1: [[pos2, "single"]], models, target, use_cuda, len2)
 
     s = StructuralChange2(chr1, len1)
     if orientation1 == "+":
@@ -265,6 +405,22 @@ def process_single_breakpoint(chr1, pos1, chr2, pos2, orientation1, orientation2
     breakpos = s.coord_points[-1]
     s = s + s2
     total = s.coord_points[-1]
+    fused = chr1 + "|" + chr2
+    if window_radius == _R256:
+        alt_round = total - total % _BIN256
+        if alt_round < 2 * _R256:
+            wpos, pieces = _R256, s[0:alt_round]
+            seq, normmats = _retrieve_multi(list(pieces) + [[padding_chr, 0, 2 * _R256 - alt_round, "+"]], genome, target=False,
+                                            normmat=True, use_cuda=use_cuda, models=models,
+                                            normmat_regionlist=[[fused, 0, alt_round, "+"], [padding_chr, 0, 2 * _R256 - alt_round, "+"]])
+        else:
+            wpos = coord_clip(breakpos, alt_round, window_radius=_R256)
+            pieces = s[wpos - _R256: wpos + _R256]
+            seq, normmats = _retrieve_multi(list(pieces), genome, target=False, normmat=True, use_cuda=use_cuda, models=models,
+                                            normmat_regionlist=[[fused, wpos - _R256, wpos + _R256, "+"]])
+        anno = process_anno([[pieces[0].end - pieces[0].start, "double"]], base=0, window_radius=_R256)
+        alt = _predict256(seq, fused, normmats, alt_round, breakpos, wpos, models, anno, padding_chr, None, use_cuda)
+        return ref_1, ref_2, alt
     if total < 2 * window_radius + 128000:   # fused chromosome shorter than a window (+ one coord_clip bin)
         radius = total // 2
         wpos = radius
@@ -278,5 +434,5 @@ def process_single_breakpoint(chr1, pos1, chr2, pos2, orientation1, orientation2
     if n != 32000000:
         wpos = wpos + (32000000 - n) // 2
     anno = process_anno([[first_len, "double"]], base=0, window_radius=window_radius)
-    alt = _predict(seq, chr1 + "|" + chr2, breakpos, wpos, models, anno, None, use_cuda)
+    alt = _predict(seq, fused, breakpos, wpos, models, anno, None, use_cuda)
     return ref_1, ref_2, alt

@@ -192,7 +192,6 @@ def sv_driver_cases():
     ins_seq = "".join("ACGTN"[i] for i in rs.choice(5, 7001, p=[0.24, 0.24, 0.24, 0.24, 0.04]))
     return [
         ("region", "process_region", ("chrS", 11_000_000, 11_600_000), {}),
-        ("del_mid", "process_del", ("chrS", 15_200_000, 15_850_000), {}),
         ("del_edge", "process_del", ("chrS", 2_000_000, 2_300_000), {}),
         ("dup", "process_dup", ("chrS", 20_000_000, 21_500_000), {}),
         ("inv", "process_inv", ("chrS", 30_100_000, 33_000_000), {}),
@@ -226,3 +225,95 @@ def summarize_outputs(outputs):
                 d[f"o{k}_m{m}_stats_{j}"] = np.array([p.sum(), (p * p).sum(), np.abs(p).max()])
                 d[f"o{k}_m{m}_sub_{j}"] = p[::10, ::10].astype(np.float32)
     return d
+
+
+# ---- 256 Mb structural-variant drivers: the views are pinned WITHOUT running a model (a 256 Mb CPU forward of even a
+# stand-in model costs minutes): both sides replace `genomepredict_256Mb` by this recorder and the fixtures keep what
+# each view would have been called with - an exact position-weighted digest of the 256 Mb sequence, digests of the
+# per-model distance backgrounds, and every scalar argument.
+def sv_driver_genome_256():
+    from .genome import PackedGenome
+    return PackedGenome.random({"chrX": 250_000_000, "chrL": 150_016_000, "chr1": 140_000_000}, seed=9, n_runs=2, fast=True)
+
+
+def sv_driver_cases_256():
+    return [
+        ("del256", "process_del", ("chrL", 60_200_000, 61_850_000), {}),
+        ("dup256_long", "process_dup", ("chrX", 100_000_000, 110_000_000), {}),      # mutated chromosome > 256 Mb: clipped window
+        ("inv256", "process_inv", ("chrL", 30_100_000, 93_000_000), {}),
+        ("bp256_long", "process_single_breakpoint", ("chrX", 200_000_000, "chrL", 30_000_000, "+", "-"), {}),
+        ("bp256_short", "process_single_breakpoint", ("chrL", 100_000_000, "chrX", 90_000_000, "-", "+"), {}),
+    ]
+
+
+class Background256:
+    """Carrier of `background_cis` / `background_trans` (what `_retrieve_multi` reads from the 256 Mb models)."""
+
+    def __init__(self, seed):
+        d = np.arange(8000 + 2000, dtype=np.float64)
+        self.background_cis = np.exp(-1.1 * np.log1p(d) - 2.0 + 0.02 * np.cos(d / 53.0 + seed))
+        self.background_trans = float(np.exp(-12.5 - 0.1 * seed))
+
+
+class FakeTarget256:
+    """Stand-in for `selene_utils2.Genomic2DFeatures` at 32 kb resolution: a smooth function of the two absolute
+    coordinates (cis) or a constant (trans).  The reference's `process_del` cannot run at 256 Mb WITHOUT targets
+    (`targets` is unbound otherwise, `orca_predict.py:1627-1669`), so the 256 Mb fixtures carry one."""
+
+    def get_feature_data(self, chrom, start, end, chrom2=None, start2=None, end2=None):
+        if chrom2 is None:
+            chrom2, start2, end2 = chrom, start, end
+        a = np.arange(start, end, 32000, dtype=np.float64)[: int((end - start) / 32000)]
+        b = np.arange(start2, end2, 32000, dtype=np.float64)[: int((end2 - start2) / 32000)]
+        if chrom != chrom2:
+            return np.full((a.shape[0], b.shape[0]), 1e-3 * (1 + len(chrom) + len(chrom2)))
+        return 1.0 / (1.0 + np.abs(a[:, None] - b[None, :]) / 32000.0) + 1e-9 * (a[:, None] + 2 * b[None, :])
+
+
+def seq_digest(sequence, binsize=1_024_000):
+    """Exact digest of a [1,L,4] float one-hot sequence or of [1,L] base codes: per `binsize` bin,
+    sum over positions of (pos % 1000 + 1) * sum_c (c + 1) * x[pos, c]  (an 'N' row counts 2.5)."""
+    if hasattr(sequence, "detach"):
+        sequence = sequence.detach().cpu().numpy()
+    x = np.asarray(sequence)[0]
+    L = x.shape[0]
+    assert L % binsize == 0 and binsize % 1000 == 0
+    w = np.tile(np.arange(1, 1001, dtype=np.float64), binsize // 1000)
+    out = np.zeros(L // binsize)
+    lut = np.array([1.0, 2.0, 3.0, 4.0, 2.5], dtype=np.float64)
+    for b in range(L // binsize):
+        blk = x[b * binsize:(b + 1) * binsize]
+        v = lut[np.minimum(blk, 4)] if blk.ndim == 1 else blk.astype(np.float64) @ lut[:4]
+        out[b] = float(v @ w)
+    return out
+
+
+class Recorder256:
+    """Drop-in for genomepredict_256Mb (reference keyword/positional order, `orca_predict.py:543-556`)."""
+
+    def __init__(self):
+        self.calls = []
+
+    def __call__(self, sequence, mchr, normmats, chrlen, mpos=-1, wpos=-1, models=None, targets=None, annotation=None,
+                 padding_chr=None, use_cuda=True, nan_thresh=1):
+        rec = {"seq": seq_digest(sequence), "chr": str(mchr), "chrlen": int(chrlen), "mpos": int(mpos), "wpos": int(wpos),
+               "padding_chr": str(padding_chr), "has_targets": targets is not None,
+               "anno": repr([[float(v) if not isinstance(v, str) else v for v in r] for r in annotation]) if annotation is not None else "None"}
+        mats = [(f"nm{k}", nm) for k, nm in enumerate(normmats)]
+        if targets is not None:
+            mats += [(f"tgt{k}", t[0]) for k, t in enumerate(targets)]
+        for key, nm in mats:
+            nm = np.asarray(nm.numpy() if hasattr(nm, "numpy") else nm, dtype=np.float64)
+            rec[f"{key}_shape"] = np.array(nm.shape)
+            flat = nm.ravel()
+            rec[f"{key}_stats"] = np.array([flat.sum(), float(np.dot(flat, flat)), flat.max(), flat.min()])
+            rec[f"{key}_sub"] = nm[::200, ::200].copy()
+        self.calls.append(rec)
+        return {"call": len(self.calls) - 1}
+
+    def summary(self, first=0):
+        d = {}
+        for i, rec in enumerate(self.calls[first:]):
+            for k, v in rec.items():
+                d[f"v{i}_{k}"] = v if isinstance(v, np.ndarray) else np.array([v])
+        return d

@@ -174,3 +174,28 @@ def test_sv_drivers_device_genome_equals_host_route(cuda):
                 assert np.isfinite(ph).all() and maxabs(ph, pd_) < 1e-6
         # the alternative allele differs from the reference allele around the variant
         assert max(maxabs(x, y) for x, y in zip(outs_d[0]["predictions"][0], outs_d[-1]["predictions"][0])) > 1e-3
+
+
+def test_sv_drivers_256mb_on_device(cuda):
+    """window_radius=128000000 on the MI355X with a H1esc_256M-shaped model and the genome in HBM: each view of
+    `process_del` equals a direct `genomepredict_256Mb` call on the same (independently gathered) codes and background,
+    and the deletion changes the maps.  The drivers' agreement with the reference's is pinned on CPU (G13)."""
+    from orca_amd import genome as G
+    from orca_amd import sv_drivers
+    model = M.H1esc_256M(synthetic_seed=0)
+    g = G.PackedGenome.random({"chrL": 150_016_000, "chr1": 120_000_000}, seed=9, fast=True).to(cuda)
+    mstart, mend = 60_200_000, 61_850_000
+    ref_l, ref_r, alt = P.process_del("chrL", mstart, mend, g, custom_models=[model], target=False, window_radius=128000000,
+                                      padding_chr="chr1")
+    for o in (ref_l, ref_r, alt):
+        assert len(o["predictions"][0]) == 4 and all(np.isfinite(p).all() and p.shape == (250, 250) for p in o["predictions"][0])
+    # reference allele, assembled by hand
+    clen = 150_016_000 - 150_016_000 % 32000
+    regions = [["chrL", 0, clen, "+"], ["chr1", 0, 256_000_000 - clen, "+"]]
+    codes = torch.cat([g.get_codes_from_coords(c, s, e) for c, s, e, _ in regions])[None]
+    _, normmats = sv_drivers._retrieve_multi(regions, g, target=False, use_cuda=True, models=[model])
+    direct = P.genomepredict_256Mb(codes, "chrL", normmats, clen, mstart, 128_000_000, models=[model], padding_chr="chr1")
+    assert direct["start_coords"] == ref_l["start_coords"]
+    for a, b in zip(direct["predictions"][0], ref_l["predictions"][0]):
+        assert maxabs(a, b) < 1e-6
+    assert max(maxabs(a, b) for a, b in zip(ref_l["predictions"][0], alt["predictions"][0])) > 1e-3

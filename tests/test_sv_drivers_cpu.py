@@ -54,8 +54,8 @@ def test_process_anno_and_errors():
     g = synth.sv_driver_genome()
     with pytest.raises(ValueError):
         orca_predict.process_del("chrS", 1, 2, g, custom_models=[object()], window_radius=1234, use_cuda=False)
-    with pytest.raises(NotImplementedError):
-        orca_predict.process_del("chrS", 1, 2, g, custom_models=[object()], window_radius=128000000, use_cuda=False)
+    with pytest.raises(NotImplementedError):   # plotting is the reference's job
+        orca_predict.process_del("chrS", 1, 2, g, custom_models=[object()], file="x", use_cuda=False)
 
 
 def test_packed_genome_selene_semantics():
@@ -103,3 +103,52 @@ def test_sv_driver_matches_reference(sv_setup, case):
             np.testing.assert_array_equal(want, have, err_msg=k)
         else:
             np.testing.assert_allclose(have, want, rtol=2e-5, atol=2e-5, err_msg=k)
+
+
+@pytest.fixture(scope="module")
+def sv_setup_256():
+    saved, saved_fn = dict(orca_predict.model_dict_global), orca_predict.genomepredict_256Mb
+    orca_predict.model_dict_global["h1esc_256m"] = synth.Background256(0)
+    orca_predict.model_dict_global["hff_256m"] = synth.Background256(1)
+    rec = synth.Recorder256()
+    orca_predict.genomepredict_256Mb = rec
+    # .to("cpu"): the drivers take their packed-codes route (what they do with the genome in HBM), on the host
+    yield synth.sv_driver_genome_256().to("cpu"), np.load(os.path.join(GOLD, "G13_sv_drivers_256.npz")), rec
+    orca_predict.genomepredict_256Mb = saved_fn
+    orca_predict.model_dict_global.clear()
+    orca_predict.model_dict_global.update(saved)
+
+
+@pytest.mark.parametrize("case", [c[0] for c in synth.sv_driver_cases_256()])
+def test_sv_driver_256mb_views_match_reference(sv_setup_256, case):
+    """window_radius=128000000: every view the reference's driver hands to genomepredict_256Mb - the 256 Mb sequence
+    (exact position-weighted digest), the per-model distance backgrounds and targets from `_retrieve_multi`, chromosome
+    label, rounded length, anchor, window centre, annotation - recorded on both sides instead of running a model."""
+    genome, gold, rec = sv_setup_256
+    name, fn, a, kw = next(c for c in synth.sv_driver_cases_256() if c[0] == case)
+    first = len(rec.calls)
+    tgt = [synth.FakeTarget256()] if fn == "process_del" else False    # the reference's process_del needs targets at 256 Mb
+    outs = getattr(orca_predict, fn)(*a, genome, custom_models=[object(), object()], target=tgt,
+                                     use_cuda=True, window_radius=128000000, padding_chr="chr1", **kw)
+    got = rec.summary(first)
+    got["order"] = np.array([o["call"] - first for o in outs])
+    keys = [k for k in gold.files if k.startswith(name + ".")]
+    assert len(keys) == len(got) and len(keys) > 10
+    for k in keys:
+        want, have = gold[k], got[k[len(name) + 1:]]
+        if want.dtype.kind in "US":
+            assert str(want[0]) == str(have[0]), k
+        elif want.dtype.kind in "ib":
+            np.testing.assert_array_equal(want, have, err_msg=k)
+        elif k.endswith("_seq"):
+            np.testing.assert_array_equal(want, have, err_msg=k)        # exact: sums of quarter-integers in float64
+        else:
+            np.testing.assert_allclose(have, want, rtol=1e-12, atol=0, err_msg=k)
+    rec.calls[first:] = [{} for _ in rec.calls[first:]]                 # free the digests' memory
+
+
+def test_sv_drivers_256mb_unsupported_forms():
+    g = synth.sv_driver_genome()
+    for fn, a in (("process_ins", ("chrS", 5, "ACGT")), ("process_custom", ([], [], 0))):
+        with pytest.raises(NotImplementedError):
+            getattr(orca_predict, fn)(*a, g, custom_models=[object()], window_radius=128000000, use_cuda=False)

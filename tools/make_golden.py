@@ -274,6 +274,30 @@ def main():
             np.savez_compressed(os.path.join(GOLD, "G11_sv_drivers.npz"), **d)
             print("G11 done")
 
+        # ---- G13: the 256 Mb structural-variant views through the REAL process_* (model forward replaced by a recorder)
+        if want("G13"):
+            import orca_predict as op
+            genome = synth.sv_driver_genome_256()
+            op.h1esc_256m, op.hff_256m = synth.Background256(0), synth.Background256(1)   # what _retrieve_multi reads
+            rec = synth.Recorder256()
+            op.genomepredict_256Mb = rec
+            op.genomeplot_256Mb = lambda *a, **k: None       # process_dup needs a file name at 256 Mb (:1365-1367)
+            op.target_dict_global["fake"] = type("T", (synth.FakeTarget256, op.Genomic2DFeatures), {"__init__": lambda self: None})()
+            d = {}
+            for name, fn, a, kw in synth.sv_driver_cases_256():
+                t = time.time()
+                first = len(rec.calls)
+                extra = {"file": "/tmp/g13"} if fn == "process_dup" else {}
+                tgt = ["fake"] if fn == "process_del" else False   # process_del cannot run without targets at 256 Mb
+                outs = getattr(op, fn)(*a, genome, custom_models=[object(), object()], target=tgt, use_cuda=False,
+                                       window_radius=128000000, padding_chr="chr1", **extra, **kw)
+                d[f"{name}.order"] = np.array([o["call"] - first for o in outs])
+                for k, v in rec.summary(first).items():
+                    d[f"{name}.{k}"] = v
+                print("G13", name, len(rec.calls) - first, "views", "%.1fs" % (time.time() - t))
+            np.savez_compressed(os.path.join(GOLD, "G13_sv_drivers_256.npz"), **d)
+            print("G13 done")
+
         # ---- G12: StructuralChange2 edit scripts (orca_utils.py:737-965) -------------------------
         if want("G12"):
             import orca_utils as ou
