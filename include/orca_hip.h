@@ -198,6 +198,14 @@ int orca_decoder1m_forward(orca_ctx* ctx, orca_net* net, const float* x, int64_t
  * (orca_predict.py:514-523) for contiguous [n,n] maps. */
 int orca_strand_merge(orca_ctx* ctx, const float* fwd, const float* rev, float* out, int n);
 
+/* Replaces: the kernel-size-1 Conv1d (+ folded BatchNorm) + activation layers of `Net.final_1d`, the auxiliary
+ * 1-D head of the 1 Mb model (orca_modules.py:1824-1830, :1854).
+ * y[b][co][m] = act(bias[co] + sum_ci w[co][ci] * x[b][ci][m]);  w [cout][cin] and bias [cout] are DEVICE memory
+ * (folded on the host, uploaded once by the caller); x/y rows have stride ldx/ldy, batches x_bs/y_bs (elements).
+ * act: 0 = identity, 1 = ReLU, 2 = sigmoid. */
+int orca_pointwise1d_forward(orca_ctx* ctx, const float* w_dev, const float* bias_dev, int cout, int cin, const float* x,
+                             int64_t x_bs, int64_t ldx, float* y, int64_t y_bs, int64_t ldy, int B, int64_t n, int act);
+
 /* ---- single-layer entry points (kernel unit tests; same kernels the nets use) ---
  * y = [relu](conv1d_k9(x) + b) [+ r1] [+ r2], all [B,C,n] with row stride ld
  * (elements) and batch stride bs.  w/b as in orca_conv_desc (host, folded).

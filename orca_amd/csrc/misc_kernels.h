@@ -163,3 +163,19 @@ __global__ void pad_rows_kernel(const float* __restrict__ src, float* __restrict
   if (to_padded) dst[row * ORCA_LDW + j] = (j < n) ? src[row * n + j] : 0.f;
   else if (j < n) dst[row * n + j] = src[row * ORCA_LDW + j];
 }
+
+// y[b][co][m] = act(bias[co] + sum_ci w[co][ci] * x[b][ci][m])  - the kernel-size-1 Conv1d layers of Net.final_1d.
+// grid (ceil(n/256), cout, B); x reads are coalesced along m, w/bias are wave-uniform (scalar loads).
+__global__ void pointwise1d_kernel(const float* __restrict__ w, const float* __restrict__ bias, int cin, const float* __restrict__ x,
+                                   long x_bs, long ldx, float* __restrict__ y, long y_bs, long ldy, long n, int act) {
+  const long m = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int co = blockIdx.y, b = blockIdx.z;
+  if (m >= n) return;
+  const float* xp = x + (long)b * x_bs + m;
+  const float* wp = w + (long)co * cin;
+  float acc = bias[co];
+  for (int ci = 0; ci < cin; ++ci) acc = fmaf(wp[ci], xp[(long)ci * ldx], acc);
+  if (act == 1) acc = fmaxf(acc, 0.f);
+  else if (act == 2) acc = 1.f / (1.f + expf(-acc));
+  y[(long)b * y_bs + (long)co * ldy + m] = acc;
+}

@@ -1253,6 +1253,19 @@ extern "C" int orca_conv2d_forward(orca_ctx* ctx, const orca_conv_desc* conv, co
   return rc;
 }
 
+extern "C" int orca_pointwise1d_forward(orca_ctx* ctx, const float* w_dev, const float* bias_dev, int cout, int cin, const float* x,
+                                        int64_t x_bs, int64_t ldx, float* y, int64_t y_bs, int64_t ldy, int B, int64_t n, int act) {
+  if (!ctx || !w_dev || !bias_dev || !x || !y) return fail(ORCA_EINVAL, "orca_pointwise1d_forward: NULL argument");
+  if (cout <= 0 || cin <= 0 || B <= 0 || n < 0 || act < 0 || act > 2) return fail(ORCA_EINVAL, "orca_pointwise1d_forward: bad shape / activation");
+  if (n == 0) return ORCA_OK;
+  HIPCHECK(hipSetDevice(ctx->device));
+  dim3 grid((unsigned)((n + 255) / 256), (unsigned)cout, (unsigned)B);
+  hipLaunchKernelGGL(pointwise1d_kernel, grid, dim3(256), 0, ctx->stream, w_dev, bias_dev, cin, x, (long)x_bs, (long)ldx, y, (long)y_bs,
+                     (long)ldy, (long)n, act);
+  LAUNCHCHECK("pointwise1d_kernel");
+  return ORCA_OK;
+}
+
 extern "C" int orca_maxpool1d_forward(orca_ctx* ctx, const float* x, int64_t ldx, float* y, int64_t ldy, int64_t rows,
                                       int64_t n_out, int k) {
   if (!ctx || !x || !y) return fail(ORCA_EINVAL, "orca_maxpool1d_forward: NULL argument");

@@ -377,3 +377,18 @@ def maxpool1d(x, k):
     ctx = get_context(x.device)
     check(_lib.load().orca_maxpool1d_forward(ctx.handle, _p(x), n, _p(y), n // k, B * C, n // k, k), "orca_maxpool1d_forward")
     return y
+
+
+def pointwise1d(x, w_dev, b_dev, act="none"):
+    """Kernel-size-1 Conv1d + activation (Net.final_1d layers): x [B,cin,n] ROCm fp32, w_dev [cout,cin] / b_dev [cout]
+    ROCm tensors (folded weights).  act: "none" | "relu" | "sigmoid"."""
+    x = _f32_cuda(x, "x").contiguous()
+    B, cin, n = x.shape
+    cout = w_dev.shape[0]
+    if tuple(w_dev.shape) != (cout, cin) or not w_dev.is_cuda or not w_dev.is_contiguous():
+        raise ValueError("w_dev must be a contiguous [cout,cin] ROCm tensor")
+    y = torch.empty((B, cout, n), dtype=torch.float32, device=x.device)
+    ctx = get_context(x.device)
+    check(_lib.load().orca_pointwise1d_forward(ctx.handle, _p(w_dev), _p(b_dev), cout, cin, _p(x), cin * n, n, _p(y), cout * n, n, B, n,
+                                               {"none": 0, "relu": 1, "sigmoid": 2}[act]), "orca_pointwise1d_forward")
+    return y

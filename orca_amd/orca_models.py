@@ -1,5 +1,5 @@
 """Model containers with the reference's attribute protocol
-(/root/reference/orca_models.py: H1esc :17-175, Hff :178-333,
+(/root/reference/orca_models.py: H1esc :17-175, Hff :178-333, H1esc_1M :449-493, Hff_1M :496-542,
 H1esc_256M :545-649, Hff_256M :652-760):
 
     .net0 .net (.net1) .denet_<level> .denet_1_pt .denets{} .normmats{} .epss{}
@@ -26,7 +26,7 @@ import torch
 from torch import nn
 
 from . import synth
-from .orca_modules import Decoder, Decoder_1m, Encoder, Encoder2, Encoder3
+from .orca_modules import Decoder, Decoder_1m, Encoder, Encoder2, Encoder3, Net
 
 ORCA_PATH = os.environ.get("ORCA_PATH", str(pathlib.Path(__file__).parent.absolute()))
 
@@ -172,3 +172,51 @@ class H1esc_256M(_Orca256M):
 class Hff_256M(_Orca256M):
     """Orca HFF model (32-256Mb), orca_models.py:652-760."""
     modelstr, base32, bg_prefix = "hff_256m", "hff", "4DNFI643OYP9"
+
+
+class _Orca1M(nn.Module):
+    """Orca 1 Mb model (orca_models.py:449-542): ``Net`` with the auxiliary 1-D head, loaded from the stage-a
+    checkpoint ``orca_<cell>.net0.statedict``; ``forward(x)`` returns the [B,1,250,250] map only.
+    ``normmats[1]`` / ``epss[1]``: 4 kb block means of the first 1000 entries of the 1 kb expected curve."""
+
+    modelstr = None
+    expected_file = None
+    num_1d = None
+    expected_is_log = True
+
+    def __init__(self, model_dir=None, synthetic_seed=None):
+        super().__init__()
+        self.net = Net(num_1d=self.num_1d)
+        if synthetic_seed is not None:
+            _synth_into(self.net, int(synthetic_seed))
+            expected = np.exp(synth.synth_expected_log(1000, int(synthetic_seed)))
+        else:
+            root = model_dir or ORCA_PATH
+            path = os.path.join(root, "models", "orca_" + self.modelstr + ".net0.statedict")
+            if not os.path.exists(path):
+                raise FileNotFoundError(f"{path} not found (reference README.md:63-72), or pass synthetic_seed=...")
+            _load_file(self.net, path, filtered=True)
+            expected = np.exp(np.load(os.path.join(root, "resources", self.expected_file))[:1000])
+        self.eval()
+        normmat = expected[np.abs(np.arange(1000)[None, :] - np.arange(1000)[:, None])]
+        normmat_r = np.reshape(normmat, (250, 4, 250, 4)).mean(axis=1).mean(axis=2)
+        self.normmats = {1: normmat_r}
+        self.epss = {1: np.min(normmat_r)}
+
+    def forward(self, x):
+        pred, _ = self.net.forward(x)
+        return pred
+
+
+class H1esc_1M(_Orca1M):
+    """Orca H1-ESC 1 Mb model, orca_models.py:449-493."""
+    modelstr = "h1esc"
+    expected_file = "4DNFI9GMP2J8.rebinned.mcool.expected.res1000.npy"
+    num_1d = 32
+
+
+class Hff_1M(_Orca1M):
+    """Orca HFF 1 Mb model, orca_models.py:496-542."""
+    modelstr = "hff"
+    expected_file = "4DNFI643OYP9.rebinned.mcool.expected.res1000.npy"
+    num_1d = 22

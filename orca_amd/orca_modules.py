@@ -1,6 +1,6 @@
 """Drop-in counterparts of the reference ``orca_modules`` classes
 (/root/reference/orca_modules.py: Encoder :803-980, Encoder2 :984-1169,
-Encoder3 :1279-1406, Decoder :16-488, Decoder_1m :491-800).
+Encoder3 :1279-1406, Decoder :16-488, Decoder_1m :491-800, Net :1409-1900).
 
 Each class is an ``nn.Module`` whose parameter tree has exactly the reference's
 ``state_dict`` keys and shapes (checked against tests/golden/G0_manifest.npz),
@@ -15,6 +15,7 @@ the identity, i.e. the reference's ``.eval()`` behaviour (orca_models.py:125-133
 """
 import os
 
+import numpy as np
 import torch
 from torch import nn
 
@@ -303,3 +304,78 @@ class Decoder_1m(_HipModule):
             base = out.clone()   # a retry must not accumulate twice
             return self._run_guarded(net, lambda: engine.decoder1m_forward(net, x, out=out.copy_(base), accumulate=True), "f32")
         return self._run_guarded(net, lambda: engine.decoder1m_forward(net, x, out=out, accumulate=accumulate), "f32")
+
+
+class Net(nn.Module):
+    """The 1 Mb Orca model (orca_modules.py:1409-1900): the Encoder's seven stages on a [B,4,1000000] sequence,
+    the 19-pair 2-D head of Decoder_1m on the pairwise sum of the resulting [B,128,250] encoding and - with
+    ``num_1d`` - the auxiliary 1-D head ``final_1d`` (two kernel-size-1 convolutions, sigmoid).
+
+    The state dict is the reference's (Encoder keys + Decoder_1m keys + ``final_1d.*``, checked in
+    tests/golden/G0_manifest.npz), so ``orca_<cell>.net0.statedict`` loads unchanged.  The parameter containers are
+    SHARED with an internal Encoder and Decoder_1m, which own the two device-side engine nets; ``forward`` is
+    ``Decoder_1m(Encoder(x))`` on the HIP kernels (one Encoder chunk: the reference runs the stack over the whole
+    1 Mb at once, `run0` :1836-1857) plus ``orca_pointwise1d_forward`` for the 1-D head."""
+
+    def __init__(self, num_1d=None, precision=None):
+        super().__init__()
+        enc, dec = Encoder(precision), Decoder_1m()
+        for name, child in list(enc.named_children()) + list(dec.named_children()):
+            self.add_module(name, child)
+        if num_1d is not None:
+            self.final_1d = nn.Sequential(nn.Conv1d(128, 128, kernel_size=1, padding=0), nn.BatchNorm1d(128), nn.ReLU(inplace=True),
+                                          nn.Conv1d(128, num_1d, kernel_size=1, padding=0), nn.Sigmoid())
+        self.num_1d = num_1d
+        # not registered as sub-modules: they only borrow the containers above
+        object.__setattr__(self, "_enc", enc)
+        object.__setattr__(self, "_dec", dec)
+        self._head1d = {}
+
+    @property
+    def precision(self):
+        return self._enc.precision
+
+    @precision.setter
+    def precision(self, name):
+        self._enc.precision = name
+
+    def _invalidate(self):
+        self._enc.invalidate()
+        self._dec.invalidate()
+        self._head1d = {}
+
+    def _apply(self, fn, *a, **k):
+        self._invalidate()
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, state_dict, *a, **k):
+        self._invalidate()
+        own = set(self.state_dict().keys())
+        fixed = {}
+        for key, v in state_dict.items():
+            kk = key
+            while kk not in own and kk.startswith("module."):
+                kk = kk[len("module."):]
+            fixed[kk] = v
+        return super().load_state_dict(fixed, *a, **k)
+
+    def _head1d_weights(self, device):
+        w = self._head1d.get(device)
+        if w is None:
+            sd = self.state_dict()
+            a = engine.fold_conv(sd, "final_1d.0", "final_1d.1")
+            b = engine.fold_conv(sd, "final_1d.3")
+            w = tuple(torch.from_numpy(np.ascontiguousarray(t)).to(device) for t in
+                      (a["w"][:, :, 0], a["b"], b["w"][:, :, 0], b["b"]))
+            self._head1d[device] = w
+        return w
+
+    def forward(self, x):
+        """x: [B,4,L] float32 ROCm tensor, L = 1000000 in the reference (any L whose 4 kb-bin count is <= 256).
+        Returns the [B,1,n,n] map, or (map, [B,num_1d,n]) with the auxiliary head."""
+        enc = self._enc(x)
+        cur = self._dec(enc)
+        if self.num_1d:
+            w1, b1, w2, b2 = self._head1d_weights(x.device)
+            return cur, engine.pointwise1d(engine.pointwise1d(enc, w1, b1, "relu"), w2, b2, "sigmoid")
+        return cur

@@ -175,3 +175,30 @@ def test_encoder_from_packed_codes_and_reverse_complement(cuda):
     bad[0, :, 1234] = torch.tensor([0.3, 0.2, 0.4, 0.1], device=cuda)
     _, ok2 = engine.pack_sequence(bad)
     assert not ok2
+
+
+def test_net_1mb_model_vs_reference_and_oracle(cuda):
+    """Net / H1esc_1M on the HIP kernels: the reference's output for one 1 Mb sequence (G14), a batch of
+    two against the oracle, the container's forward, and DataParallel-prefixed checkpoint keys."""
+    from orca_amd import orca_models as M
+    g = golden("G14_net1m.npz")
+    net = product_module("Net", 0, device=cuda, num_1d=32)
+    x = torch.from_numpy(synth.synth_sequence(1_000_000, seed=61, n_frac=0.002)).to(cuda).transpose(1, 2)
+    pred, out1d = net(x)
+    assert pred.shape == (1, 1, 250, 250) and out1d.shape == (1, 32, 250)
+    assert maxabs(pred[0, 0].cpu().numpy(), g["pred"]) < 1e-4
+    assert maxabs(out1d[0].cpu().numpy(), g["out1d"]) < 1e-5
+    net0 = product_module("Net", 3, device=cuda)
+    assert maxabs(net0(x)[0, 0, ::5, ::5].cpu().numpy(), g["pred_no1d_sub"]) < 1e-4
+    # batch of two shorter sequences (n = 126 bins) against the oracle
+    xb = torch.from_numpy(synth.synth_sequence(504_000, seed=62, batch=2)).transpose(1, 2)
+    pb, ob = net(xb.to(cuda))
+    rb, rob = O.net_forward(synth_sd("Net", 0, num_1d=32), xb, num_1d=32)
+    assert maxabs(pb.cpu().numpy(), rb.numpy()) < 1e-4 and maxabs(ob.cpu().numpy(), rob.numpy()) < 1e-5
+    # container: same weights as Net seed 0, map only; reference checkpoint keys carry 'module.' prefixes
+    m = M.H1esc_1M(synthetic_seed=0).to(cuda)
+    assert maxabs(m(x)[0, 0].cpu().numpy(), g["pred"]) < 1e-4 and sorted(m.normmats) == [1]
+    sd = {"module." + k: v for k, v in net.state_dict().items()}
+    net2 = type(net)(num_1d=32)
+    net2.load_state_dict(sd)
+    assert maxabs(net2.to(cuda)(x)[0].cpu().numpy(), pred.cpu().numpy()) == 0.0

@@ -103,8 +103,8 @@ def main():
         # ---- G0: state-dict key/shape manifest of every hot-path module -----------
         if want("G0"):
             man = {}
-            for cls in ("Encoder", "Encoder2", "Encoder3", "Decoder", "Decoder_1m"):
-                m = getattr(om, cls)()
+            for cls in ("Encoder", "Encoder2", "Encoder3", "Decoder", "Decoder_1m", "Net"):
+                m = om.Net(num_1d=32) if cls == "Net" else getattr(om, cls)()
                 man[cls] = np.array([f"{k}|{','.join(map(str, v.shape))}" for k, v in m.state_dict().items()])
             np.savez_compressed(os.path.join(GOLD, "G0_manifest.npz"), **man)
             print("G0 done")
@@ -273,6 +273,19 @@ def main():
                 print("G11", name, "%.1fs" % (time.time() - t))
             np.savez_compressed(os.path.join(GOLD, "G11_sv_drivers.npz"), **d)
             print("G11 done")
+
+        # ---- G14: Net, the 1 Mb model (orca_modules.py:1409-1900), one 1 Mb sequence with an N run ----------
+        if want("G14"):
+            t = time.time()
+            net = load_synth(om.Net(num_1d=32), seed=0)
+            seq = synth.synth_sequence(1_000_000, seed=61, n_frac=0.002)
+            x = torch.from_numpy(seq).transpose(1, 2)
+            pred, out1d = net(x)
+            net0 = load_synth(om.Net(), seed=3)
+            pred0 = net0(x)
+            np.savez_compressed(os.path.join(GOLD, "G14_net1m.npz"), pred=pred[0, 0].numpy(), out1d=out1d[0].numpy(),
+                                pred_no1d_stats=stats(pred0), pred_no1d_sub=pred0[0, 0, ::5, ::5].numpy())
+            print("G14 done %.1fs" % (time.time() - t), float(pred.abs().max()), float(out1d.min()), float(out1d.max()))
 
         # ---- G13: the 256 Mb structural-variant views through the REAL process_* (model forward replaced by a recorder)
         if want("G13"):

@@ -67,4 +67,17 @@ for label, g in (("device_genome", g_dev), ("host_route", g_host)):
     sync(); dt = time.perf_counter() - t
     res["config5_drivers_" + label] = {"variants": len(calls), "views": nviews, "s_per_view": round(dt / nviews, 4),
                                        "s_per_variant": round(dt / len(calls), 4)}
+
+# ---- 1 Mb model (Net / H1esc_1M): batches of random 1 Mb sequences ----------------------------------
+del h1; engine.get_context(dev).release_workspace(); torch.cuda.empty_cache()
+m1 = M.H1esc_1M(synthetic_seed=0).to(dev)
+for B in (1, 8, 32):
+    xb = torch.from_numpy(synth.synth_sequence(1_000_000, seed=70, batch=B)).to(dev).transpose(1, 2)
+    m1(xb); sync()
+    t = time.perf_counter()
+    for _ in range(3):
+        m1(xb)
+    sync(); dt = (time.perf_counter() - t) / 3
+    res[f"model_1M_B{B}"] = {"ms_per_forward": round(dt * 1e3, 2), "sequences_per_s": round(B / dt, 1), "Mb_per_s": round(B / dt, 1),
+                             "tflops_algorithmic": round(B * (0.4656 + 0.1774) / dt, 1)}
 print(json.dumps(res, indent=1))
