@@ -31,6 +31,10 @@ def load_resources(models=("32M",), use_cuda=True, model_dir=None):
         for key, cls in (("h1esc_256m", orca_models.H1esc_256M), ("hff_256m", orca_models.Hff_256M)):
             if key not in model_dict_global:
                 model_dict_global[key] = cls(model_dir=model_dir)
+    if "1M" in models or "1m" in models:      # orca_predict.py:120-133
+        for key, cls in (("h1esc_1m", orca_models.H1esc_1M), ("hff_1m", orca_models.Hff_1M)):
+            if key not in model_dict_global:
+                model_dict_global[key] = cls(model_dir=model_dir)
     if use_cuda:
         for m in model_dict_global.values():
             m.cuda()
