@@ -52,7 +52,8 @@ enum orca_net_kind {
   ORCA_NET_ENCODER2 = 2,   /* orca_modules.Encoder2    (orca_modules.py:984-1169)  */
   ORCA_NET_ENCODER3 = 3,   /* orca_modules.Encoder3    (orca_modules.py:1279-1406) */
   ORCA_NET_DECODER = 4,    /* orca_modules.Decoder     (orca_modules.py:16-488)    */
-  ORCA_NET_DECODER_1M = 5  /* orca_modules.Decoder_1m  (orca_modules.py:491-800)   */
+  ORCA_NET_DECODER_1M = 5, /* orca_modules.Decoder_1m  (orca_modules.py:491-800)   */
+  ORCA_NET_ENCODER2B = 6   /* orca_modules.Encoder2b   (orca_modules.py:1173-1276): Encoder2 without the expanding path */
 };
 
 /* Decoder(upsample_mode=...) of orca_modules.py:17,430; containers use bilinear
@@ -173,6 +174,7 @@ int64_t orca_encoder_num_bins(int64_t L);
 /* Replaces: model.net(enc0) / model.net1(enc0) = Encoder2.forward
  * (orca_modules.py:1151-1169) and Encoder3.forward (:1388-1406).
  * x: [B,128,n] (strides in elements), n divisible by 2^nlev (nlev = 5 / 3).
+ * An ORCA_NET_ENCODER2B net (Encoder2b.forward, :1262-1276; 5 levels) returns the contracting path's encodings.
  * outs: HOST array of nlev+1 device pointers; outs[i] receives the
  * contiguous [B,128,n>>i] encoding (fine -> coarse, as the reference returns). */
 int orca_unet_forward(orca_ctx* ctx, orca_net* net, const float* x, int64_t sx_b, int64_t sx_c,

@@ -11,7 +11,7 @@ from ctypes import POINTER, c_char_p, c_int, c_int32, c_int64, c_size_t, c_void_
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "liborca_hip.so")
 
-ORCA_NET_ENCODER, ORCA_NET_ENCODER2, ORCA_NET_ENCODER3, ORCA_NET_DECODER, ORCA_NET_DECODER_1M = 1, 2, 3, 4, 5
+ORCA_NET_ENCODER, ORCA_NET_ENCODER2, ORCA_NET_ENCODER3, ORCA_NET_DECODER, ORCA_NET_DECODER_1M, ORCA_NET_ENCODER2B = 1, 2, 3, 4, 5, 6
 ORCA_UPSAMPLE_NEAREST, ORCA_UPSAMPLE_BILINEAR = 0, 1
 PRECISIONS = {"f32": 0, "bf16": 1, "bf16x2": 2, "bf16x3": 3, "f16x2": 4}
 

@@ -638,6 +638,8 @@ static void expected_shapes(int kind, std::vector<Shape>* s) {
   } else if (kind == ORCA_NET_ENCODER2 || kind == ORCA_NET_ENCODER3) {
     const int nlev = kind == ORCA_NET_ENCODER2 ? 5 : 3;
     for (int i = 0; i < 8 * nlev; ++i) c1(128, 128);
+  } else if (kind == ORCA_NET_ENCODER2B) {
+    for (int i = 0; i < 4 * 5; ++i) c1(128, 128);
   } else if (kind == ORCA_NET_DECODER) {
     c2(64, 129); c2(64, 64); c2(64, 64); c2(64, 64);  // lcombinerD, combinerD
     c2(64, 65); c2(64, 64); c2(64, 64); c2(64, 64);   // lcombiner, combiner
@@ -925,9 +927,11 @@ extern "C" int orca_pack_sequence(orca_ctx* ctx, const float* x, int64_t sx_c, i
 extern "C" int orca_unet_forward(orca_ctx* ctx, orca_net* net, const float* x, int64_t sx_b, int64_t sx_c, int64_t sx_l, int B,
                                  int n, float* const* outs, int n_outs) {
   if (!ctx || !net || !x || !outs) return fail(ORCA_EINVAL, "orca_unet_forward: NULL argument");
-  if (net->kind != ORCA_NET_ENCODER2 && net->kind != ORCA_NET_ENCODER3) return fail(ORCA_EINVAL, "orca_unet_forward: wrong net kind");
+  if (net->kind != ORCA_NET_ENCODER2 && net->kind != ORCA_NET_ENCODER3 && net->kind != ORCA_NET_ENCODER2B)
+    return fail(ORCA_EINVAL, "orca_unet_forward: wrong net kind");
   HIPCHECK(hipSetDevice(ctx->device));
-  const int nlev = net->kind == ORCA_NET_ENCODER2 ? 5 : 3;
+  const bool up_only = net->kind == ORCA_NET_ENCODER2B;   // Encoder2b: the contracting path IS the output
+  const int nlev = net->kind == ORCA_NET_ENCODER3 ? 3 : 5;
   if (n_outs != nlev + 1) return fail(ORCA_EINVAL, "expected %d output pointers, got %d", nlev + 1, n_outs);
   if (n <= 0 || (n % (1 << nlev))) return fail(ORCA_EINVAL, "length %d not divisible by %d", n, 1 << nlev);
   if (B <= 0) return ORCA_OK;
@@ -937,7 +941,7 @@ extern "C" int orca_unet_forward(orca_ctx* ctx, orca_net* net, const float* x, i
   need += 3 * ru256(full * sizeof(float));
   ORCA_TRY(ws_ensure(ctx, need));
   std::vector<float*> encs(nlev + 1);
-  for (int i = 0; i < nlev; ++i) encs[i] = ws_take(ctx, full >> i);
+  for (int i = 0; i < nlev; ++i) encs[i] = up_only ? outs[i] : ws_take(ctx, full >> i);
   encs[nlev] = outs[nlev];
   float* t0 = ws_take(ctx, full);
   float* t1 = ws_take(ctx, full);
@@ -957,6 +961,7 @@ extern "C" int orca_unet_forward(orca_ctx* ctx, orca_net* net, const float* x, i
     ORCA_TRY(launch_conv1d(ctx, L[4 * i + 2], t2, bs, no, t1, bs, no, nullptr, nullptr, B, no, 1, 0));
     ORCA_TRY(launch_conv1d(ctx, L[4 * i + 3], t1, bs, no, encs[i + 1], bs, no, t2, nullptr, B, no, 1, 0));
   }
+  if (up_only) return ORCA_OK;
   // expanding path
   const float* cur = encs[nlev];
   for (int i = 0; i < nlev; ++i) {

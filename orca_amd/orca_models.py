@@ -26,7 +26,7 @@ import torch
 from torch import nn
 
 from . import synth
-from .orca_modules import Decoder, Decoder_1m, Encoder, Encoder2, Encoder3, Net
+from .orca_modules import Decoder, Decoder_1m, Encoder, Encoder2, Encoder2b, Encoder3, Net
 
 ORCA_PATH = os.environ.get("ORCA_PATH", str(pathlib.Path(__file__).parent.absolute()))
 
@@ -220,3 +220,41 @@ class Hff_1M(_Orca1M):
     modelstr = "hff"
     expected_file = "4DNFI643OYP9.rebinned.mcool.expected.res1000.npy"
     num_1d = 22
+
+
+class HCTnoc(nn.Module):
+    """Orca HCT116 cohesin-depleted model (orca_models.py:335-446): Encoder + Encoder2b (no expanding path) + six
+    Decoders with the default nearest-neighbour upsampling, and NO ``denet_1_pt`` - as in the reference, it therefore
+    cannot go through ``genomepredict``'s 1 Mb level; its sub-networks are used directly."""
+
+    modelstr = "hctnoc"
+    expected_file = "4DNFILP99QJS.HCT_auxin6h.rebinned.mcool.expected.res4000.npy"
+    levels = (1, 2, 4, 8, 16, 32)
+
+    def __init__(self, model_dir=None, synthetic_seed=None):
+        super().__init__()
+        self.net0 = Encoder()
+        self.net = Encoder2b()
+        for lv in self.levels:
+            setattr(self, f"denet_{lv}", Decoder())
+        if synthetic_seed is not None:
+            s = int(synthetic_seed)
+            _synth_into(self.net0, s)
+            _synth_into(self.net, s)
+            for lv in self.levels:
+                _synth_into(getattr(self, f"denet_{lv}"), s + lv)
+            expected_log = synth.synth_expected_log(8000, s)
+        else:
+            root = model_dir or ORCA_PATH
+            base = os.path.join(root, "models", "orca_" + self.modelstr)
+            if not os.path.exists(base + ".net.statedict"):
+                raise FileNotFoundError(f"{base}.net.statedict not found (reference README.md:63-72), or pass synthetic_seed=...")
+            _load_file(self.net, base + ".net.statedict")
+            for lv in self.levels:
+                _load_file(getattr(self, f"denet_{lv}"), f"{base}.d{lv}.statedict")
+            _load_file(self.net0, base + ".net0.statedict")
+            expected_log = np.load(os.path.join(root, "resources", self.expected_file))
+        self.eval()
+        idx = np.abs(np.arange(8000)[None, :] - np.arange(8000)[:, None])
+        self.normmats, self.epss = _pyramid(np.exp(expected_log[idx]), self.levels)
+        self.denets = {lv: getattr(self, f"denet_{lv}") for lv in self.levels}

@@ -208,6 +208,29 @@ class Encoder2(_UNetEncoder):
     _nlev = 5
 
 
+class Encoder2b(_HipModule):
+    """Encoder2 without the expanding path (orca_modules.py:1173-1276; the HCTnoc model): returns the six encodings
+    of the contracting path, fine to coarse."""
+    _kind = _lib.ORCA_NET_ENCODER2B
+    _nlev = 5
+
+    def __init__(self):
+        super().__init__()
+        c1 = dict(kernel_size=9, padding=4)
+        self.lblocks = nn.ModuleList(
+            [_linear_pair(nn.Conv1d, nn.BatchNorm1d, 128, 128, 128, nn.MaxPool1d(kernel_size=2, stride=2), **c1) for _ in range(5)])
+        self.blocks = nn.ModuleList([_relu_pair(nn.Conv1d, nn.BatchNorm1d, 128, 128, 128, **c1) for _ in range(5)])
+
+    def _conv_items(self):
+        items = []
+        for i in range(5):
+            items += [(f"lblocks.{i}", self.lblocks[i], 1), (f"blocks.{i}", self.blocks[i], 1)]
+        return items
+
+    def forward(self, x):
+        return engine.unet_forward(self._net(x.device), x, 5)
+
+
 class Encoder3(_UNetEncoder):
     """128 kb -> 1024 kb U-shaped encoder (orca_modules.py:1279-1406)."""
     _kind = _lib.ORCA_NET_ENCODER3

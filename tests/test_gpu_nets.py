@@ -202,3 +202,23 @@ def test_net_1mb_model_vs_reference_and_oracle(cuda):
     net2 = type(net)(num_1d=32)
     net2.load_state_dict(sd)
     assert maxabs(net2.to(cuda)(x)[0].cpu().numpy(), pred.cpu().numpy()) == 0.0
+
+
+def test_encoder2b_vs_reference_and_hctnoc_container(cuda):
+    """Encoder2b (the HCTnoc variant: contracting path only) vs the reference fixture G15 and, batched and strided,
+    vs the oracle; the HCTnoc container exposes the reference's attributes (no denet_1_pt, nearest-upsampling decoders)."""
+    from orca_amd import orca_models as M
+    g = golden("G15_encoder2b.npz")
+    e2b = product_module("Encoder2b", 0, device=cuda)
+    x = torch.from_numpy((np.random.RandomState(33).rand(1, 128, 2048) * 0.5).astype(np.float32))
+    outs = e2b(x.to(cuda))
+    assert len(outs) == 6 and maxabs(outs[0].cpu().numpy(), x.numpy()) == 0.0
+    for i in range(1, 6):
+        assert maxabs(outs[i][0].cpu().numpy(), g[f"o{i}"]) < 1e-4
+    xb = torch.from_numpy(np.random.RandomState(34).randn(2, 128, 640).astype(np.float32) * 0.4)
+    ref = O.encoder2b_forward(synth_sd("Encoder2b", 0), xb[:, :, ::2])
+    for a, b in zip(e2b(xb.to(cuda)[:, :, ::2]), ref):
+        assert maxabs(a.cpu().numpy(), b.numpy()) < 1e-4
+    m = M.HCTnoc(synthetic_seed=0)
+    assert sorted(m.denets) == [1, 2, 4, 8, 16, 32] and not hasattr(m, "denet_1_pt") and type(m.net).__name__ == "Encoder2b"
+    assert m.denets[8]._upsample == 0 and sorted(m.normmats) == [1, 2, 4, 8, 16, 32]

@@ -103,7 +103,7 @@ def main():
         # ---- G0: state-dict key/shape manifest of every hot-path module -----------
         if want("G0"):
             man = {}
-            for cls in ("Encoder", "Encoder2", "Encoder3", "Decoder", "Decoder_1m", "Net"):
+            for cls in ("Encoder", "Encoder2", "Encoder2b", "Encoder3", "Decoder", "Decoder_1m", "Net"):
                 m = om.Net(num_1d=32) if cls == "Net" else getattr(om, cls)()
                 man[cls] = np.array([f"{k}|{','.join(map(str, v.shape))}" for k, v in m.state_dict().items()])
             np.savez_compressed(os.path.join(GOLD, "G0_manifest.npz"), **man)
@@ -273,6 +273,14 @@ def main():
                 print("G11", name, "%.1fs" % (time.time() - t))
             np.savez_compressed(os.path.join(GOLD, "G11_sv_drivers.npz"), **d)
             print("G11 done")
+
+        # ---- G15: Encoder2b (orca_modules.py:1173-1276), the HCTnoc variant of Encoder2 ----------------------
+        if want("G15"):
+            e2b = load_synth(om.Encoder2b(), seed=0)
+            x = torch.from_numpy((np.random.RandomState(33).rand(1, 128, 2048) * 0.5).astype(np.float32))
+            outs = e2b(x)
+            np.savez_compressed(os.path.join(GOLD, "G15_encoder2b.npz"), **{f"o{i}": o[0].numpy() for i, o in enumerate(outs) if i > 0})
+            print("G15 done", [tuple(o.shape) for o in outs])
 
         # ---- G14: Net, the 1 Mb model (orca_modules.py:1409-1900), one 1 Mb sequence with an N run ----------
         if want("G14"):
