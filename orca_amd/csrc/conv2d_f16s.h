@@ -270,3 +270,6 @@ __global__ void final_sym_nhwc_kernel(FinalArgs a) {
 // instead of one 8-wave one) was correct but 30 % slower per Decoder (5.2 vs 4.0 ms at B=2): these kernels are bound by
 // the per-row latency chain global -> registers -> split -> LDS -> MFMA over only 2-4 chunks, and halving the chunk
 // doubled the number of links.  Several rows per workgroup is slower still, so it is not dispatch-bound either.
+// Also measured and dropped: running the 64-cout layers as two 32-cout workgroups per row (67 KB LDS each, two resident
+// per CU): no change (3.72 vs 3.73 ms per Decoder); keeping TWO K-chunks of global loads in flight (register slots
+// 0/1): 166 VGPRs for COUT 32 cost the second resident workgroup, 4.0-4.4 ms, and 5.8 ms when capped at 128 VGPRs.
