@@ -27,6 +27,7 @@ struct Conv2dF16Args {
   int H, W, dil, nchunks, relu;
   int banded;        // grid.x = 8 * ceil(H/8), XCD-banded row order (see the kernel)
   unsigned* flag;
+  unsigned long long* stamps;   // tools/microbench_c2.hip only (NULL in the library): s_memtime stamps of one workgroup
 };
 
 template <int COUT>
@@ -75,6 +76,9 @@ __global__ __launch_bounds__(512) void conv2d_3x3_f16s_kernel(Conv2dF16Args a) {
     wskip[kx] = (x0 + 31 < 0) || (x0 >= W);
   }
 
+  int nst = 0;
+#define C2_STAMP() if (a.stamps && blockIdx.x == 100 && blockIdx.y == 0 && lane == 0 && nst < 40) a.stamps[wave * 40 + nst++] = __builtin_readcyclecounter();
+  C2_STAMP();
   f32x16 acc[NW];
 #pragma unroll
   for (int j = 0; j < NW; ++j)
@@ -125,8 +129,11 @@ __global__ __launch_bounds__(512) void conv2d_3x3_f16s_kernel(Conv2dF16Args a) {
   }
 
   C2_LOAD_CHUNK(0);
+  C2_STAMP();   // 1: first loads issued
   C2_STORE_CHUNK();
+  C2_STAMP();   // 2: first chunk landed, split, in LDS
   __syncthreads();
+  C2_STAMP();   // 3
 
   const f32x4* xa0 = smem + g * (3 * PX);                  // + s*2*3*PX + ky*PX + px
   const f32x4* wb0 = smem + XU + g * COUT + l31;           // + ((s*9+tap)*2)*COUT + j*32
@@ -134,6 +141,7 @@ __global__ __launch_bounds__(512) void conv2d_3x3_f16s_kernel(Conv2dF16Args a) {
   for (int c = 0; c < a.nchunks; ++c) {
     const bool more = (c + 1 < a.nchunks);
     if (more) C2_LOAD_CHUNK(c + 1);
+    C2_STAMP();   // +0: prefetch issued
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
       if (!rowok[ky]) continue;   // workgroup-uniform: the whole source row is zero padding
@@ -158,10 +166,14 @@ __global__ __launch_bounds__(512) void conv2d_3x3_f16s_kernel(Conv2dF16Args a) {
         }
       }
     }
+    C2_STAMP();   // +1: MFMA block issued
     if (!more) break;
     __syncthreads();
+    C2_STAMP();   // +2: everyone done with the LDS image
     C2_STORE_CHUNK();
+    C2_STAMP();   // +3: prefetch landed, split, stored
     __syncthreads();
+    C2_STAMP();   // +4
   }
 #undef C2_LOAD_CHUNK
 #undef C2_STORE_CHUNK
@@ -186,6 +198,7 @@ __global__ __launch_bounds__(512) void conv2d_3x3_f16s_kernel(Conv2dF16Args a) {
       *reinterpret_cast<f32x4*>(yp + co) = v;
     }
   }
+  C2_STAMP();   // last: epilogue issued
   if (overflow && a.flag) *a.flag = 1u;
 }
 
@@ -270,6 +283,14 @@ __global__ void final_sym_nhwc_kernel(FinalArgs a) {
 // instead of one 8-wave one) was correct but 30 % slower per Decoder (5.2 vs 4.0 ms at B=2): these kernels are bound by
 // the per-row latency chain global -> registers -> split -> LDS -> MFMA over only 2-4 chunks, and halving the chunk
 // doubled the number of links.  Several rows per workgroup is slower still, so it is not dispatch-bound either.
-// Also measured and dropped: running the 64-cout layers as two 32-cout workgroups per row (67 KB LDS each, two resident
+// Per-wave s_memtime stamps (tools/microbench_c2.hip; COUT 32, 4 K-chunks, ~36 000 cycles per workgroup, two workgroups
+// resident per CU): per chunk ~8 200 cycles = issuing the next chunk's loads 2 200-2 700 (each wave-instruction touches
+// 16 half-used 128-B lines of the [px][64 ch] rows: TA-bound) + MFMA block 2 500 (the matrix pipe is shared with the
+// other resident workgroup) + barrier 1 200 + wait/split/ds_write 1 200 + barrier 1 000.  Dispatch is not the limit
+// (an empty 500-workgroup launch with the same LDS: 12 ns per workgroup).  A channel-chunk-planar feature-map layout
+// ([C/16][row][px][16]) would halve the load-issue cost; LDS-DMA from pre-split maps needs a double-buffered X image
+// (96 KB) and loses the second resident workgroup.
+// Also measured and dropped: one accumulator per MFMA product (acc 48 -> 144 registers for COUT 64): the block is
+// pipe-bound, not dependency-bound, and the registers cost occupancy (5.0 vs 3.7 ms); running the 64-cout layers as two 32-cout workgroups per row (67 KB LDS each, two resident
 // per CU): no change (3.72 vs 3.73 ms per Decoder); keeping TWO K-chunks of global loads in flight (register slots
 // 0/1): 166 VGPRs for COUT 32 cost the second resident workgroup, 4.0-4.4 ms, and 5.8 ms when capped at 128 VGPRs.

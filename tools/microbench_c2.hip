@@ -1,0 +1,49 @@
+// Stamp micro-benchmark of conv2d_3x3_f16s_kernel (Decoder convs).  hipcc --offload-arch=gfx950 -O3 -std=c++17 -I orca_amd/csrc ...
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#include "conv2d_f16s.h"
+template <int COUT>
+static void run(int cin, int dil, int banded) {
+  const int n = 250, B = 2; const size_t plane = (size_t)n * 256;
+  float *x, *y, *r, *bias; void* w; unsigned long long* st;
+  hipMalloc(&x, B * plane * cin * 4); hipMalloc(&y, B * plane * COUT * 4); hipMalloc(&r, B * plane * COUT * 4); hipMalloc(&bias, 256);
+  hipMalloc(&w, (size_t)(cin / 16) * 2 * 9 * 2 * COUT * 16); hipMalloc(&st, 8 * 40 * 8);
+  std::vector<float> hx(B * plane * cin); unsigned s = 1u;
+  for (auto& v : hx) { s = s * 1664525u + 1013904223u; v = ((s >> 8) & 0xffff) / 65536.f - 0.5f; }
+  hipMemcpy(x, hx.data(), hx.size() * 4, hipMemcpyHostToDevice); hipMemset(w, 0x2c, (size_t)(cin / 16) * 2 * 9 * 2 * COUT * 16);
+  hipMemset(bias, 0, 256); hipMemset(r, 0, B * plane * COUT * 4); hipMemset(st, 0, 8 * 40 * 8);
+  Conv2dF16Args a{}; a.x = x; a.w = w; a.bias = bias; a.y = y; a.r = r; a.x_bs = plane * cin; a.y_bs = plane * COUT; a.r_bs = plane * COUT;
+  a.xc = cin; a.yc = COUT; a.rc = COUT; a.H = n; a.W = n; a.dil = dil; a.nchunks = cin / 16; a.relu = 1; a.banded = banded; a.flag = nullptr; a.stamps = st;
+  dim3 grid(banded ? 256 : n, B);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1); float best = 1e9;
+  for (int it = 0; it < 5; ++it) {
+    hipEventRecord(e0, 0); hipLaunchKernelGGL((conv2d_3x3_f16s_kernel<COUT>), grid, dim3(512), 0, 0, a); hipEventRecord(e1, 0); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); if (it > 0 && ms < best) best = ms;
+  }
+  std::vector<unsigned long long> h(8 * 40); hipMemcpy(h.data(), st, h.size() * 8, hipMemcpyDeviceToHost);
+  printf("COUT=%d cin=%d dil=%d: %.1f us  [%s]\n  wave0 stamps (cycles since start):", COUT, cin, dil, best * 1e3, hipGetErrorString(hipGetLastError()));
+  for (int k = 0; k < 40 && h[k]; ++k) printf(" %llu", h[k] - h[0]);
+  printf("\n  wave7:"); for (int k = 0; k < 40 && h[7 * 40 + k]; ++k) printf(" %llu", h[7 * 40 + k] - h[0]);
+  printf("\n");
+  hipFree(x); hipFree(y); hipFree(r); hipFree(bias); hipFree(w); hipFree(st);
+}
+template <int LDSB>
+__global__ __launch_bounds__(512) void empty_kernel(float* p) {
+  __shared__ float buf[LDSB / 4];
+  if (p == nullptr) { buf[threadIdx.x] = 1.f; __syncthreads(); p[0] = buf[5]; }   // never taken: keeps the LDS allocation
+}
+template <int LDSB>
+static void run_empty(int nwg) {
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1); float best = 1e9; float* d; hipMalloc(&d, 64);
+  for (int it = 0; it < 6; ++it) {
+    hipEventRecord(e0, 0); hipLaunchKernelGGL((empty_kernel<LDSB>), dim3(nwg), dim3(512), 0, 0, d); hipEventRecord(e1, 0); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); if (it > 0 && ms < best) best = ms;
+  }
+  printf("empty kernel, %d workgroups x 512 threads, %d B LDS: %.1f us (%.0f ns per workgroup)\n", nwg, LDSB, best * 1e3, best * 1e6 / nwg);
+}
+int main() {
+  run_empty<1024>(500); run_empty<67584>(500); run_empty<67584>(250); run_empty<67584>(1000); run_empty<86272>(500);
+  run<32>(64, 8, 0); run<32>(64, 1, 1); run<64>(32, 8, 0); run<64>(32, 1, 1);
+  return 0;
+}
