@@ -97,12 +97,13 @@ __global__ __launch_bounds__(512) void conv2d_3x3_f16s_kernel(Conv2dF16Args a) {
     const int ys = y0 + (ky - 1) * d;
     xvalid[it] = (ys >= 0 && ys < H);
     xoff[it] = (long)(xvalid[it] ? ys : y0) * rowpitch + (long)px * a.xc + 4 * q;
+    if (a.stamps && a.relu == 7) xoff[it] = (long)(xvalid[it] ? ys : y0) * (PX * 16) + (long)px * 16 + 4 * q;   // microbench: access pattern of a chunk-planar map (values meaningless)
     xdst[it] = ((((q >> 1) * 3 + ky) * PX) + px) * 16 + (q & 1) * 8;
   }
 #define C2_LOAD_CHUNK(c)                                                                     \
   {                                                                                          \
     _Pragma("unroll") for (int it = 0; it < XIT; ++it) {                                     \
-      f32x4 v = *reinterpret_cast<const f32x4*>(xb + xoff[it] + 16 * (c));                   \
+      f32x4 v = *reinterpret_cast<const f32x4*>(xb + xoff[it] + ((a.stamps && a.relu == 7) ? (long)(c) * H * PX * 16 : 16L * (c)));   \
       if (!xvalid[it]) v = (f32x4)(0.f);                                                     \
       xr[it] = v;                                                                            \
     }                                                                                        \
@@ -178,9 +179,26 @@ __global__ __launch_bounds__(512) void conv2d_3x3_f16s_kernel(Conv2dF16Args a) {
 #undef C2_LOAD_CHUNK
 #undef C2_STORE_CHUNK
 
-  const int px = wave * 32 + l31;
-  float* yp = a.y + (long)b * a.y_bs + ((long)y0 * PX + px) * a.yc;
-  const float* rp = a.r ? a.r + (long)b * a.r_bs + ((long)y0 * PX + px) * a.rc : nullptr;
+  // Epilogue.  A lane owns ONE pixel and 4-cout groups, and a pixel's channels are 128-256 contiguous bytes of the
+  // channel-last map: written straight from the accumulators, every store (and residual load) instruction would touch
+  // 64 different lines, 16 bytes each - stamps put that at 12-24 000 cycles for COUT 64, a third of the workgroup's
+  // life.  Instead each wave transposes its 32 px x COUT tile through its own slice of the (now idle) operand LDS
+  // (row pitch + 16 B: conflict-free both ways) and moves whole pixel rows: 1 KB contiguous per instruction.
+  constexpr int PITCH = COUT + 4;        // floats
+  constexpr int LPR = COUT / 4;          // lanes per pixel row
+  constexpr int RPI = 64 / LPR;          // pixel rows per wave instruction
+  constexpr int NI = 32 / RPI;
+  static_assert(8 * 32 * PITCH * 4 <= (XU + WU) * 16, "tile transposition needs the operand images' LDS");
+  const int lr = lane / LPR, lc = (lane % LPR) * 4;
+  const long pix0 = (long)y0 * PX + wave * 32;
+  f32x4 rres[NI];
+  if (a.r) {   // residual rows, fetched before the transposition
+    const float* rp = a.r + (long)b * a.r_bs + pix0 * a.rc + lc;
+#pragma unroll
+    for (int k = 0; k < NI; ++k) rres[k] = *reinterpret_cast<const f32x4*>(rp + (long)(k * RPI + lr) * a.rc);
+  }
+  __syncthreads();                       // every wave is done reading the operand images
+  float* tile = reinterpret_cast<float*>(smem) + wave * (32 * PITCH);
 #pragma unroll
   for (int j = 0; j < NW; ++j) {
 #pragma unroll
@@ -193,10 +211,18 @@ __global__ __launch_bounds__(512) void conv2d_3x3_f16s_kernel(Conv2dF16Args a) {
       v.z = acc[j][4 * q + 2] + bias.z;
       v.w = acc[j][4 * q + 3] + bias.w;
       if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-      if (rp) v += *reinterpret_cast<const f32x4*>(rp + co);
-      if (px >= W) v = (f32x4)(0.f);   // keep the pad pixels of every feature map at zero
-      *reinterpret_cast<f32x4*>(yp + co) = v;
+      *reinterpret_cast<f32x4*>(tile + l31 * PITCH + co) = v;
     }
+  }
+  // same-wave LDS writes and reads complete in order: no barrier needed for the wave-private tile
+  float* yp = a.y + (long)b * a.y_bs + pix0 * a.yc + lc;
+#pragma unroll
+  for (int k = 0; k < NI; ++k) {
+    const int row = k * RPI + lr;
+    f32x4 v = *reinterpret_cast<const f32x4*>(tile + row * PITCH + lc);
+    if (a.r) v += rres[k];
+    if (wave * 32 + row >= W) v = (f32x4)(0.f);   // keep the pad pixels of every feature map at zero
+    *reinterpret_cast<f32x4*>(yp + (long)row * a.yc) = v;
   }
   C2_STAMP();   // last: epilogue issued
   if (overflow && a.flag) *a.flag = 1u;

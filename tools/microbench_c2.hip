@@ -4,7 +4,7 @@
 #include <vector>
 #include "conv2d_f16s.h"
 template <int COUT>
-static void run(int cin, int dil, int banded) {
+static void run(int cin, int dil, int banded, int planar_pattern = 0) {
   const int n = 250, B = 2; const size_t plane = (size_t)n * 256;
   float *x, *y, *r, *bias; void* w; unsigned long long* st;
   hipMalloc(&x, B * plane * cin * 4); hipMalloc(&y, B * plane * COUT * 4); hipMalloc(&r, B * plane * COUT * 4); hipMalloc(&bias, 256);
@@ -14,7 +14,7 @@ static void run(int cin, int dil, int banded) {
   hipMemcpy(x, hx.data(), hx.size() * 4, hipMemcpyHostToDevice); hipMemset(w, 0x2c, (size_t)(cin / 16) * 2 * 9 * 2 * COUT * 16);
   hipMemset(bias, 0, 256); hipMemset(r, 0, B * plane * COUT * 4); hipMemset(st, 0, 8 * 40 * 8);
   Conv2dF16Args a{}; a.x = x; a.w = w; a.bias = bias; a.y = y; a.r = r; a.x_bs = plane * cin; a.y_bs = plane * COUT; a.r_bs = plane * COUT;
-  a.xc = cin; a.yc = COUT; a.rc = COUT; a.H = n; a.W = n; a.dil = dil; a.nchunks = cin / 16; a.relu = 1; a.banded = banded; a.flag = nullptr; a.stamps = st;
+  a.xc = cin; a.yc = COUT; a.rc = COUT; a.H = n; a.W = n; a.dil = dil; a.nchunks = cin / 16; a.relu = planar_pattern ? 7 : 1; a.banded = banded; a.flag = nullptr; a.stamps = st;
   dim3 grid(banded ? 256 : n, B);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1); float best = 1e9;
   for (int it = 0; it < 5; ++it) {
@@ -22,7 +22,7 @@ static void run(int cin, int dil, int banded) {
     float ms; hipEventElapsedTime(&ms, e0, e1); if (it > 0 && ms < best) best = ms;
   }
   std::vector<unsigned long long> h(8 * 40); hipMemcpy(h.data(), st, h.size() * 8, hipMemcpyDeviceToHost);
-  printf("COUT=%d cin=%d dil=%d: %.1f us  [%s]\n  wave0 stamps (cycles since start):", COUT, cin, dil, best * 1e3, hipGetErrorString(hipGetLastError()));
+  printf("COUT=%d cin=%d dil=%d%s: %.1f us  [%s]\n  wave0 stamps (cycles since start):", COUT, cin, dil, planar_pattern ? " (chunk-planar READ pattern)" : "", best * 1e3, hipGetErrorString(hipGetLastError()));
   for (int k = 0; k < 40 && h[k]; ++k) printf(" %llu", h[k] - h[0]);
   printf("\n  wave7:"); for (int k = 0; k < 40 && h[7 * 40 + k]; ++k) printf(" %llu", h[7 * 40 + k] - h[0]);
   printf("\n");
@@ -44,6 +44,6 @@ static void run_empty(int nwg) {
 }
 int main() {
   run_empty<1024>(500); run_empty<67584>(500); run_empty<67584>(250); run_empty<67584>(1000); run_empty<86272>(500);
-  run<32>(64, 8, 0); run<32>(64, 1, 1); run<64>(32, 8, 0); run<64>(32, 1, 1);
+  run<32>(64, 8, 0); run<32>(64, 8, 0, 1); run<32>(64, 1, 1); run<32>(64, 1, 1, 1); run<64>(32, 8, 0); run<64>(32, 8, 0, 1);
   return 0;
 }
