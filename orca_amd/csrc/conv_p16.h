@@ -140,8 +140,13 @@ __device__ __forceinline__ void p16_lds_wait(f16x8 (&a)[2][MW], f16x8 (&b)[2][NW
 
 // CT = couts per workgroup tile (cout blocks of CT are separate tiles), wave tile = MW x NW subtiles of 32x32.
 // OM = out_mode, R1 = residual present: compile-time, the epilogue is branch-free.
-// ABL (micro-benchmark only, 0 in the library): 1 = no DMA after the first step, 8 = LDS operands read once,
-// 16 = no epilogue stores, 128 = per-wave s_memtime stamps into a.stamps.
+// ABL (micro-benchmark only, 0 in the library): 1 = no DMA after the first step (64 / 256: only the W / X pieces are
+// dropped), 2 = stores in a position-blocked plane order, 8 = LDS operands read once, 16 = no epilogue stores,
+// 32 = stores folded into an L2-resident window, 128 = per-wave s_memtime stamps into a.stamps.
+// Cost split of the 64 -> 64 conv at 32 M positions (5.89 ms): X DMA 11 %, W DMA 4 %, stores 7 % (half of it issue,
+// half HBM), LDS operand reads ~7 %; with all DMA and stores off 4.65 ms (507 TFLOP/s-eq) at the higher clock that buys.
+// K depth matters: 128 input channels (8 steps per tile) run at 440-460 TFLOP/s-eq against 380-400 for 64 (4 steps):
+// the step that carries the epilogue costs ~1.8 plain steps more.
 // s_memtime stamps (ABL & 128, tools/microbench_p16.hip) of the first version of this kernel, per step of
 // ~12 000 cycles at the 1.8 GHz the part sustains here: MFMA block 6 700 (the pipe needs 6 912), epilogue 2 150
 // (8 300 per tile - VALU- and store-issue-bound), DMA issue burst 1 440, vmcnt + barrier tail 3 000.  Hence:
@@ -279,6 +284,8 @@ __global__ __launch_bounds__(WM * 64, WM / 4) void conv1d_k9_p16_kernel(ConvP16A
         char* yb_ = reinterpret_cast<char*>(a.y) + (long)(co >> 3) * 2 * ypl16;                                  \
         if (ABL & 16) {                                                                                          \
           asm volatile("" ::"v"(unit_));                                                                         \
+        } else if (OM == 0 && (ABL & 32)) {   /* micro-benchmark: same stores, folded into a 2 MB (L2-resident) window */ \
+          *reinterpret_cast<u32x4_t*>(reinterpret_cast<char*>(a.y) + ((((long)(co >> 3) * 2 * ypl16 + (P16_GUARD + p0) * 16 + lane_unit)) & 0x1FFFF0L)) = unit_; \
         } else if (OM == 0) {                                                                                    \
           *reinterpret_cast<u32x4_t*>(yb_ + (P16_GUARD + p0) * 16 + lane_unit) = unit_;                          \
         } else {                                                                                                 \
@@ -336,7 +343,7 @@ __global__ __launch_bounds__(WM * 64, WM / 4) void conv1d_k9_p16_kernel(ConvP16A
       if (more && tap < 5 && !(ABL & 1)) {   // the next buffer's DMA, spread over the first taps
 #pragma unroll
         for (int d = 0; d < DPT; ++d)
-          if (tap * DPT + d < NIT) P16_DMA_ONE(tap * DPT + d, cur ^ 1);
+          if (tap * DPT + d < NIT && !((ABL & 64) && !isx[tap * DPT + d]) && !((ABL & 256) && isx[tap * DPT + d])) P16_DMA_ONE(tap * DPT + d, cur ^ 1);   // ABL 64 / 256: no W / no X pieces
       }
       if (tap + 1 < 9) p16_lds_wait<2 * (MW + NW), MW, NW>(av[fb], bv[fb]);   // this tap's fragments are in, the next tap's stay in flight
       else p16_lds_wait<0, MW, NW>(av[fb], bv[fb]);

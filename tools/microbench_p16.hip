@@ -58,12 +58,21 @@ int main(int argc, char** argv) {
   a.out_mode = 0;
   run<64, 2, 2, 8, 0, false, 0>(a, "warm");
   run<64, 2, 2, 8, 0, false, 0>(a, "plain");
+  run<64, 2, 2, 8, 0, false, 16>(a, "no stores");
+  run<64, 2, 2, 8, 0, false, 32>(a, "stores folded into an L2-resident window");
+  run<64, 2, 2, 8, 0, false, 1>(a, "no DMA after the first step");
+  run<64, 2, 2, 8, 0, false, 64>(a, "no W DMA after the first step");
+  run<64, 2, 2, 8, 0, false, 256>(a, "no X DMA after the first step");
+  run<64, 2, 2, 8, 0, false, 1 + 16>(a, "no DMA, no stores");
   a.r1 = x;
   run<64, 2, 2, 8, 0, true, 0>(a, "r1");
   run<64, 2, 2, 8, 1, true, 0>(a, "r1 pool");
   run<64, 2, 2, 8, 2, true, 0>(a, "r1 f32 out");
   a.r1 = nullptr;
   { ConvP16Args b = a; b.cout = 96; b.nchunks = 6; run<96, 1, 3, 8, 0, false, 0>(b, "96"); }
+  { ConvP16Args b = a; b.cout = 128; b.nchunks = 8; run<64, 2, 2, 8, 0, false, 0>(b, "128 -> 128"); }
+  { ConvP16Args b = a; b.cout = 64; b.nchunks = 8; run<64, 2, 2, 8, 0, false, 0>(b, "128 -> 64"); }
+  { ConvP16Args b = a; b.cout = 128; b.nchunks = 4; run<64, 2, 2, 8, 0, false, 0>(b, "64 -> 128"); }
   run<64, 2, 2, 8, 0, false, 128>(a, "stamped");
   report(st);
   run<64, 2, 2, 8, 0, false, 128 + 1 + 16>(a, "stamped, no DMA, no stores");
