@@ -222,3 +222,47 @@ def test_encoder2b_vs_reference_and_hctnoc_container(cuda):
     m = M.HCTnoc(synthetic_seed=0)
     assert sorted(m.denets) == [1, 2, 4, 8, 16, 32] and not hasattr(m, "denet_1_pt") and type(m.net).__name__ == "Encoder2b"
     assert m.denets[8]._upsample == 0 and sorted(m.normmats) == [1, 2, 4, 8, 16, 32]
+
+
+@pytest.mark.parametrize("nbins", [1, 2, 3, 5, 7, 28, 29, 57, 113, 251, 253, 512, 1025, 2051])
+def test_encoder_length_sweep_split_fp16_vs_exact_fp32(cuda, nbins):
+    """The default arithmetic (P16 / split-fp16 MFMA kernels, fused pooling, ragged last tiles) against the independent
+    exact-fp32-MFMA code path of the same library over awkward lengths, float and packed input, both strands."""
+    L = 4000 * nbins
+    seq = synth.synth_sequence(L, seed=100 + nbins, n_frac=0.01)
+    x = torch.from_numpy(seq).to(cuda).transpose(1, 2)
+    enc = product_module("Encoder", 0, device=cuda)
+    enc.precision = "f32"
+    ref = enc(x)
+    enc.precision = "f16x2"
+    got = enc(x)
+    assert got.shape == (1, 128, nbins) and maxabs(got.cpu().numpy(), ref.cpu().numpy()) < 1e-4
+    from orca_amd import engine
+    codes, ok = engine.pack_sequence(x)
+    assert ok
+    assert maxabs(enc.forward_codes(codes).cpu().numpy(), ref.cpu().numpy()) < 1e-4
+    xr = torch.from_numpy(np.ascontiguousarray(seq[:, ::-1, ::-1])).to(cuda).transpose(1, 2)
+    enc.precision = "f32"
+    ref_r = enc(xr)
+    enc.precision = "f16x2"
+    assert maxabs(enc.forward_codes(codes, reverse=True).cpu().numpy(), ref_r.cpu().numpy()) < 1e-4
+
+
+@pytest.mark.parametrize("n", [2, 4, 18, 62, 126, 250, 256])
+def test_decoder_size_sweep_split_fp16_vs_exact_fp32(cuda, n):
+    """Decoder / Decoder_1m on map sizes from 2 to the 256-pixel pitch: split-fp16 kernels (XCD-banded rows, LDS-transposed
+    epilogue, border tap skipping with dilations up to 64 > n) against the exact-fp32 kernels of the same library."""
+    rs = np.random.RandomState(n)
+    x = torch.from_numpy(rs.randn(2, 128, n).astype(np.float32) * 0.5).to(cuda)
+    de = torch.from_numpy(rs.randn(2, 1, n, n).astype(np.float32)).to(cuda)
+    y = torch.from_numpy(rs.randn(2, 1, n // 2, n // 2).astype(np.float32)).to(cuda)
+    for cls, args in (("Decoder", (x, de)), ("Decoder", (x, de, y)), ("Decoder_1m", (x,))):
+        kw = {"upsample_mode": "bilinear"} if cls == "Decoder" else {}
+        m = product_module(cls, 1, device=cuda, **kw)
+        m.precision = "f32"
+        ref = m(*args)
+        m.precision = "f16x2"
+        got = m(*args)
+        assert got.shape == (2, 1, n, n) and bool(torch.isfinite(got).all())
+        assert maxabs(got.cpu().numpy(), ref.cpu().numpy()) < 1e-4, (cls, len(args))
+        assert maxabs(got.cpu().numpy(), got.transpose(2, 3).cpu().numpy()) < 1e-6     # symmetrised output
