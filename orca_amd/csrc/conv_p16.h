@@ -14,7 +14,9 @@
 // the DMA of step s+1 is issued inside the MFMA block of step s and lands underneath it; one barrier per step.
 // Arithmetic: 3 fp16 MFMA products per fp32 product (hi*hi + hi*lo + lo*hi), fp32 accumulate.
 // Tried and dropped (tools/microbench_p16.hip has the per-wave s_memtime stamp harness that judged them):
-//   * de-phased two-group variant (waves 0-3 / 4-7 on different tiles, rotated K-chunk order): 15 % slower;
+//   * de-phased two-group variant (waves 0-3 / 4-7 on different tiles, rotated K-chunk order): 15 % slower with the
+//     first epilogue; re-checked against the current kernel by moving the epilogues of waves 4-7 half a tile later
+//     (ABL 512, timing only): no gain either;
 //   * epilogue software-pipelined into the next step's MFMA block from a parked accumulator copy: 256 VGPRs are
 //     not enough (acc 64 + copy 64 + fragments 64 + ...), the spill reloads are VMEM loads whose vmcnt(0)
 //     serialises against the in-flight DMA - 40 % slower;
@@ -142,7 +144,8 @@ __device__ __forceinline__ void p16_lds_wait(f16x8 (&a)[2][MW], f16x8 (&b)[2][NW
 // OM = out_mode, R1 = residual present: compile-time, the epilogue is branch-free.
 // ABL (micro-benchmark only, 0 in the library): 1 = no DMA after the first step (64 / 256: only the W / X pieces are
 // dropped), 2 = stores in a position-blocked plane order, 8 = LDS operands read once, 16 = no epilogue stores,
-// 32 = stores folded into an L2-resident window, 128 = per-wave s_memtime stamps into a.stamps.
+// 32 = stores folded into an L2-resident window, 128 = per-wave s_memtime stamps into a.stamps, 512 = epilogues of
+// the upper half of the waves half a tile late (timing of a de-phased variant).
 // Cost split of the 64 -> 64 conv at 32 M positions (5.89 ms): X DMA 11 %, W DMA 4 %, stores 7 % (half of it issue,
 // half HBM), LDS operand reads ~7 %; with all DMA and stores off 4.65 ms (507 TFLOP/s-eq) at the higher clock that buys.
 // K depth matters: 128 input channels (8 steps per tile) run at 440-460 TFLOP/s-eq against 380-400 for 64 (4 steps):
@@ -361,6 +364,9 @@ __global__ __launch_bounds__(WM * 64, WM / 4) void conv1d_k9_p16_kernel(ConvP16A
 #undef P16_READ_FRAGS
 
     P16_STAMP(3);
+    if (ABL & 512) {   // micro-benchmark: TIMING of a de-phased variant - waves WM/2.. take their epilogue half a tile later
+      if (wave < WM / 2 ? last_chunk : (c + 1 == a.nchunks / 2)) epi_tile = tile;   // (the late group's results are meaningless)
+    } else
     if (last_chunk) epi_tile = tile;
 
     if (!more) break;

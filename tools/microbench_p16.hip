@@ -58,6 +58,9 @@ int main(int argc, char** argv) {
   a.out_mode = 0;
   run<64, 2, 2, 8, 0, false, 0>(a, "warm");
   run<64, 2, 2, 8, 0, false, 0>(a, "plain");
+  run<64, 2, 2, 8, 0, false, 512>(a, "epilogues of waves 4-7 half a tile late (timing only)");
+  run<64, 2, 2, 8, 0, false, 0>(a, "plain");
+  run<64, 2, 2, 8, 0, false, 512>(a, "epilogues of waves 4-7 half a tile late (timing only)");
   run<64, 2, 2, 8, 0, false, 16>(a, "no stores");
   run<64, 2, 2, 8, 0, false, 32>(a, "stores folded into an L2-resident window");
   run<64, 2, 2, 8, 0, false, 1>(a, "no DMA after the first step");
