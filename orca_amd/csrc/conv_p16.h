@@ -46,6 +46,14 @@ struct ConvP16Args {
   int out_mode;        // 0: P16 same length; 1: P16 with MaxPool1d(4) fused (length n/4); 2: fp32 [n][cout]
   unsigned* flag;      // raised when a value written to P16 leaves the fp16 range
   unsigned long long* stamps;   // micro-benchmark only (ABL & 128): s_memtime stamps of workgroup 0 / wave 0
+  // fused first layer (template flag F1): x is not read; the input tiles are PRODUCED from the packed bases
+  const unsigned char* f1_codes;   // 1 byte per base of the whole sequence (see FirstMfmaArgs)
+  long f1_codes_L, f1_codes_off;   // chunk position p is strand position codes_off + p
+  int f1_reverse;
+  const float* f1_table;           // [9 taps][4 K-chunks][6 codes][4 quads][4] fp32: folded first-layer weights per base code
+                                   // (4 = N, 5 = padding); (code, quad) adjacent so the 16 lanes of a ds_read_b128 group -
+                                   // 4 positions x 4 channel quads - hit 16 different 16-byte bank slots
+  const float* f1_bias;            // [64] folded first-layer bias
 };
 
 __device__ __forceinline__ void p16_split_store(char* plane_hi, long plen_bytes, f32x4 v, bool valid, bool& ovf) {
@@ -127,6 +135,30 @@ __device__ __forceinline__ f16x8 p16_lds_read16(unsigned addr, const int off) { 
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "i"(off));
   return r;
 }
+__device__ __forceinline__ f32x4 p16_lds_read16f(unsigned addr, const int off) {   // off: constant after unrolling
+  f32x4 r;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "i"(off));
+  return r;
+}
+// LDS traffic of the fused-first-layer producer, all hidden from the compiler: with an LDS-DMA in flight it guards
+// every LDS access it can see with s_waitcnt vmcnt(0) (possible alias with the DMA's destination) and the producer
+// would wait out the W-chunk DMA in the middle of the MFMA block.  The regions are disjoint by construction.
+__device__ __forceinline__ void p16_lds_read3(unsigned addr, unsigned& d0, unsigned& d1, unsigned& d2) {
+  asm volatile("ds_read_b32 %0, %3\n\tds_read_b32 %1, %3 offset:4\n\tds_read_b32 %2, %3 offset:8\n\ts_waitcnt lgkmcnt(0)"
+               : "=&v"(d0), "=&v"(d1), "=&v"(d2) : "v"(addr));
+}
+__device__ __forceinline__ void p16_lds_write8(unsigned addr, u32x2 v, const int off) {
+  asm volatile("ds_write_b64 %0, %1 offset:%2" : : "v"(addr), "v"(v), "i"(off) : "memory");
+}
+__device__ __forceinline__ void p16_lds_wait0(f32x4& a, f32x4& b, f32x4& c) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c));
+}
+template <int MW, int NW>
+__device__ __forceinline__ void p16_f1_wait0(f16x8 (&a)[2][MW], f16x8 (&b)[2][NW], f32x4 (&r)[5]) {
+  static_assert(MW == 2 && NW == 2, "fused first layer: 64 x 64 wave tile");
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[1][0]), "+v"(a[1][1]), "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[1][0]),
+               "+v"(b[1][1]), "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]));
+}
 template <int N, int MW, int NW>
 __device__ __forceinline__ void p16_lds_wait(f16x8 (&a)[2][MW], f16x8 (&b)[2][NW]) {
   static_assert(MW <= 2 && NW <= 3, "operand list below");
@@ -160,8 +192,16 @@ __device__ __forceinline__ void p16_lds_wait(f16x8 (&a)[2][MW], f16x8 (&b)[2][NW
 //   * MaxPool1d(4) on DPP quad permutes, the 4 lanes of a quad store one dword each of the pooled unit;
 //   * the LDS-DMA of the next buffer is issued inside taps 0..4 of the MFMA block, two pieces per tap, instead of
 //     as a burst in front of it (8 waves x 9 x 1 KB against the CU's 64 B/clk path).
-template <int CT, int MW, int NW, int WM, int OM, bool R1, int ABL = 0>
+//
+// F1 (fused first layer; the conv right after it, 64 -> 64): the 16-channel input image of the next step is not
+// DMA'd from a stored first-layer output but PRODUCED in place from the packed bases.  With one-hot input the 4 -> 64
+// k9 convolution is a table sum, out[p][ch] = b[ch] + sum_t T[t][code(p + t - 4)][ch]  (T = the folded weights per base
+// code: 13.8 KB of LDS), i.e. per step and thread 4 x (9 ds_read_b128 + 36 adds + hi/lo split + 2 ds_write_b64) - cheaper
+// than the DMA of the same 33 KB (timing emulation: 5.07 vs 5.96 ms for 32 M positions) and the first-layer kernel with
+// its 8 GB store / re-load of the 64-channel tensor disappears (2.4 ms per strand).
+template <int CT, int MW, int NW, int WM, int OM, bool R1, int ABL = 0, bool F1 = false>
 __global__ __launch_bounds__(WM * 64, WM / 4) void conv1d_k9_p16_kernel(ConvP16Args a) {
+  static_assert(!F1 || (CT == 64 && WM == 8 && MW == 2), "fused first layer: 64-cout tiles of 512 positions");
   static_assert(NW * 32 == CT, "one wave covers all couts of the tile");
   constexpr int NT = WM * 64;
   constexpr int MT = WM * MW * 32;
@@ -184,6 +224,100 @@ __global__ __launch_bounds__(WM * 64, WM / 4) void conv1d_k9_p16_kernel(ConvP16A
 
   float* bias_s = reinterpret_cast<float*>(smem + 2 * BU);
   if (tid < a.cout) bias_s[tid] = a.bias[tid];   // visible after the first barrier
+  constexpr int F1_WIN = 544;                          // bases a tile's producer looks at: positions m0-8 .. m0+MT+12 (528 used)
+  __shared__ float f1_tab[F1 ? 9 * 6 * 64 : 4];
+  __shared__ float f1_b[F1 ? 64 : 4];
+  __shared__ unsigned char f1_win[F1 ? 2 * F1_WIN : 4];   // two tiles' windows
+  if (F1) {
+    for (int i = tid; i < 9 * 6 * 64; i += NT) f1_tab[i] = a.f1_table[i];
+    if (tid < 64) f1_b[tid] = a.f1_bias[tid];
+  }
+  // base code at chunk position p (5 = outside the chunk: the first layer's zero padding).  Split in two so that the
+  // global load (f1_fetch) and the use of its result (f1_fix) can sit a whole step apart.
+  auto f1_fetch = [&](long p) -> unsigned char {
+    if (p < 0 || p >= a.n) return (unsigned char)5;
+    const long P = a.f1_codes_off + p;
+    return a.f1_reverse ? a.f1_codes[a.f1_codes_L - 1 - P] : a.f1_codes[P];
+  };
+  auto f1_fix = [&](unsigned char raw) -> unsigned char {
+    int cc = raw;
+    if (a.f1_reverse && cc < 4) cc = 3 - cc;
+    return (unsigned char)(cc > 4 ? 5 : cc);
+  };
+  // Producer of one input position col i (0 .. XROW-1) of K-chunk `kc` of the tile at m0 -> buffer `buf`, in two parts
+  // so that the work can be spread over the taps of the MFMA block: WINDOW decodes the 9 bases the position looks at
+  // (3 aligned dwords of the window), QUAD computes 4 of the chunk's 16 channels.
+#define P16_F1_WINDOW(i_, m0_, slot_, kc_)                                                                             \
+  {                                                                                                                \
+    const int ii_ = (i_) < XROW ? (i_) : 0;                                                                        \
+    unsigned d0_, d1_, d2_;                                                                                        \
+    p16_lds_read3(f1_win_lds + (slot_) * F1_WIN + (ii_ & ~3), d0_, d1_, d2_);                                      \
+    const int sh_ = (ii_ & 3) * 8;                                                                                 \
+    const unsigned long long lo_ = (((unsigned long long)d1_ << 32) | d0_) >> sh_;        /* bases i .. */          \
+    const unsigned long long hi_ = (((unsigned long long)d2_ << 32) | d1_) >> sh_;        /* bases i+4 .. */        \
+    _Pragma("unroll") for (int t_ = 0; t_ < 9; ++t_) {   /* byte offset of T[t][kc][code][0][0] */                 \
+      const unsigned code_ = (unsigned)((t_ < 4 ? lo_ >> (8 * t_) : hi_ >> (8 * (t_ - 4))) & 0xff);                \
+      f1_off[t_] = f1_tab_lds + (unsigned)(((t_ * 4 + (kc_)) * 6) * 64) + code_ * 64;                              \
+    }                                                                                                              \
+    const long p_ = (m0_) + ii_ - P16_GUARD;                                                                       \
+    f1_in = p_ >= 0 && p_ < a.n;                     /* else: this conv's own zero padding / ragged tail */         \
+  }
+#define P16_F1_QUAD(i_, quad_, kc_, buf_)                                                                          \
+  if ((i_) < XROW) {                                                                                               \
+    f32x4 v_ = p16_lds_read16f(f1_b_lds + 64 * (kc_), (quad_) * 16);          /* retired by the first wait below */ \
+    /* the 9 table rows in 3 batches of 3 asm reads: left to the compiler, each read is followed by a full       \
+       lgkmcnt(0) wait (it recycles one register quad) and a quad costs 9 LDS round trips */                     \
+    _Pragma("unroll") for (int t_ = 0; t_ < 9; t_ += 3) {                                                          \
+      f32x4 r0_ = p16_lds_read16f(f1_off[t_], (quad_) * 16), r1_ = p16_lds_read16f(f1_off[t_ + 1], (quad_) * 16),  \
+            r2_ = p16_lds_read16f(f1_off[t_ + 2], (quad_) * 16);                                                   \
+      p16_lds_wait0(r0_, r1_, r2_);                                                                                \
+      v_ += r0_; v_ += r1_; v_ += r2_;                                                                             \
+    }                                                                                                              \
+    if (!f1_in) v_ = (f32x4)(0.f);                                                                                 \
+    vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v_.x), fabsf(v_.y))), fmaxf(fabsf(v_.z), fabsf(v_.w)));                   \
+    unsigned h0_, h1_, l0_, l1_;                                                                                   \
+    p16_split_hl(v_, h0_, h1_, l0_, l1_);                                                                          \
+    const unsigned xd_ = smem_lds + (unsigned)((buf_) * BU * 16) + (unsigned)((i_) * 16);                          \
+    u32x2 hh_, ll_;                                                                                                \
+    hh_.x = h0_; hh_.y = h1_; ll_.x = l0_; ll_.y = l1_;                                                            \
+    p16_lds_write8(xd_, hh_, ((quad_) >> 1) * XROW * 16 + ((quad_) & 1) * 8);                                      \
+    p16_lds_write8(xd_, ll_, (2 + ((quad_) >> 1)) * XROW * 16 + ((quad_) & 1) * 8);                                \
+  }
+  // Software-pipelined form used inside the MFMA block: tap t ISSUES half a quad's table reads (5 LDS reads), tap t+1
+  // CONSUMES them - by then they have landed behind the 12 MFMAs in between, so the producer never waits on LDS
+  // (a 250-cycle round trip under load; done naively a quad is 4 of them and stalls the wave's MFMAs for a microsecond).
+  // Half h of quad q: h = 0 -> bias + rows 0..3, h = 1 -> rows 4..8.  At most 8 + 5 + 2 LDS operations are in flight.
+#define P16_F1_ISSUE(quad_, half_, kc_)                                                                            \
+  {                                                                                                                \
+    if ((half_) == 0) {                                                                                            \
+      f1_r[0] = p16_lds_read16f(f1_b_lds + 64 * (kc_), (quad_) * 16);                                              \
+      _Pragma("unroll") for (int t_ = 0; t_ < 4; ++t_) f1_r[1 + t_] = p16_lds_read16f(f1_off[t_], (quad_) * 16);   \
+    } else {                                                                                                       \
+      _Pragma("unroll") for (int t_ = 0; t_ < 5; ++t_) f1_r[t_] = p16_lds_read16f(f1_off[4 + t_], (quad_) * 16);   \
+    }                                                                                                              \
+  }
+#define P16_F1_CONSUME(i_, quad_, half_, buf_)                                                                     \
+  {                                                                                                                \
+    if ((half_) == 0) f1_v = ((f1_r[0] + f1_r[1]) + (f1_r[2] + f1_r[3])) + f1_r[4];                                \
+    else {                                                                                                         \
+      f32x4 v_ = f1_v + (((f1_r[0] + f1_r[1]) + (f1_r[2] + f1_r[3])) + f1_r[4]);                                   \
+      if (!f1_in) v_ = (f32x4)(0.f);                                                                               \
+      vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v_.x), fabsf(v_.y))), fmaxf(fabsf(v_.z), fabsf(v_.w)));                 \
+      unsigned h0_, h1_, l0_, l1_;                                                                                 \
+      p16_split_hl(v_, h0_, h1_, l0_, l1_);                                                                        \
+      const unsigned xd_ = smem_lds + (unsigned)((buf_) * BU * 16) + (unsigned)((i_) * 16);                        \
+      u32x2 hh_, ll_;                                                                                              \
+      hh_.x = h0_; hh_.y = h1_; ll_.x = l0_; ll_.y = l1_;                                                          \
+      p16_lds_write8(xd_, hh_, ((quad_) >> 1) * XROW * 16 + ((quad_) & 1) * 8);                                    \
+      p16_lds_write8(xd_, ll_, (2 + ((quad_) >> 1)) * XROW * 16 + ((quad_) & 1) * 8);                              \
+    }                                                                                                              \
+  }
+  f32x4 f1_r[5], f1_v = (f32x4)(0.f);
+#pragma unroll
+  for (int k = 0; k < 5; ++k) f1_r[k] = (f32x4)(0.f);
+  unsigned f1_off[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};      // LDS byte addresses of T[t][kc][code][0][0]
+  const unsigned f1_tab_lds = p16_lds_addr(f1_tab), f1_b_lds = p16_lds_addr(f1_b), f1_win_lds = p16_lds_addr(f1_win), smem_lds = p16_lds_addr(smem);
+  bool f1_in = false;
 
   // thread-constant DMA geometry (16-byte units): unit i = tid + it*NT of the buffer image
   int xrel[NIT];    // X: (g*2 + s) * x_plen + col        W: grp * cout + cc
@@ -212,7 +346,7 @@ __global__ __launch_bounds__(WM * 64, WM / 4) void conv1d_k9_p16_kernel(ConvP16A
     wsrc = a.w + (long)(c) * wchunk + tcb_ * CT;                                       \
   }
 #define P16_DMA_ONE(it, buf) \
-  if (act[it]) p16_glds16((isx[it] ? xsrc : wsrc) + xrel[it], smem + (buf) * BU + (it) * NT + wave * 64);
+  if (act[it] && !(F1 && isx[it])) p16_glds16((isx[it] ? xsrc : wsrc) + xrel[it], smem + (buf) * BU + (it) * NT + wave * 64);
 
   // accumulators start from the bias of the tile's cout block
   f32x16 acc[MW][NW];
@@ -302,6 +436,18 @@ __global__ __launch_bounds__(WM * 64, WM / 4) void conv1d_k9_p16_kernel(ConvP16A
   P16_SRC(tile, 0);
 #pragma unroll
   for (int it = 0; it < NIT; ++it) P16_DMA_ONE(it, 0);
+  int f1_slot = 0;                      // window slot of the CURRENT tile
+  unsigned char f1_next[2] = {5, 5};    // bases of the next tile's window, in flight between step 0 and step 1 of a tile
+  if (F1) {
+    const long m0_ = (tile % a.tiles_per_row) * MT;
+    for (int k = tid; k < F1_WIN; k += NT) f1_win[k] = f1_fix(f1_fetch(m0_ - 8 + k));
+    __syncthreads();                    // window + table + bias visible
+    for (int r = 0; r < 2; ++r) {
+      P16_F1_WINDOW(tid + r * NT, m0_, 0, 0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) P16_F1_QUAD(tid + r * NT, q, 0, 0);
+    }
+  }
   __syncthreads();   // drains vmcnt (the DMA) and joins the waves; the bias is visible
   P16_ACC_INIT(tile);
 
@@ -328,6 +474,20 @@ __global__ __launch_bounds__(WM * 64, WM / 4) void conv1d_k9_p16_kernel(ConvP16A
     }
     P16_STAMP(1);
     if (more) P16_SRC(ntile, nc);
+    if (F1) {   // the next tile's bases: fetched during the tile's first step, parked in LDS during its second
+      const long nxt_ = tile + gridDim.x;
+      const long m0n_ = (nxt_ % a.tiles_per_row) * MT - 8;
+      if (c == 0 && nxt_ < ntiles) {
+        f1_next[0] = f1_fetch(m0n_ + tid);                      // raw: nothing may touch the loaded byte during this step
+        if (tid < F1_WIN - NT) f1_next[1] = f1_fetch(m0n_ + NT + tid);
+      }
+      if (c == 1 && nxt_ < ntiles) {
+        f1_win[(f1_slot ^ 1) * F1_WIN + tid] = f1_fix(f1_next[0]);
+        if (tid < F1_WIN - NT) f1_win[(f1_slot ^ 1) * F1_WIN + NT + tid] = f1_fix(f1_next[1]);
+      }
+    }
+    const long f1_m0 = F1 ? (ntile % a.tiles_per_row) * MT : 0;      // tile whose input the producer builds during this step
+    const int f1_ws = (F1 && last_chunk) ? (f1_slot ^ 1) : f1_slot;
 
     const unsigned xa0 = p16_lds_addr(smem + cur * BU + g * XROW + wave * (MW * 32) + l31);   // + (s*2*XROW + i*32 + tap)*16
     const unsigned wb0 = p16_lds_addr(smem + cur * BU + XU + g * CT + l31);                    // + (((s*9+tap)*2)*CT + j*32)*16
@@ -342,13 +502,33 @@ __global__ __launch_bounds__(WM * 64, WM / 4) void conv1d_k9_p16_kernel(ConvP16A
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int fb = (ABL & 8) ? 0 : (tap & 1);
+      if constexpr (F1) {
+        // all LDS reads issued so far (this tap's fragments, the producer's half quad of the previous tap) have had a whole
+        // tap to land: retire them together; the fragment wait further down then only orders the MFMAs
+        p16_f1_wait0<MW, NW>(av[fb], bv[fb], f1_r);
+        if (more) {   // the next step's input image, position `tid`: tap t consumes half-quad t-1 and issues half-quad t
+          if (tap >= 1) P16_F1_CONSUME(tid, (tap - 1) >> 1, (tap - 1) & 1, cur ^ 1);
+          if (tap == 0) P16_F1_WINDOW(tid, f1_m0, f1_ws, nc);
+          if (tap < 8) P16_F1_ISSUE(tap >> 1, tap & 1, nc);
+          // the XROW - NT = 8 halo positions beyond the threads: lanes 0..7 of waves 0..3 (one per SIMD), wave q computes
+          // channel quad q of all eight - un-pipelined (4 LDS round trips), after this wave's own last half quad
+          if (tap == 8 && wave < 4 && lane < XROW - NT) {
+            P16_F1_WINDOW(NT + lane, f1_m0, f1_ws, nc);
+            if (wave == 0) { P16_F1_QUAD(NT + lane, 0, nc, cur ^ 1) }
+            else if (wave == 1) { P16_F1_QUAD(NT + lane, 1, nc, cur ^ 1) }
+            else if (wave == 2) { P16_F1_QUAD(NT + lane, 2, nc, cur ^ 1) }
+            else { P16_F1_QUAD(NT + lane, 3, nc, cur ^ 1) }
+          }
+        }
+      }
       if (tap + 1 < 9 && !(ABL & 8)) P16_READ_FRAGS(fb ^ 1, tap + 1);
       if (more && tap < 5 && !(ABL & 1)) {   // the next buffer's DMA, spread over the first taps
 #pragma unroll
         for (int d = 0; d < DPT; ++d)
           if (tap * DPT + d < NIT && !((ABL & 64) && !isx[tap * DPT + d]) && !((ABL & 256) && isx[tap * DPT + d])) P16_DMA_ONE(tap * DPT + d, cur ^ 1);   // ABL 64 / 256: no W / no X pieces
       }
-      if (tap + 1 < 9) p16_lds_wait<2 * (MW + NW), MW, NW>(av[fb], bv[fb]);   // this tap's fragments are in, the next tap's stay in flight
+      if (F1) p16_lds_wait<15, MW, NW>(av[fb], bv[fb]);                      // already retired above: ordering only
+      else if (tap + 1 < 9) p16_lds_wait<2 * (MW + NW), MW, NW>(av[fb], bv[fb]);   // this tap's fragments are in, the next tap's stay in flight
       else p16_lds_wait<0, MW, NW>(av[fb], bv[fb]);
 #pragma unroll
       for (int p = 0; p < 3; ++p) {
@@ -359,6 +539,7 @@ __global__ __launch_bounds__(WM * 64, WM / 4) void conv1d_k9_p16_kernel(ConvP16A
           for (int j = 0; j < NW; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bv[fb][PB[p]][j], av[fb][PA[p]][i], acc[i][j], 0, 0, 0);  // D[cout][pos]
       }
+      if ((ABL & 128) && blockIdx.x == 0 && lane == 0 && nstamp == 250 && (wave & 3) == 0) a.stamps[8100 + (wave >> 2) * 16 + tap] = __builtin_readcyclecounter();   // per-tap stamps of waves 0 and 4, one step
       __builtin_amdgcn_sched_barrier(0);
     }
 #undef P16_READ_FRAGS
@@ -372,6 +553,7 @@ __global__ __launch_bounds__(WM * 64, WM / 4) void conv1d_k9_p16_kernel(ConvP16A
     if (!more) break;
     if (ABL & 128) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); P16_STAMP(4); ++nstamp; }
     __syncthreads();   // next buffer has landed (vmcnt drained), everyone is done reading the current one
+    if (F1 && last_chunk) f1_slot ^= 1;
     tile = ntile;
     c = nc;
     cur ^= 1;
@@ -385,6 +567,10 @@ __global__ __launch_bounds__(WM * 64, WM / 4) void conv1d_k9_p16_kernel(ConvP16A
 #undef P16_ACC_INIT
 #undef P16_DMA_ONE
 #undef P16_SRC
+#undef P16_F1_CONSUME
+#undef P16_F1_ISSUE
+#undef P16_F1_QUAD
+#undef P16_F1_WINDOW
   if (OM != 2 && vmax > 65504.f && a.flag) *a.flag = 1u;
 }
 

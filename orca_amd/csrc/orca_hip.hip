@@ -117,6 +117,7 @@ struct orca_net {
   int precision = ORCA_PRECISION_F32;
   float* d_first_w = nullptr;   // Encoder: folded [64][4][9] weights of the first layer, unpacked (conv1d_first_p16_kernel)
   void* d_first_w16 = nullptr;  // same as a K=48 fp16 split pack [2][3][2][64][8] (conv1d_first_mfma_p16_kernel)
+  float* d_first_tab = nullptr; // same as a per-base-code table [9 taps][6 codes][64] (fused first layer of conv1d_k9_p16_kernel)
   int upsample_mode = ORCA_UPSAMPLE_BILINEAR;
   std::vector<ConvLayer> convs;
 };
@@ -457,6 +458,25 @@ static void launch_p16_k(hipStream_t s, ConvP16Args a) {
   hipLaunchKernelGGL((conv1d_k9_p16_kernel<CT, MW, NW, WM, OM, R1>), grid, dim3(WM * 64), 0, s, a);
 }
 
+// the conv that follows the first layer, with the first layer fused into its input-tile producer (conv_p16.h, F1)
+static void launch_p16_fused_first(hipStream_t s, ConvP16Args a) {
+  constexpr int MT = 512;
+  static int resident = [] {
+    int dev = 0, ncu = 256, per_cu = 1;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv1d_k9_p16_kernel<64, 2, 2, 8, 0, false, 0, true>, 512, 0) != hipSuccess || per_cu < 1) {
+      (void)hipGetLastError();
+      per_cu = 1;
+    }
+    return ncu * per_cu;
+  }();
+  a.tiles_per_row = (a.n + MT - 1) / MT;
+  const long ntiles = a.tiles_per_row;
+  dim3 grid((unsigned)(ntiles < resident ? ntiles : resident));
+  hipLaunchKernelGGL((conv1d_k9_p16_kernel<64, 2, 2, 8, 0, false, 0, true>), grid, dim3(512), 0, s, a);
+}
+
 // out_mode and the residual are compile-time in the kernel (its epilogue is branch-free)
 template <int CT, int MW, int NW, int WM>
 static void launch_p16_t(hipStream_t s, const ConvP16Args& a) {
@@ -472,8 +492,16 @@ static void launch_p16_t(hipStream_t s, const ConvP16Args& a) {
 }
 
 // x: P16 [cin] of n positions; y: P16 (out_mode 0: n positions, 1: n/4 pooled) or fp32 [n][cout] (2); r1: P16 [cout], n
+struct FusedFirst {   // packed bases + first-layer table: the conv's input is produced instead of read (x may be NULL)
+  const unsigned char* codes = nullptr;
+  long codes_L = 0, codes_off = 0;
+  int reverse = 0;
+  const float* table = nullptr;
+  const float* bias = nullptr;
+};
+
 static int launch_conv1d_p16(orca_ctx* ctx, const ConvLayer& L, const float* x, void* y, const float* r1, long n, int relu,
-                             int out_mode) {
+                             int out_mode, const FusedFirst* f1 = nullptr) {
   if (!L.d_wf16 || L.ksize != 9) return fail(ORCA_EINVAL, "layer has no fp16 split pack");
   if (!L.f16_ok) return fail(ORCA_EINVAL, "layer weights exceed the fp16 range: use ORCA_PRECISION_BF16X3");
   if (n <= 0) return ORCA_OK;
@@ -488,6 +516,13 @@ static int launch_conv1d_p16(orca_ctx* ctx, const ConvLayer& L, const float* x, 
     HIPCHECK(hipEventCreate(&tl.e1));
     HIPCHECK(hipEventRecord(tl.e0, ctx->stream));
   }
+  a.f1_codes = nullptr; a.f1_codes_L = a.f1_codes_off = 0; a.f1_reverse = 0; a.f1_table = a.f1_bias = nullptr; a.stamps = nullptr;
+  if (f1) {
+    if (L.cout != 64 || L.cin != 64 || out_mode != 0 || r1) return fail(ORCA_EINVAL, "fused first layer: only the 64 -> 64 conv that follows it");
+    a.f1_codes = f1->codes; a.f1_codes_L = f1->codes_L; a.f1_codes_off = f1->codes_off; a.f1_reverse = f1->reverse;
+    a.f1_table = f1->table; a.f1_bias = f1->bias;
+    launch_p16_fused_first(ctx->stream, a);
+  } else
   if (L.cout == 96) launch_p16_t<96, 1, 3, 8>(ctx->stream, a);
   else if (L.cout % 64 == 0) launch_p16_t<64, 2, 2, 8>(ctx->stream, a);
   else return fail(ORCA_EINVAL, "p16 conv1d cout %d unsupported", L.cout);
@@ -691,6 +726,22 @@ extern "C" int orca_net_create(orca_ctx* ctx, int kind, const orca_conv_desc* co
       orca_net_free(net);
       return fail(ORCA_EHIP, "first-layer fp16 pack upload failed");
     }
+    // table form for one-hot input: T[tap][K-chunk][code][quad][4] (cout = 16*chunk + 4*quad + e); code 0..3 = the base's
+    // weight column, 4 = 'N' (0.25 of each), 5 = zero
+    std::vector<float> tab((size_t)9 * 6 * 64, 0.f);
+    auto at = [&](int t, int code, int co) -> float& { return tab[((((size_t)t * 4 + co / 16) * 6 + code) * 4 + (co % 16) / 4) * 4 + co % 4]; };
+    for (int co = 0; co < 64; ++co)
+      for (int t = 0; t < 9; ++t) {
+        float sum = 0.f;
+        for (int bse = 0; bse < 4; ++bse) {
+          const float v = w0[((size_t)co * 4 + bse) * 9 + t];
+          at(t, bse, co) = v;
+          sum += 0.25f * v;
+        }
+        at(t, 4, co) = sum;
+      }
+    rc = upload(tab, &net->d_first_tab);
+    if (rc != ORCA_OK) { orca_net_free(net); return rc; }
   }
   *out = net;
   return ORCA_OK;
@@ -712,6 +763,7 @@ extern "C" int orca_net_free(orca_net* net) {
   for (auto& L : net->convs) free_layer(L);
   if (net->d_first_w) (void)hipFree(net->d_first_w);
   if (net->d_first_w16) (void)hipFree(net->d_first_w16);
+  if (net->d_first_tab) (void)hipFree(net->d_first_tab);
   delete net;
   return ORCA_OK;
 }
@@ -769,8 +821,18 @@ static int encoder_chunk(orca_ctx* ctx, orca_net* net, const SeqSource& src, lon
       fa.x = x; fa.sc = sx_c; fa.sl = sx_l; fa.n = n1; fa.w = nullptr; fa.bias = L[0].d_bias; fa.y = reinterpret_cast<f32x4*>(buf[1]);
       fa.y_plen = p16_plen(n1); fa.flag = ctx->d_flag;
       fa.w = net->d_first_w;
+      // packed input: the first layer is fused into the input-tile producer of the conv that follows it (conv_p16.h, F1)
+      static const bool no_fuse1 = getenv("ORCA_NO_FUSE1") != nullptr;   // A/B switch
+      const bool fuse1 = src.codes && !no_fuse1;
+      FusedFirst f1;
+      f1.codes = src.codes; f1.codes_L = src.codes_L; f1.codes_off = src.codes_off; f1.reverse = src.reverse;
+      f1.table = net->d_first_tab; f1.bias = L[0].d_bias;
+      if (fuse1) {
+        // nothing to launch: buf[1] is never materialised
+      } else
       ORCA_TRY(launch_p16_zero_pads(ctx, buf[1], 64, n1));
-      if (src.codes || (sx_c == 1 && sx_l == 4 && al16(x) && !getenv("ORCA_FIRST_VALU"))) {
+      if (fuse1) {
+      } else if (src.codes || (sx_c == 1 && sx_l == 4 && al16(x) && !getenv("ORCA_FIRST_VALU"))) {
         FirstMfmaArgs fm;   // K=48 GEMM on the flat [L][4] window (or straight from the packed bases)
         fm.x = src.codes ? nullptr : x; fm.n = n1;
         fm.codes = src.codes; fm.codes_L = src.codes_L; fm.codes_off = src.codes_off; fm.reverse = src.reverse; fm.w = reinterpret_cast<const f32x4*>(net->d_first_w16); fm.bias = L[0].d_bias;
@@ -792,7 +854,7 @@ static int encoder_chunk(orca_ctx* ctx, orca_net* net, const SeqSource& src, lon
           ORCA_TRY(launch_conv1d_p16(ctx, Ls[0], buf[S], buf[T], nullptr, n, 0, 0));
         }
         ORCA_TRY(launch_p16_zero_pads(ctx, buf[LO], C, n));
-        ORCA_TRY(launch_conv1d_p16(ctx, Ls[1], buf[T], buf[LO], nullptr, n, 0, 0));           // lout
+        ORCA_TRY(launch_conv1d_p16(ctx, Ls[1], buf[T], buf[LO], nullptr, n, 0, 0, (st0 == 0 && fuse1) ? &f1 : nullptr));   // lout
         ORCA_TRY(launch_p16_zero_pads(ctx, buf[T], C, n));
         ORCA_TRY(launch_conv1d_p16(ctx, Ls[2], buf[LO], buf[T], nullptr, n, 1, 0));
         if (st0 < 2) {

@@ -238,7 +238,9 @@ def run_cascade(model, encodings, levels, unit, B, reverse_flags, background, zo
 def cascade_32m(model, xs, mpos, wpos, reverse_flags, distencs=None):
     """32 Mb model on device-resident strands: ``xs`` = list of [B,4,L] tensors (e.g. forward strand and reverse
     complement), ``reverse_flags`` the matching booleans.  net0 per strand, then Encoder2 and the six decoder
-    levels batched over the strands.  Returns (preds[6] each [S*B,1,250,250], starts[k][6] in 4 kb bins)."""
+    levels batched over the strands.  Returns (preds[6] each [S*B,1,250,250], starts[k][6] in 4 kb bins).
+    A strand may also be given as packed bases - a uint8 [B,L] tensor of the FORWARD strand (engine.pack_sequence);
+    its flag then also tells the Encoder to read it as the reverse complement (no second copy exists)."""
     B = xs[0].shape[0]
     cache = {}
 
@@ -250,7 +252,9 @@ def cascade_32m(model, xs, mpos, wpos, reverse_flags, distencs=None):
         return cache[level]
 
     def forward():
-        enc0 = torch.cat([model.net0(x) for x in xs], dim=0) if len(xs) > 1 else model.net0(xs[0])
+        def encode(x, rev):
+            return model.net0.forward_codes(x, reverse=rev) if x.dtype == torch.uint8 else model.net0(x)
+        enc0 = torch.cat([encode(x, r) for x, r in zip(xs, reverse_flags)], dim=0) if len(xs) > 1 else encode(xs[0], reverse_flags[0])
         encodings = dict(zip([1, 2, 4, 8, 16, 32], model.net(enc0)))
         return run_cascade(model, encodings, [32, 16, 8, 4, 2, 1], lambda lv: lv, B, list(reverse_flags), background,
                            lambda lv, st, rev: zoom_index_32m(lv, st, mpos, wpos, rev), add_1m_level=1)

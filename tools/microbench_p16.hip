@@ -4,18 +4,18 @@
 #include <vector>
 #include <algorithm>
 #include "conv_p16.h"
-template <int CT, int MW, int NW, int WM, int OM, bool R1, int ABL>
+template <int CT, int MW, int NW, int WM, int OM, bool R1, int ABL, bool F1 = false>
 static void run(ConvP16Args a, const char* what) {
   constexpr int MT = WM * MW * 32;
   int per_cu = 1;
-  (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv1d_k9_p16_kernel<CT, MW, NW, WM, OM, R1, ABL>, WM * 64, 0);
+  (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv1d_k9_p16_kernel<CT, MW, NW, WM, OM, R1, ABL, F1>, WM * 64, 0);
   a.tiles_per_row = (a.n + MT - 1) / MT; a.out_mode = OM;
   long ntiles = a.tiles_per_row * (a.cout / CT), grid = 256L * per_cu; if (grid > ntiles) grid = ntiles;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   float best = 1e9;
   for (int r = 0; r < 4; ++r) {
     hipEventRecord(e0, 0);
-    hipLaunchKernelGGL((conv1d_k9_p16_kernel<CT, MW, NW, WM, OM, R1, ABL>), dim3((unsigned)grid), dim3(WM * 64), 0, 0, a);
+    hipLaunchKernelGGL((conv1d_k9_p16_kernel<CT, MW, NW, WM, OM, R1, ABL, F1>), dim3((unsigned)grid), dim3(WM * 64), 0, 0, a);
     hipEventRecord(e1, 0); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); if (r > 0 && ms < best) best = ms;
   }
@@ -25,6 +25,7 @@ static void run(ConvP16Args a, const char* what) {
 static void report(unsigned long long* st) {
   std::vector<unsigned long long> h(8192); hipMemcpy(h.data(), st, 8192 * 8, hipMemcpyDeviceToHost);
   printf("  shader clock during the kernel: %.0f MHz\n", (double)h[8190] / ((double)h[8191] * 0.01));
+  for (int w = 0; w < 2; ++w) { printf("  step 250, wave %d: cycles per tap:", w * 4); for (int t = 1; t < 9; ++t) printf(" %llu", h[8100 + w * 16 + t] - h[8100 + w * 16 + t - 1]); printf("\n"); }
   // per wave, relative to the step's earliest start: averages over plain steps and over epilogue steps
   for (int kind = 0; kind < 2; ++kind) {
     double sum[8][5] = {}; long cnt = 0; double steplen = 0;
@@ -80,6 +81,21 @@ int main(int argc, char** argv) {
   { ConvP16Args b = a; b.cout = 128; b.nchunks = 4; run<64, 2, 2, 8, 0, false, 0>(b, "64 -> 128"); }
   run<64, 2, 2, 8, 0, false, 128>(a, "stamped");
   report(st);
+  {   // fused first layer: the input image is produced from packed bases
+    unsigned char* codes; float *tab, *b1;
+    hipMalloc(&codes, n); hipMalloc(&tab, 9 * 6 * 64 * 4); hipMalloc(&b1, 256);
+    std::vector<unsigned char> hc(n); unsigned sd = 99u;
+    for (auto& c : hc) { sd = sd * 1664525u + 1013904223u; c = (sd >> 24) & 3; }
+    std::vector<float> ht(9 * 6 * 64);
+    for (auto& v : ht) { sd = sd * 1664525u + 1013904223u; v = ((sd >> 8) & 0xffff) / 65536.f - 0.5f; }
+    hipMemcpy(codes, hc.data(), n, hipMemcpyHostToDevice); hipMemcpy(tab, ht.data(), ht.size() * 4, hipMemcpyHostToDevice); hipMemset(b1, 0, 256);
+    ConvP16Args f = a; f.f1_codes = codes; f.f1_codes_L = n; f.f1_codes_off = 0; f.f1_reverse = 0; f.f1_table = tab; f.f1_bias = b1;
+    run<64, 2, 2, 8, 0, false, 0, true>(f, "fused first layer");
+    run<64, 2, 2, 8, 0, false, 0, false>(a, "plain");
+    run<64, 2, 2, 8, 0, false, 0, true>(f, "fused first layer");
+    run<64, 2, 2, 8, 0, false, 128, true>(f, "fused first layer, stamped");
+    report(st);
+  }
   run<64, 2, 2, 8, 0, false, 128 + 1 + 16>(a, "stamped, no DMA, no stores");
   report(st);
   run<64, 2, 2, 8, 0, false, 128 + 1 + 16 + 8>(a, "stamped, no DMA, no stores, LDS once");
