@@ -71,6 +71,9 @@ struct orca_ctx {
   bool timing = false;
   std::vector<TimedLaunch> timed;
   unsigned* d_flag = nullptr;   // fp16-range overflow flag written by the f16x2 kernels
+  // Decoders with an even batch run as two half-batches on two streams (see decoder_nhwc)
+  hipStream_t aux = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
 static int ws_ensure(orca_ctx* ctx, size_t bytes) {
@@ -595,6 +598,7 @@ extern "C" int orca_ctx_destroy(orca_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->ws) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(ctx->ws); }
   if (ctx->d_flag) (void)hipFree(ctx->d_flag);
+  if (ctx->aux) { (void)hipStreamSynchronize(ctx->aux); (void)hipStreamDestroy(ctx->aux); (void)hipEventDestroy(ctx->ev_fork); (void)hipEventDestroy(ctx->ev_join); }
   delete ctx;
   return ORCA_OK;
 }
@@ -1067,70 +1071,99 @@ static int decoder_nhwc(orca_ctx* ctx, orca_net* net, const float* x, long sx_b,
   const size_t szIN = px * cIN, szA = px * cA, sz64 = px * 64, sz32 = px * 32;
   const size_t need = ru256(B * szIN * 4) + ru256(B * szA * 4) + 3 * ru256(B * sz64 * 4) + ru256(B * sz32 * 4);
   ORCA_TRY(ws_ensure(ctx, need));
-  float* IN = ws_take(ctx, B * szIN);
-  float* A = ws_take(ctx, B * szA);
-  float* Bf = ws_take(ctx, B * sz64);
-  float* Cf = ws_take(ctx, B * sz64);
-  float* Df = ws_take(ctx, B * sz64);
-  float* T = ws_take(ctx, B * sz32);
-  hipStream_t s = ctx->stream;
-  for (int b = 0; b < B; ++b) {
-    hipLaunchKernelGGL(outer_sum_nhwc_kernel, dim3(32, (unsigned)n), dim3(cIN / 4, 8), 0, s, x + (long)b * sx_b, sx_c, sx_l,
-                       de ? de + (long)b * sd_b : nullptr, sd_h, sd_w, IN + b * szIN, n, cIN);
-    LAUNCHCHECK("outer_sum_nhwc_kernel");
-  }
-  const ConvLayer* L = net->convs.data();
-  const ConvLayer* pairs;
-  int npairs;
+  float* const IN0 = ws_take(ctx, B * szIN);
+  float* const A0 = ws_take(ctx, B * szA);
+  float* const Bf0 = ws_take(ctx, B * sz64);
+  float* const Cf0 = ws_take(ctx, B * sz64);
+  float* const Df0 = ws_take(ctx, B * sz64);
+  float* const T0 = ws_take(ctx, B * sz32);
+  // maps [b0, b0 + nb) of the batch, on ctx->stream
+  auto run = [&](int b0, int nb) -> int {
+    float* IN = IN0 + b0 * szIN;
+    float* A = A0 + b0 * szA;
+    float* Bf = Bf0 + b0 * sz64;
+    float* Cf = Cf0 + b0 * sz64;
+    float* Df = Df0 + b0 * sz64;
+    float* T = T0 + b0 * sz32;
+    hipStream_t s = ctx->stream;
+    for (int b = 0; b < nb; ++b) {
+      hipLaunchKernelGGL(outer_sum_nhwc_kernel, dim3(32, (unsigned)n), dim3(cIN / 4, 8), 0, s, x + (long)(b0 + b) * sx_b, sx_c, sx_l,
+                         de ? de + (long)(b0 + b) * sd_b : nullptr, sd_h, sd_w, IN + b * szIN, n, cIN);
+      LAUNCHCHECK("outer_sum_nhwc_kernel");
+    }
+    const ConvLayer* L = net->convs.data();
+    const ConvLayer* pairs;
+    int npairs;
 #define C2(layer, src, sbs, sc, dst, dbs, dc, res, rbs, rc, relu) \
-  ORCA_TRY(launch_conv2d_f16(ctx, layer, src, sbs, sc, dst, dbs, dc, res, rbs, rc, B, n, relu))
-  if (!is1m) {
-    C2(L[0], IN, szIN, cIN, Bf, sz64, 64, nullptr, 0, 0, 0);
-    C2(L[1], Bf, sz64, 64, Cf, sz64, 64, nullptr, 0, 0, 0);
-    C2(L[2], Cf, sz64, 64, Bf, sz64, 64, nullptr, 0, 0, 1);
-    C2(L[3], Bf, sz64, 64, A, szA, cA, Cf, sz64, 64, 1);           // A[..., 0:64] = combinerD(.) + .
-    pairs = L + 8; npairs = 28;
-    if (y) {
-      for (int b = 0; b < B; ++b) {
-        hipLaunchKernelGGL(upsample2d_nhwc_kernel, dim3((unsigned)n), dim3(256), 0, s, y + (long)b * sy_b, sy_h, sy_w, A + b * szA, n,
-                           cA, 64, net->upsample_mode == ORCA_UPSAMPLE_BILINEAR ? 1 : 0);
-        LAUNCHCHECK("upsample2d_nhwc_kernel");
+  ORCA_TRY(launch_conv2d_f16(ctx, layer, src, sbs, sc, dst, dbs, dc, res, rbs, rc, nb, n, relu))
+    if (!is1m) {
+      C2(L[0], IN, szIN, cIN, Bf, sz64, 64, nullptr, 0, 0, 0);
+      C2(L[1], Bf, sz64, 64, Cf, sz64, 64, nullptr, 0, 0, 0);
+      C2(L[2], Cf, sz64, 64, Bf, sz64, 64, nullptr, 0, 0, 1);
+      C2(L[3], Bf, sz64, 64, A, szA, cA, Cf, sz64, 64, 1);           // A[..., 0:64] = combinerD(.) + .
+      pairs = L + 8; npairs = 28;
+      if (y) {
+        for (int b = 0; b < nb; ++b) {
+          hipLaunchKernelGGL(upsample2d_nhwc_kernel, dim3((unsigned)n), dim3(256), 0, s, y + (long)(b0 + b) * sy_b, sy_h, sy_w,
+                             A + b * szA, n, cA, 64, net->upsample_mode == ORCA_UPSAMPLE_BILINEAR ? 1 : 0);
+          LAUNCHCHECK("upsample2d_nhwc_kernel");
+        }
+        C2(L[4], A, szA, cA, Bf, sz64, 64, nullptr, 0, 0, 0);
+        C2(L[5], Bf, sz64, 64, Cf, sz64, 64, nullptr, 0, 0, 0);
+        C2(L[6], Cf, sz64, 64, Bf, sz64, 64, nullptr, 0, 0, 1);
+        C2(L[7], Bf, sz64, 64, Df, sz64, 64, Cf, sz64, 64, 1);
+      } else {
+        C2(pairs[0], A, szA, cA, T, sz32, 32, nullptr, 0, 0, 0);
+        C2(pairs[1], T, sz32, 32, Cf, sz64, 64, nullptr, 0, 0, 0);
+        C2(pairs[2], Cf, sz64, 64, T, sz32, 32, nullptr, 0, 0, 1);
+        C2(pairs[3], T, sz32, 32, Df, sz64, 64, Cf, sz64, 64, 1);
       }
-      C2(L[4], A, szA, cA, Bf, sz64, 64, nullptr, 0, 0, 0);
-      C2(L[5], Bf, sz64, 64, Cf, sz64, 64, nullptr, 0, 0, 0);
-      C2(L[6], Cf, sz64, 64, Bf, sz64, 64, nullptr, 0, 0, 1);
-      C2(L[7], Bf, sz64, 64, Df, sz64, 64, Cf, sz64, 64, 1);
     } else {
-      C2(pairs[0], A, szA, cA, T, sz32, 32, nullptr, 0, 0, 0);
+      pairs = L; npairs = 19;
+      C2(pairs[0], IN, szIN, cIN, T, sz32, 32, nullptr, 0, 0, 0);
       C2(pairs[1], T, sz32, 32, Cf, sz64, 64, nullptr, 0, 0, 0);
       C2(pairs[2], Cf, sz64, 64, T, sz32, 32, nullptr, 0, 0, 1);
       C2(pairs[3], T, sz32, 32, Df, sz64, 64, Cf, sz64, 64, 1);
     }
-  } else {
-    pairs = L; npairs = 19;
-    C2(pairs[0], IN, szIN, cIN, T, sz32, 32, nullptr, 0, 0, 0);
-    C2(pairs[1], T, sz32, 32, Cf, sz64, 64, nullptr, 0, 0, 0);
-    C2(pairs[2], Cf, sz64, 64, T, sz32, 32, nullptr, 0, 0, 1);
-    C2(pairs[3], T, sz32, 32, Df, sz64, 64, Cf, sz64, 64, 1);
-  }
-  float* cur = Df;
-  float* oth = Cf;
-  for (int i = 1; i < npairs; ++i) {
-    const ConvLayer* p = pairs + 4 * i;
-    C2(p[0], cur, sz64, 64, T, sz32, 32, nullptr, 0, 0, 0);
-    C2(p[1], T, sz32, 32, oth, sz64, 64, cur, sz64, 64, 0);
-    C2(p[2], oth, sz64, 64, T, sz32, 32, nullptr, 0, 0, 1);
-    C2(p[3], T, sz32, 32, cur, sz64, 64, oth, sz64, 64, 1);
-  }
+    float* cur = Df;
+    float* oth = Cf;
+    for (int i = 1; i < npairs; ++i) {
+      const ConvLayer* p = pairs + 4 * i;
+      C2(p[0], cur, sz64, 64, T, sz32, 32, nullptr, 0, 0, 0);
+      C2(p[1], T, sz32, 32, oth, sz64, 64, cur, sz64, 64, 0);
+      C2(p[2], oth, sz64, 64, T, sz32, 32, nullptr, 0, 0, 1);
+      C2(p[3], T, sz32, 32, cur, sz64, 64, oth, sz64, 64, 1);
+    }
 #undef C2
-  const ConvLayer& fa = net->convs[net->convs.size() - 2];
-  const ConvLayer& fb = net->convs[net->convs.size() - 1];
-  FinalArgs fa_;
-  fa_.cur = cur; fa_.w1 = fa.d_w; fa_.b1 = fa.d_bias; fa_.w2 = fb.d_w; fa_.b2 = fb.d_bias; fa_.out = out;
-  fa_.cur_bs = sz64; fa_.out_bs = (long)n * n; fa_.n = n; fa_.accumulate = accumulate;
-  hipLaunchKernelGGL(final_sym_nhwc_kernel, dim3((unsigned)n, (unsigned)B), dim3(256), 0, s, fa_);
-  LAUNCHCHECK("final_sym_nhwc_kernel");
-  return ORCA_OK;
+    const ConvLayer& fa = net->convs[net->convs.size() - 2];
+    const ConvLayer& fb = net->convs[net->convs.size() - 1];
+    FinalArgs fa_;
+    fa_.cur = cur; fa_.w1 = fa.d_w; fa_.b1 = fa.d_bias; fa_.w2 = fb.d_w; fa_.b2 = fb.d_bias; fa_.out = out + (size_t)b0 * n * n;
+    fa_.cur_bs = sz64; fa_.out_bs = (long)n * n; fa_.n = n; fa_.accumulate = accumulate;
+    hipLaunchKernelGGL(final_sym_nhwc_kernel, dim3((unsigned)n, (unsigned)nb), dim3(256), 0, s, fa_);
+    LAUNCHCHECK("final_sym_nhwc_kernel");
+    return ORCA_OK;
+  };
+  // A Decoder is a chain of ~120 dependent launches of 250 workgroups per map, each launch with a dispatch ramp and a
+  // tail in which most CUs idle.  The maps of a batch are independent, so an even batch runs as two half-batches on
+  // two streams: one half's ramps and tails are filled by the other half's workgroups.
+  static const bool one_stream = getenv("ORCA_DECODER_ONE_STREAM") != nullptr;   // A/B switch
+  if (B < 2 || (B & 1) || one_stream) return run(0, B);
+  if (!ctx->aux) {
+    HIPCHECK(hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking));
+    HIPCHECK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+    HIPCHECK(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+  }
+  hipStream_t main_s = ctx->stream;
+  HIPCHECK(hipEventRecord(ctx->ev_fork, main_s));
+  HIPCHECK(hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
+  int rc = run(0, B / 2);
+  ctx->stream = ctx->aux;
+  const int rc2 = rc == ORCA_OK ? run(B / 2, B / 2) : rc;
+  ctx->stream = main_s;
+  HIPCHECK(hipEventRecord(ctx->ev_join, ctx->aux));
+  HIPCHECK(hipStreamWaitEvent(main_s, ctx->ev_join, 0));
+  return rc2;
 }
 
 static int decoder_common(orca_ctx* ctx, orca_net* net, const float* x, long sx_b, long sx_c, long sx_l, const float* de,
