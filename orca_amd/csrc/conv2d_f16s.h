@@ -320,3 +320,7 @@ __global__ void final_sym_nhwc_kernel(FinalArgs a) {
 // pipe-bound, not dependency-bound, and the registers cost occupancy (5.0 vs 3.7 ms); running the 64-cout layers as two 32-cout workgroups per row (67 KB LDS each, two resident
 // per CU): no change (3.72 vs 3.73 ms per Decoder); keeping TWO K-chunks of global loads in flight (register slots
 // 0/1): 166 VGPRs for COUT 32 cost the second resident workgroup, 4.0-4.4 ms, and 5.8 ms when capped at 128 VGPRs.
+// Two output rows (y, y + d) per 16-wave workgroup from the FOUR source rows y-d .. y+2d and one W image (33 % less X
+// and 50 % less W traffic per output row; parity green): COUT 32 26.0 vs 24.3 us per launch, COUT 64 (128-VGPR cap at
+// 1024 threads: spills) 47.8 vs 33.5 us - the K loop is bound by its latency chain, not by L2 bandwidth, and the
+// bigger workgroup costs the second resident one.  Dropped.
