@@ -192,7 +192,20 @@ int orca_decoder_forward(orca_ctx* ctx, orca_net* net, const float* x, int64_t s
                          const float* y, int64_t sy_b, int64_t sy_h, int64_t sy_w, int B, int n,
                          float* out, int accumulate);
 
-/* Replaces: model.denet_1_pt.forward(x) = Decoder_1m.forward (orca_modules.py:782-800). */
+/* Multi-target decoders (orca_leukemia.py:512-990 `Decoder(num_2d)`, :996-1316 `Decoder_1m(num_2d)`; containers
+ * OrcaLeukemiaA/B :1604-1873): the same network with T = num_2d maps per prediction - distenc [B,T,n,n], coarse y
+ * [B,T,n/2,n/2], `final` 64 -> max(5,T) -> T, out contiguous [B,T,n,n].  T is taken from the width of the last
+ * layer handed to orca_net_create (1 <= T <= 8).  Replaces: the same call site as orca_decoder_forward,
+ * `model.denets[level].forward(x, distenc, y)` (orca_predict.py:356-379), for models whose normmats are 3-D. */
+int orca_decoder_forward_mt(orca_ctx* ctx, orca_net* net, const float* x, int64_t sx_b, int64_t sx_c,
+                            int64_t sx_l, const float* distenc, int64_t sd_b, int64_t sd_c, int64_t sd_h,
+                            int64_t sd_w, const float* y, int64_t sy_b, int64_t sy_c, int64_t sy_h, int64_t sy_w,
+                            int B, int n, float* out, int accumulate);
+
+/* T (num_2d) of a Decoder / Decoder_1m net; 1 for every other kind. */
+int orca_net_num_targets(orca_net* net, int* num_2d);
+
+/* Replaces: model.denet_1_pt.forward(x) = Decoder_1m.forward (orca_modules.py:782-800); out [B,T,n,n]. */
 int orca_decoder1m_forward(orca_ctx* ctx, orca_net* net, const float* x, int64_t sx_b, int64_t sx_c,
                            int64_t sx_l, int B, int n, float* out, int accumulate);
 

@@ -229,10 +229,10 @@ __global__ __launch_bounds__(512) void conv2d_3x3_f16s_kernel(Conv2dF16Args a) {
 }
 
 // ---- channel-last helpers of the Decoder --------------------------------------------------------------
-// mat[i][j][c] = x[c][i] + x[c][j] (c<128); channel 128 = distenc[i][j] (if given); other pad channels and
+// mat[i][j][c] = x[c][i] + x[c][j] (c<128); channels 128..128+nt-1 = distenc[t][i][j] (if given); other pad channels and
 // pad pixels = 0.  out [n][256][cp].  block = (cp/4 threads x 8 pixels), grid = (32, n)
-__global__ void outer_sum_nhwc_kernel(const float* __restrict__ x, long sx_c, long sx_l, const float* __restrict__ de, long sd_h,
-                                      long sd_w, float* __restrict__ out, int n, int cp) {
+__global__ void outer_sum_nhwc_kernel(const float* __restrict__ x, long sx_c, long sx_l, const float* __restrict__ de, long sd_c, long sd_h,
+                                      long sd_w, int nt, float* __restrict__ out, int n, int cp) {
   const int c4 = threadIdx.x, j = blockIdx.x * blockDim.y + threadIdx.y, i = blockIdx.y;
   f32x4 v = (f32x4)(0.f);
   if (j < n) {
@@ -241,68 +241,65 @@ __global__ void outer_sum_nhwc_kernel(const float* __restrict__ x, long sx_c, lo
       const int c = 4 * c4 + e;
       float t = 0.f;
       if (c < 128) t = x[c * sx_c + i * sx_l] + x[c * sx_c + j * sx_l];
-      else if (c == 128 && de) t = de[i * sd_h + j * sd_w];
+      else if (c < 128 + nt && de) t = de[(c - 128) * sd_c + i * sd_h + j * sd_w];
       v[e] = t;
     }
   }
   *reinterpret_cast<f32x4*>(out + ((long)i * 256 + j) * cp + 4 * c4) = v;
 }
 
-// bilinear / nearest x2 upsample of y [n/2][n/2] into channels [c0, c0+16) of an [n][256][cp] map
-// (channel c0 = value, c0+1.. = 0; pad pixels 0).  block 256 (pixels), grid n
-__global__ void upsample2d_nhwc_kernel(const float* __restrict__ y, long sy_h, long sy_w, float* __restrict__ out, int n, int cp, int c0,
-                                       int bilinear) {
+// bilinear / nearest x2 upsample of y [nt][n/2][n/2] into channels [c0, c0+16) of an [n][256][cp] map
+// (channels c0..c0+nt-1 = values, the rest = 0; pad pixels 0).  block 256 (pixels), grid n
+__global__ void upsample2d_nhwc_kernel(const float* __restrict__ y, long sy_c, long sy_h, long sy_w, int nt, float* __restrict__ out, int n,
+                                       int cp, int c0, int bilinear) {
   const int j = threadIdx.x, i = blockIdx.x, h = n / 2;
-  float v = 0.f;
+  float v[16];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) v[t] = 0.f;
   if (j < n) {
-    if (!bilinear) {
-      v = y[(i >> 1) * sy_h + (j >> 1) * sy_w];
-    } else {
-      const float fy = fmaxf(0.5f * (i + 0.5f) - 0.5f, 0.f), fx = fmaxf(0.5f * (j + 0.5f) - 0.5f, 0.f);
-      const int y0 = (int)fy, x0 = (int)fx;
-      const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < h - 1 ? 1 : 0);
-      const float ly = fy - y0, lx = fx - x0, hy = 1.f - ly, hx = 1.f - lx;
-      v = hy * (hx * y[y0 * sy_h + x0 * sy_w] + lx * y[y0 * sy_h + x1 * sy_w]) +
-          ly * (hx * y[y1 * sy_h + x0 * sy_w] + lx * y[y1 * sy_h + x1 * sy_w]);
+    const float fy = fmaxf(0.5f * (i + 0.5f) - 0.5f, 0.f), fx = fmaxf(0.5f * (j + 0.5f) - 0.5f, 0.f);
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < h - 1 ? 1 : 0);
+    const float ly = fy - y0, lx = fx - x0, hy = 1.f - ly, hx = 1.f - lx;
+#pragma unroll
+    for (int t = 0; t < ORCA_MAX_TARGETS; ++t) {
+      if (t >= nt) break;
+      const float* yt = y + t * sy_c;
+      if (!bilinear) v[t] = yt[(i >> 1) * sy_h + (j >> 1) * sy_w];
+      else
+        v[t] = hy * (hx * yt[y0 * sy_h + x0 * sy_w] + lx * yt[y0 * sy_h + x1 * sy_w]) +
+               ly * (hx * yt[y1 * sy_h + x0 * sy_w] + lx * yt[y1 * sy_h + x1 * sy_w]);
     }
   }
-  float* o = out + ((long)i * 256 + j) * cp + c0;
-  f32x4 z = (f32x4)(0.f), f = z;
-  f.x = v;
-  reinterpret_cast<f32x4*>(o)[0] = f;
-  reinterpret_cast<f32x4*>(o)[1] = z;
-  reinterpret_cast<f32x4*>(o)[2] = z;
-  reinterpret_cast<f32x4*>(o)[3] = z;
+  f32x4* o = reinterpret_cast<f32x4*>(out + ((long)i * 256 + j) * cp + c0);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    f32x4 f;
+    f.x = v[4 * q]; f.y = v[4 * q + 1]; f.z = v[4 * q + 2]; f.w = v[4 * q + 3];
+    o[q] = f;
+  }
 }
 
 // `final` head + symmetrisation on a channel-last [n][256][64] map (see final_sym_kernel)
 __global__ void final_sym_nhwc_kernel(FinalArgs a) {
-  __shared__ float w1s[5 * 64], b1s[5], w2s[5], b2s;
-  for (int t = threadIdx.x; t < 320; t += blockDim.x) w1s[t] = a.w1[t];
-  if (threadIdx.x < 5) { b1s[threadIdx.x] = a.b1[threadIdx.x]; w2s[threadIdx.x] = a.w2[threadIdx.x]; }
-  if (threadIdx.x == 0) b2s = a.b2[0];
-  __syncthreads();
+  ORCA_FINAL_LOAD_HEAD();
   const int j = threadIdx.x, i = blockIdx.x, b = blockIdx.y, n = a.n;
   if (j >= n) return;
   const float* cur = a.cur + (long)b * a.cur_bs;
   const f32x4* pu = reinterpret_cast<const f32x4*>(cur + ((long)i * 256 + j) * 64);
   const f32x4* pv = reinterpret_cast<const f32x4*>(cur + ((long)j * 256 + i) * 64);
-  float h1[5], h2[5];
+  float h1[ORCA_MAX_TARGETS], h2[ORCA_MAX_TARGETS];
 #pragma unroll
-  for (int o = 0; o < 5; ++o) { h1[o] = b1s[o]; h2[o] = b1s[o]; }
+  for (int o = 0; o < ORCA_MAX_TARGETS; ++o) { h1[o] = b1s[o]; h2[o] = b1s[o]; }
   for (int c4 = 0; c4 < 16; ++c4) {
     const f32x4 u = pu[c4], v = pv[c4];
 #pragma unroll
     for (int e = 0; e < 4; ++e)
 #pragma unroll
-      for (int o = 0; o < 5; ++o) { h1[o] = fmaf(w1s[o * 64 + 4 * c4 + e], u[e], h1[o]); h2[o] = fmaf(w1s[o * 64 + 4 * c4 + e], v[e], h2[o]); }
+      for (int o = 0; o < ORCA_MAX_TARGETS; ++o)
+        if (o < a.F) { h1[o] = fmaf(w1s[o * 64 + 4 * c4 + e], u[e], h1[o]); h2[o] = fmaf(w1s[o * 64 + 4 * c4 + e], v[e], h2[o]); }
   }
-  float f1 = b2s, f2 = b2s;
-#pragma unroll
-  for (int o = 0; o < 5; ++o) { f1 = fmaf(w2s[o], fmaxf(h1[o], 0.f), f1); f2 = fmaf(w2s[o], fmaxf(h2[o], 0.f), f2); }
-  float* op = a.out + (long)b * a.out_bs + (long)i * n + j;
-  const float r = 0.5f * f1 + 0.5f * f2;
-  *op = a.accumulate ? (*op + r) : r;
+  final_head_store(a, h1, h2, w2s, b2s, b, i, j);
 }
 
 // Tried and dropped (round 1): a tap-paired variant with 8-channel chunks (45 KB LDS, three 4-wave workgroups per CU

@@ -64,8 +64,8 @@ __global__ void copy2d_kernel(const float* __restrict__ src, long lds_, long sco
 // Decoder input (orca_modules.py:462-463): mat[c][i][j] = x[c][i] + x[c][j] (c<128),
 // channel 128 = distenc[i][j] (if given), remaining pad channels = 0.
 // out layout [cpad][n][256]; one thread writes a float4 of columns.
-__global__ void outer_sum_kernel(const float* __restrict__ x, long sx_c, long sx_l, const float* __restrict__ de, long sd_h, long sd_w,
-                                 float* __restrict__ out, int n, int cpad) {
+__global__ void outer_sum_kernel(const float* __restrict__ x, long sx_c, long sx_l, const float* __restrict__ de, long sd_c, long sd_h,
+                                 long sd_w, int nt, float* __restrict__ out, int n, int cpad) {
   const int j4 = threadIdx.x;  // 0..63 -> columns 4*j4..4*j4+3
   const int i = blockIdx.x;
   const int c = blockIdx.y;
@@ -76,7 +76,7 @@ __global__ void outer_sum_kernel(const float* __restrict__ x, long sx_c, long sx
     float t = 0.f;
     if (j < n) {
       if (c < 128) t = x[c * sx_c + i * sx_l] + x[c * sx_c + j * sx_l];
-      else if (c == 128 && de) t = de[i * sd_h + j * sd_w];
+      else if (c < 128 + nt && de) t = de[(c - 128) * sd_c + i * sd_h + j * sd_w];
     }
     v[e] = t;
   }
@@ -86,13 +86,15 @@ __global__ void outer_sum_kernel(const float* __restrict__ x, long sx_c, long sx
 // nn.Upsample(scale_factor=(2,2), mode) of y [n/2][n/2] written into ONE channel plane
 // [n][256] (orca_modules.py:430,468); the 7 pad planes behind it are zeroed.
 // bilinear = PyTorch align_corners=False: src = max((dst+0.5)/2-0.5, 0).
-__global__ void upsample2d_x2_kernel(const float* __restrict__ y, long sy_h, long sy_w, float* __restrict__ out, int n, int bilinear, int nplanes) {
+__global__ void upsample2d_x2_kernel(const float* __restrict__ y, long sy_c, long sy_h, long sy_w, int nt, float* __restrict__ out, int n,
+                                     int bilinear, int nplanes) {
   const int j = threadIdx.x;
   const int i = blockIdx.x;
   const int p = blockIdx.y;
   float v = 0.f;
   const int h = n / 2;
-  if (p == 0 && j < n) {
+  if (p < nt && j < n) {
+    y += p * sy_c;
     if (!bilinear) {
       v = y[(i >> 1) * sy_h + (j >> 1) * sy_w];
     } else {
@@ -110,43 +112,65 @@ __global__ void upsample2d_x2_kernel(const float* __restrict__ y, long sy_h, lon
 
 // `final` head (orca_modules.py:423-428) + symmetrisation (:488):
 // f(i,j) = w2 . relu(W1 cur[:,i,j] + b1) + b2 ; out[i][j] = 0.5 f(i,j) + 0.5 f(j,i) (+= if accumulate)
+#define ORCA_MAX_TARGETS 8   // num_2d of the multi-target decoders (orca_leukemia.py:512-990); hidden width F = max(5, T)
 struct FinalArgs {
   const float* cur;  // [64][n][256]
-  const float* w1;   // [5][64] (BN folded)
-  const float* b1;   // [5]
-  const float* w2;   // [5]
-  const float* b2;   // [1]
-  float* out;        // [n][n]
+  const float* w1;   // [F][64] (BN folded)
+  const float* b1;   // [F]
+  const float* w2;   // [T][F]
+  const float* b2;   // [T]
+  float* out;        // [T][n][n]
   long cur_bs, out_bs;
   int n;
   int accumulate;
+  int F, T;
 };
 
-__global__ void final_sym_kernel(FinalArgs a) {
-  __shared__ float w1s[5 * 64], b1s[5], w2s[5], b2s;
-  for (int t = threadIdx.x; t < 320; t += blockDim.x) w1s[t] = a.w1[t];
-  if (threadIdx.x < 5) { b1s[threadIdx.x] = a.b1[threadIdx.x]; w2s[threadIdx.x] = a.w2[threadIdx.x]; }
-  if (threadIdx.x == 0) b2s = a.b2[0];
+// shared tail of the two `final` kernels: h1 / h2 = W1 cur[:, i, j] + b1 and the same at (j, i)
+__device__ __forceinline__ void final_head_store(const FinalArgs& a, const float* h1, const float* h2, const float* w2s, const float* b2s,
+                                                  int b, int i, int j) {
+  const int n = a.n;
+  for (int t = 0; t < a.T; ++t) {
+    float f1 = b2s[t], f2 = b2s[t];
+#pragma unroll
+    for (int o = 0; o < ORCA_MAX_TARGETS; ++o)
+      if (o < a.F) { f1 = fmaf(w2s[t * ORCA_MAX_TARGETS + o], fmaxf(h1[o], 0.f), f1); f2 = fmaf(w2s[t * ORCA_MAX_TARGETS + o], fmaxf(h2[o], 0.f), f2); }
+    float* op = a.out + (long)b * a.out_bs + ((long)t * n + i) * n + j;
+    const float r = 0.5f * f1 + 0.5f * f2;
+    *op = a.accumulate ? (*op + r) : r;
+  }
+}
+
+#define ORCA_FINAL_LOAD_HEAD()                                                                              \
+  __shared__ float w1s[ORCA_MAX_TARGETS * 64], b1s[ORCA_MAX_TARGETS], w2s[ORCA_MAX_TARGETS * ORCA_MAX_TARGETS], b2s[ORCA_MAX_TARGETS]; \
+  for (int t = threadIdx.x; t < ORCA_MAX_TARGETS * 64; t += blockDim.x) w1s[t] = t < a.F * 64 ? a.w1[t] : 0.f; \
+  if (threadIdx.x < ORCA_MAX_TARGETS) {                                                                     \
+    b1s[threadIdx.x] = threadIdx.x < a.F ? a.b1[threadIdx.x] : 0.f;                                         \
+    b2s[threadIdx.x] = threadIdx.x < a.T ? a.b2[threadIdx.x] : 0.f;                                         \
+  }                                                                                                         \
+  if (threadIdx.x < ORCA_MAX_TARGETS * ORCA_MAX_TARGETS) {                                                  \
+    const int t_ = threadIdx.x / ORCA_MAX_TARGETS, o_ = threadIdx.x % ORCA_MAX_TARGETS;                     \
+    w2s[threadIdx.x] = (t_ < a.T && o_ < a.F) ? a.w2[t_ * a.F + o_] : 0.f;                                  \
+  }                                                                                                         \
   __syncthreads();
+
+__global__ void final_sym_kernel(FinalArgs a) {
+  ORCA_FINAL_LOAD_HEAD();
   const int j = threadIdx.x, i = blockIdx.x, b = blockIdx.y, n = a.n;
   if (j >= n) return;
   const float* cur = a.cur + (long)b * a.cur_bs;
   const long cs = (long)n * ORCA_LDW;
-  float h1[5], h2[5];
+  float h1[ORCA_MAX_TARGETS], h2[ORCA_MAX_TARGETS];
 #pragma unroll
-  for (int o = 0; o < 5; ++o) { h1[o] = b1s[o]; h2[o] = b1s[o]; }
+  for (int o = 0; o < ORCA_MAX_TARGETS; ++o) { h1[o] = b1s[o]; h2[o] = b1s[o]; }
   for (int c = 0; c < 64; ++c) {
     const float u = cur[c * cs + (long)i * ORCA_LDW + j];
     const float v = cur[c * cs + (long)j * ORCA_LDW + i];
 #pragma unroll
-    for (int o = 0; o < 5; ++o) { h1[o] = fmaf(w1s[o * 64 + c], u, h1[o]); h2[o] = fmaf(w1s[o * 64 + c], v, h2[o]); }
+    for (int o = 0; o < ORCA_MAX_TARGETS; ++o)
+      if (o < a.F) { h1[o] = fmaf(w1s[o * 64 + c], u, h1[o]); h2[o] = fmaf(w1s[o * 64 + c], v, h2[o]); }
   }
-  float f1 = b2s, f2 = b2s;
-#pragma unroll
-  for (int o = 0; o < 5; ++o) { f1 = fmaf(w2s[o], fmaxf(h1[o], 0.f), f1); f2 = fmaf(w2s[o], fmaxf(h2[o], 0.f), f2); }
-  float* op = a.out + (long)b * a.out_bs + (long)i * n + j;
-  const float r = 0.5f * f1 + 0.5f * f2;
-  *op = a.accumulate ? (*op + r) : r;
+  final_head_store(a, h1, h2, w2s, b2s, b, i, j);
 }
 
 // strand merge (orca_predict.py:514-523): out = 0.5*fwd + 0.5*rev[::-1, ::-1]

@@ -122,6 +122,7 @@ struct orca_net {
   void* d_first_w16 = nullptr;  // same as a K=48 fp16 split pack [2][3][2][64][8] (conv1d_first_mfma_p16_kernel)
   float* d_first_tab = nullptr; // same as a per-base-code table [9 taps][6 codes][64] (fused first layer of conv1d_k9_p16_kernel)
   int upsample_mode = ORCA_UPSAMPLE_BILINEAR;
+  int num_2d = 1;               // Decoder / Decoder_1m: target maps per prediction (orca_leukemia.py:512-990); 1 = the Orca models
   std::vector<ConvLayer> convs;
 };
 
@@ -666,7 +667,8 @@ extern "C" int orca_ctx_release_workspace(orca_ctx* ctx) {
 // ---------------------------------------------------------------------------
 struct Shape { int cout, cin, k; };
 
-static void expected_shapes(int kind, std::vector<Shape>* s) {
+static void expected_shapes(int kind, std::vector<Shape>* s, int T = 1) {
+  const int F = T > 5 ? T : 5;   // hidden width of the `final` head
   s->clear();
   auto c1 = [&](int co, int ci) { s->push_back({co, ci, 9}); };
   auto c2 = [&](int co, int ci) { s->push_back({co, ci, 3}); };
@@ -680,13 +682,13 @@ static void expected_shapes(int kind, std::vector<Shape>* s) {
   } else if (kind == ORCA_NET_ENCODER2B) {
     for (int i = 0; i < 4 * 5; ++i) c1(128, 128);
   } else if (kind == ORCA_NET_DECODER) {
-    c2(64, 129); c2(64, 64); c2(64, 64); c2(64, 64);  // lcombinerD, combinerD
-    c2(64, 65); c2(64, 64); c2(64, 64); c2(64, 64);   // lcombiner, combiner
+    c2(64, 128 + T); c2(64, 64); c2(64, 64); c2(64, 64);  // lcombinerD, combinerD
+    c2(64, 64 + T); c2(64, 64); c2(64, 64); c2(64, 64);   // lcombiner, combiner
     for (int i = 0; i < 28; ++i) { c2(32, 64); c2(64, 32); c2(32, 64); c2(64, 32); }
-    s->push_back({5, 64, 1}); s->push_back({1, 5, 1});
+    s->push_back({F, 64, 1}); s->push_back({T, F, 1});
   } else if (kind == ORCA_NET_DECODER_1M) {
     for (int i = 0; i < 19; ++i) { c2(32, i == 0 ? 128 : 64); c2(64, 32); c2(32, 64); c2(64, 32); }
-    s->push_back({5, 64, 1}); s->push_back({1, 5, 1});
+    s->push_back({F, 64, 1}); s->push_back({T, F, 1});
   }
 }
 
@@ -694,7 +696,12 @@ extern "C" int orca_net_create(orca_ctx* ctx, int kind, const orca_conv_desc* co
   if (!ctx || !convs || !out) return fail(ORCA_EINVAL, "orca_net_create: NULL argument");
   HIPCHECK(hipSetDevice(ctx->device));
   std::vector<Shape> exp;
-  expected_shapes(kind, &exp);
+  int T = 1;   // multi-target decoders: the number of maps is the width of the last layer
+  if ((kind == ORCA_NET_DECODER || kind == ORCA_NET_DECODER_1M) && n_convs > 0) {
+    T = convs[n_convs - 1].cout;
+    if (T < 1 || T > ORCA_MAX_TARGETS) return fail(ORCA_EINVAL, "decoder with %d target maps (supported: 1..%d)", T, ORCA_MAX_TARGETS);
+  }
+  expected_shapes(kind, &exp, T);
   if (exp.empty()) return fail(ORCA_EINVAL, "unknown net kind %d", kind);
   if ((int)exp.size() != n_convs) return fail(ORCA_EINVAL, "net kind %d expects %zu convs, got %d", kind, exp.size(), n_convs);
   for (int i = 0; i < n_convs; ++i)
@@ -702,7 +709,7 @@ extern "C" int orca_net_create(orca_ctx* ctx, int kind, const orca_conv_desc* co
       return fail(ORCA_EINVAL, "net kind %d conv %d: expected cout=%d cin=%d k=%d, got cout=%d cin=%d k=%d", kind, i,
                   exp[i].cout, exp[i].cin, exp[i].k, convs[i].cout, convs[i].cin, convs[i].ksize);
   orca_net* net = new orca_net();
-  net->ctx = ctx; net->kind = kind; net->upsample_mode = upsample_mode;
+  net->ctx = ctx; net->kind = kind; net->upsample_mode = upsample_mode; net->num_2d = T;
   net->convs.resize(n_convs);
   for (int i = 0; i < n_convs; ++i) {
     int rc = make_layer(convs[i], &net->convs[i]);
@@ -1055,7 +1062,8 @@ static int launch_final(orca_ctx* ctx, orca_net* net, const float* cur, long cur
   const ConvLayer& fb = net->convs[net->convs.size() - 1];
   FinalArgs a;
   a.cur = cur; a.w1 = fa.d_w; a.b1 = fa.d_bias; a.w2 = fb.d_w; a.b2 = fb.d_bias; a.out = out;
-  a.cur_bs = cur_bs; a.out_bs = (long)n * n; a.n = n; a.accumulate = accumulate;
+  a.cur_bs = cur_bs; a.out_bs = (long)net->num_2d * n * n; a.n = n; a.accumulate = accumulate;
+  a.T = net->num_2d; a.F = fa.cout;
   hipLaunchKernelGGL(final_sym_kernel, dim3((unsigned)n, (unsigned)B), dim3(256), 0, ctx->stream, a);
   LAUNCHCHECK("final_sym_kernel");
   return ORCA_OK;
@@ -1063,8 +1071,9 @@ static int launch_final(orca_ctx* ctx, orca_net* net, const float* cur, long cur
 
 // Decoder / Decoder_1m on the fp16 matrix cores, channel-last feature maps [n][256 px][C]
 static int decoder_nhwc(orca_ctx* ctx, orca_net* net, const float* x, long sx_b, long sx_c, long sx_l, const float* de, long sd_b,
-                        long sd_h, long sd_w, const float* y, long sy_b, long sy_h, long sy_w, int B, int n, float* out,
-                        int accumulate) {
+                        long sd_c, long sd_h, long sd_w, const float* y, long sy_b, long sy_c, long sy_h, long sy_w, int B, int n,
+                        float* out, int accumulate) {
+  const int nt2 = net->num_2d;
   const bool is1m = net->kind == ORCA_NET_DECODER_1M;
   const size_t px = (size_t)n * 256;
   const int cIN = is1m ? 128 : 144, cA = 80;
@@ -1088,7 +1097,7 @@ static int decoder_nhwc(orca_ctx* ctx, orca_net* net, const float* x, long sx_b,
     hipStream_t s = ctx->stream;
     for (int b = 0; b < nb; ++b) {
       hipLaunchKernelGGL(outer_sum_nhwc_kernel, dim3(32, (unsigned)n), dim3(cIN / 4, 8), 0, s, x + (long)(b0 + b) * sx_b, sx_c, sx_l,
-                         de ? de + (long)(b0 + b) * sd_b : nullptr, sd_h, sd_w, IN + b * szIN, n, cIN);
+                         de ? de + (long)(b0 + b) * sd_b : nullptr, sd_c, sd_h, sd_w, nt2, IN + b * szIN, n, cIN);
       LAUNCHCHECK("outer_sum_nhwc_kernel");
     }
     const ConvLayer* L = net->convs.data();
@@ -1104,7 +1113,7 @@ static int decoder_nhwc(orca_ctx* ctx, orca_net* net, const float* x, long sx_b,
       pairs = L + 8; npairs = 28;
       if (y) {
         for (int b = 0; b < nb; ++b) {
-          hipLaunchKernelGGL(upsample2d_nhwc_kernel, dim3((unsigned)n), dim3(256), 0, s, y + (long)(b0 + b) * sy_b, sy_h, sy_w,
+          hipLaunchKernelGGL(upsample2d_nhwc_kernel, dim3((unsigned)n), dim3(256), 0, s, y + (long)(b0 + b) * sy_b, sy_c, sy_h, sy_w, nt2,
                              A + b * szA, n, cA, 64, net->upsample_mode == ORCA_UPSAMPLE_BILINEAR ? 1 : 0);
           LAUNCHCHECK("upsample2d_nhwc_kernel");
         }
@@ -1138,8 +1147,8 @@ static int decoder_nhwc(orca_ctx* ctx, orca_net* net, const float* x, long sx_b,
     const ConvLayer& fa = net->convs[net->convs.size() - 2];
     const ConvLayer& fb = net->convs[net->convs.size() - 1];
     FinalArgs fa_;
-    fa_.cur = cur; fa_.w1 = fa.d_w; fa_.b1 = fa.d_bias; fa_.w2 = fb.d_w; fa_.b2 = fb.d_bias; fa_.out = out + (size_t)b0 * n * n;
-    fa_.cur_bs = sz64; fa_.out_bs = (long)n * n; fa_.n = n; fa_.accumulate = accumulate;
+    fa_.cur = cur; fa_.w1 = fa.d_w; fa_.b1 = fa.d_bias; fa_.w2 = fb.d_w; fa_.b2 = fb.d_bias; fa_.out = out + (size_t)b0 * nt2 * n * n;
+    fa_.cur_bs = sz64; fa_.out_bs = (long)nt2 * n * n; fa_.n = n; fa_.accumulate = accumulate; fa_.T = nt2; fa_.F = fa.cout;
     hipLaunchKernelGGL(final_sym_nhwc_kernel, dim3((unsigned)n, (unsigned)nb), dim3(256), 0, s, fa_);
     LAUNCHCHECK("final_sym_nhwc_kernel");
     return ORCA_OK;
@@ -1167,13 +1176,14 @@ static int decoder_nhwc(orca_ctx* ctx, orca_net* net, const float* x, long sx_b,
 }
 
 static int decoder_common(orca_ctx* ctx, orca_net* net, const float* x, long sx_b, long sx_c, long sx_l, const float* de,
-                          long sd_b, long sd_h, long sd_w, const float* y, long sy_b, long sy_h, long sy_w, int B, int n,
-                          float* out, int accumulate) {
+                          long sd_b, long sd_c, long sd_h, long sd_w, const float* y, long sy_b, long sy_c, long sy_h, long sy_w,
+                          int B, int n, float* out, int accumulate) {
+  const int nt2 = net->num_2d;
   if (n <= 0 || n > ORCA_LDW || (n & 1)) return fail(ORCA_EINVAL, "map size %d unsupported (even, <=256)", n);
   if (B <= 0) return ORCA_OK;
   HIPCHECK(hipSetDevice(ctx->device));
   if (net->precision == ORCA_PRECISION_F16X2)
-    return decoder_nhwc(ctx, net, x, sx_b, sx_c, sx_l, de, sd_b, sd_h, sd_w, y, sy_b, sy_h, sy_w, B, n, out, accumulate);
+    return decoder_nhwc(ctx, net, x, sx_b, sx_c, sx_l, de, sd_b, sd_c, sd_h, sd_w, y, sy_b, sy_c, sy_h, sy_w, B, n, out, accumulate);
   const bool is1m = net->kind == ORCA_NET_DECODER_1M;
   const size_t plane = (size_t)n * ORCA_LDW;
   const int cin0 = is1m ? 128 : 136;
@@ -1189,7 +1199,7 @@ static int decoder_common(orca_ctx* ctx, orca_net* net, const float* x, long sx_
   hipStream_t s = ctx->stream;
   for (int b = 0; b < B; ++b) {
     hipLaunchKernelGGL(outer_sum_kernel, dim3((unsigned)n, (unsigned)cin0), dim3(64), 0, s, x + (long)b * sx_b, sx_c, sx_l,
-                       de ? de + (long)b * sd_b : nullptr, sd_h, sd_w, IN + b * szIN, n, cin0);
+                       de ? de + (long)b * sd_b : nullptr, sd_c, sd_h, sd_w, nt2, IN + b * szIN, n, cin0);
     LAUNCHCHECK("outer_sum_kernel");
   }
   const ConvLayer* L = net->convs.data();
@@ -1203,7 +1213,7 @@ static int decoder_common(orca_ctx* ctx, orca_net* net, const float* x, long sx_
     pairs = L + 8; npairs = 28;
     if (y) {
       for (int b = 0; b < B; ++b) {
-        hipLaunchKernelGGL(upsample2d_x2_kernel, dim3((unsigned)n, 8), dim3(ORCA_LDW), 0, s, y + (long)b * sy_b, sy_h, sy_w,
+        hipLaunchKernelGGL(upsample2d_x2_kernel, dim3((unsigned)n, 8), dim3(ORCA_LDW), 0, s, y + (long)b * sy_b, sy_c, sy_h, sy_w, nt2,
                            A + b * szA + 64 * plane, n, net->upsample_mode == ORCA_UPSAMPLE_BILINEAR ? 1 : 0, 8);
         LAUNCHCHECK("upsample2d_x2_kernel");
       }
@@ -1241,14 +1251,30 @@ extern "C" int orca_decoder_forward(orca_ctx* ctx, orca_net* net, const float* x
                                     int64_t sy_b, int64_t sy_h, int64_t sy_w, int B, int n, float* out, int accumulate) {
   if (!ctx || !net || !x || !distenc || !out) return fail(ORCA_EINVAL, "orca_decoder_forward: NULL argument");
   if (net->kind != ORCA_NET_DECODER) return fail(ORCA_EINVAL, "orca_decoder_forward: net is not a Decoder");
-  return decoder_common(ctx, net, x, sx_b, sx_c, sx_l, distenc, sd_b, sd_h, sd_w, y, sy_b, sy_h, sy_w, B, n, out, accumulate);
+  if (net->num_2d != 1) return fail(ORCA_EINVAL, "orca_decoder_forward: net predicts %d maps, use orca_decoder_forward_mt", net->num_2d);
+  return decoder_common(ctx, net, x, sx_b, sx_c, sx_l, distenc, sd_b, 0, sd_h, sd_w, y, sy_b, 0, sy_h, sy_w, B, n, out, accumulate);
+}
+
+extern "C" int orca_decoder_forward_mt(orca_ctx* ctx, orca_net* net, const float* x, int64_t sx_b, int64_t sx_c, int64_t sx_l,
+                                       const float* distenc, int64_t sd_b, int64_t sd_c, int64_t sd_h, int64_t sd_w, const float* y,
+                                       int64_t sy_b, int64_t sy_c, int64_t sy_h, int64_t sy_w, int B, int n, float* out,
+                                       int accumulate) {
+  if (!ctx || !net || !x || !distenc || !out) return fail(ORCA_EINVAL, "orca_decoder_forward_mt: NULL argument");
+  if (net->kind != ORCA_NET_DECODER) return fail(ORCA_EINVAL, "orca_decoder_forward_mt: net is not a Decoder");
+  return decoder_common(ctx, net, x, sx_b, sx_c, sx_l, distenc, sd_b, sd_c, sd_h, sd_w, y, sy_b, sy_c, sy_h, sy_w, B, n, out, accumulate);
 }
 
 extern "C" int orca_decoder1m_forward(orca_ctx* ctx, orca_net* net, const float* x, int64_t sx_b, int64_t sx_c, int64_t sx_l,
                                       int B, int n, float* out, int accumulate) {
   if (!ctx || !net || !x || !out) return fail(ORCA_EINVAL, "orca_decoder1m_forward: NULL argument");
   if (net->kind != ORCA_NET_DECODER_1M) return fail(ORCA_EINVAL, "orca_decoder1m_forward: net is not a Decoder_1m");
-  return decoder_common(ctx, net, x, sx_b, sx_c, sx_l, nullptr, 0, 0, 0, nullptr, 0, 0, 0, B, n, out, accumulate);
+  return decoder_common(ctx, net, x, sx_b, sx_c, sx_l, nullptr, 0, 0, 0, 0, nullptr, 0, 0, 0, 0, B, n, out, accumulate);
+}
+
+extern "C" int orca_net_num_targets(orca_net* net, int* num_2d) {
+  if (!net || !num_2d) return fail(ORCA_EINVAL, "orca_net_num_targets: NULL argument");
+  *num_2d = net->num_2d;
+  return ORCA_OK;
 }
 
 extern "C" int orca_strand_merge(orca_ctx* ctx, const float* fwd, const float* rev, float* out, int n) {

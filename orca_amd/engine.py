@@ -165,6 +165,14 @@ class Net:
         check(lib.orca_net_create(ctx.handle, kind, descs, len(convs), upsample_mode, ctypes.byref(self.handle)), "orca_net_create")
         self._finalizer = weakref.finalize(self, lib.orca_net_free, self.handle)
 
+    def num_targets(self):
+        """Maps per prediction of a Decoder / Decoder_1m net (num_2d); 1 for the other kinds."""
+        if getattr(self, "_num_targets", None) is None:
+            t = ctypes.c_int(0)
+            check(_lib.load().orca_net_num_targets(self.handle, ctypes.byref(t)), "orca_net_num_targets")
+            self._num_targets = int(t.value)
+        return self._num_targets
+
     def set_precision(self, name):
         if name not in _lib.PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(_lib.PRECISIONS)}, got {name!r}")
@@ -254,40 +262,54 @@ def unet_forward(net, x, nlev):
 
 
 def decoder_forward(net, x, distenc, y=None, out=None, accumulate=False):
+    """x [B,128,n]; distenc [B or 1, T, n, n]; y None or [B,T,n/2,n/2]; returns / fills [B,T,n,n]
+    (T = the net's number of target maps: 1 for the Orca models, num_2d for the orca_leukemia decoders)."""
     x = _f32_cuda(x, "x")
     distenc = _f32_cuda(distenc, "distenc")
     B, C, n = x.shape
+    T = net.num_targets()
     if C != 128:
         raise ValueError(f"Decoder input must be [B,128,n], got {tuple(x.shape)}")
-    if distenc.dim() != 4 or distenc.shape[1] != 1 or distenc.shape[2] != n or distenc.shape[3] != n:
-        raise ValueError(f"distenc must be [B,1,{n},{n}], got {tuple(distenc.shape)}")
+    if distenc.dim() != 4 or distenc.shape[1] != T or distenc.shape[2] != n or distenc.shape[3] != n:
+        raise ValueError(f"distenc must be [B,{T},{n},{n}], got {tuple(distenc.shape)}")
     if distenc.shape[0] not in (1, B):
         raise ValueError("distenc batch mismatch")
     sd_b = distenc.stride(0) if distenc.shape[0] == B else 0
-    yp, sy = ctypes.c_void_p(0), (0, 0, 0)
+    yp, sy = ctypes.c_void_p(0), (0, 0, 0, 0)
     if y is not None:
         y = _f32_cuda(y, "y")
-        if tuple(y.shape) != (B, 1, n // 2, n // 2):
-            raise ValueError(f"coarse prediction must be [{B},1,{n // 2},{n // 2}], got {tuple(y.shape)}")
-        yp, sy = _p(y), (y.stride(0), y.stride(2), y.stride(3))
+        if tuple(y.shape) != (B, T, n // 2, n // 2):
+            raise ValueError(f"coarse prediction must be [{B},{T},{n // 2},{n // 2}], got {tuple(y.shape)}")
+        yp, sy = _p(y), (y.stride(0), y.stride(1), y.stride(2), y.stride(3))
     if out is None:
-        out = torch.empty((B, 1, n, n), dtype=torch.float32, device=x.device)
+        out = torch.empty((B, T, n, n), dtype=torch.float32, device=x.device)
         accumulate = False
+    elif tuple(out.shape) != (B, T, n, n) or not out.is_contiguous():
+        raise ValueError(f"out must be a contiguous [{B},{T},{n},{n}] tensor")
     net.ctx.sync_stream()
-    check(_lib.load().orca_decoder_forward(net.ctx.handle, net.handle, _p(x), x.stride(0), x.stride(1), x.stride(2), _p(distenc),
-                                           sd_b, distenc.stride(2), distenc.stride(3), yp, sy[0], sy[1], sy[2], B, n, _p(out),
-                                           1 if accumulate else 0), "orca_decoder_forward")
+    if T == 1:
+        check(_lib.load().orca_decoder_forward(net.ctx.handle, net.handle, _p(x), x.stride(0), x.stride(1), x.stride(2), _p(distenc),
+                                               sd_b, distenc.stride(2), distenc.stride(3), yp, sy[0], sy[2], sy[3], B, n, _p(out),
+                                               1 if accumulate else 0), "orca_decoder_forward")
+    else:
+        check(_lib.load().orca_decoder_forward_mt(net.ctx.handle, net.handle, _p(x), x.stride(0), x.stride(1), x.stride(2),
+                                                  _p(distenc), sd_b, distenc.stride(1), distenc.stride(2), distenc.stride(3), yp,
+                                                  sy[0], sy[1], sy[2], sy[3], B, n, _p(out), 1 if accumulate else 0),
+              "orca_decoder_forward_mt")
     return out
 
 
 def decoder1m_forward(net, x, out=None, accumulate=False):
     x = _f32_cuda(x, "x")
     B, C, n = x.shape
+    T = net.num_targets()
     if C != 128:
         raise ValueError(f"Decoder_1m input must be [B,128,n], got {tuple(x.shape)}")
     if out is None:
-        out = torch.empty((B, 1, n, n), dtype=torch.float32, device=x.device)
+        out = torch.empty((B, T, n, n), dtype=torch.float32, device=x.device)
         accumulate = False
+    elif tuple(out.shape) != (B, T, n, n) or not out.is_contiguous():
+        raise ValueError(f"out must be a contiguous [{B},{T},{n},{n}] tensor")
     net.ctx.sync_stream()
     check(_lib.load().orca_decoder1m_forward(net.ctx.handle, net.handle, _p(x), x.stride(0), x.stride(1), x.stride(2), B, n,
                                              _p(out), 1 if accumulate else 0), "orca_decoder1m_forward")

@@ -241,9 +241,20 @@ def _c2(d):
     return dict(kernel_size=(3, 3), padding=d, dilation=d)
 
 
-def _final_head():
-    return nn.Sequential(nn.Conv2d(64, 5, kernel_size=(1, 1), padding=0), nn.BatchNorm2d(5), nn.ReLU(inplace=True),
-                         nn.Conv2d(5, 1, kernel_size=(1, 1), padding=0))
+MAX_TARGETS = 8   # ORCA_MAX_TARGETS of the HIP library
+
+
+def _final_head(num_2d=1):
+    """64 -> max(5, num_2d) -> num_2d (orca_modules.py:423-428; orca_leukemia.py:922-927 for num_2d > 1)."""
+    hidden = num_2d if num_2d > 5 else 5
+    return nn.Sequential(nn.Conv2d(64, hidden, kernel_size=(1, 1), padding=0), nn.BatchNorm2d(hidden), nn.ReLU(inplace=True),
+                         nn.Conv2d(hidden, num_2d, kernel_size=(1, 1), padding=0))
+
+
+def _check_num_2d(num_2d):
+    if not (isinstance(num_2d, int) and 1 <= num_2d <= MAX_TARGETS):
+        raise ValueError(f"num_2d must be an int in 1..{MAX_TARGETS}, got {num_2d!r}")
+    return num_2d
 
 
 class Decoder(_HipModule):
@@ -251,11 +262,14 @@ class Decoder(_HipModule):
 
     _kind = _lib.ORCA_NET_DECODER
 
-    def __init__(self, upsample_mode="nearest", precision=None):
+    def __init__(self, upsample_mode="nearest", precision=None, num_2d=1):
         """precision: "f16x2" (dilated 3x3 convs on the fp16 matrix cores with 2-way split fp32 operands,
         ~2^-22 relative error, device range guard with automatic "f32" retry; default) or "f32" (fp32 MFMA).
-        Default: $ORCA_DECODER_PRECISION or "f16x2"."""
+        Default: $ORCA_DECODER_PRECISION or "f16x2".
+        num_2d: maps per prediction (the multi-target decoders of orca_leukemia.py:512-990): distenc and the
+        coarse prediction y then carry num_2d channels, and so does the output."""
         super().__init__()
+        self.num_2d = _check_num_2d(num_2d)
         self.precision = precision or os.environ.get("ORCA_DECODER_PRECISION", "f16x2")
         if self.precision not in ("f16x2", "f32"):
             raise ValueError("Decoder precision must be 'f16x2' or 'f32'")
@@ -266,11 +280,11 @@ class Decoder(_HipModule):
             _linear_pair(nn.Conv2d, nn.BatchNorm2d, 64, 32, 64, nn.Dropout(p=0.1) if i == 0 else None, **_c2(d))
             for i, d in enumerate(DECODER_DILATIONS)])
         self.convtwos = nn.ModuleList([_relu_pair(nn.Conv2d, nn.BatchNorm2d, 64, 32, 64, **_c2(d)) for d in DECODER_DILATIONS])
-        self.final = _final_head()
+        self.final = _final_head(num_2d)
         self.upsample = nn.Upsample(scale_factor=(2, 2), mode=upsample_mode)
-        self.lcombiner = _linear_pair(nn.Conv2d, nn.BatchNorm2d, 65, 64, 64, nn.Dropout(p=0.1), **_c2(1))
+        self.lcombiner = _linear_pair(nn.Conv2d, nn.BatchNorm2d, 64 + num_2d, 64, 64, nn.Dropout(p=0.1), **_c2(1))
         self.combiner = _relu_pair(nn.Conv2d, nn.BatchNorm2d, 64, 64, 64, **_c2(1))
-        self.lcombinerD = _linear_pair(nn.Conv2d, nn.BatchNorm2d, 129, 64, 64, **_c2(1))
+        self.lcombinerD = _linear_pair(nn.Conv2d, nn.BatchNorm2d, 128 + num_2d, 64, 64, **_c2(1))
         self.combinerD = _relu_pair(nn.Conv2d, nn.BatchNorm2d, 64, 64, 64, **_c2(1))
 
     def _conv_items(self):
@@ -282,7 +296,7 @@ class Decoder(_HipModule):
         return items
 
     def forward(self, x, distenc, y=None):
-        """x [B,128,n], distenc [B,1,n,n] (log background), y None or [B,1,n/2,n/2]."""
+        """x [B,128,n], distenc [B,num_2d,n,n] (log background), y None or [B,num_2d,n/2,n/2] -> [B,num_2d,n,n]."""
         net = self._net(x.device)
         return self._run_guarded(net, lambda: engine.decoder_forward(net, x, distenc, y), "f32")
 
@@ -299,8 +313,9 @@ class Decoder_1m(_HipModule):
 
     _kind = _lib.ORCA_NET_DECODER_1M
 
-    def __init__(self, precision=None):
+    def __init__(self, precision=None, num_2d=1):
         super().__init__()
+        self.num_2d = _check_num_2d(num_2d)
         self.precision = precision or os.environ.get("ORCA_DECODER_PRECISION", "f16x2")
         if self.precision not in ("f16x2", "f32"):
             raise ValueError("Decoder_1m precision must be 'f16x2' or 'f32'")
@@ -308,7 +323,7 @@ class Decoder_1m(_HipModule):
             _linear_pair(nn.Conv2d, nn.BatchNorm2d, 128 if i == 0 else 64, 32, 64, nn.Dropout(p=0.1) if i == 0 else None, **_c2(d))
             for i, d in enumerate(DECODER1M_DILATIONS)])
         self.convtwos = nn.ModuleList([_relu_pair(nn.Conv2d, nn.BatchNorm2d, 64, 32, 64, **_c2(d)) for d in DECODER1M_DILATIONS])
-        self.final = _final_head()
+        self.final = _final_head(num_2d)
 
     def _conv_items(self):
         items = []
@@ -340,9 +355,10 @@ class Net(nn.Module):
     ``Decoder_1m(Encoder(x))`` on the HIP kernels (one Encoder chunk: the reference runs the stack over the whole
     1 Mb at once, `run0` :1836-1857) plus ``orca_pointwise1d_forward`` for the 1-D head."""
 
-    def __init__(self, num_1d=None, precision=None):
+    def __init__(self, num_1d=None, precision=None, num_2d=1):
         super().__init__()
-        enc, dec = Encoder(precision), Decoder_1m()
+        enc, dec = Encoder(precision), Decoder_1m(num_2d=num_2d)
+        self.num_2d = num_2d
         for name, child in list(enc.named_children()) + list(dec.named_children()):
             self.add_module(name, child)
         if num_1d is not None:

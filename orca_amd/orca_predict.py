@@ -153,9 +153,14 @@ def _decode(model, level, enc_slice, distenc, coarse, add_1m):
 
 def _coarse_grain(mat, nblock, nan_thresh):
     """nan-aware block mean of the leading [T, 250*nblock, 250*nblock] window
-    (orca_predict.py:404-436)."""
+    (orca_predict.py:404-436): mean over the block rows of the per-row means, blocks with more than
+    ``nan_thresh`` missing entries set to NaN.  NaN-free windows (every background after the reference's in-place
+    fill, orca_predict.py:664-667) take plain means - bit-identical to ``nanmean`` there (same pairwise sums,
+    same counts) and 8x quicker on the 8000 x 8000 level-256 window."""
     T = mat.shape[0]
     r = np.reshape(mat, (T, 250, nblock, 250, nblock))
+    if not np.isnan(mat).any():
+        return np.mean(np.mean(r, axis=4), axis=2)
     with np.errstate(invalid="ignore"):
         import warnings
         with warnings.catch_warnings():
@@ -373,8 +378,12 @@ def genomepredict_256Mb(sequence, mchr, normmats, chrlen, mpos=-1, wpos=-1, mode
 
             def background(level, k, start, normmat=normmat, ns=ns):
                 w = 250 * (level // 8)
-                ns[k][level] = _coarse_grain(normmat[None, start: start + w, start: start + w], level // 8, 1)
-                return _log_background(ns[k][level], 1, use_cuda, flip=(k != 0))   # flipped on the reverse strand (:703)
+                other = ns[1 - k].get(level)
+                if other is not None and other[0] == start:   # both strands start level 256 at 0: grain once
+                    ns[k][level] = other
+                else:
+                    ns[k][level] = (start, _coarse_grain(normmat[None, start: start + w, start: start + w], level // 8, 1))
+                return _log_background(ns[k][level][1], 1, use_cuda, flip=(k != 0))   # flipped on the reverse strand (:703)
 
             def on_level(j, level, starts_now, ii=ii, ns=ns, ts=ts, annos=annos):
                 s0, w = starts_now[0], 250 * (level // 8)
@@ -382,8 +391,8 @@ def genomepredict_256Mb(sequence, mchr, normmats, chrlen, mpos=-1, wpos=-1, mode
                     tgt = targets[ii]
                     tgt = tgt.numpy() if isinstance(tgt, torch.Tensor) else np.asarray(tgt)
                     tr = _coarse_grain(tgt[:, s0: s0 + w, s0: s0 + w], level // 8, nan_thresh)
-                    eps = np.nanmin(ns[0][level])
-                    lf = np.log((tr + eps) / (ns[0][level] + eps))
+                    eps = np.nanmin(ns[0][level][1])
+                    lf = np.log((tr + eps) / (ns[0][level][1] + eps))
                     ts.append(lf[0, :, :] if tr.shape[0] == 1 else lf)
                 if annotation is not None:
                     annos.append(_scale_annotation(annotation, s0 / 8000.0, (s0 + w) / 8000.0))
@@ -398,8 +407,8 @@ def genomepredict_256Mb(sequence, mchr, normmats, chrlen, mpos=-1, wpos=-1, mode
             preds, starts = engine.run_with_overflow_retry(forward, strands.device)
             predictions.append(_merge(preds, batch))
             allstarts.append(starts[0])
-            allnormmats.append(ns[0])
-            allnormmats_rev.append(ns[1])
+            allnormmats.append({lv: v[1] for lv, v in ns[0].items()})
+            allnormmats_rev.append({lv: v[1] for lv, v in ns[1].items()})
             if targets:
                 alltargets.append(ts)
             if annotation is not None:

@@ -282,6 +282,40 @@ def main():
             np.savez_compressed(os.path.join(GOLD, "G15_encoder2b.npz"), **{f"o{i}": o[0].numpy() for i, o in enumerate(outs) if i > 0})
             print("G15 done", [tuple(o.shape) for o in outs])
 
+        # ---- G16: multi-target decoders of orca_leukemia.py (Decoder(num_2d) :512-990, Decoder_1m(num_2d) :996-1316,
+        # Encoder2 :1499-1601 = the up-path-only U-net).  The module cannot be imported as a whole - it needs ORCA_PATH
+        # set before line 10 and instantiates OrcaLeukemiaA/B (checkpoint + resource files) at import, :1872-1873 - so
+        # the class definitions above `class OrcaLeukemiaA` are executed in a scratch module.
+        if want("G16"):
+            import types
+            src = open(os.path.join(REF, "orca_leukemia.py")).read()
+            ol = types.ModuleType("orca_leukemia_classes")
+            ol.__dict__["ORCA_PATH"] = REF
+            exec(compile(src[:src.index("class OrcaLeukemiaA")], os.path.join(REF, "orca_leukemia.py"), "exec"), ol.__dict__)
+            man = {}
+            for name, m in (("Decoder2", ol.Decoder(2)), ("Decoder6", ol.Decoder(6)), ("Decoder_1m2", ol.Decoder_1m(2)),
+                            ("Encoder2", ol.Encoder2()), ("Net2_3", ol.Net(num_2d=2, num_1d=3))):
+                man[name] = np.array([f"{k}|{','.join(map(str, v.shape))}" for k, v in m.state_dict().items()])
+            d = {f"manifest_{k}": v for k, v in man.items()}
+            nm, _ = synth.synth_normmats_32m()
+            x = torch.from_numpy((np.random.RandomState(71).rand(1, 128, 250) * 0.5).astype(np.float32))
+            for T, lv in ((2, 8), (6, 2)):
+                bg = np.stack([nm[lv] * (1.0 + 0.15 * t) for t in range(T)])
+                de = torch.log(torch.from_numpy(bg[None].astype(np.float32)))
+                dec = load_synth(ol.Decoder(T), seed=5)
+                p0 = dec(x, de)
+                yc = p0[:, :, 29:154, 29:154]
+                p1 = dec(x, de, yc)
+                if T == 2:
+                    d["T2_noy"], d["T2_y"] = p0[0].numpy(), p1[0].numpy()
+                else:   # every 3rd row/column + whole-map statistics keep the fixture small
+                    d[f"T{T}_noy_sub"], d[f"T{T}_y_sub"] = p0[0, :, ::3, ::3].numpy(), p1[0, :, ::3, ::3].numpy()
+                    d[f"T{T}_noy_stats"], d[f"T{T}_y_stats"] = stats(p0), stats(p1)
+            d1m = load_synth(ol.Decoder_1m(2), seed=5)
+            d["T2_dec1m"] = d1m(x)[0].numpy()
+            np.savez_compressed(os.path.join(GOLD, "G16_multitarget.npz"), **d)
+            print("G16 done", {k: v.shape for k, v in d.items() if not k.startswith("manifest")})
+
         # ---- G14: Net, the 1 Mb model (orca_modules.py:1409-1900), one 1 Mb sequence with an N run ----------
         if want("G14"):
             t = time.time()
