@@ -321,3 +321,9 @@ __global__ void final_sym_nhwc_kernel(FinalArgs a) {
 // and 50 % less W traffic per output row; parity green): COUT 32 26.0 vs 24.3 us per launch, COUT 64 (128-VGPR cap at
 // 1024 threads: spills) 47.8 vs 33.5 us - the K loop is bound by its latency chain, not by L2 bandwidth, and the
 // bigger workgroup costs the second resident one.  Dropped.
+// A wave-specialised persistent variant (waves 0-7 MFMA + epilogue only, waves 8-11 global -> registers two steps
+// ahead -> split -> the other of two 66 KB LDS images; stream of (map, row, 32-cout half, chunk) steps, one barrier
+// per step; parity green): 3.79 vs 3.42 ms per Decoder.  With one 12-wave workgroup per CU the bytes in flight per CU
+// drop from 2 x 67 KB to ~85 KB and the loop becomes latency-bound (4.3 TB/s out of the L2s instead of 8.8): what
+// these layers need is more bytes in flight per CU (LDS-DMA from pre-split, chunk-planar maps), not a different
+// split of the work between waves.  Dropped.
