@@ -1,8 +1,11 @@
 // conv2d_f16s.h - dilated 3x3 Conv2d of the Decoders on the fp16 matrix cores with 2-way split fp32
 // operands (3 MFMA products per fp32 product, ~2^-22 relative error; see conv_bf16s.h).
 //
-// Feature maps are channel-LAST: [row][256 px][C] fp32 (row pitch padded 250 -> 256 px; pad pixels are
-// kept at ZERO by every producer so that reads past the right edge need no mask).  One workgroup = one
+// Feature maps are CHUNK-PLANAR: [C/16][row][256 px][16 ch] fp32 (row pitch padded 250 -> 256 px; pad pixels are
+// kept at ZERO by every producer so that reads past the right edge need no mask): the 16 channels of one K-chunk of a
+// pixel are 64 contiguous bytes and consecutive pixels are adjacent, so every wave-level load of the K loop and every
+// store of the epilogue covers whole 128-byte lines (a pixel-major [row][px][C] map has them half used; measured
+// 24.3 -> 23.3 / 33.5 -> 33.1 us per launch for COUT 32 / 64, 105.7 -> 104.0 ms per step).  One workgroup = one
 // output row; wave w owns pixels [32w, 32w+32) and all COUT channels.  K walks chunks of 16 input
 // channels x 9 taps; per chunk the LDS holds
 //   X image [split][g][3 source rows][256 px][8 ch] fp16     (split while staging)
@@ -17,13 +20,13 @@
 #include "misc_kernels.h"
 
 struct Conv2dF16Args {
-  const float* x;    // [B][H][256][xc]
+  const float* x;    // [B][xc/16][H][256][16]
   const void* w;     // packed fp16 [nchunks][2][9][2][COUT][8]
   const float* bias;
-  float* y;          // [B][H][256][yc]   (channels 0..COUT-1 written)
-  const float* r;    // optional residual [B][H][256][rc]
+  float* y;          // [B][yc/16][H][256][16]   (channels 0..COUT-1 written)
+  const float* r;    // optional residual, same layout
   long x_bs, y_bs, r_bs;
-  int xc, yc, rc;    // channels per pixel (pixel stride) of x / y / r
+  long x_cs, y_cs, r_cs;   // chunk strides (H * 256 * 16 floats of the respective buffer)
   int H, W, dil, nchunks, relu;
   int banded;        // grid.x = 8 * ceil(H/8), XCD-banded row order (see the kernel)
   unsigned* flag;
@@ -57,7 +60,6 @@ __global__ __launch_bounds__(512) void conv2d_3x3_f16s_kernel(Conv2dF16Args a) {
   const f32x4* wg = reinterpret_cast<const f32x4*>(a.w);
   float* bias_s = reinterpret_cast<float*>(smem + XU + WU);
   if (tid < COUT) bias_s[tid] = a.bias[tid];   // visible after the first barrier
-  const long rowpitch = (long)PX * a.xc;
 
   bool rowok[3];
 #pragma unroll
@@ -96,14 +98,13 @@ __global__ __launch_bounds__(512) void conv2d_3x3_f16s_kernel(Conv2dF16Args a) {
     const int q = u & 3, px = (u >> 2) & (PX - 1), ky = u >> 10;
     const int ys = y0 + (ky - 1) * d;
     xvalid[it] = (ys >= 0 && ys < H);
-    xoff[it] = (long)(xvalid[it] ? ys : y0) * rowpitch + (long)px * a.xc + 4 * q;
-    if (a.stamps && a.relu == 7) xoff[it] = (long)(xvalid[it] ? ys : y0) * (PX * 16) + (long)px * 16 + 4 * q;   // microbench: access pattern of a chunk-planar map (values meaningless)
+    xoff[it] = (long)(xvalid[it] ? ys : y0) * (PX * 16) + (long)px * 16 + 4 * q;
     xdst[it] = ((((q >> 1) * 3 + ky) * PX) + px) * 16 + (q & 1) * 8;
   }
 #define C2_LOAD_CHUNK(c)                                                                     \
   {                                                                                          \
     _Pragma("unroll") for (int it = 0; it < XIT; ++it) {                                     \
-      f32x4 v = *reinterpret_cast<const f32x4*>(xb + xoff[it] + ((a.stamps && a.relu == 7) ? (long)(c) * H * PX * 16 : 16L * (c)));   \
+      f32x4 v = *reinterpret_cast<const f32x4*>(xb + xoff[it] + (long)(c) * a.x_cs);           \
       if (!xvalid[it]) v = (f32x4)(0.f);                                                     \
       xr[it] = v;                                                                            \
     }                                                                                        \
@@ -193,9 +194,9 @@ __global__ __launch_bounds__(512) void conv2d_3x3_f16s_kernel(Conv2dF16Args a) {
   const long pix0 = (long)y0 * PX + wave * 32;
   f32x4 rres[NI];
   if (a.r) {   // residual rows, fetched before the transposition
-    const float* rp = a.r + (long)b * a.r_bs + pix0 * a.rc + lc;
+    const float* rp = a.r + (long)b * a.r_bs + (long)(lc >> 4) * a.r_cs + pix0 * 16 + (lc & 15);
 #pragma unroll
-    for (int k = 0; k < NI; ++k) rres[k] = *reinterpret_cast<const f32x4*>(rp + (long)(k * RPI + lr) * a.rc);
+    for (int k = 0; k < NI; ++k) rres[k] = *reinterpret_cast<const f32x4*>(rp + (long)(k * RPI + lr) * 16);
   }
   __syncthreads();                       // every wave is done reading the operand images
   float* tile = reinterpret_cast<float*>(smem) + wave * (32 * PITCH);
@@ -215,14 +216,14 @@ __global__ __launch_bounds__(512) void conv2d_3x3_f16s_kernel(Conv2dF16Args a) {
     }
   }
   // same-wave LDS writes and reads complete in order: no barrier needed for the wave-private tile
-  float* yp = a.y + (long)b * a.y_bs + pix0 * a.yc + lc;
+  float* yp = a.y + (long)b * a.y_bs + (long)(lc >> 4) * a.y_cs + pix0 * 16 + (lc & 15);
 #pragma unroll
   for (int k = 0; k < NI; ++k) {
     const int row = k * RPI + lr;
     f32x4 v = *reinterpret_cast<const f32x4*>(tile + row * PITCH + lc);
     if (a.r) v += rres[k];
     if (wave * 32 + row >= W) v = (f32x4)(0.f);   // keep the pad pixels of every feature map at zero
-    *reinterpret_cast<f32x4*>(yp + (long)row * a.yc) = v;
+    *reinterpret_cast<f32x4*>(yp + (long)row * 16) = v;
   }
   C2_STAMP();   // last: epilogue issued
   if (overflow && a.flag) *a.flag = 1u;
@@ -230,7 +231,7 @@ __global__ __launch_bounds__(512) void conv2d_3x3_f16s_kernel(Conv2dF16Args a) {
 
 // ---- channel-last helpers of the Decoder --------------------------------------------------------------
 // mat[i][j][c] = x[c][i] + x[c][j] (c<128); channels 128..128+nt-1 = distenc[t][i][j] (if given); other pad channels and
-// pad pixels = 0.  out [n][256][cp].  block = (cp/4 threads x 8 pixels), grid = (32, n)
+// pad pixels = 0.  out [cp/16][n][256][16].  block = (cp/4 threads x 8 pixels), grid = (32, n)
 __global__ void outer_sum_nhwc_kernel(const float* __restrict__ x, long sx_c, long sx_l, const float* __restrict__ de, long sd_c, long sd_h,
                                       long sd_w, int nt, float* __restrict__ out, int n, int cp) {
   const int c4 = threadIdx.x, j = blockIdx.x * blockDim.y + threadIdx.y, i = blockIdx.y;
@@ -245,10 +246,10 @@ __global__ void outer_sum_nhwc_kernel(const float* __restrict__ x, long sx_c, lo
       v[e] = t;
     }
   }
-  *reinterpret_cast<f32x4*>(out + ((long)i * 256 + j) * cp + 4 * c4) = v;
+  *reinterpret_cast<f32x4*>(out + (long)(c4 >> 2) * ((long)n * 256 * 16) + ((long)i * 256 + j) * 16 + 4 * (c4 & 3)) = v;
 }
 
-// bilinear / nearest x2 upsample of y [nt][n/2][n/2] into channels [c0, c0+16) of an [n][256][cp] map
+// bilinear / nearest x2 upsample of y [nt][n/2][n/2] into channels [c0, c0+16) (one chunk) of a [cp/16][n][256][16] map
 // (channels c0..c0+nt-1 = values, the rest = 0; pad pixels 0).  block 256 (pixels), grid n
 __global__ void upsample2d_nhwc_kernel(const float* __restrict__ y, long sy_c, long sy_h, long sy_w, int nt, float* __restrict__ out, int n,
                                        int cp, int c0, int bilinear) {
@@ -271,7 +272,7 @@ __global__ void upsample2d_nhwc_kernel(const float* __restrict__ y, long sy_c, l
                ly * (hx * yt[y1 * sy_h + x0 * sy_w] + lx * yt[y1 * sy_h + x1 * sy_w]);
     }
   }
-  f32x4* o = reinterpret_cast<f32x4*>(out + ((long)i * 256 + j) * cp + c0);
+  f32x4* o = reinterpret_cast<f32x4*>(out + (long)(c0 >> 4) * ((long)n * 256 * 16) + ((long)i * 256 + j) * 16);   // c0 % 16 == 0
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     f32x4 f;
@@ -280,19 +281,20 @@ __global__ void upsample2d_nhwc_kernel(const float* __restrict__ y, long sy_c, l
   }
 }
 
-// `final` head + symmetrisation on a channel-last [n][256][64] map (see final_sym_kernel)
+// `final` head + symmetrisation on a chunk-planar [4][n][256][16] map (see final_sym_kernel)
 __global__ void final_sym_nhwc_kernel(FinalArgs a) {
   ORCA_FINAL_LOAD_HEAD();
   const int j = threadIdx.x, i = blockIdx.x, b = blockIdx.y, n = a.n;
   if (j >= n) return;
   const float* cur = a.cur + (long)b * a.cur_bs;
-  const f32x4* pu = reinterpret_cast<const f32x4*>(cur + ((long)i * 256 + j) * 64);
-  const f32x4* pv = reinterpret_cast<const f32x4*>(cur + ((long)j * 256 + i) * 64);
+  const long cs4 = (long)n * 256 * 4;   // chunk stride in float4 units
+  const f32x4* pu = reinterpret_cast<const f32x4*>(cur + ((long)i * 256 + j) * 16);
+  const f32x4* pv = reinterpret_cast<const f32x4*>(cur + ((long)j * 256 + i) * 16);
   float h1[ORCA_MAX_TARGETS], h2[ORCA_MAX_TARGETS];
 #pragma unroll
   for (int o = 0; o < ORCA_MAX_TARGETS; ++o) { h1[o] = b1s[o]; h2[o] = b1s[o]; }
   for (int c4 = 0; c4 < 16; ++c4) {
-    const f32x4 u = pu[c4], v = pv[c4];
+    const f32x4 u = pu[(c4 >> 2) * cs4 + (c4 & 3)], v = pv[(c4 >> 2) * cs4 + (c4 & 3)];
 #pragma unroll
     for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -308,11 +310,11 @@ __global__ void final_sym_nhwc_kernel(FinalArgs a) {
 // doubled the number of links.  Several rows per workgroup is slower still, so it is not dispatch-bound either.
 // Per-wave s_memtime stamps (tools/microbench_c2.hip; COUT 32, 4 K-chunks, ~36 000 cycles per workgroup, two workgroups
 // resident per CU): per chunk ~8 200 cycles = issuing the next chunk's loads 2 200-2 700 (each wave-instruction touches
-// 16 half-used 128-B lines of the [px][64 ch] rows: TA-bound) + MFMA block 2 500 (the matrix pipe is shared with the
+// 16 half-used 128-B lines of the then pixel-major [px][64 ch] rows: TA-bound) + MFMA block 2 500 (the matrix pipe is shared with the
 // other resident workgroup) + barrier 1 200 + wait/split/ds_write 1 200 + barrier 1 000.  Dispatch is not the limit
-// (an empty 500-workgroup launch with the same LDS: 12 ns per workgroup).  A channel-chunk-planar feature-map layout
-// ([C/16][row][px][16]) would halve the load-issue cost; LDS-DMA from pre-split maps needs a double-buffered X image
-// (96 KB) and loses the second resident workgroup.
+// (an empty 500-workgroup launch with the same LDS: 12 ns per workgroup).  The chunk-planar layout adopted since
+// halves the load-issue cost; LDS-DMA from pre-split maps needs a double-buffered X image (96 KB) and loses the
+// second resident workgroup.
 // Also measured and dropped: one accumulator per MFMA product (acc 48 -> 144 registers for COUT 64): the block is
 // pipe-bound, not dependency-bound, and the registers cost occupancy (5.0 vs 3.7 ms); running the 64-cout layers as two 32-cout workgroups per row (67 KB LDS each, two resident
 // per CU): no change (3.72 vs 3.73 ms per Decoder); keeping TWO K-chunks of global loads in flight (register slots

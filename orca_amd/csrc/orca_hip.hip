@@ -338,9 +338,11 @@ static int launch_conv2d_f16(orca_ctx* ctx, const ConvLayer& L, const float* x, 
   if (L.ksize != 3 || !L.d_wf16) return fail(ORCA_EINVAL, "launch_conv2d_f16 on a layer without an fp16 pack");
   if (!L.f16_ok) return fail(ORCA_EINVAL, "layer weights exceed the fp16 range");
   Conv2dF16Args a;
+  const long cs = (long)n * ORCA_LDW * 16;   // chunk stride of every chunk-planar map [C/16][n][256][16]
   a.x = x; a.w = L.d_wf16; a.bias = L.d_bias; a.y = y; a.r = r; a.x_bs = x_bs; a.y_bs = y_bs; a.r_bs = r_bs;
-  a.xc = xc; a.yc = yc; a.rc = rc; a.H = n; a.W = n; a.dil = L.dil; a.nchunks = (L.cin + 15) / 16; a.relu = relu; a.flag = ctx->d_flag; a.stamps = nullptr;
+  a.x_cs = cs; a.y_cs = cs; a.r_cs = cs; a.H = n; a.W = n; a.dil = L.dil; a.nchunks = (L.cin + 15) / 16; a.relu = relu; a.flag = ctx->d_flag; a.stamps = nullptr;
   if (a.nchunks * 16 > xc) return fail(ORCA_EINVAL, "conv2d_f16: input has %d channels per pixel, layer needs %d", xc, a.nchunks * 16);
+  if (L.cout > yc || (r && L.cout > rc)) return fail(ORCA_EINVAL, "conv2d_f16: output / residual map narrower than the layer");
   static const bool no_banded = getenv("ORCA_NO_BANDED") != nullptr;   // A/B switch
   a.banded = (L.dil < 8 && n >= 64 && !no_banded) ? 1 : 0;
   dim3 grid((unsigned)(a.banded ? 8 * ((n + 7) / 8) : n), (unsigned)B);

@@ -14,7 +14,7 @@ static void run(int cin, int dil, int banded, int planar_pattern = 0) {
   hipMemcpy(x, hx.data(), hx.size() * 4, hipMemcpyHostToDevice); hipMemset(w, 0x2c, (size_t)(cin / 16) * 2 * 9 * 2 * COUT * 16);
   hipMemset(bias, 0, 256); hipMemset(r, 0, B * plane * COUT * 4); hipMemset(st, 0, 8 * 40 * 8);
   Conv2dF16Args a{}; a.x = x; a.w = w; a.bias = bias; a.y = y; a.r = r; a.x_bs = plane * cin; a.y_bs = plane * COUT; a.r_bs = plane * COUT;
-  a.xc = cin; a.yc = COUT; a.rc = COUT; a.H = n; a.W = n; a.dil = dil; a.nchunks = cin / 16; a.relu = planar_pattern ? 7 : 1; a.banded = banded; a.flag = nullptr; a.stamps = st;
+  a.x_cs = a.y_cs = a.r_cs = (long)n * 256 * 16; a.H = n; a.W = n; a.dil = dil; a.nchunks = cin / 16; a.relu = planar_pattern ? 7 : 1; a.banded = banded; a.flag = nullptr; a.stamps = st;
   dim3 grid(banded ? 256 : n, B);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1); float best = 1e9;
   for (int it = 0; it < 5; ++it) {
