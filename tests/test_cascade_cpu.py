@@ -43,7 +43,7 @@ def model32():
 def test_genomepredict_matches_reference(model32):
     g = golden("G7_cascade32.npz")
     seq = synth.synth_sequence(320000, seed=41)
-    for ci in (1, 2, 3):   # case 0 runs in test_genomepredict_targets_and_annotation; all four run on the GPU (test_gpu_e2e)
+    for ci in (1, 2):   # the clip-at-0 / clip-at-125 cases; case 0 runs in test_genomepredict_targets_and_annotation, all four on the GPU (test_gpu_e2e)
         mpos, wpos = (int(v) for v in g[f"c{ci}_args"])
         out = P.genomepredict(seq, "chrS", mpos, wpos, models=[model32], use_cuda=False)
         assert out["start_coords"] == list(g[f"c{ci}_start"])
