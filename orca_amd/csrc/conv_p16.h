@@ -22,7 +22,10 @@
 //     serialises against the in-flight DMA - 40 % slower;
 //   * LDS-DMA issued by the younger wave of each SIMD only, 16 waves of 32x64 per workgroup, inter-workgroup
 //     start stagger: all within +-1 %.  The part runs this kernel at 1.70-1.82 GHz (s_memtime / s_memrealtime),
-//     rising to 1.93 GHz with DMA, stores and LDS reads ablated: it is power-limited, not issue-limited.
+//     rising to 1.93 GHz with DMA, stores and LDS reads ablated: it is power-limited, not issue-limited;
+//   * residual units of the finishing tile fetched during the last taps of its last MFMA block instead of at the head of
+//     the epilogue (64 more live registers, 244 VGPRs, no spills): same-box A/B 42.25 vs 41.90 ms per 32 Mb Encoder -
+//     slower, although the epilogue no longer waits for the loads.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
