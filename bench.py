@@ -65,7 +65,7 @@ def cpu_baseline(seed):
     from tests.util import synth_sd
     ncores = usable_cores()
     torch.set_num_threads(ncores)
-    sample_bp = 4_000_000
+    sample_bp = 8_000_000   # 10 reference blocks: ~13 s on the GPU box's 16 host cores, ~15 s with the rest
     x = torch.from_numpy(synth.synth_sequence(sample_bp, seed=1)).transpose(1, 2)
     sd0 = synth_sd("Encoder", seed)
     O.encoder_forward(sd0, x[:, :, :912000])  # warm-up
@@ -86,7 +86,7 @@ def cpu_baseline(seed):
     t_rest = time.perf_counter() - t
     t_strand = t_enc * (L_BP / sample_bp) + t_rest
     return {"value": round(L_BP / 1e6 / t_strand, 4), "unit": "Mb/s", "cores": ncores, "kind": "port",
-            "sample": f"Encoder on {sample_bp // 1000000} Mb (5 reference blocks, {t_enc:.1f}s, scaled x{L_BP // sample_bp}) + "
+            "sample": f"Encoder on {sample_bp // 1000000} Mb ({sample_bp // 800000} reference blocks, {t_enc:.1f}s, scaled x{L_BP // sample_bp}) + "
                       f"Encoder2(8000 bins) + 6 Decoder + Decoder_1m ({t_rest:.1f}s), torch CPU fp32, {ncores} threads",
             "t_encoder_sample_s": round(t_enc, 2), "t_decoders_s": round(t_rest, 2)}
 
