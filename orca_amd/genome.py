@@ -12,6 +12,8 @@ input (`orca_encoder_forward_codes`) without ever expanding to floats.
 One-hot encoding parity is unpinned by the reference (selene is not vendored): A,C,G,T in that channel
 order, case-insensitive, every other symbol -> 0.25 x 4, consistent with `selene_utils2.py:216-222,272`.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -59,21 +61,79 @@ class PackedGenome:
 
     # ---- construction ------------------------------------------------------------------------------------
     @classmethod
-    def from_fasta(cls, path):
-        """Plain multi-FASTA reader (the reference indexes with pyfaidx; no index is needed when every
-        chromosome is packed in memory once)."""
-        chroms, name, parts = {}, None, []
+    def from_fasta(cls, path, chroms=None):
+        """Multi-FASTA reader.  With ``chroms`` (an iterable of names) only those records are packed; if a samtools
+        ``.fai`` index sits next to the file (``path + ".fai"``, the reference's pyfaidx layout: name, length, byte
+        offset, bases per line, bytes per line) each wanted record is read with one seek instead of a scan of the whole
+        file.  The reference indexes with pyfaidx (selene_utils2.py:97-140)."""
+        want = None if chroms is None else {str(c) for c in chroms}
+        fai = path + ".fai"
+        if want is not None and os.path.exists(fai):
+            return cls(cls._read_indexed(path, fai, want))
+        out, name, parts = {}, None, []
+
+        def flush():
+            if name is not None and (want is None or name in want):
+                out[name] = np.concatenate(parts) if parts else np.zeros(0, np.uint8)
+
+        with open(path, "rb") as f:
+            for line in f:
+                if line.startswith(b">"):
+                    flush()
+                    name, parts = line[1:].split()[0].decode("ascii"), []
+                elif want is None or name in want:
+                    parts.append(sequence_to_codes(line.strip()))
+        flush()
+        if want is not None and want - set(out):
+            raise KeyError(f"{path}: no record named {sorted(want - set(out))}")
+        return cls(out)
+
+    @staticmethod
+    def _read_indexed(path, fai, want):
+        index = {}
+        with open(fai) as f:
+            for line in f:
+                p = line.rstrip("\n").split("\t")
+                if len(p) >= 5:
+                    index[p[0]] = tuple(int(v) for v in p[1:5])
+        missing = want - set(index)
+        if missing:
+            raise KeyError(f"{fai}: no record named {sorted(missing)}")
+        out = {}
+        with open(path, "rb") as f:
+            for name in sorted(want, key=lambda c: index[c][1]):
+                length, offset, linebases, linewidth = index[name]
+                nlines = (length + linebases - 1) // linebases if linebases else 0
+                f.seek(offset)
+                raw = np.frombuffer(f.read(length + nlines * (linewidth - linebases)), dtype=np.uint8)
+                codes = _LUT[raw[(raw != 10) & (raw != 13)]]     # drop the line ends
+                if codes.shape[0] < length:
+                    raise ValueError(f"{path}: record {name} is shorter than its index entry ({codes.shape[0]} < {length})")
+                out[name] = codes[:length]
+        return out
+
+    @staticmethod
+    def write_fai(path):
+        """Write ``path + ".fai"`` (samtools faidx format) for a FASTA with uniform line lengths per record."""
+        rows, name, length, offset, lb, lw, pos = [], None, 0, 0, 0, 0, 0
         with open(path, "rb") as f:
             for line in f:
                 if line.startswith(b">"):
                     if name is not None:
-                        chroms[name] = np.concatenate(parts) if parts else np.zeros(0, np.uint8)
-                    name, parts = line[1:].split()[0].decode("ascii"), []
+                        rows.append((name, length, offset, lb, lw))
+                    name, length, offset, lb, lw = line[1:].split()[0].decode("ascii"), 0, pos + len(line), 0, 0
                 else:
-                    parts.append(sequence_to_codes(line.strip()))
+                    n = len(line.rstrip(b"\r\n"))
+                    if lb == 0:
+                        lb, lw = n, len(line)
+                    length += n
+                pos += len(line)
         if name is not None:
-            chroms[name] = np.concatenate(parts) if parts else np.zeros(0, np.uint8)
-        return cls(chroms)
+            rows.append((name, length, offset, lb, lw))
+        with open(path + ".fai", "w") as f:
+            for r in rows:
+                f.write("\t".join(str(v) for v in r) + "\n")
+        return path + ".fai"
 
     @classmethod
     def random(cls, lengths, seed=0, n_runs=0, fast=False):

@@ -1,0 +1,61 @@
+"""PackedGenome: the selene query API of the reference's MemmapGenome (selene_utils2.py:38-272) on 1 byte/base storage.
+The reference pins no encoding test (selene is not vendored); the semantics asserted here are the ones its code
+states: channel order A,C,G,T, unknown symbols 0.25 x 4, '-' strand = both axes flipped, pad = 0.25 beyond the ends."""
+import numpy as np
+import pytest
+
+from orca_amd.genome import PackedGenome, codes_to_encoding, revcomp_codes, sequence_to_codes, sequence_to_encoding
+
+
+def _write_fasta(path, records, width=60):
+    with open(path, "w") as f:
+        for name, seq in records.items():
+            f.write(f">{name} some description\n")
+            for i in range(0, len(seq), width):
+                f.write(seq[i:i + width] + "\n")
+
+
+@pytest.fixture
+def fasta(tmp_path):
+    rs = np.random.RandomState(5)
+    recs = {f"chr{k}": "".join(rs.choice(list("ACGTacgtNRY"), size=n)) for k, n in ((1, 1234), (2, 60), (3, 7), (4, 0), (5, 601))}
+    p = str(tmp_path / "g.fa")
+    _write_fasta(p, recs)
+    return p, recs
+
+
+def test_fasta_scan_and_indexed_reads_agree(fasta):
+    path, recs = fasta
+    g = PackedGenome.from_fasta(path)
+    assert g.get_chr_lens() == sorted((k, len(v)) for k, v in recs.items())
+    for k, v in recs.items():
+        assert np.array_equal(g.get_codes_from_coords(k, 0, len(v)), sequence_to_codes(v))
+    sub = PackedGenome.from_fasta(path, chroms=["chr5", "chr2"])          # no index yet: scan, selected records only
+    assert sub.get_chrs() == ["chr2", "chr5"]
+    PackedGenome.write_fai(path)
+    idx = PackedGenome.from_fasta(path, chroms=["chr5", "chr1", "chr4", "chr3"])   # one seek per record
+    for k in ("chr1", "chr3", "chr4", "chr5"):
+        assert np.array_equal(idx.get_codes_from_coords(k, 0, len(recs[k])), sequence_to_codes(recs[k])), k
+    with pytest.raises(KeyError):
+        PackedGenome.from_fasta(path, chroms=["chrX"])
+
+
+def test_encoding_semantics():
+    enc = sequence_to_encoding("ACGTNacgtR")
+    assert enc.dtype == np.float32 and enc.shape == (10, 4)
+    assert np.array_equal(enc[:4], np.eye(4, dtype=np.float32)) and np.array_equal(enc[5:9], np.eye(4, dtype=np.float32))
+    assert np.all(enc[4] == 0.25) and np.all(enc[9] == 0.25)
+    g = PackedGenome({"c": sequence_to_codes("AACCGGTTNN")})
+    plus = g.get_encoding_from_coords("c", 2, 8)
+    minus = g.get_encoding_from_coords("c", 2, 8, strand="-")
+    assert np.array_equal(minus, plus[::-1, ::-1])                       # selene_utils2.py:227-228
+    assert np.array_equal(codes_to_encoding(revcomp_codes(g.get_codes_from_coords("c", 2, 8))), minus)
+    padded = g.get_encoding_from_coords("c", -3, 12, pad=True)
+    assert padded.shape == (15, 4) and np.all(padded[:3] == 0.25) and np.all(padded[13:] == 0.25)
+    assert np.array_equal(padded[3:13], g.get_encoding_from_coords("c", 0, 10))
+    with pytest.raises(AssertionError):
+        g.get_encoding_from_coords("c", 5, 11)                           # beyond the end without pad (selene_utils2.py:257)
+    _, unk = g.get_encoding_from_coords_check_unk("c", 8, 10)
+    assert unk                                                           # looks at the first row only (:264-272)
+    _, unk = g.get_encoding_from_coords_check_unk("c", 7, 10)
+    assert not unk
