@@ -26,6 +26,12 @@
 //   * residual units of the finishing tile fetched during the last taps of its last MFMA block instead of at the head of
 //     the epilogue (64 more live registers, 244 VGPRs, no spills): same-box A/B 42.25 vs 41.90 ms per 32 Mb Encoder -
 //     slower, although the epilogue no longer waits for the loads.
+// Power: with all-zero operands (the micro-benchmarks' inputs) the plain 64->64 launch at n = 32 M takes 4.3 ms, with
+// real activations and weights 6.2 ms - same instruction stream, the matrix pipe's switching power sets the clock.
+// Fused first layer (F1), cost split on zero data (ABL 1024 / 2048 / 4096 / 8192 = no halo tail / no image writes / no
+// table reads / no in-loop producer): fused 5.36 ms vs 4.11 without the producer; tail 0.15, table reads 0.20, image
+// writes 0.03 - the remaining 0.8 ms is the producer's VALU stream itself (window decode, 36 adds, range guard, split,
+// zero-select per position and quad).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -291,7 +297,7 @@ __global__ __launch_bounds__(WM * 64, WM / 4) void conv1d_k9_p16_kernel(ConvP16A
   // (a 250-cycle round trip under load; done naively a quad is 4 of them and stalls the wave's MFMAs for a microsecond).
   // Half h of quad q: h = 0 -> bias + rows 0..3, h = 1 -> rows 4..8.  At most 8 + 5 + 2 LDS operations are in flight.
 #define P16_F1_ISSUE(quad_, half_, kc_)                                                                            \
-  {                                                                                                                \
+  if (!(ABL & 4096)) {                                                                                             \
     if ((half_) == 0) {                                                                                            \
       f1_r[0] = p16_lds_read16f(f1_b_lds + 64 * (kc_), (quad_) * 16);                                              \
       _Pragma("unroll") for (int t_ = 0; t_ < 4; ++t_) f1_r[1 + t_] = p16_lds_read16f(f1_off[t_], (quad_) * 16);   \
@@ -311,8 +317,10 @@ __global__ __launch_bounds__(WM * 64, WM / 4) void conv1d_k9_p16_kernel(ConvP16A
       const unsigned xd_ = smem_lds + (unsigned)((buf_) * BU * 16) + (unsigned)((i_) * 16);                        \
       u32x2 hh_, ll_;                                                                                              \
       hh_.x = h0_; hh_.y = h1_; ll_.x = l0_; ll_.y = l1_;                                                          \
+      if (ABL & 2048) { asm volatile("" ::"v"(hh_), "v"(ll_), "v"(xd_)); } else {                                  \
       p16_lds_write8(xd_, hh_, ((quad_) >> 1) * XROW * 16 + ((quad_) & 1) * 8);                                    \
       p16_lds_write8(xd_, ll_, (2 + ((quad_) >> 1)) * XROW * 16 + ((quad_) & 1) * 8);                              \
+      }                                                                                                            \
     }                                                                                                              \
   }
   f32x4 f1_r[5], f1_v = (f32x4)(0.f);
@@ -509,13 +517,13 @@ __global__ __launch_bounds__(WM * 64, WM / 4) void conv1d_k9_p16_kernel(ConvP16A
         // all LDS reads issued so far (this tap's fragments, the producer's half quad of the previous tap) have had a whole
         // tap to land: retire them together; the fragment wait further down then only orders the MFMAs
         p16_f1_wait0<MW, NW>(av[fb], bv[fb], f1_r);
-        if (more) {   // the next step's input image, position `tid`: tap t consumes half-quad t-1 and issues half-quad t
+        if (more && !(ABL & 8192)) {   // the next step's input image, position `tid`: tap t consumes half-quad t-1 and issues half-quad t
           if (tap >= 1) P16_F1_CONSUME(tid, (tap - 1) >> 1, (tap - 1) & 1, cur ^ 1);
           if (tap == 0) P16_F1_WINDOW(tid, f1_m0, f1_ws, nc);
           if (tap < 8) P16_F1_ISSUE(tap >> 1, tap & 1, nc);
           // the XROW - NT = 8 halo positions beyond the threads: lanes 0..7 of waves 0..3 (one per SIMD), wave q computes
           // channel quad q of all eight - un-pipelined (4 LDS round trips), after this wave's own last half quad
-          if (tap == 8 && wave < 4 && lane < XROW - NT) {
+          if (tap == 8 && wave < 4 && lane < XROW - NT && !(ABL & 1024)) {
             P16_F1_WINDOW(NT + lane, f1_m0, f1_ws, nc);
             if (wave == 0) { P16_F1_QUAD(NT + lane, 0, nc, cur ^ 1) }
             else if (wave == 1) { P16_F1_QUAD(NT + lane, 1, nc, cur ^ 1) }
