@@ -27,7 +27,8 @@
 //     the epilogue (64 more live registers, 244 VGPRs, no spills): same-box A/B 42.25 vs 41.90 ms per 32 Mb Encoder -
 //     slower, although the epilogue no longer waits for the loads.
 // Power: with all-zero operands (the micro-benchmarks' inputs) the plain 64->64 launch at n = 32 M takes 4.3 ms, with
-// real activations and weights 6.2 ms - same instruction stream, the matrix pipe's switching power sets the clock.
+// real activations and weights 6.2 ms - same instruction stream, the matrix pipe's switching power sets the clock
+// (issuing the MFMAs so that the W operand stays unchanged for 2*MW consecutive instructions: no difference).
 // Fused first layer (F1), cost split on zero data (ABL 1024 / 2048 / 4096 / 8192 = no halo tail / no image writes / no
 // table reads / no in-loop producer): fused 5.36 ms vs 4.11 without the producer; tail 0.15, table reads 0.20, image
 // writes 0.03 - the remaining 0.8 ms is the producer's VALU stream itself (window decode, 36 adds, range guard, split,
