@@ -26,6 +26,13 @@
 //   * residual units of the finishing tile fetched during the last taps of its last MFMA block instead of at the head of
 //     the epilogue (64 more live registers, 244 VGPRs, no spills): same-box A/B 42.25 vs 41.90 ms per 32 Mb Encoder -
 //     slower, although the epilogue no longer waits for the loads.
+//   * ONE wave per SIMD (4 waves of 128 x 64, accumulators in AGPRs - 184 VGPRs + 128 AGPRs, no spills; parity green):
+//     42.4 vs 41.0 ms per 32 Mb Encoder.  With the upper half of a finished tile parked in 64 more AGPRs (asm "a"
+//     operands: left alone the compiler moves the parked copy to VGPRs and spills; parking all 128 leaves no AGPR for
+//     the spills - scratch traffic, 70 ms) and its epilogue issued piece by piece BETWEEN the MFMAs of the next tile's
+//     first step (sched_barrier after every MFMA): 42.7 ms.  The epilogue overlap buys nothing because the 4-wave form
+//     pays elsewhere: every wave issues 18 instead of 9 LDS-DMA pieces per step (100-180 cycles each, in order, with no
+//     second wave on the SIMD to issue MFMAs meanwhile).
 // Power: with all-zero operands (the micro-benchmarks' inputs) the plain 64->64 launch at n = 32 M takes 4.3 ms, with
 // real activations and weights 6.2 ms - same instruction stream, the matrix pipe's switching power sets the clock
 // (issuing the MFMAs so that the W operand stays unchanged for 2*MW consecutive instructions: no difference).
