@@ -33,6 +33,9 @@
 //     first step (sched_barrier after every MFMA): 42.7 ms.  The epilogue overlap buys nothing because the 4-wave form
 //     pays elsewhere: every wave issues 18 instead of 9 LDS-DMA pieces per step (100-180 cycles each, in order, with no
 //     second wave on the SIMD to issue MFMAs meanwhile).
+//   * two dedicated DMA waves per workgroup (10 waves: waves 8-9 issue all 70 pieces of a step, piece addresses computed
+//     on the fly; parity green): three waves on two of the SIMDs cap the kernel at 168 VGPRs, the matrix waves' path
+//     then spills (170-500 bytes of scratch per lane) - 58 vs 40 ms.  Needs a register diet of the matrix path first.
 // Power: with all-zero operands (the micro-benchmarks' inputs) the plain 64->64 launch at n = 32 M takes 4.3 ms, with
 // real activations and weights 6.2 ms - same instruction stream, the matrix pipe's switching power sets the clock
 // (issuing the MFMAs so that the W operand stays unchanged for 2*MW consecutive instructions: no difference).
