@@ -43,7 +43,7 @@
 // bits of every lo half cleared (17 significant bits), 40.2 / 39.75 ms with 3 / 5 low bits of every hi half cleared (the
 // exact residual in lo: 19 / 17 bits), 37.9 ms with lo reduced to sign and exponent.  Not used: 2 % for 4-5 bits of
 // the fp32-class precision the parity claim rests on.
-// Fused first layer (F1), cost split on zero data (ABL 1024 / 2048 / 4096 / 8192 = no halo tail / no image writes / no
+// Fused first layer (F1), cost split on zero data (`tools/microbench_f1.hip`; ABL 1024 / 2048 / 4096 / 8192 = no halo tail / no image writes / no
 // table reads / no in-loop producer): fused 5.36 ms vs 4.11 without the producer; tail 0.15, table reads 0.20, image
 // writes 0.03 - the remaining 0.8 ms is the producer's VALU stream itself (window decode, 36 adds, range guard, split,
 // zero-select per position and quad).
