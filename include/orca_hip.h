@@ -237,6 +237,11 @@ int orca_conv1d_nlc_forward(orca_ctx* ctx, const orca_conv_desc* conv, int preci
  * out_mode 0/1 round-trip through the planar split-fp16 storage, out_mode 2 writes fp32 directly. */
 int orca_conv1d_p16_forward(orca_ctx* ctx, const orca_conv_desc* conv, const float* x, float* y, const float* r1,
                             int64_t n, int relu, int out_mode);
+/* The same kernel on "B16" activations - ONE bf16 plane per 8 channels, plain bf16 operands, one MFMA product,
+ * 32 input channels per step (the ORCA_PRECISION_BF16 Encoder of BASELINE config 3); cin % 32 == 0.  Inputs
+ * and outputs are rounded to bf16 on the way through the planar storage (out_mode 2 writes fp32). */
+int orca_conv1d_b16_forward(orca_ctx* ctx, const orca_conv_desc* conv, const float* x, float* y, const float* r1,
+                            int64_t n, int relu, int out_mode);
 /* y = [relu](conv2d_3x3_dilated(x) + b) [+ r]; x: contiguous [B,cin,n,n], y/r: [B,cout,n,n]. */
 int orca_conv2d_forward(orca_ctx* ctx, const orca_conv_desc* conv, const float* x, float* y, const float* r,
                         int B, int n, int relu);

@@ -223,9 +223,17 @@ __device__ __forceinline__ void p16_lds_wait(f16x8 (&a)[2][MW], f16x8 (&b)[2][NW
 // code: 13.8 KB of LDS), i.e. per step and thread 4 x (9 ds_read_b128 + 36 adds + hi/lo split + 2 ds_write_b64) - cheaper
 // than the DMA of the same 33 KB (timing emulation: 5.07 vs 5.96 ms for 32 M positions) and the first-layer kernel with
 // its 8 GB store / re-load of the 64-channel tensor disappears (2.4 ms per strand).
-template <int CT, int MW, int NW, int WM, int OM, bool R1, int ABL = 0, bool F1 = false>
+// FMT = 0: P16 (2-way split fp16, 3 products, 16 input channels per step).
+// FMT = 1: "B16" - ONE bf16 plane per 8 channels (2 bytes per element, the throughput mode of BASELINE config 3), one
+//   product, 32 input channels per step.  The LDS image of a step has the same shape in both formats - the split index
+//   s of P16 becomes the k-pair index of B16 (channels 16 s + 8 g + e of the step's 32) - so the DMA geometry, the
+//   fragment reads and the counted waits are shared; only the product list and the epilogue differ.
+//   B16 planes: unit(p = ch/8, pos) at base + (p * PLEN + 4 + pos) * 16 bytes, guards as in P16.
+//   B16 weight pack: [cin/32][2 k-pairs][9][2][cout][8] bf16.
+template <int CT, int MW, int NW, int WM, int OM, bool R1, int ABL = 0, bool F1 = false, int FMT = 0>
 __global__ __launch_bounds__(WM * 64, WM / 4) void conv1d_k9_p16_kernel(ConvP16Args a) {
   static_assert(!F1 || (CT == 64 && WM == 8 && MW == 2), "fused first layer: 64-cout tiles of 512 positions");
+  static_assert(!F1 || FMT == 0, "fused first layer: P16 only");
   static_assert(NW * 32 == CT, "one wave covers all couts of the tile");
   constexpr int NT = WM * 64;
   constexpr int MT = WM * MW * 32;
@@ -356,7 +364,7 @@ __global__ __launch_bounds__(WM * 64, WM / 4) void conv1d_k9_p16_kernel(ConvP16A
     if (isx[it]) {
       const int row = i / XROW, col = i - row * XROW;      // row = s*2 + g
       const int s = row >> 1, gg = row & 1;
-      xrel[it] = (int)((gg * 2 + s) * a.x_plen) + col;
+      xrel[it] = (int)((FMT == 1 ? (s * 2 + gg) : (gg * 2 + s)) * a.x_plen) + col;
     } else {
       const int u = (i < BU ? i : BU - 1) - XU;
       const int grp = u / CT, cc = u - grp * CT;           // grp = (s*9 + tap)*2 + g
@@ -400,7 +408,66 @@ __global__ __launch_bounds__(WM * 64, WM / 4) void conv1d_k9_p16_kernel(ConvP16A
 
   // Runs at the START of the next step (after the barrier that drained this step's DMA): its stores drain
   // underneath that step's MFMA block and are retired by the step's closing barrier.
-#define P16_EPILOGUE()                                                                                           \
+#define P16_EPILOGUE_B16()                                                                                       \
+  {                                                                                                              \
+    const long tcb = epi_tile / a.tiles_per_row;                                                                 \
+    const long m0 = (epi_tile - tcb * a.tiles_per_row) * MT + wave * (MW * 32);                                  \
+    u32x4_t rr[R1 ? NG / 2 : 1];                                                                                 \
+    if (R1) {                                                                                                    \
+      _Pragma("unroll") for (int i = 0; i < MW; ++i) _Pragma("unroll") for (int j = 0; j < NW; ++j) _Pragma("unroll") for (int qp = 0; qp < 2; ++qp) { \
+        const char* rb_ = reinterpret_cast<const char*>(a.r1) + (long)(((int)tcb * CT + j * 32) / 8 + 2 * qp) * xpl16 + (P16_GUARD + m0 + i * 32) * 16; \
+        rr[(i * NW + j) * 2 + qp] = *reinterpret_cast<const u32x4_t*>(rb_ + lane_res);                           \
+      }                                                                                                          \
+    }                                                                                                            \
+    _Pragma("unroll") for (int i = 0; i < MW; ++i) _Pragma("unroll") for (int j = 0; j < NW; ++j) _Pragma("unroll") for (int qp = 0; qp < 2; ++qp) { \
+      const int co = (int)tcb * CT + j * 32 + 16 * qp;   /* q0 = 2 qp: couts co + 4g .. +3, q1: co + 8 + 4g .. */ \
+      const long p0 = m0 + i * 32;                       /* + l31 per lane */                                    \
+      f32x4 v0, v1;                                                                                              \
+      v0.x = fmaxf(acc[i][j][8 * qp + 0], relu_lo); v0.y = fmaxf(acc[i][j][8 * qp + 1], relu_lo);                \
+      v0.z = fmaxf(acc[i][j][8 * qp + 2], relu_lo); v0.w = fmaxf(acc[i][j][8 * qp + 3], relu_lo);                \
+      v1.x = fmaxf(acc[i][j][8 * qp + 4], relu_lo); v1.y = fmaxf(acc[i][j][8 * qp + 5], relu_lo);                \
+      v1.z = fmaxf(acc[i][j][8 * qp + 6], relu_lo); v1.w = fmaxf(acc[i][j][8 * qp + 7], relu_lo);                \
+      if (R1) {   /* the lane loaded the whole unit of plane 2 qp + g: trade halves with lane l +- 32 */          \
+        const u32x4_t u_ = rr[(i * NW + j) * 2 + qp];                                                            \
+        unsigned ux_ = u_.x, uy_ = u_.y, uz_ = u_.z, uw_ = u_.w;                                                 \
+        p16_swap32(ux_, uz_);   /* ux, uy = couts 4g..4g+3 of q0;  uz, uw = the same of q1 */                    \
+        p16_swap32(uy_, uw_);                                                                                    \
+        v0.x += bf16lo_f32(ux_); v0.y += bf16hi_f32(ux_); v0.z += bf16lo_f32(uy_); v0.w += bf16hi_f32(uy_);      \
+        v1.x += bf16lo_f32(uz_); v1.y += bf16hi_f32(uz_); v1.z += bf16lo_f32(uw_); v1.w += bf16hi_f32(uw_);      \
+      }                                                                                                          \
+      if (OM == 2) {                                                                                             \
+        if (p0 + l31 < a.n) {                                                                                    \
+          char* o_ = reinterpret_cast<char*>(a.y) + (p0 * a.cout + co) * 4 + lane_f32;                           \
+          *reinterpret_cast<f32x4*>(o_) = v0;                                                                    \
+          *reinterpret_cast<f32x4*>(o_ + 32) = v1;                                                               \
+        }                                                                                                        \
+      } else {                                                                                                   \
+        bool ok_ = p0 + l31 < a.n;                                                                               \
+        if (OM == 1) {                                                                                           \
+          v0.x = p16_dpp_quad_max(v0.x); v0.y = p16_dpp_quad_max(v0.y); v0.z = p16_dpp_quad_max(v0.z); v0.w = p16_dpp_quad_max(v0.w); \
+          v1.x = p16_dpp_quad_max(v1.x); v1.y = p16_dpp_quad_max(v1.y); v1.z = p16_dpp_quad_max(v1.z); v1.w = p16_dpp_quad_max(v1.w); \
+          ok_ = p0 + (l31 | 3) < a.n;                                                                            \
+        }                                                                                                        \
+        if (!ok_) { v0 = (f32x4)(0.f); v1 = (f32x4)(0.f); }                                                      \
+        unsigned a0_ = cvt_pk_bf16(v0.x, v0.y), a1_ = cvt_pk_bf16(v0.z, v0.w);                                   \
+        unsigned b0_ = cvt_pk_bf16(v1.x, v1.y), b1_ = cvt_pk_bf16(v1.z, v1.w);                                   \
+        p16_swap32(a0_, b0_);   /* g=0: {a, b} = couts 0-3 | 4-7 of plane 2 qp;  g=1: of plane 2 qp + 1 */       \
+        p16_swap32(a1_, b1_);                                                                                    \
+        u32x4_t unit_;                                                                                           \
+        unit_.x = a0_; unit_.y = a1_; unit_.z = b0_; unit_.w = b1_;                                              \
+        char* yb_ = reinterpret_cast<char*>(a.y) + (long)(co >> 3) * ypl16;                                      \
+        if (ABL & 16) {                                                                                          \
+          asm volatile("" ::"v"(unit_));                                                                         \
+        } else if (OM == 0) {                                                                                    \
+          *reinterpret_cast<u32x4_t*>(yb_ + (P16_GUARD + p0) * 16 + lane_unit) = unit_;                          \
+        } else {                                                                                                 \
+          const unsigned d01_ = (quad_r & 1) ? unit_.y : unit_.x, d23_ = (quad_r & 1) ? unit_.w : unit_.z;       \
+          *reinterpret_cast<unsigned*>(yb_ + (P16_GUARD + (p0 >> 2)) * 16 + lane_pool) = (quad_r & 2) ? d23_ : d01_; \
+        }                                                                                                        \
+      }                                                                                                          \
+    }                                                                                                            \
+  }
+#define P16_EPILOGUE_P16()                                                                                       \
   {                                                                                                              \
     const long tcb = epi_tile / a.tiles_per_row;                                                                 \
     const long m0 = (epi_tile - tcb * a.tiles_per_row) * MT + wave * (MW * 32);                                  \
@@ -458,6 +525,7 @@ __global__ __launch_bounds__(WM * 64, WM / 4) void conv1d_k9_p16_kernel(ConvP16A
       }                                                                                                          \
     }                                                                                                            \
   }
+#define P16_EPILOGUE() { if constexpr (FMT == 1) P16_EPILOGUE_B16() else P16_EPILOGUE_P16() }
 
   P16_SRC(tile, 0);
 #pragma unroll
@@ -556,6 +624,15 @@ __global__ __launch_bounds__(WM * 64, WM / 4) void conv1d_k9_p16_kernel(ConvP16A
       if (F1) p16_lds_wait<15, MW, NW>(av[fb], bv[fb]);                      // already retired above: ordering only
       else if (tap + 1 < 9) p16_lds_wait<2 * (MW + NW), MW, NW>(av[fb], bv[fb]);   // this tap's fragments are in, the next tap's stay in flight
       else p16_lds_wait<0, MW, NW>(av[fb], bv[fb]);
+      if constexpr (FMT == 1) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p)   // the two k-pairs of the step's 32 input channels
+#pragma unroll
+          for (int i = 0; i < MW; ++i)
+#pragma unroll
+            for (int j = 0; j < NW; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bv[fb][p][j]), __builtin_bit_cast(bf16x8, av[fb][p][i]), acc[i][j], 0, 0, 0);
+      } else {
 #pragma unroll
       for (int p = 0; p < 3; ++p) {
         constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};   // lo*hi, hi*lo, hi*hi (largest last)
@@ -564,6 +641,7 @@ __global__ __launch_bounds__(WM * 64, WM / 4) void conv1d_k9_p16_kernel(ConvP16A
 #pragma unroll
           for (int j = 0; j < NW; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bv[fb][PB[p]][j], av[fb][PA[p]][i], acc[i][j], 0, 0, 0);  // D[cout][pos]
+      }
       }
       if ((ABL & 128) && blockIdx.x == 0 && lane == 0 && nstamp == 250 && (wave & 3) == 0) a.stamps[8100 + (wave >> 2) * 16 + tap] = __builtin_readcyclecounter();   // per-tap stamps of waves 0 and 4, one step
       __builtin_amdgcn_sched_barrier(0);
@@ -590,6 +668,8 @@ __global__ __launch_bounds__(WM * 64, WM / 4) void conv1d_k9_p16_kernel(ConvP16A
     a.stamps[8191] = __builtin_amdgcn_s_memrealtime() - rt0;
   }
 #undef P16_EPILOGUE
+#undef P16_EPILOGUE_P16
+#undef P16_EPILOGUE_B16
 #undef P16_ACC_INIT
 #undef P16_DMA_ONE
 #undef P16_SRC
@@ -597,7 +677,7 @@ __global__ __launch_bounds__(WM * 64, WM / 4) void conv1d_k9_p16_kernel(ConvP16A
 #undef P16_F1_ISSUE
 #undef P16_F1_QUAD
 #undef P16_F1_WINDOW
-  if (OM != 2 && vmax > 65504.f && a.flag) *a.flag = 1u;
+  if (FMT == 0 && OM != 2 && vmax > 65504.f && a.flag) *a.flag = 1u;
 }
 
 // zero the guard / tail units of every plane: [0,4) and [4 + n_valid, plen)
@@ -690,7 +770,8 @@ struct FirstMfmaArgs {
 };
 
 // ABL (tools/microbench_first.hip only): 1 = no MFMA, 16 = no stores, 32 = input not re-fetched per tile
-template <int ABL = 0>
+// FMT = 1: the output is B16 (one bf16 plane per 8 channels) instead of P16; the arithmetic is unchanged.
+template <int ABL = 0, int FMT = 0>
 __global__ __launch_bounds__(256, 2) void conv1d_first_mfma_p16_kernel(FirstMfmaArgs a) {
   constexpr int MT = 256, WIN = MT + 12;          // positions m0-4 .. m0+MT+7 (9-tap window + k padding overrun)
   constexpr int WU = 2 * 3 * 2 * 64;              // 768 units
@@ -777,6 +858,29 @@ __global__ __launch_bounds__(256, 2) void conv1d_first_mfma_p16_kernel(FirstMfma
     // (g = 0: the hi unit, g = 1: the lo unit); positions >= n get zeros (they are tail guard units of the plane)
     const long ypl = a.y_plen * 16;
     const unsigned lane_unit = (unsigned)(l31 * 16) + (g ? (unsigned)ypl : 0u);
+    if constexpr (FMT == 1) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const long p0 = tile * MT + wave * 64 + i * 32;
+        const bool ok = p0 + l31 < a.n;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int qp = 0; qp < 2; ++qp) {
+            f32x4 v0, v1;
+            v0.x = acc[i][j][8 * qp + 0]; v0.y = acc[i][j][8 * qp + 1]; v0.z = acc[i][j][8 * qp + 2]; v0.w = acc[i][j][8 * qp + 3];
+            v1.x = acc[i][j][8 * qp + 4]; v1.y = acc[i][j][8 * qp + 5]; v1.z = acc[i][j][8 * qp + 6]; v1.w = acc[i][j][8 * qp + 7];
+            if (!ok) { v0 = (f32x4)(0.f); v1 = (f32x4)(0.f); }
+            unsigned a0 = cvt_pk_bf16(v0.x, v0.y), a1 = cvt_pk_bf16(v0.z, v0.w), b0 = cvt_pk_bf16(v1.x, v1.y), b1 = cvt_pk_bf16(v1.z, v1.w);
+            p16_swap32(a0, b0);
+            p16_swap32(a1, b1);
+            u32x4_t unit;
+            unit.x = a0; unit.y = a1; unit.z = b0; unit.w = b1;
+            *reinterpret_cast<u32x4_t*>(reinterpret_cast<char*>(a.y) + (long)(j * 4 + 2 * qp) * ypl + (P16_GUARD + p0) * 16 + lane_unit) = unit;
+          }
+      }
+      continue;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const long p0 = tile * MT + wave * 64 + i * 32;
@@ -802,7 +906,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_first_mfma_p16_kernel(FirstMfma
     }
   }
   if (vmax > 65504.f) overflow = true;
-  if (overflow && a.flag) *a.flag = 1u;
+  if (FMT == 0 && overflow && a.flag) *a.flag = 1u;
 }
 
 // ---- packed sequence helpers --------------------------------------------------------------------------------
@@ -848,6 +952,29 @@ __global__ void nlc_to_p16_kernel(const float* __restrict__ x, f32x4* __restrict
   const f32x4 v = *reinterpret_cast<const f32x4*>(x + pos * C + 4 * c4);
   bool ovf = false;
   p16_split_store(reinterpret_cast<char*>(y) + (long)(c4 >> 1) * 2 * plen * 16 + (P16_GUARD + pos) * 16 + (c4 & 1) * 8, plen * 16, v, true, ovf);
+}
+// fp32 channel-last [n][C] -> B16 (one bf16 plane per 8 channels), and back
+__global__ void nlc_to_b16_kernel(const float* __restrict__ x, f32x4* __restrict__ y, long n, int C, long plen) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c4n = C / 4;
+  if (idx >= n * c4n) return;
+  const long pos = idx / c4n;
+  const int c4 = (int)(idx - pos * c4n);
+  const f32x4 v = *reinterpret_cast<const f32x4*>(x + pos * C + 4 * c4);
+  u32x2 pk;
+  pk.x = cvt_pk_bf16(v.x, v.y); pk.y = cvt_pk_bf16(v.z, v.w);
+  *reinterpret_cast<u32x2*>(reinterpret_cast<char*>(y) + (long)(c4 >> 1) * plen * 16 + (P16_GUARD + pos) * 16 + (c4 & 1) * 8) = pk;
+}
+__global__ void b16_to_nlc_kernel(const f32x4* __restrict__ x, float* __restrict__ y, long n, int C, long plen) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c4n = C / 4;
+  if (idx >= n * c4n) return;
+  const long pos = idx / c4n;
+  const int c4 = (int)(idx - pos * c4n);
+  const u32x2 pk = *reinterpret_cast<const u32x2*>(reinterpret_cast<const char*>(x) + (long)(c4 >> 1) * plen * 16 + (P16_GUARD + pos) * 16 + (c4 & 1) * 8);
+  f32x4 v;
+  v.x = bf16lo_f32(pk.x); v.y = bf16hi_f32(pk.x); v.z = bf16lo_f32(pk.y); v.w = bf16hi_f32(pk.y);
+  *reinterpret_cast<f32x4*>(y + pos * C + 4 * c4) = v;
 }
 // P16 -> fp32 channel-last [n][C]
 __global__ void p16_to_nlc_kernel(const f32x4* __restrict__ x, float* __restrict__ y, long n, int C, long plen) {

@@ -23,6 +23,15 @@ __global__ void seq_to_channel_major_kernel(const float* __restrict__ x, long sc
   y[i] = v0; y[ld + i] = v1; y[2 * ld + i] = v2; y[3 * ld + i] = v3;
 }
 
+// x viewed as [4][L] with element strides (sc, sl)  ->  y [L][4] contiguous rows (input of the first-layer MFMA kernel)
+__global__ void seq_to_rows_kernel(const float* __restrict__ x, long sc, long sl, long L, float* __restrict__ y) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= L) return;
+  float4 q;
+  q.x = x[i * sl]; q.y = x[i * sl + sc]; q.z = x[i * sl + 2 * sc]; q.w = x[i * sl + 3 * sc];
+  reinterpret_cast<float4*>(y)[i] = q;
+}
+
 // nn.MaxPool1d(k, k): y[r][m] = max_j x[r][k*m+j]
 template <int K>
 __global__ void maxpool1d_kernel(const float* __restrict__ x, long ldx, float* __restrict__ y, long ldy, long n_out) {

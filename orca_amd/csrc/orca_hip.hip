@@ -111,6 +111,7 @@ struct ConvLayer {
   float* d_bias = nullptr;
   void* d_wb16 = nullptr;   // k=9, cin%16==0: bf16 3-way split pack [cin/16][3][9][2][cout][8]
   void* d_wf16 = nullptr;   // same, fp16 2-way split pack [cin/16][2][9][2][cout][8]
+  void* d_wb16p = nullptr;  // k=9, cin%32==0: plain bf16 pack [cin/32][2 k-pairs][9][2][cout][8] (B16 format of conv_p16.h)
   bool f16_ok = true;       // all |w| < 65504
 };
 
@@ -149,7 +150,8 @@ static inline float bf16_f32(uint16_t h) {
 static void free_layer(ConvLayer& L) {
   if (L.d_wb16) (void)hipFree(L.d_wb16);
   if (L.d_wf16) (void)hipFree(L.d_wf16);
-  L.d_wb16 = L.d_wf16 = nullptr;
+  if (L.d_wb16p) (void)hipFree(L.d_wb16p);
+  L.d_wb16 = L.d_wf16 = L.d_wb16p = nullptr;
   if (L.d_w) (void)hipFree(L.d_w);
   if (L.d_bias) (void)hipFree(L.d_bias);
   L.d_w = L.d_bias = nullptr;
@@ -235,6 +237,21 @@ static int make_layer(const orca_conv_desc& d, ConvLayer* out) {
     e1 = hipMalloc(&L.d_wf16, pf.size() * 2);
     if (e1 == hipSuccess) e1 = hipMemcpy(L.d_wf16, pf.data(), pf.size() * 2, hipMemcpyHostToDevice);
     if (e1 != hipSuccess) { free_layer(L); return fail(ORCA_EHIP, "fp16 weight upload failed: %s", hipGetErrorString(e1)); }
+  }
+  if (d.ksize == 9 && d.cin % 32 == 0) {
+    // plain bf16 pack for the B16 format: channel ci = 32 c + 16 kp + 8 g + e
+    const int nc = d.cin / 32;
+    std::vector<uint16_t> pk((size_t)nc * 2 * 9 * 2 * d.cout * 8);
+    for (int co = 0; co < d.cout; ++co)
+      for (int ci = 0; ci < d.cin; ++ci)
+        for (int t = 0; t < 9; ++t) {
+          const float v = d.weight_host[((size_t)co * d.cin + ci) * 9 + t];
+          const int c = ci / 32, kp = (ci % 32) / 16, gg = (ci % 16) / 8, e = ci % 8;
+          pk[(((((size_t)c * 2 + kp) * 9 + t) * 2 + gg) * d.cout + co) * 8 + e] = bf16_rne(v);
+        }
+    hipError_t e1 = hipMalloc(&L.d_wb16p, pk.size() * 2);
+    if (e1 == hipSuccess) e1 = hipMemcpy(L.d_wb16p, pk.data(), pk.size() * 2, hipMemcpyHostToDevice);
+    if (e1 != hipSuccess) { free_layer(L); return fail(ORCA_EHIP, "bf16 plain weight upload failed: %s", hipGetErrorString(e1)); }
   }
   if (d.ksize == 3) {
     // fp16 2-way split pack for conv2d_f16s.h: [cin_pad16/16][2][9][2][cout][8], pad channels = 0
@@ -438,21 +455,21 @@ static int launch_conv1d_b16(orca_ctx* ctx, const ConvLayer& L, int precision, c
 // last tile (128 * ceil(4n'/512) positions) inside the plane for every n'
 static inline long p16_plen(long n) { return ((n + 512) / 512) * 512 + 2 * P16_GUARD; }
 
-static int launch_p16_zero_pads(orca_ctx* ctx, float* base, int C, long n_valid) {
-  hipLaunchKernelGGL(p16_zero_pads_kernel, dim3((unsigned)(C / 8 * 2)), dim3(256), 0, ctx->stream, reinterpret_cast<f32x4*>(base),
+static int launch_p16_zero_pads(orca_ctx* ctx, float* base, int C, long n_valid, int fmt = 0) {
+  hipLaunchKernelGGL(p16_zero_pads_kernel, dim3((unsigned)(fmt == 1 ? C / 8 : C / 8 * 2)), dim3(256), 0, ctx->stream, reinterpret_cast<f32x4*>(base),
                      p16_plen(n_valid), n_valid);
   LAUNCHCHECK("p16_zero_pads_kernel");
   return ORCA_OK;
 }
 
-template <int CT, int MW, int NW, int WM, int OM, bool R1>
+template <int CT, int MW, int NW, int WM, int OM, bool R1, int FMT = 0>
 static void launch_p16_k(hipStream_t s, ConvP16Args a) {
   constexpr int MT = WM * MW * 32;
   static int resident = [] {
     int dev = 0, ncu = 256, per_cu = 1;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv1d_k9_p16_kernel<CT, MW, NW, WM, OM, R1>, WM * 64, 0) != hipSuccess || per_cu < 1) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv1d_k9_p16_kernel<CT, MW, NW, WM, OM, R1, 0, false, FMT>, WM * 64, 0) != hipSuccess || per_cu < 1) {
       (void)hipGetLastError();
       per_cu = 1;
     }
@@ -461,7 +478,7 @@ static void launch_p16_k(hipStream_t s, ConvP16Args a) {
   a.tiles_per_row = (a.n + MT - 1) / MT;
   const long ntiles = a.tiles_per_row * (a.cout / CT);
   dim3 grid((unsigned)(ntiles < resident ? ntiles : resident));
-  hipLaunchKernelGGL((conv1d_k9_p16_kernel<CT, MW, NW, WM, OM, R1>), grid, dim3(WM * 64), 0, s, a);
+  hipLaunchKernelGGL((conv1d_k9_p16_kernel<CT, MW, NW, WM, OM, R1, 0, false, FMT>), grid, dim3(WM * 64), 0, s, a);
 }
 
 // the conv that follows the first layer, with the first layer fused into its input-tile producer (conv_p16.h, F1)
@@ -484,16 +501,16 @@ static void launch_p16_fused_first(hipStream_t s, ConvP16Args a) {
 }
 
 // out_mode and the residual are compile-time in the kernel (its epilogue is branch-free)
-template <int CT, int MW, int NW, int WM>
+template <int CT, int MW, int NW, int WM, int FMT = 0>
 static void launch_p16_t(hipStream_t s, const ConvP16Args& a) {
   const bool r1 = a.r1 != nullptr;
   switch (a.out_mode * 2 + (r1 ? 1 : 0)) {
-    case 0: launch_p16_k<CT, MW, NW, WM, 0, false>(s, a); break;
-    case 1: launch_p16_k<CT, MW, NW, WM, 0, true>(s, a); break;
-    case 2: launch_p16_k<CT, MW, NW, WM, 1, false>(s, a); break;
-    case 3: launch_p16_k<CT, MW, NW, WM, 1, true>(s, a); break;
-    case 4: launch_p16_k<CT, MW, NW, WM, 2, false>(s, a); break;
-    default: launch_p16_k<CT, MW, NW, WM, 2, true>(s, a); break;
+    case 0: launch_p16_k<CT, MW, NW, WM, 0, false, FMT>(s, a); break;
+    case 1: launch_p16_k<CT, MW, NW, WM, 0, true, FMT>(s, a); break;
+    case 2: launch_p16_k<CT, MW, NW, WM, 1, false, FMT>(s, a); break;
+    case 3: launch_p16_k<CT, MW, NW, WM, 1, true, FMT>(s, a); break;
+    case 4: launch_p16_k<CT, MW, NW, WM, 2, false, FMT>(s, a); break;
+    default: launch_p16_k<CT, MW, NW, WM, 2, true, FMT>(s, a); break;
   }
 }
 
@@ -506,15 +523,16 @@ struct FusedFirst {   // packed bases + first-layer table: the conv's input is p
   const float* bias = nullptr;
 };
 
+// fmt 0: P16 activations (fp32-class f16x2 arithmetic); fmt 1: B16 activations (plain bf16, BASELINE config 3)
 static int launch_conv1d_p16(orca_ctx* ctx, const ConvLayer& L, const float* x, void* y, const float* r1, long n, int relu,
-                             int out_mode, const FusedFirst* f1 = nullptr) {
-  if (!L.d_wf16 || L.ksize != 9) return fail(ORCA_EINVAL, "layer has no fp16 split pack");
-  if (!L.f16_ok) return fail(ORCA_EINVAL, "layer weights exceed the fp16 range: use ORCA_PRECISION_BF16X3");
+                             int out_mode, const FusedFirst* f1 = nullptr, int fmt = 0) {
+  if (L.ksize != 9 || (fmt == 0 ? !L.d_wf16 : !L.d_wb16p)) return fail(ORCA_EINVAL, "layer has no %s pack", fmt == 0 ? "fp16 split" : "bf16");
+  if (fmt == 0 && !L.f16_ok) return fail(ORCA_EINVAL, "layer weights exceed the fp16 range: use ORCA_PRECISION_BF16X3");
   if (n <= 0) return ORCA_OK;
   ConvP16Args a;
-  a.x = reinterpret_cast<const f32x4*>(x); a.w = reinterpret_cast<const f32x4*>(L.d_wf16); a.bias = L.d_bias; a.y = y;
+  a.x = reinterpret_cast<const f32x4*>(x); a.w = reinterpret_cast<const f32x4*>(fmt == 0 ? L.d_wf16 : L.d_wb16p); a.bias = L.d_bias; a.y = y;
   a.r1 = reinterpret_cast<const f32x4*>(r1); a.x_plen = p16_plen(n); a.y_plen = p16_plen(out_mode == 1 ? n / 4 : n); a.n = n;
-  a.nchunks = L.cin / 16; a.cout = L.cout; a.relu = relu; a.out_mode = out_mode; a.flag = ctx->d_flag;
+  a.nchunks = fmt == 0 ? L.cin / 16 : L.cin / 32; a.cout = L.cout; a.relu = relu; a.out_mode = out_mode; a.flag = ctx->d_flag;
   const bool timed = ctx->timing && n >= 65536;
   TimedLaunch tl;
   if (timed) {
@@ -524,10 +542,14 @@ static int launch_conv1d_p16(orca_ctx* ctx, const ConvLayer& L, const float* x, 
   }
   a.f1_codes = nullptr; a.f1_codes_L = a.f1_codes_off = 0; a.f1_reverse = 0; a.f1_table = a.f1_bias = nullptr; a.stamps = nullptr;
   if (f1) {
-    if (L.cout != 64 || L.cin != 64 || out_mode != 0 || r1) return fail(ORCA_EINVAL, "fused first layer: only the 64 -> 64 conv that follows it");
+    if (L.cout != 64 || L.cin != 64 || out_mode != 0 || r1 || fmt != 0) return fail(ORCA_EINVAL, "fused first layer: only the 64 -> 64 P16 conv that follows it");
     a.f1_codes = f1->codes; a.f1_codes_L = f1->codes_L; a.f1_codes_off = f1->codes_off; a.f1_reverse = f1->reverse;
     a.f1_table = f1->table; a.f1_bias = f1->bias;
     launch_p16_fused_first(ctx->stream, a);
+  } else if (fmt == 1) {
+    if (L.cout == 96) launch_p16_t<96, 1, 3, 8, 1>(ctx->stream, a);
+    else if (L.cout % 64 == 0) launch_p16_t<64, 2, 2, 8, 1>(ctx->stream, a);
+    else return fail(ORCA_EINVAL, "b16 conv1d cout %d unsupported", L.cout);
   } else
   if (L.cout == 96) launch_p16_t<96, 1, 3, 8>(ctx->stream, a);
   else if (L.cout % 64 == 0) launch_p16_t<64, 2, 2, 8>(ctx->stream, a);
@@ -535,7 +557,7 @@ static int launch_conv1d_p16(orca_ctx* ctx, const ConvLayer& L, const float* x, 
   LAUNCHCHECK("conv1d_k9_p16_kernel");
   if (timed) {
     HIPCHECK(hipEventRecord(tl.e1, ctx->stream));
-    tl.rec.cout = L.cout; tl.rec.cin = L.cin; tl.rec.tile = -5; tl.rec.batch = 1; tl.rec.n = n; tl.rec.ms = 0.f; tl.rec.pad_ = 0;
+    tl.rec.cout = L.cout; tl.rec.cin = L.cin; tl.rec.tile = fmt == 1 ? -6 : -5; tl.rec.batch = 1; tl.rec.n = n; tl.rec.ms = 0.f; tl.rec.pad_ = 0;
     ctx->timed.push_back(tl);
   }
   return ORCA_OK;
@@ -810,7 +832,12 @@ static int encoder_chunk(orca_ctx* ctx, orca_net* net, const SeqSource& src, lon
   long n = n1, ld = ld1;
   const float* x = src.x;
   long sx_c = src.sx_c, sx_l = src.sx_l;
-  const bool use_p16 = net->precision == ORCA_PRECISION_F16X2 && !getenv("ORCA_NO_P16");
+  // planar 16-bit activation formats of conv_p16.h for stages 1-3 (96 % of the FLOPs):
+  //   f16x2 -> P16 (2-way split fp16, fp32-class);  bf16 -> B16 (one bf16 plane, throughput mode of BASELINE config 3)
+  static const bool no_p16 = getenv("ORCA_NO_P16") != nullptr, no_b16 = getenv("ORCA_NO_B16") != nullptr;   // A/B switches
+  const bool use_b16 = net->precision == ORCA_PRECISION_BF16 && !no_b16;
+  const bool use_p16 = (net->precision == ORCA_PRECISION_F16X2 && !no_p16) || use_b16;
+  const int fmt = use_b16 ? 1 : 0;
   if (src.codes && !use_p16) {
     // the other arithmetic modes start from float rows: expand the packed bases into buf[2] as [n][4]
     hipLaunchKernelGGL(expand_codes_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, s, src.codes, src.codes_L, src.codes_off,
@@ -828,7 +855,7 @@ static int encoder_chunk(orca_ctx* ctx, orca_net* net, const SeqSource& src, lon
     const int prec = net->precision;
     int st0 = 0;
     if (use_p16) {
-      // stages 1-3 (96 % of the FLOPs) on P16 activations with LDS-DMA staging (conv_p16.h)
+      // stages 1-3 on planar 16-bit activations with LDS-DMA staging (conv_p16.h)
       const ConvLayer* L = net->convs.data();
       FirstP16Args fa;
       fa.x = x; fa.sc = sx_c; fa.sl = sx_l; fa.n = n1; fa.w = nullptr; fa.bias = L[0].d_bias; fa.y = reinterpret_cast<f32x4*>(buf[1]);
@@ -836,22 +863,34 @@ static int encoder_chunk(orca_ctx* ctx, orca_net* net, const SeqSource& src, lon
       fa.w = net->d_first_w;
       // packed input: the first layer is fused into the input-tile producer of the conv that follows it (conv_p16.h, F1)
       static const bool no_fuse1 = getenv("ORCA_NO_FUSE1") != nullptr;   // A/B switch
-      const bool fuse1 = src.codes && !no_fuse1;
+      const bool fuse1 = src.codes && !no_fuse1 && fmt == 0;
       FusedFirst f1;
       f1.codes = src.codes; f1.codes_L = src.codes_L; f1.codes_off = src.codes_off; f1.reverse = src.reverse;
       f1.table = net->d_first_tab; f1.bias = L[0].d_bias;
       if (fuse1) {
         // nothing to launch: buf[1] is never materialised
       } else
-      ORCA_TRY(launch_p16_zero_pads(ctx, buf[1], 64, n1));
+      ORCA_TRY(launch_p16_zero_pads(ctx, buf[1], 64, n1, fmt));
       if (fuse1) {
-      } else if (src.codes || (sx_c == 1 && sx_l == 4 && al16(x) && !getenv("ORCA_FIRST_VALU"))) {
+      } else if (src.codes || (sx_c == 1 && sx_l == 4 && al16(x) && (fmt == 1 || !getenv("ORCA_FIRST_VALU")))) {
         FirstMfmaArgs fm;   // K=48 GEMM on the flat [L][4] window (or straight from the packed bases)
         fm.x = src.codes ? nullptr : x; fm.n = n1;
         fm.codes = src.codes; fm.codes_L = src.codes_L; fm.codes_off = src.codes_off; fm.reverse = src.reverse; fm.w = reinterpret_cast<const f32x4*>(net->d_first_w16); fm.bias = L[0].d_bias;
         fm.y = reinterpret_cast<f32x4*>(buf[1]); fm.y_plen = p16_plen(n1); fm.flag = ctx->d_flag;
         const long nt = (n1 + 255) / 256;
-        hipLaunchKernelGGL(conv1d_first_mfma_p16_kernel<0>, dim3((unsigned)(nt < 2048 ? nt : 2048)), dim3(256), 0, s, fm);
+        if (fmt == 1) hipLaunchKernelGGL((conv1d_first_mfma_p16_kernel<0, 1>), dim3((unsigned)(nt < 2048 ? nt : 2048)), dim3(256), 0, s, fm);
+        else hipLaunchKernelGGL((conv1d_first_mfma_p16_kernel<0, 0>), dim3((unsigned)(nt < 2048 ? nt : 2048)), dim3(256), 0, s, fm);
+        LAUNCHCHECK("conv1d_first_mfma_p16_kernel");
+      } else if (fmt == 1) {
+        // strided float rows: gather them into a flat [n][4] copy (buf[2] is free until the second conv), then the MFMA kernel
+        hipLaunchKernelGGL(seq_to_rows_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, s, x, sx_c, sx_l, n1, buf[2]);
+        LAUNCHCHECK("seq_to_rows_kernel");
+        FirstMfmaArgs fm;
+        fm.x = buf[2]; fm.n = n1; fm.codes = nullptr; fm.codes_L = fm.codes_off = 0; fm.reverse = 0;
+        fm.w = reinterpret_cast<const f32x4*>(net->d_first_w16); fm.bias = L[0].d_bias;
+        fm.y = reinterpret_cast<f32x4*>(buf[1]); fm.y_plen = p16_plen(n1); fm.flag = ctx->d_flag;
+        const long nt = (n1 + 255) / 256;
+        hipLaunchKernelGGL((conv1d_first_mfma_p16_kernel<0, 1>), dim3((unsigned)(nt < 2048 ? nt : 2048)), dim3(256), 0, s, fm);
         LAUNCHCHECK("conv1d_first_mfma_p16_kernel");
       } else {
         hipLaunchKernelGGL(conv1d_first_p16_kernel, dim3((unsigned)((n1 + 255) / 256), 8), dim3(256), 0, s, fa);
@@ -863,19 +902,19 @@ static int encoder_chunk(orca_ctx* ctx, orca_net* net, const SeqSource& src, lon
         const ConvLayer* Ls = L + 4 * st0;
         const int C = Ls[3].cout;
         if (st0 > 0) {  // first conv of the stage: previous (pooled) output in buf[S] -> buf[T]
-          ORCA_TRY(launch_p16_zero_pads(ctx, buf[T], C, n));
-          ORCA_TRY(launch_conv1d_p16(ctx, Ls[0], buf[S], buf[T], nullptr, n, 0, 0));
+          ORCA_TRY(launch_p16_zero_pads(ctx, buf[T], C, n, fmt));
+          ORCA_TRY(launch_conv1d_p16(ctx, Ls[0], buf[S], buf[T], nullptr, n, 0, 0, nullptr, fmt));
         }
-        ORCA_TRY(launch_p16_zero_pads(ctx, buf[LO], C, n));
-        ORCA_TRY(launch_conv1d_p16(ctx, Ls[1], buf[T], buf[LO], nullptr, n, 0, 0, (st0 == 0 && fuse1) ? &f1 : nullptr));   // lout
-        ORCA_TRY(launch_p16_zero_pads(ctx, buf[T], C, n));
-        ORCA_TRY(launch_conv1d_p16(ctx, Ls[2], buf[LO], buf[T], nullptr, n, 1, 0));
+        ORCA_TRY(launch_p16_zero_pads(ctx, buf[LO], C, n, fmt));
+        ORCA_TRY(launch_conv1d_p16(ctx, Ls[1], buf[T], buf[LO], nullptr, n, 0, 0, (st0 == 0 && fuse1) ? &f1 : nullptr, fmt));   // lout
+        ORCA_TRY(launch_p16_zero_pads(ctx, buf[T], C, n, fmt));
+        ORCA_TRY(launch_conv1d_p16(ctx, Ls[2], buf[LO], buf[T], nullptr, n, 1, 0, nullptr, fmt));
         if (st0 < 2) {
-          ORCA_TRY(launch_p16_zero_pads(ctx, buf[S], C, n / 4));
-          ORCA_TRY(launch_conv1d_p16(ctx, Ls[3], buf[T], buf[S], buf[LO], n, 1, 1));          // relu(.)+lout, MaxPool1d(4)
+          ORCA_TRY(launch_p16_zero_pads(ctx, buf[S], C, n / 4, fmt));
+          ORCA_TRY(launch_conv1d_p16(ctx, Ls[3], buf[T], buf[S], buf[LO], n, 1, 1, nullptr, fmt));          // relu(.)+lout, MaxPool1d(4)
           n /= 4;
         } else {
-          ORCA_TRY(launch_conv1d_p16(ctx, Ls[3], buf[T], buf[S], buf[LO], n, 1, 2));          // fp32 channel-last hand-over
+          ORCA_TRY(launch_conv1d_p16(ctx, Ls[3], buf[T], buf[S], buf[LO], n, 1, 2, nullptr, fmt));          // fp32 channel-last hand-over
         }
       }
       P = S;
@@ -1316,9 +1355,9 @@ extern "C" int orca_conv1d_nlc_forward(orca_ctx* ctx, const orca_conv_desc* conv
   return rc;
 }
 
-extern "C" int orca_conv1d_p16_forward(orca_ctx* ctx, const orca_conv_desc* conv, const float* x, float* y, const float* r1, int64_t n,
-                                       int relu, int out_mode) {
-  if (!ctx || !conv || !x || !y) return fail(ORCA_EINVAL, "orca_conv1d_p16_forward: NULL argument");
+static int conv1d_planar_test(orca_ctx* ctx, const orca_conv_desc* conv, const float* x, float* y, const float* r1, int64_t n, int relu,
+                              int out_mode, int fmt) {
+  if (!ctx || !conv || !x || !y) return fail(ORCA_EINVAL, "orca_conv1d_p16/b16_forward: NULL argument");
   HIPCHECK(hipSetDevice(ctx->device));
   ConvLayer L;
   ORCA_TRY(make_layer(*conv, &L));
@@ -1331,22 +1370,39 @@ extern "C" int orca_conv1d_p16_forward(orca_ctx* ctx, const orca_conv_desc* conv
     float* rp = ws_take(ctx, sr);
     hipStream_t s = ctx->stream;
     auto blocks = [](long n_, int C) { return dim3((unsigned)((n_ * (C / 4) + 255) / 256)); };
-    (void)launch_p16_zero_pads(ctx, xp, conv->cin, n);
-    hipLaunchKernelGGL(nlc_to_p16_kernel, blocks(n, conv->cin), dim3(256), 0, s, x, reinterpret_cast<f32x4*>(xp), (long)n, conv->cin, p16_plen(n));
+    auto to_planar = [&](const float* src, float* dst, int C) {
+      if (fmt == 1) hipLaunchKernelGGL(nlc_to_b16_kernel, blocks(n, C), dim3(256), 0, s, src, reinterpret_cast<f32x4*>(dst), (long)n, C, p16_plen(n));
+      else hipLaunchKernelGGL(nlc_to_p16_kernel, blocks(n, C), dim3(256), 0, s, src, reinterpret_cast<f32x4*>(dst), (long)n, C, p16_plen(n));
+    };
+    (void)launch_p16_zero_pads(ctx, xp, conv->cin, n, fmt);
+    to_planar(x, xp, conv->cin);
     if (r1) {
-      (void)launch_p16_zero_pads(ctx, rp, conv->cout, n);
-      hipLaunchKernelGGL(nlc_to_p16_kernel, blocks(n, conv->cout), dim3(256), 0, s, r1, reinterpret_cast<f32x4*>(rp), (long)n, conv->cout, p16_plen(n));
+      (void)launch_p16_zero_pads(ctx, rp, conv->cout, n, fmt);
+      to_planar(r1, rp, conv->cout);
     }
-    if (out_mode != 2) (void)launch_p16_zero_pads(ctx, yp, conv->cout, nout);
-    rc = launch_conv1d_p16(ctx, L, xp, out_mode == 2 ? (void*)y : (void*)yp, r1 ? rp : nullptr, n, relu, out_mode);
-    if (rc == ORCA_OK && out_mode != 2)
-      hipLaunchKernelGGL(p16_to_nlc_kernel, blocks(nout, conv->cout), dim3(256), 0, s, reinterpret_cast<const f32x4*>(yp), y, nout, conv->cout, p16_plen(nout));
+    if (out_mode != 2) (void)launch_p16_zero_pads(ctx, yp, conv->cout, nout, fmt);
+    rc = launch_conv1d_p16(ctx, L, xp, out_mode == 2 ? (void*)y : (void*)yp, r1 ? rp : nullptr, n, relu, out_mode, nullptr, fmt);
+    if (rc == ORCA_OK && out_mode != 2) {
+      if (fmt == 1) hipLaunchKernelGGL(b16_to_nlc_kernel, blocks(nout, conv->cout), dim3(256), 0, s, reinterpret_cast<const f32x4*>(yp), y, nout, conv->cout, p16_plen(nout));
+      else hipLaunchKernelGGL(p16_to_nlc_kernel, blocks(nout, conv->cout), dim3(256), 0, s, reinterpret_cast<const f32x4*>(yp), y, nout, conv->cout, p16_plen(nout));
+    }
     hipError_t e = hipGetLastError();
-    if (rc == ORCA_OK && e != hipSuccess) rc = fail(ORCA_EHIP, "p16 test path: %s", hipGetErrorString(e));
+    if (rc == ORCA_OK && e != hipSuccess) rc = fail(ORCA_EHIP, "planar conv test path: %s", hipGetErrorString(e));
   }
   (void)hipStreamSynchronize(ctx->stream);
   free_layer(L);
   return rc;
+}
+
+extern "C" int orca_conv1d_p16_forward(orca_ctx* ctx, const orca_conv_desc* conv, const float* x, float* y, const float* r1, int64_t n,
+                                       int relu, int out_mode) {
+  return conv1d_planar_test(ctx, conv, x, y, r1, n, relu, out_mode, 0);
+}
+
+extern "C" int orca_conv1d_b16_forward(orca_ctx* ctx, const orca_conv_desc* conv, const float* x, float* y, const float* r1, int64_t n,
+                                       int relu, int out_mode) {
+  if (conv && conv->cin % 32) return fail(ORCA_EINVAL, "orca_conv1d_b16_forward: cin %d is not a multiple of 32", conv->cin);
+  return conv1d_planar_test(ctx, conv, x, y, r1, n, relu, out_mode, 1);
 }
 
 extern "C" int orca_conv2d_forward(orca_ctx* ctx, const orca_conv_desc* conv, const float* x, float* y, const float* r, int B,

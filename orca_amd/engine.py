@@ -361,8 +361,9 @@ def conv1d_nlc(x, w, b, precision="bf16x3", relu=False, r1=None):
     return y
 
 
-def conv1d_p16(x, w, b, relu=False, r1=None, out_mode=0):
-    """P16 / LDS-DMA conv (test wrapper): x [n,cin] channel-last fp32 -> [n or n/4, cout]."""
+def conv1d_p16(x, w, b, relu=False, r1=None, out_mode=0, fmt="p16"):
+    """P16 / LDS-DMA conv (test wrapper): x [n,cin] channel-last fp32 -> [n or n/4, cout].
+    fmt="b16": the same kernel on single-plane bf16 activations (cin % 32 == 0)."""
     x = _f32_cuda(x, "x").contiguous()
     n, cin = x.shape
     w = np.ascontiguousarray(w, dtype=np.float32)
@@ -372,8 +373,8 @@ def conv1d_p16(x, w, b, relu=False, r1=None, out_mode=0):
     y = torch.empty((n // 4 if out_mode == 1 else n, cout), dtype=torch.float32, device=x.device)
     ctx = get_context(x.device)
     r1 = r1.contiguous() if r1 is not None else None
-    check(_lib.load().orca_conv1d_p16_forward(ctx.handle, d, _p(x), _p(y), _p(r1) if r1 is not None else None, n,
-                                              1 if relu else 0, out_mode), "orca_conv1d_p16_forward")
+    fn = _lib.load().orca_conv1d_b16_forward if fmt == "b16" else _lib.load().orca_conv1d_p16_forward
+    check(fn(ctx.handle, d, _p(x), _p(y), _p(r1) if r1 is not None else None, n, 1 if relu else 0, out_mode), f"orca_conv1d_{fmt}_forward")
     return y
 
 

@@ -130,3 +130,31 @@ def test_conv1d_p16_dma(cuda, cin, cout, n, out_mode):
         err = float((y.cpu().t()[None] - ref).abs().max())
         assert y.shape[0] == ref.shape[2]
         assert err < 2e-5, (cin, cout, n, out_mode, relu, err)
+
+
+def _bf16(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+@pytest.mark.parametrize("cin,cout,n", [(64, 64, 2000), (64, 64, 513), (64, 96, 1500), (96, 96, 777), (96, 128, 1030), (128, 128, 3000),
+                                        (64, 64, 4097), (64, 64, 300000)])
+@pytest.mark.parametrize("out_mode", [0, 1, 2])
+def test_conv1d_b16_dma(cuda, cin, cout, n, out_mode):
+    """conv_p16.h, FMT = 1 (B16): single-plane bf16 activations, bf16 weights, ONE MFMA product, fp32 accumulate.
+    Products of bf16 operands are exact in fp32, so against torch fp32 on the SAME bf16-rounded operands only the
+    summation order differs (2e-5) - plus, where the output goes back to the planar bf16 storage (out_mode 0 / 1),
+    one final round-to-nearest-even to bf16 (half an ulp = 2^-9 relative)."""
+    rs = np.random.RandomState(cin + cout + n + out_mode)
+    x = _bf16(torch.from_numpy(rs.randn(1, cin, n).astype(np.float32)))
+    w = _bf16(torch.from_numpy((rs.randn(cout, cin, 9) / np.sqrt(cin * 9)).astype(np.float32))).numpy()
+    b = rs.randn(cout).astype(np.float32) * 0.1
+    r1 = _bf16(torch.from_numpy(rs.randn(1, cout, n).astype(np.float32)))
+    for relu, ra in [(False, None), (True, r1)]:
+        y = engine.conv1d_p16(x[0].t().contiguous().to(cuda), w, b, relu, None if ra is None else ra[0].t().contiguous().to(cuda), out_mode, fmt="b16")
+        ref = _ref_conv1d(x, w, b, relu, ra, None)
+        if out_mode == 1:
+            ref = F.max_pool1d(ref, 4, 4)
+        assert y.shape[0] == ref.shape[2]
+        d = (y.cpu().t()[None] - ref).abs()
+        bound = 2e-5 + (ref.abs() * 2.0 ** -8 if out_mode != 2 else 0.0)
+        assert bool((d <= bound).all()), (cin, cout, n, out_mode, relu, float(d.max()))
