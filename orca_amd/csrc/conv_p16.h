@@ -145,6 +145,19 @@ __device__ __forceinline__ float p16_dpp_quad_max(float v) {
   return v;
 }
 
+// plain v_max_f32 / v_max3_f32: fmaxf() compiles to TWO instructions per value (a canonicalising v_max x,x in front of the
+// real one - 128 instead of 64 VALU per tile epilogue), which the epilogue cannot afford: it runs with the matrix pipe idle
+__device__ __forceinline__ float p16_vmax(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float p16_vmax3_abs(float m, float a, float b) {   // max(m, |a|, |b|)
+  float r;
+  asm("v_max3_f32 %0, |%1|, |%2|, %3" : "=v"(r) : "v"(a), "v"(b), "v"(m));
+  return r;
+}
+
 // LDS operand reads the compiler cannot see.  While an LDS-DMA (`global_load_lds`) is in flight the compiler
 // treats it as a pending FLAT access and turns EVERY lgkmcnt wait into lgkmcnt(0) - which also waits for the
 // fragment prefetch issued a moment earlier and exposes the LDS latency once per two taps (~2 000 of a step's
@@ -253,6 +266,10 @@ __global__ __launch_bounds__(WM * 64, WM / 4) void conv1d_k9_p16_kernel(ConvP16A
   const long ntiles = a.tiles_per_row * ncb;
   long tile = blockIdx.x;
   if (tile >= ntiles) return;
+  // (cout block, position tile) of a tile index, carried incrementally: a 64-bit division per use is ~130 scalar instructions
+  int tile_cb = 0;
+  long tile_pos = tile;
+  while (tile_pos >= a.tiles_per_row) { tile_pos -= a.tiles_per_row; ++tile_cb; }
 
   float* bias_s = reinterpret_cast<float*>(smem + 2 * BU);
   if (tid < a.cout) bias_s[tid] = a.bias[tid];   // visible after the first barrier
@@ -306,7 +323,7 @@ __global__ __launch_bounds__(WM * 64, WM / 4) void conv1d_k9_p16_kernel(ConvP16A
       v_ += r0_; v_ += r1_; v_ += r2_;                                                                             \
     }                                                                                                              \
     if (!f1_in) v_ = (f32x4)(0.f);                                                                                 \
-    vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v_.x), fabsf(v_.y))), fmaxf(fabsf(v_.z), fabsf(v_.w)));                   \
+    vmax = p16_vmax3_abs(p16_vmax3_abs(vmax, v_.x, v_.y), v_.z, v_.w);                                                     \
     unsigned h0_, h1_, l0_, l1_;                                                                                   \
     p16_split_hl(v_, h0_, h1_, l0_, l1_);                                                                          \
     const unsigned xd_ = smem_lds + (unsigned)((buf_) * BU * 16) + (unsigned)((i_) * 16);                          \
@@ -334,7 +351,7 @@ __global__ __launch_bounds__(WM * 64, WM / 4) void conv1d_k9_p16_kernel(ConvP16A
     else {                                                                                                         \
       f32x4 v_ = f1_v + (((f1_r[0] + f1_r[1]) + (f1_r[2] + f1_r[3])) + f1_r[4]);                                   \
       if (!f1_in) v_ = (f32x4)(0.f);                                                                               \
-      vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v_.x), fabsf(v_.y))), fmaxf(fabsf(v_.z), fabsf(v_.w)));                 \
+      vmax = p16_vmax3_abs(p16_vmax3_abs(vmax, v_.x, v_.y), v_.z, v_.w);                                                   \
       unsigned h0_, h1_, l0_, l1_;                                                                                 \
       p16_split_hl(v_, h0_, h1_, l0_, l1_);                                                                        \
       const unsigned xd_ = smem_lds + (unsigned)((buf_) * BU * 16) + (unsigned)((i_) * 16);                        \
@@ -373,20 +390,19 @@ __global__ __launch_bounds__(WM * 64, WM / 4) void conv1d_k9_p16_kernel(ConvP16A
   }
   const long wchunk = (long)2 * 9 * 2 * a.cout;            // units per K-chunk in the weight pack
   const f32x4 *xsrc = nullptr, *wsrc = nullptr;            // uniform sources of the (tile, chunk) being fetched
-#define P16_SRC(t, c)                                                                  \
+#define P16_SRC(cb, pos, c)                                                            \
   {                                                                                    \
-    const long tcb_ = (t) / a.tiles_per_row;                                           \
-    xsrc = a.x + (long)(c) * 4 * a.x_plen + ((t) - tcb_ * a.tiles_per_row) * MT;       \
-    wsrc = a.w + (long)(c) * wchunk + tcb_ * CT;                                       \
+    xsrc = a.x + (long)(c) * 4 * a.x_plen + (pos) * MT;                                \
+    wsrc = a.w + (long)(c) * wchunk + (cb) * CT;                                       \
   }
 #define P16_DMA_ONE(it, buf) \
   if (act[it] && !(F1 && isx[it])) p16_glds16((isx[it] ? xsrc : wsrc) + xrel[it], smem + (buf) * BU + (it) * NT + wave * 64);
 
   // accumulators start from the bias of the tile's cout block
   f32x16 acc[MW][NW];
-#define P16_ACC_INIT(t)                                                                                       \
+#define P16_ACC_INIT(cb)                                                                                      \
   {                                                                                                           \
-    const int co0_ = (int)((t) / a.tiles_per_row) * CT + 4 * g;                                               \
+    const int co0_ = (cb) * CT + 4 * g;                                                                       \
     _Pragma("unroll") for (int j = 0; j < NW; ++j) _Pragma("unroll") for (int q = 0; q < 4; ++q) {            \
       const f32x4 b_ = *reinterpret_cast<const f32x4*>(bias_s + co0_ + j * 32 + 8 * q);                       \
       _Pragma("unroll") for (int i = 0; i < MW; ++i) {                                                        \
@@ -396,7 +412,6 @@ __global__ __launch_bounds__(WM * 64, WM / 4) void conv1d_k9_p16_kernel(ConvP16A
   }
 
   // ---- epilogue (uniform bases, thread-constant lane offsets) ----
-  const float relu_lo = a.relu ? 0.f : -3.0e38f;
   const int quad_r = l31 & 3;
   const long xpl16 = a.x_plen * 16, ypl16 = a.y_plen * 16;
   const unsigned lane_unit = (unsigned)(l31 * 16) + (g ? (unsigned)ypl16 : 0u);        // OM 0: g=0 stores the hi unit, g=1 the lo unit
@@ -405,13 +420,15 @@ __global__ __launch_bounds__(WM * 64, WM / 4) void conv1d_k9_p16_kernel(ConvP16A
   const unsigned lane_f32 = (unsigned)(l31 * a.cout * 4 + g * 16);                     // OM 2
   float vmax = 0.f;    // running max |value| written to P16 (fp16 range guard)
   long epi_tile = -1;  // finished tile whose accumulators still await their epilogue (-1: none)
+  int epi_cb = 0;
+  long epi_pos = 0;
 
   // Runs at the START of the next step (after the barrier that drained this step's DMA): its stores drain
   // underneath that step's MFMA block and are retired by the step's closing barrier.
 #define P16_EPILOGUE_B16()                                                                                       \
   {                                                                                                              \
-    const long tcb = epi_tile / a.tiles_per_row;                                                                 \
-    const long m0 = (epi_tile - tcb * a.tiles_per_row) * MT + wave * (MW * 32);                                  \
+    const long tcb = epi_cb;                                                                                     \
+    const long m0 = epi_pos * MT + wave * (MW * 32);                                                             \
     u32x4_t rr[R1 ? NG / 2 : 1];                                                                                 \
     if (R1) {                                                                                                    \
       _Pragma("unroll") for (int i = 0; i < MW; ++i) _Pragma("unroll") for (int j = 0; j < NW; ++j) _Pragma("unroll") for (int qp = 0; qp < 2; ++qp) { \
@@ -423,10 +440,8 @@ __global__ __launch_bounds__(WM * 64, WM / 4) void conv1d_k9_p16_kernel(ConvP16A
       const int co = (int)tcb * CT + j * 32 + 16 * qp;   /* q0 = 2 qp: couts co + 4g .. +3, q1: co + 8 + 4g .. */ \
       const long p0 = m0 + i * 32;                       /* + l31 per lane */                                    \
       f32x4 v0, v1;                                                                                              \
-      v0.x = fmaxf(acc[i][j][8 * qp + 0], relu_lo); v0.y = fmaxf(acc[i][j][8 * qp + 1], relu_lo);                \
-      v0.z = fmaxf(acc[i][j][8 * qp + 2], relu_lo); v0.w = fmaxf(acc[i][j][8 * qp + 3], relu_lo);                \
-      v1.x = fmaxf(acc[i][j][8 * qp + 4], relu_lo); v1.y = fmaxf(acc[i][j][8 * qp + 5], relu_lo);                \
-      v1.z = fmaxf(acc[i][j][8 * qp + 6], relu_lo); v1.w = fmaxf(acc[i][j][8 * qp + 7], relu_lo);                \
+      v0.x = acc[i][j][8 * qp + 0]; v0.y = acc[i][j][8 * qp + 1]; v0.z = acc[i][j][8 * qp + 2]; v0.w = acc[i][j][8 * qp + 3]; \
+      v1.x = acc[i][j][8 * qp + 4]; v1.y = acc[i][j][8 * qp + 5]; v1.z = acc[i][j][8 * qp + 6]; v1.w = acc[i][j][8 * qp + 7]; \
       if (R1) {   /* the lane loaded the whole unit of plane 2 qp + g: trade halves with lane l +- 32 */          \
         const u32x4_t u_ = rr[(i * NW + j) * 2 + qp];                                                            \
         unsigned ux_ = u_.x, uy_ = u_.y, uz_ = u_.z, uw_ = u_.w;                                                 \
@@ -442,13 +457,10 @@ __global__ __launch_bounds__(WM * 64, WM / 4) void conv1d_k9_p16_kernel(ConvP16A
           *reinterpret_cast<f32x4*>(o_ + 32) = v1;                                                               \
         }                                                                                                        \
       } else {                                                                                                   \
-        bool ok_ = p0 + l31 < a.n;                                                                               \
         if (OM == 1) {                                                                                           \
           v0.x = p16_dpp_quad_max(v0.x); v0.y = p16_dpp_quad_max(v0.y); v0.z = p16_dpp_quad_max(v0.z); v0.w = p16_dpp_quad_max(v0.w); \
           v1.x = p16_dpp_quad_max(v1.x); v1.y = p16_dpp_quad_max(v1.y); v1.z = p16_dpp_quad_max(v1.z); v1.w = p16_dpp_quad_max(v1.w); \
-          ok_ = p0 + (l31 | 3) < a.n;                                                                            \
         }                                                                                                        \
-        if (!ok_) { v0 = (f32x4)(0.f); v1 = (f32x4)(0.f); }                                                      \
         unsigned a0_ = cvt_pk_bf16(v0.x, v0.y), a1_ = cvt_pk_bf16(v0.z, v0.w);                                   \
         unsigned b0_ = cvt_pk_bf16(v1.x, v1.y), b1_ = cvt_pk_bf16(v1.z, v1.w);                                   \
         p16_swap32(a0_, b0_);   /* g=0: {a, b} = couts 0-3 | 4-7 of plane 2 qp;  g=1: of plane 2 qp + 1 */       \
@@ -469,8 +481,8 @@ __global__ __launch_bounds__(WM * 64, WM / 4) void conv1d_k9_p16_kernel(ConvP16A
   }
 #define P16_EPILOGUE_P16()                                                                                       \
   {                                                                                                              \
-    const long tcb = epi_tile / a.tiles_per_row;                                                                 \
-    const long m0 = (epi_tile - tcb * a.tiles_per_row) * MT + wave * (MW * 32);                                  \
+    const long tcb = epi_cb;                                                                                     \
+    const long m0 = epi_pos * MT + wave * (MW * 32);                                                             \
     u32x4_t rr[R1 ? NG : 1];                                                                                     \
     if (R1) {                                                                                                    \
       _Pragma("unroll") for (int i = 0; i < MW; ++i) _Pragma("unroll") for (int j = 0; j < NW; ++j) _Pragma("unroll") for (int q = 0; q < 4; ++q) { \
@@ -482,8 +494,7 @@ __global__ __launch_bounds__(WM * 64, WM / 4) void conv1d_k9_p16_kernel(ConvP16A
       const int co = (int)tcb * CT + j * 32 + 8 * q;   /* + 4*g per lane */                                      \
       const long p0 = m0 + i * 32;                     /* + l31 per lane */                                      \
       f32x4 v;                                                                                                   \
-      v.x = fmaxf(acc[i][j][4 * q + 0], relu_lo); v.y = fmaxf(acc[i][j][4 * q + 1], relu_lo);                    \
-      v.z = fmaxf(acc[i][j][4 * q + 2], relu_lo); v.w = fmaxf(acc[i][j][4 * q + 3], relu_lo);                    \
+      v.x = acc[i][j][4 * q + 0]; v.y = acc[i][j][4 * q + 1]; v.z = acc[i][j][4 * q + 2]; v.w = acc[i][j][4 * q + 3]; \
       if (R1) {                                                                                                  \
         const u32x4_t u_ = rr[(i * NW + j) * 4 + q];                                                             \
         unsigned ux_ = u_.x, uy_ = u_.y, uz_ = u_.z, uw_ = u_.w;                                                 \
@@ -497,14 +508,11 @@ __global__ __launch_bounds__(WM * 64, WM / 4) void conv1d_k9_p16_kernel(ConvP16A
       if (OM == 2) {                                                                                             \
         if (p0 + l31 < a.n) *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(a.y) + (p0 * a.cout + co) * 4 + lane_f32) = v; \
       } else {                                                                                                   \
-        bool ok_ = p0 + l31 < a.n;                                                                               \
         if (OM == 1) {                                                                                           \
           v.x = p16_dpp_quad_max(v.x); v.y = p16_dpp_quad_max(v.y);                                              \
           v.z = p16_dpp_quad_max(v.z); v.w = p16_dpp_quad_max(v.w);                                              \
-          ok_ = p0 + (l31 | 3) < a.n;                                                                            \
         }                                                                                                        \
-        if (!ok_) v = (f32x4)(0.f);                                                                              \
-        vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));                 \
+        vmax = p16_vmax3_abs(p16_vmax3_abs(vmax, v.x, v.y), v.z, v.w);                                                   \
         unsigned h0_, h1_, l0_, l1_;                                                                             \
         p16_split_hl(v, h0_, h1_, l0_, l1_);                                                                     \
         p16_swap32(h0_, l0_);   /* g=0: {h, l} = hi halves of couts 0-3 | 4-7;  g=1: the lo halves */            \
@@ -525,15 +533,24 @@ __global__ __launch_bounds__(WM * 64, WM / 4) void conv1d_k9_p16_kernel(ConvP16A
       }                                                                                                          \
     }                                                                                                            \
   }
-#define P16_EPILOGUE() { if constexpr (FMT == 1) P16_EPILOGUE_B16() else P16_EPILOGUE_P16() }
+  // ReLU in place on the accumulators, skipped as a whole (scalar branch) by the linear layers.  The units of a ragged last
+  // tile beyond n are written unmasked: the caller runs p16_zero_pads_kernel AFTER the conv (tail and guards must read zero).
+#define P16_EPILOGUE()                                                                                           \
+  {                                                                                                              \
+    if (a.relu) {                                                                                                \
+      _Pragma("unroll") for (int i = 0; i < MW; ++i) _Pragma("unroll") for (int j = 0; j < NW; ++j) _Pragma("unroll") for (int r = 0; r < 16; ++r) \
+        acc[i][j][r] = p16_vmax(acc[i][j][r], 0.f);                                                              \
+    }                                                                                                            \
+    if constexpr (FMT == 1) P16_EPILOGUE_B16() else P16_EPILOGUE_P16()                                           \
+  }
 
-  P16_SRC(tile, 0);
+  P16_SRC(tile_cb, tile_pos, 0);
 #pragma unroll
   for (int it = 0; it < NIT; ++it) P16_DMA_ONE(it, 0);
   int f1_slot = 0;                      // window slot of the CURRENT tile
   unsigned char f1_next[2] = {5, 5};    // bases of the next tile's window, in flight between step 0 and step 1 of a tile
   if (F1) {
-    const long m0_ = (tile % a.tiles_per_row) * MT;
+    const long m0_ = tile_pos * MT;
     for (int k = tid; k < F1_WIN; k += NT) f1_win[k] = f1_fix(f1_fetch(m0_ - 8 + k));
     __syncthreads();                    // window + table + bias visible
     for (int r = 0; r < 2; ++r) {
@@ -543,7 +560,7 @@ __global__ __launch_bounds__(WM * 64, WM / 4) void conv1d_k9_p16_kernel(ConvP16A
     }
   }
   __syncthreads();   // drains vmcnt (the DMA) and joins the waves; the bias is visible
-  P16_ACC_INIT(tile);
+  P16_ACC_INIT(tile_cb);
 
   int c = 0, cur = 0;
   int nstamp = 0;
@@ -556,21 +573,26 @@ __global__ __launch_bounds__(WM * 64, WM / 4) void conv1d_k9_p16_kernel(ConvP16A
     const long ntile = last_chunk ? tile + gridDim.x : tile;
     const int nc = last_chunk ? 0 : c + 1;
     const bool more = ntile < ntiles;
+    int nx_cb = tile_cb;            // the tile after this one (tile + gridDim.x)
+    long nx_pos = tile_pos + gridDim.x;
+    while (nx_pos >= a.tiles_per_row) { nx_pos -= a.tiles_per_row; ++nx_cb; }
+    const int ntile_cb = last_chunk ? nx_cb : tile_cb;
+    const long ntile_pos = last_chunk ? nx_pos : tile_pos;
     P16_STAMP(0);
     if (epi_tile >= 0) {
       // raised priority: the SIMD's older wave reaches its MFMA block first and would otherwise starve the
       // younger wave's epilogue VALU work until its own block is over
       __builtin_amdgcn_s_setprio(3);
       P16_EPILOGUE();
-      P16_ACC_INIT(tile);
+      P16_ACC_INIT(tile_cb);
       __builtin_amdgcn_s_setprio(0);
       epi_tile = -1;
     }
     P16_STAMP(1);
-    if (more) P16_SRC(ntile, nc);
+    if (more) P16_SRC(ntile_cb, ntile_pos, nc);
     if (F1) {   // the next tile's bases: fetched during the tile's first step, parked in LDS during its second
       const long nxt_ = tile + gridDim.x;
-      const long m0n_ = (nxt_ % a.tiles_per_row) * MT - 8;
+      const long m0n_ = nx_pos * MT - 8;
       if (c == 0 && nxt_ < ntiles) {
         f1_next[0] = f1_fetch(m0n_ + tid);                      // raw: nothing may touch the loaded byte during this step
         if (tid < F1_WIN - NT) f1_next[1] = f1_fetch(m0n_ + NT + tid);
@@ -580,7 +602,7 @@ __global__ __launch_bounds__(WM * 64, WM / 4) void conv1d_k9_p16_kernel(ConvP16A
         if (tid < F1_WIN - NT) f1_win[(f1_slot ^ 1) * F1_WIN + NT + tid] = f1_fix(f1_next[1]);
       }
     }
-    const long f1_m0 = F1 ? (ntile % a.tiles_per_row) * MT : 0;      // tile whose input the producer builds during this step
+    const long f1_m0 = F1 ? ntile_pos * MT : 0;      // tile whose input the producer builds during this step
     const int f1_ws = (F1 && last_chunk) ? (f1_slot ^ 1) : f1_slot;
 
     const unsigned xa0 = p16_lds_addr(smem + cur * BU + g * XROW + wave * (MW * 32) + l31);   // + (s*2*XROW + i*32 + tap)*16
@@ -650,15 +672,17 @@ __global__ __launch_bounds__(WM * 64, WM / 4) void conv1d_k9_p16_kernel(ConvP16A
 
     P16_STAMP(3);
     if (ABL & 512) {   // micro-benchmark: TIMING of a de-phased variant - waves WM/2.. take their epilogue half a tile later
-      if (wave < WM / 2 ? last_chunk : (c + 1 == a.nchunks / 2)) epi_tile = tile;   // (the late group's results are meaningless)
+      if (wave < WM / 2 ? last_chunk : (c + 1 == a.nchunks / 2)) { epi_tile = tile; epi_cb = tile_cb; epi_pos = tile_pos; }   // (the late group's results are meaningless)
     } else
-    if (last_chunk) epi_tile = tile;
+    if (last_chunk) { epi_tile = tile; epi_cb = tile_cb; epi_pos = tile_pos; }
 
     if (!more) break;
     if (ABL & 128) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); P16_STAMP(4); ++nstamp; }
     __syncthreads();   // next buffer has landed (vmcnt drained), everyone is done reading the current one
     if (F1 && last_chunk) f1_slot ^= 1;
     tile = ntile;
+    tile_cb = ntile_cb;
+    tile_pos = ntile_pos;
     c = nc;
     cur ^= 1;
   }
@@ -892,7 +916,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_first_mfma_p16_kernel(FirstMfma
           f32x4 v;
           v.x = acc[i][j][4 * q + 0]; v.y = acc[i][j][4 * q + 1]; v.z = acc[i][j][4 * q + 2]; v.w = acc[i][j][4 * q + 3];
           if (!ok) v = (f32x4)(0.f);
-          vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+          vmax = p16_vmax3_abs(p16_vmax3_abs(vmax, v.x, v.y), v.z, v.w);                                  
           unsigned h0, h1, l0, l1;
           p16_split_hl(v, h0, h1, l0, l1);
           p16_swap32(h0, l0);

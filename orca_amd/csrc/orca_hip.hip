@@ -867,11 +867,10 @@ static int encoder_chunk(orca_ctx* ctx, orca_net* net, const SeqSource& src, lon
       FusedFirst f1;
       f1.codes = src.codes; f1.codes_L = src.codes_L; f1.codes_off = src.codes_off; f1.reverse = src.reverse;
       f1.table = net->d_first_tab; f1.bias = L[0].d_bias;
+      // (guards and tails of every planar tensor are zeroed by p16_zero_pads_kernel AFTER its producer: the conv kernels
+      // write the units of a ragged last tile unmasked)
       if (fuse1) {
         // nothing to launch: buf[1] is never materialised
-      } else
-      ORCA_TRY(launch_p16_zero_pads(ctx, buf[1], 64, n1, fmt));
-      if (fuse1) {
       } else if (src.codes || (sx_c == 1 && sx_l == 4 && al16(x) && (fmt == 1 || !getenv("ORCA_FIRST_VALU")))) {
         FirstMfmaArgs fm;   // K=48 GEMM on the flat [L][4] window (or straight from the packed bases)
         fm.x = src.codes ? nullptr : x; fm.n = n1;
@@ -896,22 +895,23 @@ static int encoder_chunk(orca_ctx* ctx, orca_net* net, const SeqSource& src, lon
         hipLaunchKernelGGL(conv1d_first_p16_kernel, dim3((unsigned)((n1 + 255) / 256), 8), dim3(256), 0, s, fa);
         LAUNCHCHECK("conv1d_first_p16_kernel");
       }
+      if (!fuse1) ORCA_TRY(launch_p16_zero_pads(ctx, buf[1], 64, n1, fmt));
       int T = 1, LO = 2, S = 0;   // buffer roles: T holds the current input
       n = n1;
       for (st0 = 0; st0 < 3; ++st0) {
         const ConvLayer* Ls = L + 4 * st0;
         const int C = Ls[3].cout;
         if (st0 > 0) {  // first conv of the stage: previous (pooled) output in buf[S] -> buf[T]
-          ORCA_TRY(launch_p16_zero_pads(ctx, buf[T], C, n, fmt));
           ORCA_TRY(launch_conv1d_p16(ctx, Ls[0], buf[S], buf[T], nullptr, n, 0, 0, nullptr, fmt));
+          ORCA_TRY(launch_p16_zero_pads(ctx, buf[T], C, n, fmt));
         }
-        ORCA_TRY(launch_p16_zero_pads(ctx, buf[LO], C, n, fmt));
         ORCA_TRY(launch_conv1d_p16(ctx, Ls[1], buf[T], buf[LO], nullptr, n, 0, 0, (st0 == 0 && fuse1) ? &f1 : nullptr, fmt));   // lout
-        ORCA_TRY(launch_p16_zero_pads(ctx, buf[T], C, n, fmt));
+        ORCA_TRY(launch_p16_zero_pads(ctx, buf[LO], C, n, fmt));
         ORCA_TRY(launch_conv1d_p16(ctx, Ls[2], buf[LO], buf[T], nullptr, n, 1, 0, nullptr, fmt));
+        ORCA_TRY(launch_p16_zero_pads(ctx, buf[T], C, n, fmt));
         if (st0 < 2) {
-          ORCA_TRY(launch_p16_zero_pads(ctx, buf[S], C, n / 4, fmt));
           ORCA_TRY(launch_conv1d_p16(ctx, Ls[3], buf[T], buf[S], buf[LO], n, 1, 1, nullptr, fmt));          // relu(.)+lout, MaxPool1d(4)
+          ORCA_TRY(launch_p16_zero_pads(ctx, buf[S], C, n / 4, fmt));
           n /= 4;
         } else {
           ORCA_TRY(launch_conv1d_p16(ctx, Ls[3], buf[T], buf[S], buf[LO], n, 1, 2, nullptr, fmt));          // fp32 channel-last hand-over
@@ -1380,8 +1380,8 @@ static int conv1d_planar_test(orca_ctx* ctx, const orca_conv_desc* conv, const f
       (void)launch_p16_zero_pads(ctx, rp, conv->cout, n, fmt);
       to_planar(r1, rp, conv->cout);
     }
-    if (out_mode != 2) (void)launch_p16_zero_pads(ctx, yp, conv->cout, nout, fmt);
     rc = launch_conv1d_p16(ctx, L, xp, out_mode == 2 ? (void*)y : (void*)yp, r1 ? rp : nullptr, n, relu, out_mode, nullptr, fmt);
+    if (rc == ORCA_OK && out_mode != 2) (void)launch_p16_zero_pads(ctx, yp, conv->cout, nout, fmt);   // as in the Encoder: pads after the producer
     if (rc == ORCA_OK && out_mode != 2) {
       if (fmt == 1) hipLaunchKernelGGL(b16_to_nlc_kernel, blocks(nout, conv->cout), dim3(256), 0, s, reinterpret_cast<const f32x4*>(yp), y, nout, conv->cout, p16_plen(nout));
       else hipLaunchKernelGGL(p16_to_nlc_kernel, blocks(nout, conv->cout), dim3(256), 0, s, reinterpret_cast<const f32x4*>(yp), y, nout, conv->cout, p16_plen(nout));
