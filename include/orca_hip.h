@@ -119,13 +119,15 @@ int orca_net_create(orca_ctx* ctx, int kind, const orca_conv_desc* convs, int n_
                     int upsample_mode, orca_net** out);
 int orca_net_free(orca_net* net);
 
-/* Arithmetic used for the Conv1d stacks of an Encoder net.
+/* Arithmetic used for the Conv1d stacks of an Encoder net (Decoder / Decoder_1m nets take _F32, _F16X2 and _BF16).
  *  ORCA_PRECISION_F32   : v_mfma_f32_32x32x2_f32, exact fp32 products (default)
  *  ORCA_PRECISION_BF16X3: operands split into 3 bf16 parts, 6 bf16-MFMA products per fp32
  *                         product, fp32 accumulate - fp32-class error
  *                         at 2.67x the fp32-MFMA rate
  *  ORCA_PRECISION_BF16X2: 2-way split, 3 products (~2^-17 relative per product)
- *  ORCA_PRECISION_BF16  : plain bf16 operands (throughput mode) */
+ *  ORCA_PRECISION_BF16  : plain bf16 operands, one product (the throughput mode of BASELINE config 3): Encoder stages 1-3
+ *                         on single-plane bf16 activations (2 bytes per element in HBM, conv_p16.h "B16"), Decoders with
+ *                         bf16 operands and fp32 feature maps */
 #define ORCA_PRECISION_F32 0
 #define ORCA_PRECISION_BF16 1
 #define ORCA_PRECISION_BF16X2 2

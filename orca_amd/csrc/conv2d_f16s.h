@@ -33,15 +33,20 @@ struct Conv2dF16Args {
   unsigned long long* stamps;   // tools/microbench_c2.hip only (NULL in the library): s_memtime stamps of one workgroup
 };
 
-template <int COUT>
+// NS / DT: operand splits and 16-bit type (conv_bf16s.h).  <2, 1> = fp32-class f16x2 (3 products); <1, 0> = plain bf16
+// operands, ONE product (the throughput mode of BASELINE config 3; a.w is then the bf16 pack [nchunks][9][2][COUT][8]).
+template <int COUT, int NS = 2, int DT = 1>
 __global__ __launch_bounds__(512) void conv2d_3x3_f16s_kernel(Conv2dF16Args a) {
-  constexpr int NS = 2, NT = 512, NW = COUT / 32, PX = 256;
+  static_assert((NS == 2 && DT == 1) || (NS == 1 && DT == 0), "f16x2 or plain bf16");
+  constexpr int NT = 512, NW = COUT / 32, PX = 256;
   constexpr int XU = NS * 2 * 3 * PX;     // 16-byte units of the X image (6144)
   constexpr int WU = NS * 9 * 2 * COUT;   // 16-byte units of the W image
   constexpr int XF4 = 3 * PX * 4;         // float4 loads per chunk (3 rows x 256 px x 4 channel quads)
   constexpr int XIT = XF4 / NT;           // 6
   constexpr int WIT = (WU + NT - 1) / NT;
-  __shared__ f32x4 smem[XU + WU + COUT / 4];   // + bias
+  constexpr int TU = 8 * 32 * (COUT + 4) / 4;   // units of the epilogue's transposition tiles (8 waves x 32 px x (COUT + 4) floats)
+  constexpr int SU = (XU + WU) > TU ? (XU + WU) : TU;
+  __shared__ f32x4 smem[SU + COUT / 4];   // + bias
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -58,7 +63,7 @@ __global__ __launch_bounds__(512) void conv2d_3x3_f16s_kernel(Conv2dF16Args a) {
   }
   const float* xb = a.x + (long)b * a.x_bs;
   const f32x4* wg = reinterpret_cast<const f32x4*>(a.w);
-  float* bias_s = reinterpret_cast<float*>(smem + XU + WU);
+  float* bias_s = reinterpret_cast<float*>(smem + SU);
   if (tid < COUT) bias_s[tid] = a.bias[tid];   // visible after the first barrier
 
   bool rowok[3];
@@ -120,7 +125,7 @@ __global__ __launch_bounds__(512) void conv2d_3x3_f16s_kernel(Conv2dF16Args a) {
     char* xs_ = reinterpret_cast<char*>(smem);                                               \
     _Pragma("unroll") for (int it = 0; it < XIT; ++it) {                                     \
       u32x2 sp[NS];                                                                          \
-      split4<NS, 1>(xr[it], sp, overflow);                                                   \
+      split4<NS, DT>(xr[it], sp, overflow);                                                  \
       _Pragma("unroll") for (int s = 0; s < NS; ++s)                                         \
           *reinterpret_cast<u32x2*>(xs_ + s * (2 * 3 * PX * 16) + xdst[it]) = sp[s];         \
     }                                                                                        \
@@ -151,20 +156,22 @@ __global__ __launch_bounds__(512) void conv2d_3x3_f16s_kernel(Conv2dF16Args a) {
       for (int kx = 0; kx < 3; ++kx) {
         if (wskip[kx]) continue;  // wave-uniform: all 32 source pixels of this wave are padding
         const int tap = ky * 3 + kx;
-        f16x8 xv[NS], wv[NS][NW];
+        typename Op16<DT>::vec xv[NS], wv[NS][NW];
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
           f32x4 t = xa0[s * (2 * 3 * PX) + ky * PX + xsrc[kx]];
           if (!xok[kx]) t = (f32x4)(0.f);
-          xv[s] = __builtin_bit_cast(f16x8, t);
+          xv[s] = __builtin_bit_cast(typename Op16<DT>::vec, t);
 #pragma unroll
-          for (int j = 0; j < NW; ++j) wv[s][j] = __builtin_bit_cast(f16x8, wb0[((s * 9 + tap) * 2) * COUT + j * 32]);
+          for (int j = 0; j < NW; ++j) wv[s][j] = __builtin_bit_cast(typename Op16<DT>::vec, wb0[((s * 9 + tap) * 2) * COUT + j * 32]);
         }
 #pragma unroll
         for (int j = 0; j < NW; ++j) {
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wv[0][j], xv[1], acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wv[1][j], xv[0], acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wv[0][j], xv[0], acc[j], 0, 0, 0);
+          if constexpr (NS == 2) {
+            acc[j] = Op16<DT>::mfma(wv[0][j], xv[1], acc[j]);
+            acc[j] = Op16<DT>::mfma(wv[1][j], xv[0], acc[j]);
+          }
+          acc[j] = Op16<DT>::mfma(wv[0][j], xv[0], acc[j]);
         }
       }
     }
@@ -189,7 +196,7 @@ __global__ __launch_bounds__(512) void conv2d_3x3_f16s_kernel(Conv2dF16Args a) {
   constexpr int LPR = COUT / 4;          // lanes per pixel row
   constexpr int RPI = 64 / LPR;          // pixel rows per wave instruction
   constexpr int NI = 32 / RPI;
-  static_assert(8 * 32 * PITCH * 4 <= (XU + WU) * 16, "tile transposition needs the operand images' LDS");
+  static_assert(8 * 32 * PITCH * 4 <= SU * 16, "tile transposition needs the operand images' LDS");
   const int lr = lane / LPR, lc = (lane % LPR) * 4;
   const long pix0 = (long)y0 * PX + wave * 32;
   f32x4 rres[NI];
@@ -226,7 +233,7 @@ __global__ __launch_bounds__(512) void conv2d_3x3_f16s_kernel(Conv2dF16Args a) {
     *reinterpret_cast<f32x4*>(yp + (long)row * 16) = v;
   }
   C2_STAMP();   // last: epilogue issued
-  if (overflow && a.flag) *a.flag = 1u;
+  if (DT == 1 && overflow && a.flag) *a.flag = 1u;
 }
 
 // ---- channel-last helpers of the Decoder --------------------------------------------------------------

@@ -205,6 +205,8 @@ __device__ __forceinline__ void p16_lds_wait(f16x8 (&a)[2][MW], f16x8 (&b)[2][NW
     asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(a[0][0]), "+v"(a[1][0]), "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[0][2]), "+v"(b[1][0]), "+v"(b[1][1]), "+v"(b[1][2]) : "n"(N));
   else if constexpr (MW == 1 && NW == 2)
     asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(a[0][0]), "+v"(a[1][0]), "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[1][0]), "+v"(b[1][1]) : "n"(N));
+  else if constexpr (MW == 2 && NW == 1)
+    asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[1][0]), "+v"(a[1][1]), "+v"(b[0][0]), "+v"(b[1][0]) : "n"(N));
   else
     static_assert(MW == 2 && NW == 2, "add the operand list for this wave tile");
 }
@@ -412,6 +414,9 @@ __global__ __launch_bounds__(WM * 64, WM / 4) void conv1d_k9_p16_kernel(ConvP16A
   }
 
   // ---- epilogue (uniform bases, thread-constant lane offsets) ----
+  // (P16_EPILOGUE / P16_ACC_INIT stay defined for conv_ws.h, which supplies its own P16_EPI_CB / P16_EPI_M0)
+#define P16_EPI_CB epi_cb
+#define P16_EPI_M0 (epi_pos * MT + wave * (MW * 32))
   const int quad_r = l31 & 3;
   const long xpl16 = a.x_plen * 16, ypl16 = a.y_plen * 16;
   const unsigned lane_unit = (unsigned)(l31 * 16) + (g ? (unsigned)ypl16 : 0u);        // OM 0: g=0 stores the hi unit, g=1 the lo unit
@@ -427,8 +432,8 @@ __global__ __launch_bounds__(WM * 64, WM / 4) void conv1d_k9_p16_kernel(ConvP16A
   // underneath that step's MFMA block and are retired by the step's closing barrier.
 #define P16_EPILOGUE_B16()                                                                                       \
   {                                                                                                              \
-    const long tcb = epi_cb;                                                                                     \
-    const long m0 = epi_pos * MT + wave * (MW * 32);                                                             \
+    const long tcb = P16_EPI_CB;                                                                                 \
+    const long m0 = P16_EPI_M0;                                                                                  \
     u32x4_t rr[R1 ? NG / 2 : 1];                                                                                 \
     if (R1) {                                                                                                    \
       _Pragma("unroll") for (int i = 0; i < MW; ++i) _Pragma("unroll") for (int j = 0; j < NW; ++j) _Pragma("unroll") for (int qp = 0; qp < 2; ++qp) { \
@@ -470,6 +475,8 @@ __global__ __launch_bounds__(WM * 64, WM / 4) void conv1d_k9_p16_kernel(ConvP16A
         char* yb_ = reinterpret_cast<char*>(a.y) + (long)(co >> 3) * ypl16;                                      \
         if (ABL & 16) {                                                                                          \
           asm volatile("" ::"v"(unit_));                                                                         \
+        } else if (OM == 0 && (ABL & 32)) {   /* micro-benchmark (timing only): tile-major order [512-block][plane][512] */ \
+          *reinterpret_cast<u32x4_t*>(reinterpret_cast<char*>(a.y) + ((((p0 >> 9) * (a.cout >> 3) + (co >> 3) + g) << 9) + (p0 & 511) + l31) * 16) = unit_; \
         } else if (OM == 0) {                                                                                    \
           *reinterpret_cast<u32x4_t*>(yb_ + (P16_GUARD + p0) * 16 + lane_unit) = unit_;                          \
         } else {                                                                                                 \
@@ -481,8 +488,8 @@ __global__ __launch_bounds__(WM * 64, WM / 4) void conv1d_k9_p16_kernel(ConvP16A
   }
 #define P16_EPILOGUE_P16()                                                                                       \
   {                                                                                                              \
-    const long tcb = epi_cb;                                                                                     \
-    const long m0 = epi_pos * MT + wave * (MW * 32);                                                             \
+    const long tcb = P16_EPI_CB;                                                                                 \
+    const long m0 = P16_EPI_M0;                                                                                  \
     u32x4_t rr[R1 ? NG : 1];                                                                                     \
     if (R1) {                                                                                                    \
       _Pragma("unroll") for (int i = 0; i < MW; ++i) _Pragma("unroll") for (int j = 0; j < NW; ++j) _Pragma("unroll") for (int q = 0; q < 4; ++q) { \
@@ -691,10 +698,9 @@ __global__ __launch_bounds__(WM * 64, WM / 4) void conv1d_k9_p16_kernel(ConvP16A
     a.stamps[8190] = __builtin_readcyclecounter() - clk0;
     a.stamps[8191] = __builtin_amdgcn_s_memrealtime() - rt0;
   }
-#undef P16_EPILOGUE
-#undef P16_EPILOGUE_P16
-#undef P16_EPILOGUE_B16
-#undef P16_ACC_INIT
+#undef P16_EPI_CB
+#undef P16_EPI_M0
+#undef P16_STAMP
 #undef P16_DMA_ONE
 #undef P16_SRC
 #undef P16_F1_CONSUME

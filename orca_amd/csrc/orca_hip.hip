@@ -15,6 +15,7 @@
 #include "conv_bf16s.h"
 #include "conv2d_f16s.h"
 #include "conv_p16.h"
+#include "conv_ws.h"
 #include "misc_kernels.h"
 #include "orca_hip.h"
 
@@ -274,6 +275,17 @@ static int make_layer(const orca_conv_desc& d, ConvLayer* out) {
     hipError_t e1 = hipMalloc(&L.d_wf16, pf.size() * 2);
     if (e1 == hipSuccess) e1 = hipMemcpy(L.d_wf16, pf.data(), pf.size() * 2, hipMemcpyHostToDevice);
     if (e1 != hipSuccess) { free_layer(L); return fail(ORCA_EHIP, "fp16 conv2d weight upload failed: %s", hipGetErrorString(e1)); }
+    // plain bf16 pack (one product): [cin_pad16/16][9][2][cout][8]
+    std::vector<uint16_t> pb((size_t)nc * 9 * 2 * d.cout * 8, 0);
+    for (int co = 0; co < d.cout; ++co)
+      for (int ci = 0; ci < d.cin; ++ci)
+        for (int t = 0; t < 9; ++t) {
+          const int c = ci / 16, gg = (ci % 16) / 8, e = ci % 8;
+          pb[((((size_t)c * 9 + t) * 2 + gg) * d.cout + co) * 8 + e] = bf16_rne(d.weight_host[((size_t)co * d.cin + ci) * 9 + t]);
+        }
+    e1 = hipMalloc(&L.d_wb16p, pb.size() * 2);
+    if (e1 == hipSuccess) e1 = hipMemcpy(L.d_wb16p, pb.data(), pb.size() * 2, hipMemcpyHostToDevice);
+    if (e1 != hipSuccess) { free_layer(L); return fail(ORCA_EHIP, "bf16 conv2d weight upload failed: %s", hipGetErrorString(e1)); }
   }
   *out = L;
   return ORCA_OK;
@@ -351,18 +363,22 @@ static int launch_conv2d(orca_ctx* ctx, const ConvLayer& L, const float* x, long
 
 // channel-last fp16-split conv2d (conv2d_f16s.h): x [B][n][256][xc], y [B][n][256][yc], r [B][n][256][rc]
 static int launch_conv2d_f16(orca_ctx* ctx, const ConvLayer& L, const float* x, long x_bs, int xc, float* y, long y_bs, int yc,
-                             const float* r, long r_bs, int rc, int B, int n, int relu) {
-  if (L.ksize != 3 || !L.d_wf16) return fail(ORCA_EINVAL, "launch_conv2d_f16 on a layer without an fp16 pack");
-  if (!L.f16_ok) return fail(ORCA_EINVAL, "layer weights exceed the fp16 range");
+                             const float* r, long r_bs, int rc, int B, int n, int relu, bool bf16 = false) {
+  if (L.ksize != 3 || !L.d_wf16 || !L.d_wb16p) return fail(ORCA_EINVAL, "launch_conv2d_f16 on a layer without a 16-bit pack");
+  if (!bf16 && !L.f16_ok) return fail(ORCA_EINVAL, "layer weights exceed the fp16 range");
   Conv2dF16Args a;
   const long cs = (long)n * ORCA_LDW * 16;   // chunk stride of every chunk-planar map [C/16][n][256][16]
-  a.x = x; a.w = L.d_wf16; a.bias = L.d_bias; a.y = y; a.r = r; a.x_bs = x_bs; a.y_bs = y_bs; a.r_bs = r_bs;
+  a.x = x; a.w = bf16 ? L.d_wb16p : L.d_wf16; a.bias = L.d_bias; a.y = y; a.r = r; a.x_bs = x_bs; a.y_bs = y_bs; a.r_bs = r_bs;
   a.x_cs = cs; a.y_cs = cs; a.r_cs = cs; a.H = n; a.W = n; a.dil = L.dil; a.nchunks = (L.cin + 15) / 16; a.relu = relu; a.flag = ctx->d_flag; a.stamps = nullptr;
   if (a.nchunks * 16 > xc) return fail(ORCA_EINVAL, "conv2d_f16: input has %d channels per pixel, layer needs %d", xc, a.nchunks * 16);
   if (L.cout > yc || (r && L.cout > rc)) return fail(ORCA_EINVAL, "conv2d_f16: output / residual map narrower than the layer");
   static const bool no_banded = getenv("ORCA_NO_BANDED") != nullptr;   // A/B switch
   a.banded = (L.dil < 8 && n >= 64 && !no_banded) ? 1 : 0;
   dim3 grid((unsigned)(a.banded ? 8 * ((n + 7) / 8) : n), (unsigned)B);
+  if (bf16) {
+    if (L.cout == 64) hipLaunchKernelGGL((conv2d_3x3_f16s_kernel<64, 1, 0>), grid, dim3(512), 0, ctx->stream, a);
+    else hipLaunchKernelGGL((conv2d_3x3_f16s_kernel<32, 1, 0>), grid, dim3(512), 0, ctx->stream, a);
+  } else
   if (L.cout == 64) hipLaunchKernelGGL((conv2d_3x3_f16s_kernel<64>), grid, dim3(512), 0, ctx->stream, a);
   else hipLaunchKernelGGL((conv2d_3x3_f16s_kernel<32>), grid, dim3(512), 0, ctx->stream, a);
   LAUNCHCHECK("conv2d_3x3_f16s_kernel");
@@ -500,6 +516,32 @@ static void launch_p16_fused_first(hipStream_t s, ConvP16Args a) {
   hipLaunchKernelGGL((conv1d_k9_p16_kernel<64, 2, 2, 8, 0, false, 0, true>), grid, dim3(512), 0, s, a);
 }
 
+// W-stationary barrier-free form (conv_ws.h): persistent, one workgroup per CU; the grid is a multiple of the number
+// of cout blocks (of 8 x that where possible: the blocks of one position range then share an XCD)
+template <int FMT, int CIN, int CT, int MW, int NW, int OM, bool R1>
+static void launch_ws_k(hipStream_t s, const ConvP16Args& a) {
+  static int ncu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
+  const int ncb = a.cout / CT;
+  int grid = (ncu / (8 * ncb)) * (8 * ncb);
+  if (grid < ncu - 8) grid = (ncu / ncb) * ncb;
+  const long ntw = (a.n + MW * 32 - 1) / (MW * 32);
+  const long need = ((ntw + 7) / 8) * ncb;            // workgroups that get at least one wave tile
+  if (need < grid) grid = (int)(((need + 8 * ncb - 1) / (8 * ncb)) * (8 * ncb));
+  hipLaunchKernelGGL((conv1d_k9_ws_kernel<FMT, CIN, CT, MW, NW, OM, R1>), dim3((unsigned)grid), dim3(512), 0, s, a);
+}
+template <int FMT, int CIN, int CT, int MW, int NW>
+static void launch_ws_t(hipStream_t s, const ConvP16Args& a) {
+  const bool r1 = a.r1 != nullptr;
+  switch (a.out_mode * 2 + (r1 ? 1 : 0)) {
+    case 0: launch_ws_k<FMT, CIN, CT, MW, NW, 0, false>(s, a); break;
+    case 1: launch_ws_k<FMT, CIN, CT, MW, NW, 0, true>(s, a); break;
+    case 2: launch_ws_k<FMT, CIN, CT, MW, NW, 1, false>(s, a); break;
+    case 3: launch_ws_k<FMT, CIN, CT, MW, NW, 1, true>(s, a); break;
+    case 4: launch_ws_k<FMT, CIN, CT, MW, NW, 2, false>(s, a); break;
+    default: launch_ws_k<FMT, CIN, CT, MW, NW, 2, true>(s, a); break;
+  }
+}
+
 // out_mode and the residual are compile-time in the kernel (its epilogue is branch-free)
 template <int CT, int MW, int NW, int WM, int FMT = 0>
 static void launch_p16_t(hipStream_t s, const ConvP16Args& a) {
@@ -541,11 +583,21 @@ static int launch_conv1d_p16(orca_ctx* ctx, const ConvLayer& L, const float* x, 
     HIPCHECK(hipEventRecord(tl.e0, ctx->stream));
   }
   a.f1_codes = nullptr; a.f1_codes_L = a.f1_codes_off = 0; a.f1_reverse = 0; a.f1_table = a.f1_bias = nullptr; a.stamps = nullptr;
+  static const bool no_ws = getenv("ORCA_NO_WS") != nullptr;   // A/B switch: W-stationary barrier-free kernel (conv_ws.h)
+  static const bool ws_p16 = getenv("ORCA_WS_P16") != nullptr; // ... also for P16 (measured 3 % slower there: off)
+  const bool ws_ok = !no_ws && (fmt == 1 || ws_p16);
+  int tile_tag = fmt == 1 ? -6 : -5;
   if (f1) {
     if (L.cout != 64 || L.cin != 64 || out_mode != 0 || r1 || fmt != 0) return fail(ORCA_EINVAL, "fused first layer: only the 64 -> 64 P16 conv that follows it");
     a.f1_codes = f1->codes; a.f1_codes_L = f1->codes_L; a.f1_codes_off = f1->codes_off; a.f1_reverse = f1->reverse;
     a.f1_table = f1->table; a.f1_bias = f1->bias;
     launch_p16_fused_first(ctx->stream, a);
+  } else if (ws_ok && fmt == 1 && L.cin == 64 && L.cout == 64) {
+    launch_ws_t<1, 64, 64, 2, 2>(ctx->stream, a);
+    tile_tag = -8;
+  } else if (ws_ok && fmt == 0 && L.cin == 64 && (L.cout == 64 || L.cout == 96)) {
+    launch_ws_t<0, 64, 32, 2, 1>(ctx->stream, a);
+    tile_tag = -7;
   } else if (fmt == 1) {
     if (L.cout == 96) launch_p16_t<96, 1, 3, 8, 1>(ctx->stream, a);
     else if (L.cout % 64 == 0) launch_p16_t<64, 2, 2, 8, 1>(ctx->stream, a);
@@ -557,7 +609,7 @@ static int launch_conv1d_p16(orca_ctx* ctx, const ConvLayer& L, const float* x, 
   LAUNCHCHECK("conv1d_k9_p16_kernel");
   if (timed) {
     HIPCHECK(hipEventRecord(tl.e1, ctx->stream));
-    tl.rec.cout = L.cout; tl.rec.cin = L.cin; tl.rec.tile = fmt == 1 ? -6 : -5; tl.rec.batch = 1; tl.rec.n = n; tl.rec.ms = 0.f; tl.rec.pad_ = 0;
+    tl.rec.cout = L.cout; tl.rec.cin = L.cin; tl.rec.tile = tile_tag; tl.rec.batch = 1; tl.rec.n = n; tl.rec.ms = 0.f; tl.rec.pad_ = 0;
     ctx->timed.push_back(tl);
   }
   return ORCA_OK;
@@ -786,7 +838,7 @@ extern "C" int orca_net_set_precision(orca_net* net, int precision) {
   if (!net) return fail(ORCA_EINVAL, "net is NULL");
   if (precision < ORCA_PRECISION_F32 || precision > ORCA_PRECISION_F16X2) return fail(ORCA_EINVAL, "unknown precision %d", precision);
   const bool dec = net->kind == ORCA_NET_DECODER || net->kind == ORCA_NET_DECODER_1M;
-  if (precision != ORCA_PRECISION_F32 && !(net->kind == ORCA_NET_ENCODER || (dec && precision == ORCA_PRECISION_F16X2)))
+  if (precision != ORCA_PRECISION_F32 && !(net->kind == ORCA_NET_ENCODER || (dec && (precision == ORCA_PRECISION_F16X2 || precision == ORCA_PRECISION_BF16))))
     return fail(ORCA_EINVAL, "precision %d is not implemented for net kind %d", precision, net->kind);
   net->precision = precision;
   return ORCA_OK;
@@ -1145,7 +1197,7 @@ static int decoder_nhwc(orca_ctx* ctx, orca_net* net, const float* x, long sx_b,
     const ConvLayer* pairs;
     int npairs;
 #define C2(layer, src, sbs, sc, dst, dbs, dc, res, rbs, rc, relu) \
-  ORCA_TRY(launch_conv2d_f16(ctx, layer, src, sbs, sc, dst, dbs, dc, res, rbs, rc, nb, n, relu))
+  ORCA_TRY(launch_conv2d_f16(ctx, layer, src, sbs, sc, dst, dbs, dc, res, rbs, rc, nb, n, relu, net->precision == ORCA_PRECISION_BF16))
     if (!is1m) {
       C2(L[0], IN, szIN, cIN, Bf, sz64, 64, nullptr, 0, 0, 0);
       C2(L[1], Bf, sz64, 64, Cf, sz64, 64, nullptr, 0, 0, 0);
@@ -1223,7 +1275,7 @@ static int decoder_common(orca_ctx* ctx, orca_net* net, const float* x, long sx_
   if (n <= 0 || n > ORCA_LDW || (n & 1)) return fail(ORCA_EINVAL, "map size %d unsupported (even, <=256)", n);
   if (B <= 0) return ORCA_OK;
   HIPCHECK(hipSetDevice(ctx->device));
-  if (net->precision == ORCA_PRECISION_F16X2)
+  if (net->precision == ORCA_PRECISION_F16X2 || net->precision == ORCA_PRECISION_BF16)
     return decoder_nhwc(ctx, net, x, sx_b, sx_c, sx_l, de, sd_b, sd_c, sd_h, sd_w, y, sy_b, sy_c, sy_h, sy_w, B, n, out, accumulate);
   const bool is1m = net->kind == ORCA_NET_DECODER_1M;
   const size_t plane = (size_t)n * ORCA_LDW;

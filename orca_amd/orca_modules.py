@@ -264,15 +264,16 @@ class Decoder(_HipModule):
 
     def __init__(self, upsample_mode="nearest", precision=None, num_2d=1):
         """precision: "f16x2" (dilated 3x3 convs on the fp16 matrix cores with 2-way split fp32 operands,
-        ~2^-22 relative error, device range guard with automatic "f32" retry; default) or "f32" (fp32 MFMA).
+        ~2^-22 relative error, device range guard with automatic "f32" retry; default), "f32" (fp32 MFMA) or
+        "bf16" (plain bf16 operands, one product, fp32 accumulate and fp32 feature maps: the throughput mode).
         Default: $ORCA_DECODER_PRECISION or "f16x2".
         num_2d: maps per prediction (the multi-target decoders of orca_leukemia.py:512-990): distenc and the
         coarse prediction y then carry num_2d channels, and so does the output."""
         super().__init__()
         self.num_2d = _check_num_2d(num_2d)
         self.precision = precision or os.environ.get("ORCA_DECODER_PRECISION", "f16x2")
-        if self.precision not in ("f16x2", "f32"):
-            raise ValueError("Decoder precision must be 'f16x2' or 'f32'")
+        if self.precision not in ("f16x2", "f32", "bf16"):
+            raise ValueError("Decoder precision must be 'f16x2', 'f32' or 'bf16'")
         if upsample_mode not in ("nearest", "bilinear"):
             raise ValueError("upsample_mode must be 'nearest' or 'bilinear'")
         self._upsample = _lib.ORCA_UPSAMPLE_BILINEAR if upsample_mode == "bilinear" else _lib.ORCA_UPSAMPLE_NEAREST
@@ -317,8 +318,8 @@ class Decoder_1m(_HipModule):
         super().__init__()
         self.num_2d = _check_num_2d(num_2d)
         self.precision = precision or os.environ.get("ORCA_DECODER_PRECISION", "f16x2")
-        if self.precision not in ("f16x2", "f32"):
-            raise ValueError("Decoder_1m precision must be 'f16x2' or 'f32'")
+        if self.precision not in ("f16x2", "f32", "bf16"):
+            raise ValueError("Decoder_1m precision must be 'f16x2', 'f32' or 'bf16'")
         self.lconvtwos = nn.ModuleList([
             _linear_pair(nn.Conv2d, nn.BatchNorm2d, 128 if i == 0 else 64, 32, 64, nn.Dropout(p=0.1) if i == 0 else None, **_c2(d))
             for i, d in enumerate(DECODER1M_DILATIONS)])

@@ -87,6 +87,7 @@ def stats(a):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full32m", action="store_true")
+    ap.add_argument("--config3", action="store_true", help="G17: rows 0 and 5 of BASELINE config 3 (HFF-shaped model, 8 x 32 Mb), ~10 min of CPU")
     ap.add_argument("--only", default="")
     args = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
@@ -429,5 +430,55 @@ def main():
             print("G8 done: encoder %.1fs, total %.1fs" % (t_enc, time.time() - t))
 
 
+CONFIG3 = {"seed": 7, "rows": (0, 5), "row_seed0": 10, "L": 32_000_000, "mpos": 17_234_567, "wpos": 16_000_000}
+
+
+def config3_golden(om):
+    """G17 - BASELINE.json configs[2]: HFF-shaped 32 Mb model, batch of 8 random 32 Mb sequences, module-level forward
+    (net0 -> net -> six Decoder levels + denet_1_pt, forward strand; `genomepredict` itself keeps only row 0,
+    orca_predict.py:514-523).  Rows 0 and 5 through the REFERENCE's nn.Modules on CPU; the coarse-to-fine bookkeeping
+    is the build's run_cascade (pinned to the reference's genomepredict by G7)."""
+    from orca_amd import orca_predict as P
+    c = CONFIG3
+    s = c["seed"]
+
+    class Ref(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.net0 = load_synth(om.Encoder(), seed=s)
+            self.net = load_synth(om.Encoder2(), seed=s)
+            self.denets = {lv: load_synth(om.Decoder(upsample_mode="bilinear"), seed=s + lv) for lv in (1, 2, 4, 8, 16, 32)}
+            self.denet_1_pt = load_synth(om.Decoder_1m(), seed=s)
+            e = synth.synth_expected_log(8000, s)
+            idx = np.abs(np.arange(8000)[None, :] - np.arange(8000)[:, None])
+            nm = np.exp(e[idx])
+            self.normmats = {lv: np.reshape(nm[: 250 * lv, : 250 * lv], (250, lv, 250, lv)).mean(axis=1).mean(axis=2) for lv in (1, 2, 4, 8, 16, 32)}
+
+    model = Ref()
+    d = {}
+    for b in c["rows"]:
+        t = time.time()
+        codes = synth.synth_base_codes(c["L"], seed=c["row_seed0"] + b)
+        x = torch.zeros(1, 4, c["L"])
+        x[0, torch.from_numpy(codes.astype(np.int64)), torch.arange(c["L"])] = 1.0
+        enc0 = model.net0(x)
+        encs = dict(zip([1, 2, 4, 8, 16, 32], model.net(enc0)))
+        de = {lv: torch.log(torch.from_numpy(model.normmats[lv][None, None].astype(np.float32))) for lv in model.normmats}
+        preds, starts = P.run_cascade(model, encs, [32, 16, 8, 4, 2, 1], lambda lv: lv, 1, [False], lambda lv, k, st: de[lv],
+                                      lambda lv, st, rev: P.zoom_index_32m(lv, st, c["mpos"], c["wpos"], rev), add_1m_level=1)
+        d[f"enc0_row{b}"] = enc0[0].numpy()
+        d[f"maps_row{b}"] = np.stack([p[0, 0].numpy() for p in preds]).astype(np.float32)
+        d[f"starts_row{b}"] = np.array(starts[0], dtype=np.int64)
+        print("G17 row %d done in %.1fs" % (b, time.time() - t), flush=True)
+    np.savez_compressed(os.path.join(GOLD, "G17_config3.npz"), **d)
+
+
 if __name__ == "__main__":
-    main()
+    if "--config3" in sys.argv:
+        _stub_third_party()
+        import orca_modules as _om
+        torch.set_num_threads(os.cpu_count())
+        with torch.no_grad():
+            config3_golden(_om)
+    else:
+        main()

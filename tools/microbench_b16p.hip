@@ -5,6 +5,7 @@
 #include <vector>
 #include <algorithm>
 #include "conv_p16.h"
+#include "conv_ws.h"
 #ifndef BFMT
 #define BFMT 1
 #endif
@@ -26,6 +27,38 @@ static void run(ConvP16Args a, const char* what) {
   const int kc = BFMT ? 32 : 16;
   double fl = 2.0 * 9 * a.nchunks * kc * a.cout * (double)a.n;
   printf("FMT=%d CT=%d MT=%d cin=%d cout=%d n=%ld OM=%d R1=%d ABL=%3d (%s): %.3f ms  %.1f TFLOP/s  [%s]\n", BFMT, CT, MT, a.nchunks * kc, a.cout, a.n, OM, (int)R1, ABL, what, best, fl / best / 1e9, hipGetErrorString(hipGetLastError()));
+}
+template <int CT, int MW, int NW, int OM, bool R1, int ABL>
+static void run_ws(ConvP16Args a, const char* what) {
+  a.out_mode = OM;
+  const int ncb = a.cout / CT;
+  int grid = (256 / (8 * ncb)) * (8 * ncb);
+  if (grid < 248) grid = (256 / ncb) * ncb;
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  float best = 1e9;
+  for (int r = 0; r < 4; ++r) {
+    hipEventRecord(e0, 0);
+    hipLaunchKernelGGL((conv1d_k9_ws_kernel<BFMT, 64, CT, MW, NW, OM, R1, ABL>), dim3((unsigned)grid), dim3(512), 0, 0, a);
+    hipEventRecord(e1, 0); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); if (r > 0 && ms < best) best = ms;
+  }
+  double fl = 2.0 * 9 * 64 * a.cout * (double)a.n;
+  printf("WS FMT=%d CT=%d cin=64 cout=%d n=%ld OM=%d R1=%d ABL=%3d (%s): %.3f ms  %.1f TFLOP/s  [%s]\n", BFMT, CT, a.cout, a.n, OM, (int)R1, ABL, what, best, fl / best / 1e9, hipGetErrorString(hipGetLastError()));
+}
+static void report_ws(unsigned long long* st) {
+  std::vector<unsigned long long> h(8192); hipMemcpy(h.data(), st, 8192 * 8, hipMemcpyDeviceToHost);
+  printf("  shader clock during the kernel: %.0f MHz (wave 0 of workgroup 0 ran %.3f ms)\n", (double)h[8190] / ((double)h[8191] * 0.01), (double)h[8191] * 1e-5);
+  // per wave: step = [vmcnt wait | epilogue (every NCH-th step) | MFMA block]
+  for (int w = 0; w < 8; ++w) {
+    double len[2] = {0, 0}, wait[2] = {0, 0}, epi[2] = {0, 0}, blk[2] = {0, 0}; long cnt[2] = {0, 0};
+    for (int s_ = 0; s_ + 1 < 199; ++s_) {
+      const unsigned long long t0 = h[(s_ * 8 + w) * 5], t1 = h[(s_ * 8 + w) * 5 + 1], t2 = h[(s_ * 8 + w) * 5 + 2], t3 = h[(s_ * 8 + w) * 5 + 3], tn = h[((s_ + 1) * 8 + w) * 5];
+      if (!t0 || !tn) continue;
+      const int k = (t1 - t2) > 300;
+      len[k] += (double)(tn - t0); wait[k] += (double)(t2 - t0); epi[k] += (double)(t1 - t2); blk[k] += (double)(t3 - t1); ++cnt[k];
+    }
+    for (int k = 0; k < 2; ++k) if (cnt[k]) printf("    wave %d %s step (n=%ld): length %6.0f = vmcnt wait %5.0f + epilogue/prefetch %5.0f + MFMA block %5.0f\n", w, k ? "epilogue" : "plain   ", cnt[k], len[k] / cnt[k], wait[k] / cnt[k], epi[k] / cnt[k], blk[k] / cnt[k]);
+  }
 }
 static void report(unsigned long long* st) {
   std::vector<unsigned long long> h(8192); hipMemcpy(h.data(), st, 8192 * 8, hipMemcpyDeviceToHost);
@@ -81,6 +114,32 @@ int main(int argc, char** argv) {
   { ConvP16Args b = a; b.cout = 128; b.nchunks = CH * 2; b.n = n / 16; run<64, 2, 2, 8, 0, false, 0>(b, "128 -> 128, n/16"); }
   run<64, 2, 2, 8, 0, false, 128>(a, "stamped");
   report(st);
+  {
+    constexpr int WCT = BFMT ? 64 : 32, WNW = BFMT ? 2 : 1;
+    run_ws<WCT, 2, WNW, 0, false, 0>(a, "ws plain");
+    run_ws<WCT, 2, WNW, 0, false, 0>(a, "ws plain");
+    run_ws<WCT, 2, WNW, 0, false, 16>(a, "ws no stores");
+    run_ws<WCT, 2, WNW, 0, false, 1>(a, "ws no DMA after the first step");
+    run_ws<WCT, 2, WNW, 0, false, 17>(a, "ws no DMA no stores");
+    run_ws<WCT, 2, WNW, 0, false, 4>(a, "ws no MFMA (data movement only)");
+    run_ws<WCT, 2, WNW, 0, false, 4 + 16>(a, "ws no MFMA, no stores");
+    run_ws<WCT, 2, WNW, 0, false, 4 + 1>(a, "ws no MFMA, no DMA");
+    if (BFMT) {
+      run_ws<WCT, 2, WNW, 0, false, 4 + 1 + 32>(a, "ws no MFMA, no DMA, tile-major stores");
+      run_ws<WCT, 2, WNW, 0, false, 32>(a, "ws tile-major stores");
+    }
+    a.r1 = x;
+    run_ws<WCT, 2, WNW, 0, true, 0>(a, "ws r1");
+    run_ws<WCT, 2, WNW, 1, true, 0>(a, "ws r1 pool");
+    a.r1 = nullptr;
+    if (!BFMT) { ConvP16Args b = a; b.cout = 96; b.n = n / 4; run_ws<32, 2, 1, 0, false, 0>(b, "ws 64 -> 96, n/4"); run<96, 1, 3, 8, 0, false, 0>(b, "64 -> 96, n/4"); }
+    hipMemset(st, 0, 8192 * 8);
+    run_ws<WCT, 2, WNW, 0, false, 128>(a, "ws stamped");
+    report_ws(st);
+    hipMemset(st, 0, 8192 * 8);
+    run_ws<WCT, 2, WNW, 0, false, 128 + 1 + 16>(a, "ws stamped, no DMA, no stores");
+    report_ws(st);
+  }
   run<64, 2, 2, 8, 0, false, 128 + 1 + 16>(a, "stamped, no DMA, no stores");
   report(st);
   return 0;
