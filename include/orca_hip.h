@@ -215,6 +215,25 @@ int orca_decoder1m_forward(orca_ctx* ctx, orca_net* net, const float* x, int64_t
  * (orca_predict.py:514-523) for contiguous [n,n] maps. */
 int orca_strand_merge(orca_ctx* ctx, const float* fwd, const float* rev, float* out, int n);
 
+/* ---- multi-GPU exchange ----------------------------------
+ * The path shards at ONE place: the Encoder's 4 kb bins (bin_lo / bin_hi of orca_encoder_forward; blocks are
+ * independent given the 112 kb input halo, orca_modules.py:955-977), followed by ONE all-gather of the per-rank
+ * [B,128,bins] slabs before the replicated Encoder2 / Encoder3 / decoder tail.  Replaces: the `nn.DataParallel`
+ * wrappers that are the reference's only multi-GPU mechanism (orca_models.py:44-50) around `model.net0(x)`
+ * (orca_predict.py:334, :675-683).  One process per GPU; the communicator is RCCL over xGMI.
+ *
+ * RCCL is resolved at run time (dlopen; an RCCL already in the process - e.g. the one PyTorch-ROCm carries - is
+ * preferred), so single-GPU users need no RCCL at all.  orca_comm_unique_id is called on ONE rank; the 128 bytes are
+ * handed to every rank by the host's own channel (the Python host broadcasts them through torch.distributed's
+ * store) and passed to orca_comm_init_rank, which is collective over the ranks. */
+typedef struct orca_comm orca_comm;
+#define ORCA_COMM_ID_BYTES 128
+int orca_comm_unique_id(void* id128_host);
+int orca_comm_init_rank(orca_ctx* ctx, int nranks, int rank, const void* id128_host, orca_comm** out);
+int orca_comm_destroy(orca_comm* comm);
+/* recv[r*count .. (r+1)*count) = rank r's send[0 .. count): fp32 device buffers, enqueued on the context's stream. */
+int orca_allgather(orca_ctx* ctx, orca_comm* comm, const float* send, float* recv, size_t count);
+
 /* Replaces: the kernel-size-1 Conv1d (+ folded BatchNorm) + activation layers of `Net.final_1d`, the auxiliary
  * 1-D head of the 1 Mb model (orca_modules.py:1824-1830, :1854).
  * y[b][co][m] = act(bias[co] + sum_ci w[co][ci] * x[b][ci][m]);  w [cout][cin] and bias [cout] are DEVICE memory

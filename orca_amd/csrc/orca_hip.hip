@@ -4,6 +4,9 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -I../../include orca_hip.hip -o liborca_hip.so
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+#include <link.h>
+
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -69,6 +72,8 @@ struct orca_ctx {
   char* ws = nullptr;
   size_t ws_bytes = 0;
   size_t ws_off = 0;
+  hipStream_t ws_stream = nullptr;   // stream of the last call that used the arena
+  bool ws_used = false;
   bool timing = false;
   std::vector<TimedLaunch> timed;
   unsigned* d_flag = nullptr;   // fp16-range overflow flag written by the f16x2 kernels
@@ -79,6 +84,10 @@ struct orca_ctx {
 
 static int ws_ensure(orca_ctx* ctx, size_t bytes) {
   ctx->ws_off = 0;
+  // the arena is reused by every call: kernels of an EARLIER call on a different stream may still be reading it
+  if (ctx->ws_used && ctx->ws_stream != ctx->stream) HIPCHECK(hipStreamSynchronize(ctx->ws_stream));
+  ctx->ws_stream = ctx->stream;
+  ctx->ws_used = true;
   if (bytes <= ctx->ws_bytes) return ORCA_OK;
   if (ctx->ws) {
     HIPCHECK(hipStreamSynchronize(ctx->stream));
@@ -673,7 +682,11 @@ extern "C" int orca_ctx_create(int device, void* hip_stream, orca_ctx** out) {
 extern "C" int orca_ctx_destroy(orca_ctx* ctx) {
   if (!ctx) return ORCA_OK;
   (void)hipSetDevice(ctx->device);
-  if (ctx->ws) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(ctx->ws); }
+  if (ctx->ws) {
+    if (ctx->ws_used && ctx->ws_stream != ctx->stream) (void)hipStreamSynchronize(ctx->ws_stream);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(ctx->ws);
+  }
   if (ctx->d_flag) (void)hipFree(ctx->d_flag);
   if (ctx->aux) { (void)hipStreamSynchronize(ctx->aux); (void)hipStreamDestroy(ctx->aux); (void)hipEventDestroy(ctx->ev_fork); (void)hipEventDestroy(ctx->ev_join); }
   delete ctx;
@@ -731,10 +744,11 @@ extern "C" int orca_ctx_release_workspace(orca_ctx* ctx) {
   if (!ctx) return fail(ORCA_EINVAL, "ctx is NULL");
   HIPCHECK(hipSetDevice(ctx->device));
   if (ctx->ws) {
+    if (ctx->ws_used && ctx->ws_stream != ctx->stream) HIPCHECK(hipStreamSynchronize(ctx->ws_stream));
     HIPCHECK(hipStreamSynchronize(ctx->stream));
     HIPCHECK(hipFree(ctx->ws));
   }
-  ctx->ws = nullptr; ctx->ws_bytes = 0; ctx->ws_off = 0;
+  ctx->ws = nullptr; ctx->ws_bytes = 0; ctx->ws_off = 0; ctx->ws_used = false;
   return ORCA_OK;
 }
 
@@ -1375,6 +1389,107 @@ extern "C" int orca_strand_merge(orca_ctx* ctx, const float* fwd, const float* r
   HIPCHECK(hipSetDevice(ctx->device));
   hipLaunchKernelGGL(strand_merge_kernel, dim3((unsigned)((n * n + 255) / 256)), dim3(256), 0, ctx->stream, fwd, rev, out, n);
   LAUNCHCHECK("strand_merge_kernel");
+  return ORCA_OK;
+}
+
+// ---------------------------------------------------------------------------
+// multi-GPU exchange: RCCL, resolved at run time
+// ---------------------------------------------------------------------------
+struct Id128 { char internal[ORCA_COMM_ID_BYTES]; };   // = ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES 128)
+namespace {
+struct RcclApi {
+  void* lib = nullptr;
+  int (*GetUniqueId)(void*) = nullptr;
+  int (*CommInitRank)(void**, int, /* ncclUniqueId by value */ Id128, int) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+}  // namespace
+
+static int find_loaded_rccl(struct dl_phdr_info* info, size_t, void* out) {
+  const char* n = info->dlpi_name;
+  if (n && strstr(n, "librccl.so")) { *static_cast<std::string*>(out) = n; return 1; }
+  return 0;
+}
+
+static RcclApi* rccl_api() {
+  static RcclApi api;
+  static bool tried = false;
+  if (tried) return api.lib ? &api : nullptr;
+  tried = true;
+  std::string loaded;
+  dl_iterate_phdr(find_loaded_rccl, &loaded);      // PyTorch-ROCm brings its own RCCL: share it
+  void* h = nullptr;
+  if (!loaded.empty()) h = dlopen(loaded.c_str(), RTLD_NOW | RTLD_GLOBAL);
+  if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) return nullptr;
+  api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+  api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
+  api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+  api.AllGather = reinterpret_cast<decltype(api.AllGather)>(dlsym(h, "ncclAllGather"));
+  api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+  if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllGather) return nullptr;
+  api.lib = h;
+  return &api;
+}
+
+struct orca_comm {
+  void* comm = nullptr;   // ncclComm_t
+  int nranks = 1, rank = 0, device = 0;
+};
+
+static int rccl_fail(RcclApi* r, const char* what, int rc) {
+  return fail(ORCA_EHIP, "%s failed: %s (RCCL result %d)", what, r && r->GetErrorString ? r->GetErrorString(rc) : "?", rc);
+}
+
+extern "C" int orca_comm_unique_id(void* id128_host) {
+  if (!id128_host) return fail(ORCA_EINVAL, "orca_comm_unique_id: NULL argument");
+  RcclApi* r = rccl_api();
+  if (!r) return fail(ORCA_ENODEV, "RCCL (librccl.so) could not be loaded: %s", dlerror() ? dlerror() : "not found");
+  Id128 id;
+  const int rc = r->GetUniqueId(&id);
+  if (rc != 0) return rccl_fail(r, "ncclGetUniqueId", rc);
+  memcpy(id128_host, &id, sizeof id);
+  return ORCA_OK;
+}
+
+extern "C" int orca_comm_init_rank(orca_ctx* ctx, int nranks, int rank, const void* id128_host, orca_comm** out) {
+  if (!ctx || !id128_host || !out) return fail(ORCA_EINVAL, "orca_comm_init_rank: NULL argument");
+  if (nranks < 1 || rank < 0 || rank >= nranks) return fail(ORCA_EINVAL, "orca_comm_init_rank: rank %d of %d", rank, nranks);
+  RcclApi* r = rccl_api();
+  if (!r) return fail(ORCA_ENODEV, "RCCL (librccl.so) could not be loaded");
+  HIPCHECK(hipSetDevice(ctx->device));
+  Id128 id;
+  memcpy(&id, id128_host, sizeof id);
+  orca_comm* c = new orca_comm();
+  c->nranks = nranks; c->rank = rank; c->device = ctx->device;
+  const int rc = r->CommInitRank(&c->comm, nranks, id, rank);
+  if (rc != 0) { delete c; return rccl_fail(r, "ncclCommInitRank", rc); }
+  *out = c;
+  return ORCA_OK;
+}
+
+extern "C" int orca_comm_destroy(orca_comm* comm) {
+  if (!comm) return ORCA_OK;
+  RcclApi* r = rccl_api();
+  (void)hipSetDevice(comm->device);
+  if (r && comm->comm) (void)r->CommDestroy(comm->comm);
+  delete comm;
+  return ORCA_OK;
+}
+
+extern "C" int orca_allgather(orca_ctx* ctx, orca_comm* comm, const float* send, float* recv, size_t count) {
+  if (!ctx || !comm || !send || !recv) return fail(ORCA_EINVAL, "orca_allgather: NULL argument");
+  if (comm->device != ctx->device) return fail(ORCA_EINVAL, "orca_allgather: communicator lives on device %d, context on %d", comm->device, ctx->device);
+  if (count == 0) return ORCA_OK;
+  RcclApi* r = rccl_api();
+  if (!r) return fail(ORCA_ENODEV, "RCCL is not loaded");
+  HIPCHECK(hipSetDevice(ctx->device));
+  const int rc = r->AllGather(send, recv, count, /* ncclFloat32 */ 7, comm->comm, ctx->stream);
+  if (rc != 0) return rccl_fail(r, "ncclAllGather", rc);
   return ORCA_OK;
 }
 

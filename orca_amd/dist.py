@@ -81,16 +81,24 @@ class ShardedEncoder(torch.nn.Module):
         super().__init__()
         self.encoder, self.group = encoder, group
 
+    def _local(self, fn):
+        # the fp16-range retry of the rank's own bins must happen BEFORE the all-gather (a retry decided afterwards, by
+        # engine.run_with_overflow_retry, would re-enter the collective on this rank only)
+        from . import engine
+        with engine.immediate_overflow_guard():
+            return fn()
+
     def forward(self, x):
         from . import engine
         total = engine.encoder_num_bins(x.shape[2])
-        return sharded_encode(lambda t, lo, hi: self.encoder(t, bin_lo=lo, bin_hi=hi), x, total, self.group)
+        return sharded_encode(lambda t, lo, hi: self._local(lambda: self.encoder(t, bin_lo=lo, bin_hi=hi)), x, total, self.group)
 
     def forward_codes(self, codes, reverse=False):
         """Same from packed bases ([B,L] uint8 replicated on every rank, 32 MB per 32 Mb instead of 512 MB)."""
         from . import engine
         total = engine.encoder_num_bins(codes.shape[1])
-        return sharded_encode(lambda t, lo, hi: self.encoder.forward_codes(t, reverse=reverse, bin_lo=lo, bin_hi=hi), codes, total, self.group)
+        return sharded_encode(lambda t, lo, hi: self._local(lambda: self.encoder.forward_codes(t, reverse=reverse, bin_lo=lo, bin_hi=hi)),
+                              codes, total, self.group)
 
 
 def max_over_ranks(value, device):

@@ -84,27 +84,45 @@ def get_context(device):
 # ---------------------------------------------------------------------------
 import contextlib
 
-_guard = {"defer": False, "force_safe": False}
+
+class _GuardState(threading.local):
+    """Per-THREAD policy (contexts, streams and overflow flags are per thread too, see _tls): one thread's deferred scope
+    must not switch off another thread's immediate checks."""
+    defer = False
+    force_safe = False
+
+    def __getitem__(self, key):      # dict-style access kept for the modules
+        return getattr(self, key)
+
+    def __setitem__(self, key, value):
+        setattr(self, key, value)
+
+
+_guard = _GuardState()
 
 
 @contextlib.contextmanager
+def _guard_scope(key, value):
+    old = _guard[key]
+    _guard[key] = value
+    try:
+        yield
+    finally:
+        _guard[key] = old
+
+
 def defer_overflow_guard():
-    old = _guard["defer"]
-    _guard["defer"] = True
-    try:
-        yield
-    finally:
-        _guard["defer"] = old
+    return _guard_scope("defer", True)
 
 
-@contextlib.contextmanager
+def immediate_overflow_guard():
+    """Inside a deferred scope: check (and retry) right away again.  Used around rank-LOCAL work that is followed by a
+    collective (dist.ShardedEncoder): a retry decided after the collective would re-enter it on one rank only."""
+    return _guard_scope("defer", False)
+
+
 def force_safe_precision():
-    old = _guard["force_safe"]
-    _guard["force_safe"] = True
-    try:
-        yield
-    finally:
-        _guard["force_safe"] = old
+    return _guard_scope("force_safe", True)
 
 
 def run_with_overflow_retry(fn, device):

@@ -163,10 +163,15 @@ class PackedGenome:
 
     def _bounds(self, chrom, start, end, pad):
         n = self._host[chrom].shape[0]
-        if pad:
-            qs, qe = max(start, 0), min(end, n)
-            return qs, max(qe, qs), qs - start, end - max(qe, qs)
-        assert end <= n and start >= 0, "coordinates exceed the chromosome (selene_utils2.py:257)"
+        if end < start:
+            raise ValueError(f"window [{start}, {end}) has negative length")
+        if pad:   # both ends clamped: a window entirely outside the chromosome is all padding ('N')
+            qs = min(max(start, 0), n)
+            qe = min(max(end, qs), n)
+            pl = min(max(-start, 0), end - start)
+            return qs, qe, pl, (end - start) - pl - (qe - qs)
+        if not (0 <= start and end <= n):   # the reference's error type (its `assert`, selene_utils2.py:257), raised explicitly: survives python -O
+            raise AssertionError(f"coordinates [{start}, {end}) exceed chromosome {chrom} of length {n} (selene_utils2.py:257)")
         return start, end, 0, 0
 
     def get_codes_from_coords(self, chrom, start, end, strand="+", pad=False, device=None):

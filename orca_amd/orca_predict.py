@@ -65,11 +65,14 @@ class _StrandInputs:
         self.use_cuda = use_cuda
         self._fwd = self._rev = self._codes = None
         self._packable = None
+        self._device = None        # where the strands live, recorded at the first upload (never re-materialises .fwd)
+        self.uploads = 0           # H2D copies of the float window (tests: at most one per call, whatever the model count)
         if isinstance(sequence, torch.Tensor) and sequence.dtype == torch.uint8:
             # already packed: [B,L] base codes on the MI355X (orca_amd extension, see orca_amd/sv.py)
             if not (use_cuda and sequence.is_cuda and sequence.dim() == 2):
                 raise ValueError("packed input must be a [B,L] uint8 ROCm tensor with use_cuda=True")
             self.seq, self._codes, self._packable = None, sequence, True
+            self._device = sequence.device
             self.batch = sequence.shape[0]
             return
         self.seq = np.asarray(sequence, dtype=np.float32)
@@ -77,13 +80,19 @@ class _StrandInputs:
 
     @property
     def device(self):
-        return self._codes.device if self.seq is None else self.fwd.device
+        if self._device is None:
+            self._device = self.fwd.device
+        return self._device
 
     @property
     def fwd(self):
         if self._fwd is None:
             t = torch.from_numpy(np.ascontiguousarray(self.seq))
-            self._fwd = (t.cuda() if self.use_cuda else t).transpose(1, 2)
+            if self.use_cuda:
+                t = t.cuda()
+                self.uploads += 1
+            self._fwd = t.transpose(1, 2)
+            self._device = self._fwd.device
         return self._fwd
 
     @property

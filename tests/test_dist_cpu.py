@@ -74,3 +74,35 @@ def test_sharded_encoder_allgather_gloo_world2():
     assert res[0].shape == ref.shape == (1, 128, 75)
     assert np.abs(res[0] - ref).max() < 1e-5 and np.abs(res[1] - ref).max() < 1e-5
     assert np.array_equal(res[0], res[1])
+
+
+def test_overflow_guard_policy_is_per_thread_and_immediate_around_a_sharded_encoder():
+    """(a) the deferred-guard scope of one thread must not leak into another thread; (b) a ShardedEncoder runs
+    its rank-local encoder with the IMMEDIATE guard even inside a deferred scope, so that an fp16-range retry happens
+    before the all-gather and never re-enters the collective on one rank only."""
+    import threading
+
+    from orca_amd import engine
+    from orca_amd.dist import ShardedEncoder
+
+    seen = {}
+
+    class Probe(torch.nn.Module):
+        def forward(self, x, bin_lo=0, bin_hi=0):
+            seen["defer_inside_local_encode"] = engine._guard["defer"]
+            n = engine.encoder_num_bins(x.shape[2]) if bin_hi <= 0 else bin_hi
+            return torch.zeros(x.shape[0], 128, n - bin_lo)
+
+    x = torch.zeros(1, 4, 8000)
+    with engine.defer_overflow_guard():
+        assert engine._guard["defer"] is True
+        t = threading.Thread(target=lambda: seen.setdefault("defer_in_other_thread", engine._guard["defer"]))
+        t.start(); t.join()
+        try:
+            ShardedEncoder(Probe()).forward(x)
+        except Exception as e:     # encoder_num_bins needs the built library; it is present wherever the CPU suite runs
+            raise AssertionError(f"ShardedEncoder.forward failed: {e}")
+        assert engine._guard["defer"] is True            # restored
+    assert engine._guard["defer"] is False
+    assert seen["defer_in_other_thread"] is False
+    assert seen["defer_inside_local_encode"] is False

@@ -59,3 +59,20 @@ def test_encoding_semantics():
     assert unk                                                           # looks at the first row only (:264-272)
     _, unk = g.get_encoding_from_coords_check_unk("c", 7, 10)
     assert not unk
+
+
+def test_padded_window_outside_the_chromosome_is_all_n_and_unpadded_raises():
+    """selene's pad=True semantics hold for windows that lie partly or ENTIRELY beyond either end."""
+    from orca_amd.genome import N_CODE
+    g = PackedGenome({"c": np.array([0, 1, 2, 3, 0, 1], dtype=np.uint8)})
+    assert list(g.get_codes_from_coords("c", -100, -10, pad=True)) == [N_CODE] * 90
+    assert list(g.get_codes_from_coords("c", 10, 14, pad=True)) == [N_CODE] * 4
+    assert list(g.get_codes_from_coords("c", -2, 8, pad=True)) == [N_CODE] * 2 + [0, 1, 2, 3, 0, 1] + [N_CODE] * 2
+    assert list(g.get_codes_from_coords("c", 4, 9, pad=True)) == [0, 1] + [N_CODE] * 3
+    enc = g.get_encoding_from_coords("c", -3, 0, pad=True)
+    assert enc.shape == (3, 4) and np.all(enc == 0.25)
+    for bad in ((-1, 3), (2, 7)):
+        with pytest.raises(AssertionError):      # the reference's error type (selene_utils2.py:257), raised explicitly
+            g.get_codes_from_coords("c", *bad)
+    with pytest.raises(ValueError):
+        g.get_codes_from_coords("c", 5, 2, pad=True)
