@@ -1,23 +1,32 @@
 #!/usr/bin/env python
 """bench.py - headline benchmark of the Orca hot path on MI355X.
 
-Workload (BASELINE.json configs[1]): H1-ESC-shaped 32 Mb model (Encoder + Encoder2 +
-six Decoders + Decoder_1m), ONE random 32 Mb sequence, fp32.  One "step" is what the
-reference's `genomepredict` does on the device for one model: both strands through
-net0 -> net -> the 6-level decoder cascade (+ denet_1_pt at 4 kb) and the strand merge.
-The input is resident in HBM before the timed region: the sequence packed to 1 byte per base
-(what `genomepredict` keeps after one pass over the reference's float32 [1,32e6,4] array; both strands
-are encoded from that one buffer) - `--float-input` keeps the two float strands instead; weights are deterministic synthetic tensors of the
-reference architecture (the real checkpoints are a 1.3 GB download, unavailable offline).
+Timed region (the driver's contract; `value`): BASELINE.json configs[1] - H1-ESC-shaped 32 Mb model (Encoder + Encoder2 +
+six Decoders + Decoder_1m), ONE random 32 Mb sequence, fp32-class arithmetic.  One "step" is what the reference's
+`genomepredict` does on the device for one model: both strands through net0 -> net -> the 6-level decoder cascade
+(+ denet_1_pt at 4 kb) and the strand merge.  The input is resident in HBM before the timed region: the sequence packed
+to 1 byte per base (what `genomepredict` keeps after one pass over the reference's float32 [1,32e6,4] array; both strands
+are encoded from that one buffer) - `--float-input` keeps the two float strands instead; weights are
+deterministic synthetic tensors of the reference architecture (the real checkpoints are a 1.3 GB download, unavailable
+offline).  N > 1: every rank runs this workload on its own sequence (independent 32 Mb windows, the reference's
+structural-variant-screen pattern, BASELINE config 5): weak scaling, no data-path collective.
 
   python bench.py --gpus N --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-N>1: every rank runs the same workload on its own sequence (independent 32 Mb windows,
-the reference's structural-variant-screen pattern): weak scaling, no data-path collective.
+Also measured in the same run, OUTSIDE the timed region, and reported in the same JSON line:
+  * `sharded_256mb` (every N, BASELINE config 4 / north star): H1esc_256M-shaped model on one random 256 Mb sequence,
+    both strands - the Encoder's 64 000 bins sharded over the N ranks (orca_amd.dist.ShardedEncoder), ONE RCCL
+    all-gather per strand (through the C ABI's orca_allgather; torch.distributed if that cannot be set up), then
+    Encoder2(64 000 bins) -> Encoder3 -> 4 Decoders replicated on every rank.  Strong scaling: per-rank encoder ms,
+    all-gather ms, tail ms, Mb/s.
+  * `parity` (N = 1): the timed steps' own six maps against the shipped fixture tests/golden/G8_full32m.npz - the
+    REFERENCE's genomepredict on CPU for exactly this sequence, weights and zoom position.
+  * `exact_f32` (N = 1): a short second loop with every module on the exact fp32 MFMA kernels.
+  * `cpu_baseline` (N = 1): the oracle (= the torch CPU ops the reference dispatches) on a bounded sample.
 
-Prints ONE JSON line (rank 0).  value = strand-Mb of sequence encoded AND decoded per
-second over the whole job (2 strands x 32 Mb per step per rank).
+Prints ONE JSON line (rank 0).  value = strand-Mb of sequence encoded AND decoded per second over the whole job
+(2 strands x 32 Mb per step per rank).
 """
 import argparse
 import json
@@ -91,6 +100,92 @@ def cpu_baseline(seed):
             "t_encoder_sample_s": round(t_enc, 2), "t_decoders_s": round(t_rest, 2)}
 
 
+def sharded_256mb(args, rank, world, dev, dist):
+    """BASELINE config 4 / north star: the 256 Mb model with the Encoder's bins sharded over the ranks."""
+    from orca_amd import dist as odist, engine, orca_models, orca_predict, synth
+    L256 = 256_000_000
+    model = orca_models.H1esc_256M(synthetic_seed=0)
+    codes = torch.from_numpy(synth.synth_base_codes(L256, seed=2)[None]).to(dev)      # the SAME sequence on every rank
+    comm, collective = None, "none (single rank)"
+    if world > 1:
+        collective = "torch.distributed all_gather_into_tensor (RCCL)"
+        if not args.torch_collective:
+            ok = 1
+            try:
+                comm = odist.AbiComm(dev)
+            except Exception as e:      # fall back together (see below)
+                ok, comm = 0, None
+                if rank == 0:
+                    print(f"bench: C-ABI RCCL communicator unavailable ({e}); using torch.distributed", file=sys.stderr)
+            t = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            if int(t.item()) == 1:
+                collective = "RCCL all-gather through the C ABI (orca_comm_init_rank / orca_allgather)"
+            else:
+                comm = None
+    enc = odist.ShardedEncoder(model.net0, comm=comm)
+    chrlen = 138_368_000
+    nm = synth.synth_normmat_256m(chrlen, seed=0)
+    de = {}
+    for lv in (256, 128, 64, 32):      # top-left window of each level: the host-side block means are not part of this measurement
+        w = 250 * (lv // 8)
+        de[lv] = torch.log(torch.from_numpy(orca_predict._coarse_grain(nm[None, :w, :w], lv // 8, 1).astype(np.float32))[None]).to(dev)
+    mpos, wpos = 70_000_000, 128_000_000
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+    acc = np.zeros(3)
+
+    def one(timed):
+        ev[0].record()
+        ef = enc._local(lambda: model.net0.forward_codes(codes, reverse=False, **rng))      # rank-local bins, both strands
+        er = enc._local(lambda: model.net0.forward_codes(codes, reverse=True, **rng))
+        ev[1].record()
+        enc0 = torch.cat([gather(ef), gather(er)], dim=0)
+        ev[2].record()
+        preds, _ = orca_predict.cascade_256m(model, enc0, mpos, wpos, chrlen, de)
+        outs_ = [engine.strand_merge(p[0, 0], p[1, 0]) for p in preds]
+        ev[3].record()
+        if timed:
+            torch.cuda.synchronize(dev)
+            acc[:] += [ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2]), ev[2].elapsed_time(ev[3])]
+        return outs_
+
+    total_bins = engine.encoder_num_bins(L256)
+    lo, hi = odist.bin_range(total_bins, rank, world)
+    rng = {"bin_lo": lo, "bin_hi": hi} if world > 1 else {}
+    gather = (lambda part: odist.sharded_encode(lambda x, a, b: part, None, total_bins, None, comm)) if world > 1 else (lambda part: part)
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    one(False)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.sharded_steps):
+        outs_ = one(True)
+    sync()
+    el = time.perf_counter() - t0
+    parts = acc / args.sharded_steps
+    if dist is not None:
+        t = torch.tensor([el, parts[0], parts[1], parts[2]], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el, parts = float(t[0]), t[1:].cpu().numpy()
+    chk = float(sum(float(o.double().sum()) for o in outs_))
+    if comm is not None:
+        comm.close()
+    ms = el / args.sharded_steps * 1e3
+    return {"workload": "H1esc_256M-shaped model, one random 256 Mb sequence (replicated on every rank as 1 byte/base), both strands: Encoder bins "
+                        f"sharded {total_bins}/{world} per rank (112 kb input halo, orca_modules.py:955-977), one all-gather of [1,128,{-(-total_bins // world)}] fp32 "
+                        "per rank and strand, then Encoder2(64000 bins) -> Encoder3 -> 4 Decoders + strand merge replicated on every rank",
+            "n_gpus": world, "steps": args.sharded_steps, "scaling": "strong", "collective": collective,
+            "ms_per_step": round(ms, 2), "Mb_per_s": round(2 * 256 / (ms * 1e-3), 1),
+            "encoder_ms_per_rank_max": round(float(parts[0]), 2), "allgather_ms_max": round(float(parts[1]), 3), "replicated_tail_ms_max": round(float(parts[2]), 2),
+            "encoder_Mb_per_s": round(2 * 256 / (float(parts[0]) * 1e-3), 1), "maps_checksum": round(chk, 4),
+            "bins_this_rank": [int(lo), int(hi)]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -99,6 +194,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seq-mb", type=int, default=32, help="debug only: shorter sequence (invalidates the metric)")
     ap.add_argument("--float-input", action="store_true", help="keep the strands as float32 [1,4,L] views (the reference's input form)")
+    ap.add_argument("--no-sharded", action="store_true", help="skip the 256 Mb sharded-encoder section")
+    ap.add_argument("--sharded-steps", type=int, default=3)
+    ap.add_argument("--torch-collective", action="store_true", help="256 Mb section: torch.distributed all-gather instead of the C ABI's RCCL communicator")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -172,7 +270,8 @@ def main():
     PREC = {0: ("f32", "conv1d_k9_kernel", PEAK_F32_MFMA_TFLOPS, 1), 1: ("bf16", "conv1d_k9_bf16s_kernel", PEAK_16BIT_MFMA_TFLOPS, 1),
             2: ("bf16x2", "conv1d_k9_bf16s_kernel", PEAK_16BIT_MFMA_TFLOPS, 3), 3: ("bf16x3", "conv1d_k9_bf16s_kernel", PEAK_16BIT_MFMA_TFLOPS, 6),
             4: ("f16x2", "conv1d_k9_bf16s_kernel", PEAK_16BIT_MFMA_TFLOPS, 3),
-            5: ("f16x2", "conv1d_k9_p16_kernel", PEAK_16BIT_MFMA_TFLOPS, 3)}
+            5: ("f16x2", "conv1d_k9_p16_kernel", PEAK_16BIT_MFMA_TFLOPS, 3), 6: ("bf16", "conv1d_k9_p16_kernel", PEAK_16BIT_MFMA_TFLOPS, 1),
+            7: ("f16x2", "conv1d_k9_ws_kernel", PEAK_16BIT_MFMA_TFLOPS, 3), 8: ("bf16", "conv1d_k9_ws_kernel", PEAK_16BIT_MFMA_TFLOPS, 1)}
     inst = {}
     for (cout, cin, tile), g in groups.items():
         prec = -tile if tile < 0 else 0
@@ -185,16 +284,17 @@ def main():
     if inst:
         name, d = max(inst.items(), key=lambda kv: kv[1]["ms"])
         achieved = d["flop"] / (d["ms"] * 1e-3) / 1e12
-        traffic = None
+        traffic = traffic_src = None
         tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tp):
             try:
-                traffic = json.load(open(tp)).get(name)
+                tj = json.load(open(tp))
+                traffic, traffic_src = tj.get(name), tj.get("_source")
             except Exception:
                 traffic = None
         tot_ms = sum(v["ms"] for v in inst.values())
         roofline = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": d["peak"],
-                    "unit": "TFLOP/s", "frac": round(achieved / d["peak"], 4), "traffic": traffic,
+                    "unit": "TFLOP/s", "frac": round(achieved / d["peak"], 4), "traffic": traffic, "traffic_source": traffic_src,
                     "arithmetic": d["arith"], "mfma_products_per_algorithmic_mac": d["nprod"],
                     "mfma_pipe_frac": round(achieved * d["nprod"] / d["peak"], 4),
                     "frac_of_f32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
@@ -205,23 +305,64 @@ def main():
 
     ms_per_step = elapsed / args.steps * 1e3
     mb_per_s = world * 2 * (Lbp / 1e6) * args.steps / elapsed
+    enc_prec, dec_prec = model.net0.precision, model.denets[32].precision
+    ARITH = {"f32": "exact fp32 MFMA", "f16x2": "fp32 emulated as 2 x fp16 split operands, 3 MFMA products, fp32 accumulate (22 significant operand bits)",
+             "bf16x3": "fp32 emulated as 3 x bf16 split operands, 6 MFMA products, fp32 accumulate", "bf16": "plain bf16 operands, fp32 accumulate"}
     res = {
         "metric": "Mb of sequence encoded+decoded per second (32Mb H1-ESC-shaped model, both strands, 6 levels)",
         "value": round(mb_per_s, 3), "unit": "Mb/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": {"f32": "f32", "f16x2": "f32 emulated as 2xf16 split operands, 3 MFMA products, f32 accumulate (encoder convs); f32 (rest)",
-                  "bf16x3": "f32 emulated as 3xbf16 split operands, 6 MFMA products, f32 accumulate (encoder convs); f32 (rest)"}.get(model.net0.precision, model.net0.precision),
+        "dtype": f"Encoder Conv1d stages 1-7: {enc_prec} = {ARITH[enc_prec]}; Decoder / Decoder_1m Conv2d: {dec_prec} = {ARITH[dec_prec]}; "
+                 "Encoder2 Conv1d, 1x1 heads, pools, upsampling, merges: fp32",
         "data": "synthetic",
-        "config": {"workload": f"H1-ESC 32Mb model forward, single random {args.seq_mb}Mb sequence, fp32, both strands "
-                               "(genomepredict-equivalent, 1 model): Encoder+Encoder2+6 Decoder+Decoder_1m per strand",
+        "config": {"workload": f"H1-ESC 32Mb model forward, single random {args.seq_mb}Mb sequence, fp32-class ({enc_prec} split operands on the 16-bit matrix "
+                               "cores, see dtype; parity vs the reference's fp32 in `parity`), both strands (genomepredict-equivalent, 1 model): "
+                               "Encoder+Encoder2+6 Decoder+Decoder_1m per strand",
                    "sequence_bp": Lbp, "strands": 2, "levels": 6, "weights": "synthetic seed 0",
                    "input": "float32 [1,4,L] strands in HBM" if args.float_input else "1 byte/base packed sequence in HBM, both strands read from it",
-                   "parallelism": f"replicas x{world}" if world > 1 else "single GPU"},
+                   "parallelism": f"replicas x{world} (independent 32 Mb windows, no data-path collective)" if world > 1 else "single GPU"},
         "contact_map_pixels_per_s": round(world * 2 * 6 * 62500 * args.steps / elapsed, 1),
         "step_tflop_algorithmic": round(step_flops() * Lbp / L_BP, 3) if Lbp == L_BP else None,
         "whole_step_tflops": round(world * step_flops() * args.steps / elapsed, 2) if Lbp == L_BP else None,
         "roofline": roofline,
     }
+
+    # ---- parity of THIS run's maps against the reference's own output for the same sequence / weights / position (G8)
+    g8 = os.path.join(ROOT, "tests", "golden", "G8_full32m.npz")
+    if rank == 0 and Lbp == L_BP and os.path.exists(g8):
+        g = np.load(g8)
+        errs, rs = [], []
+        for j, o in enumerate(outs):
+            a, b = o.cpu().numpy().astype(np.float64), g[f"pred_{j}"].astype(np.float64)
+            errs.append(float(np.abs(a - b).max()))
+            rs.append(float(np.corrcoef(a.ravel(), b.ravel())[0, 1]))
+        res["parity"] = {"against": "tests/golden/G8_full32m.npz = the reference's genomepredict (PyTorch CPU fp32) on this sequence, these weights, this zoom position",
+                         "max_abs_per_level": [round(e, 8) for e in errs], "pearson_min": round(min(rs), 9), "tolerance": 1e-4,
+                         "ok": bool(max(errs) < 1e-4)}
+
+    # ---- exact fp32 MFMA everywhere: short second loop (N = 1)
+    if world == 1 and Lbp == L_BP:
+        mods = [model.net0] + [model.denets[lv] for lv in model.levels] + [model.denet_1_pt]
+        old = [m.precision for m in mods]
+        for m in mods:
+            m.precision = "f32"
+        step(); sync()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            step()
+        sync()
+        t32 = (time.perf_counter() - t0) / 2
+        for m, p_ in zip(mods, old):
+            m.precision = p_
+        res["exact_f32"] = {"ms_per_step": round(t32 * 1e3, 2), "Mb_per_s": round(2 * Lbp / 1e6 / t32, 2), "whole_step_tflops": round(step_flops() / t32, 2),
+                            "frac_of_157TF_fp32_mfma_peak": round(step_flops() / t32 / PEAK_F32_MFMA_TFLOPS, 4)}
+    strands = outs = None
+    engine.get_context(dev).release_workspace()
+    torch.cuda.empty_cache()
+
+    # ---- north star / config 4: 256 Mb model, Encoder bins sharded over the ranks + one RCCL all-gather per strand
+    if not args.no_sharded and Lbp == L_BP:
+        res["sharded_256mb"] = sharded_256mb(args, rank, world, dev, dist)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(0)
         res["speedup_vs_cpu"] = round(res["value"] / world / res["cpu_baseline"]["value"], 1)

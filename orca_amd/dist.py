@@ -50,21 +50,77 @@ def shard_indices(n_items, rank, world):
     return list(range(rank, n_items, world))
 
 
-def sharded_encode(encode_range, x, total_bins, group=None):
+class AbiComm:
+    """RCCL communicator owned by liborca_hip.so (orca_comm_init_rank / orca_allgather, include/orca_hip.h): the
+    all-gather is enqueued on the engine context's stream like every other step of the path.  The 128-byte unique id
+    is created on rank 0 and handed to the other ranks through torch.distributed's object broadcast (host side, any
+    backend).  ``world=1`` needs no process group (single-GPU tests)."""
+
+    def __init__(self, device, group=None, world=None, rank=None):
+        import ctypes
+
+        from . import _lib, engine
+        self.lib = _lib.load()
+        self.ctx = engine.get_context(device)
+        if world is None:
+            world, rank = dist.get_world_size(group), dist.get_rank(group)
+        self.world, self.rank = int(world), int(rank)
+        idbuf = ctypes.create_string_buffer(128)
+        if self.rank == 0:
+            _lib.check(self.lib.orca_comm_unique_id(idbuf), "orca_comm_unique_id")
+        if self.world > 1:
+            box = [idbuf.raw if self.rank == 0 else None]
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            idbuf = ctypes.create_string_buffer(box[0], 128)
+        self.handle = ctypes.c_void_p()
+        _lib.check(self.lib.orca_comm_init_rank(self.ctx.handle, self.world, self.rank, idbuf, ctypes.byref(self.handle)), "orca_comm_init_rank")
+
+    def all_gather(self, slab):
+        """slab: contiguous fp32 ROCm tensor -> [world, *slab.shape] (rank-major)."""
+        import ctypes
+
+        from . import _lib
+        assert slab.is_cuda and slab.dtype == torch.float32 and slab.is_contiguous()
+        out = torch.empty((self.world,) + tuple(slab.shape), dtype=torch.float32, device=slab.device)
+        self.ctx.sync_stream()
+        _lib.check(self.lib.orca_allgather(self.ctx.handle, self.handle, ctypes.c_void_p(slab.data_ptr()), ctypes.c_void_p(out.data_ptr()),
+                                           slab.numel()), "orca_allgather")
+        return out
+
+    def close(self):
+        if self.handle:
+            self.lib.orca_comm_destroy(self.handle)
+            self.handle = None
+
+
+def sharded_encode(encode_range, x, total_bins, group=None, comm=None):
     """encode_range(x, bin_lo, bin_hi) -> [B,128,bin_hi-bin_lo] on this rank's device.
     Every rank computes its bin range, then one all-gather assembles [B,128,total_bins]
-    on every rank.  With a single process this is just encode_range(x, 0, total_bins)."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    on every rank.  With a single process this is just encode_range(x, 0, total_bins).
+    ``comm``: an AbiComm (RCCL through the C ABI); otherwise torch.distributed's all_gather_into_tensor on ``group``
+    (RCCL under the "nccl" backend, gloo in the CPU tests)."""
+    if comm is not None:
+        world, rank = comm.world, comm.rank
+    elif dist.is_initialized():
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+    else:
+        world, rank = 1, 0
+    if world == 1:
         return encode_range(x, 0, total_bins)
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
     lo, hi = bin_range(total_bins, rank, world)
     part = encode_range(x, lo, hi)
     B = part.shape[0]
     width = -(-total_bins // world)  # ceil: every rank contributes an equal-size slab
-    slab = torch.zeros((B, 128, width), dtype=part.dtype, device=part.device)
-    slab[:, :, : hi - lo] = part
-    gathered = torch.empty((world * B, 128, width), dtype=part.dtype, device=part.device)
-    dist.all_gather_into_tensor(gathered, slab.contiguous(), group=group)  # rank-major along dim 0
+    if hi - lo == width:
+        slab = part.contiguous()
+    else:
+        slab = torch.zeros((B, 128, width), dtype=part.dtype, device=part.device)
+        slab[:, :, : hi - lo] = part
+    if comm is not None:
+        gathered = comm.all_gather(slab)
+    else:
+        gathered = torch.empty((world * B, 128, width), dtype=part.dtype, device=part.device)
+        dist.all_gather_into_tensor(gathered, slab, group=group)  # rank-major along dim 0
     gathered = gathered.view(world, B, 128, width)
     pieces = []
     for r in range(world):
@@ -77,9 +133,9 @@ class ShardedEncoder(torch.nn.Module):
     """Drop-in for ``model.net0``: same call signature as Encoder.forward, but the bins
     are computed cooperatively by all ranks of ``group`` (input replicated on every rank)."""
 
-    def __init__(self, encoder, group=None):
+    def __init__(self, encoder, group=None, comm=None):
         super().__init__()
-        self.encoder, self.group = encoder, group
+        self.encoder, self.group, self.comm = encoder, group, comm
 
     def _local(self, fn):
         # the fp16-range retry of the rank's own bins must happen BEFORE the all-gather (a retry decided afterwards, by
@@ -91,14 +147,14 @@ class ShardedEncoder(torch.nn.Module):
     def forward(self, x):
         from . import engine
         total = engine.encoder_num_bins(x.shape[2])
-        return sharded_encode(lambda t, lo, hi: self._local(lambda: self.encoder(t, bin_lo=lo, bin_hi=hi)), x, total, self.group)
+        return sharded_encode(lambda t, lo, hi: self._local(lambda: self.encoder(t, bin_lo=lo, bin_hi=hi)), x, total, self.group, self.comm)
 
     def forward_codes(self, codes, reverse=False):
         """Same from packed bases ([B,L] uint8 replicated on every rank, 32 MB per 32 Mb instead of 512 MB)."""
         from . import engine
         total = engine.encoder_num_bins(codes.shape[1])
         return sharded_encode(lambda t, lo, hi: self._local(lambda: self.encoder.forward_codes(t, reverse=reverse, bin_lo=lo, bin_hi=hi)),
-                              codes, total, self.group)
+                              codes, total, self.group, self.comm)
 
 
 def max_over_ranks(value, device):

@@ -205,6 +205,21 @@ def zoom_index_32m(level, start, mpos, wpos, reverse):
     return int(np.clip(v, 0, 125))
 
 
+def zoom_index_256m(level, start, mpos, wpos, chrlen, reverse):
+    """256 Mb cascade: window offset with chromosome-end bounds (orca_predict.py:813-835); ``start`` in 32 kb bins."""
+    half = level * 1000000 / 4
+    if not reverse:
+        proposed = (mpos - half) - (wpos - 128000000 + start * 32000)
+    else:
+        proposed = (mpos - half) - (wpos + 128000000 - start * 32000 - level * 1000000)
+    if chrlen is not None:
+        lo = 0 - (wpos - 128000000)
+        hi = chrlen - level * 1000000 / 2 - (wpos - 128000000)
+        proposed = np.clip(proposed, lo, hi) if lo < hi else lo
+    i = int(np.clip(np.floor(proposed / (4000 * level)), 0, 125))
+    return 250 - (i + 125) if reverse else i
+
+
 def _gather(t, B, idx, width, dims):
     """Per-strand crops of a [nstrands*B, ...] tensor (strand k uses offset idx[k]) restacked along the batch axis."""
     parts = []
@@ -274,6 +289,21 @@ def cascade_32m(model, xs, mpos, wpos, reverse_flags, distencs=None):
                            lambda lv, st, rev: zoom_index_32m(lv, st, mpos, wpos, rev), add_1m_level=1)
 
     return engine.run_with_overflow_retry(forward, xs[0].device)
+
+
+def cascade_256m(model, enc0, mpos, wpos, chrlen, distencs, reverse_flags=(False, True)):
+    """Device part of the 256 Mb cascade AFTER the Encoder (orca_predict.py:675-838): ``enc0`` [S*B,128,64000] (strand k =
+    rows k*B..) -> net1 -> [-1] -> net -> the four decoder levels.  ``distencs``: {level: log-background [1,1,250,250]}
+    (the host-side block means of the 8000 x 8000 background, :724-737, are the caller's business)."""
+    S = len(reverse_flags)
+    B = enc0.shape[0] // S
+
+    def forward():
+        encodings = dict(zip([32, 64, 128, 256], model.net(model.net1(enc0)[-1])))
+        return run_cascade(model, encodings, [256, 128, 64, 32], lambda lv: lv // 8, B, list(reverse_flags),
+                           lambda lv, k, st: distencs[lv], lambda lv, st, rev: zoom_index_256m(lv, st, mpos, wpos, chrlen, rev))
+
+    return engine.run_with_overflow_retry(forward, enc0.device)
 
 
 def _merge(preds, B):
@@ -362,18 +392,7 @@ def genomepredict_256Mb(sequence, mchr, normmats, chrlen, mpos=-1, wpos=-1, mode
     predictions, allstarts, allnormmats, allnormmats_rev, alltargets, allannos = [], [], [], [], [], []
 
     def zoom(level, start, reverse):
-        """window offset with chromosome-end bounds (orca_predict.py:813-835)"""
-        half = level * 1000000 / 4
-        if not reverse:
-            proposed = (mpos - half) - (wpos - 128000000 + start * 32000)
-        else:
-            proposed = (mpos - half) - (wpos + 128000000 - start * 32000 - level * 1000000)
-        if chrlen is not None:
-            lo = 0 - (wpos - 128000000)
-            hi = chrlen - level * 1000000 / 2 - (wpos - 128000000)
-            proposed = np.clip(proposed, lo, hi) if lo < hi else lo
-        i = int(np.clip(np.floor(proposed / (4000 * level)), 0, 125))
-        return 250 - (i + 125) if reverse else i
+        return zoom_index_256m(level, start, mpos, wpos, chrlen, reverse)
 
     with torch.no_grad():
         strands = _StrandInputs(sequence, use_cuda)
