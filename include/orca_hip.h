@@ -215,6 +215,12 @@ int orca_decoder1m_forward(orca_ctx* ctx, orca_net* net, const float* x, int64_t
  * (orca_predict.py:514-523) for contiguous [n,n] maps. */
 int orca_strand_merge(orca_ctx* ctx, const float* fwd, const float* rev, float* out, int n);
 
+/* Genome store, 2 bits per base + N bit-mask (replaces the float32 one-hot memmap of
+ * selene_utils2.MemmapGenome, selene_utils2.py:38-272): expands the window [start, start+n) of a chromosome to the
+ * 1-byte base codes orca_encoder_forward_codes reads (0..3 = A,C,G,T, 4 = N).  two_bit: base i in bits 2*(i%4).. of
+ * byte i/4; nmask: base i in bit i%8 of byte i/8.  Device pointers. */
+int orca_genome_unpack_2bit(orca_ctx* ctx, const uint8_t* two_bit, const uint8_t* nmask, int64_t start, int64_t n, uint8_t* codes);
+
 /* ---- multi-GPU exchange ----------------------------------
  * The path shards at ONE place: the Encoder's 4 kb bins (bin_lo / bin_hi of orca_encoder_forward; blocks are
  * independent given the 112 kb input halo, orca_modules.py:955-977), followed by ONE all-gather of the per-rank

@@ -32,6 +32,21 @@ __global__ void seq_to_rows_kernel(const float* __restrict__ x, long sc, long sl
   reinterpret_cast<float4*>(y)[i] = q;
 }
 
+// 2-bit + N-mask genome window -> 1-byte base codes (one thread = 4 consecutive output bases)
+__global__ void genome_unpack_2bit_kernel(const unsigned char* __restrict__ two, const unsigned char* __restrict__ nmask, long start, long n,
+                                          unsigned char* __restrict__ codes) {
+  const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const long o = 4 * q + e;
+    if (o >= n) return;
+    const long i = start + o;
+    const unsigned c = (two[i >> 2] >> ((i & 3) * 2)) & 3u;
+    const unsigned isn = (nmask[i >> 3] >> (i & 7)) & 1u;
+    codes[o] = (unsigned char)(isn ? 4u : c);
+  }
+}
+
 // nn.MaxPool1d(k, k): y[r][m] = max_j x[r][k*m+j]
 template <int K>
 __global__ void maxpool1d_kernel(const float* __restrict__ x, long ldx, float* __restrict__ y, long ldy, long n_out) {

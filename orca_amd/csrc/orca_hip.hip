@@ -1392,6 +1392,17 @@ extern "C" int orca_strand_merge(orca_ctx* ctx, const float* fwd, const float* r
   return ORCA_OK;
 }
 
+extern "C" int orca_genome_unpack_2bit(orca_ctx* ctx, const uint8_t* two_bit, const uint8_t* nmask, int64_t start, int64_t n, uint8_t* codes) {
+  if (!ctx || !two_bit || !nmask || !codes) return fail(ORCA_EINVAL, "orca_genome_unpack_2bit: NULL argument");
+  if (start < 0 || n < 0) return fail(ORCA_EINVAL, "orca_genome_unpack_2bit: negative window");
+  if (n == 0) return ORCA_OK;
+  HIPCHECK(hipSetDevice(ctx->device));
+  const long nq = (n + 3) / 4;
+  hipLaunchKernelGGL(genome_unpack_2bit_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, ctx->stream, two_bit, nmask, (long)start, (long)n, codes);
+  LAUNCHCHECK("genome_unpack_2bit_kernel");
+  return ORCA_OK;
+}
+
 // ---------------------------------------------------------------------------
 // multi-GPU exchange: RCCL, resolved at run time
 // ---------------------------------------------------------------------------

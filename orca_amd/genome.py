@@ -1,4 +1,5 @@
-"""Packed genome store: 1 byte per base, resident on the host or in HBM.
+"""Packed genome store: 1 byte per base (PackedGenome) or 2 bits per base + an N bit-mask (TwoBitGenome, 3 bits per
+base: ~1.2 GB for hg38), resident on the host or in HBM.
 
 The reference keeps the genome as a float32 one-hot memmap (`selene_utils2.MemmapGenome`, ~40 GB for hg38,
 `selene_utils2.py:38-272`) and materialises a 512 MB float window per `get_encoding_from_coords` call.  Here a
@@ -159,10 +160,10 @@ class PackedGenome:
         return sorted(self._host)
 
     def get_chr_lens(self):
-        return [(c, int(self._host[c].shape[0])) for c in self.get_chrs()]
+        return [(c, self._length(c)) for c in self.get_chrs()]
 
     def _bounds(self, chrom, start, end, pad):
-        n = self._host[chrom].shape[0]
+        n = self._length(chrom)
         if end < start:
             raise ValueError(f"window [{start}, {end}) has negative length")
         if pad:   # both ends clamped: a window entirely outside the chromosome is all padding ('N')
@@ -174,18 +175,24 @@ class PackedGenome:
             raise AssertionError(f"coordinates [{start}, {end}) exceed chromosome {chrom} of length {n} (selene_utils2.py:257)")
         return start, end, 0, 0
 
+    def _length(self, chrom):
+        return int(self._host[chrom].shape[0])
+
+    def _slice(self, chrom, qs, qe, on_dev):
+        return self._dev[chrom][qs:qe] if on_dev else self._host[chrom][qs:qe]
+
     def get_codes_from_coords(self, chrom, start, end, strand="+", pad=False, device=None):
         """The window as base codes: numpy uint8 [end-start], or a ROCm tensor when the genome lives on a device
         (`device=False` forces the host copy)."""
         qs, qe, pl, pr = self._bounds(chrom, start, end, pad)
-        on_dev = self._dev and device is not False
+        on_dev = bool(self._dev) and device is not False
         if on_dev:
-            c = self._dev[chrom][qs:qe]
+            c = self._slice(chrom, qs, qe, True)
             if pl or pr:
                 c = torch.cat([torch.full((pl,), N_CODE, dtype=torch.uint8, device=c.device), c,
                                torch.full((pr,), N_CODE, dtype=torch.uint8, device=c.device)])
         else:
-            c = self._host[chrom][qs:qe]
+            c = self._slice(chrom, qs, qe, False)
             if pl or pr:
                 c = np.concatenate([np.full(pl, N_CODE, np.uint8), c, np.full(pr, N_CODE, np.uint8)])
         if strand == "-":
@@ -203,3 +210,72 @@ class PackedGenome:
         return enc, bool(np.any(enc[0, :] == 0.25))
 
     sequence_to_encoding = staticmethod(sequence_to_encoding)
+
+
+
+def pack_2bit(codes):
+    """uint8 codes [n] (0..3, anything else = N) -> (2-bit array [ceil(n/4)] with base i in bits 2*(i%4).. of byte i//4,
+    N bit-mask [ceil(n/8)] with base i in bit i%8 of byte i//8; N positions carry 0 in the 2-bit array)."""
+    c = np.asarray(codes, dtype=np.uint8)
+    n = c.shape[0]
+    isn = c > 3
+    b = np.where(isn, 0, c).astype(np.uint8)
+    b = np.concatenate([b, np.zeros((-n) % 4, np.uint8)]).reshape(-1, 4)
+    two = (b[:, 0] | (b[:, 1] << 2) | (b[:, 2] << 4) | (b[:, 3] << 6)).astype(np.uint8)
+    mask = np.packbits(isn, bitorder="little")
+    return two, mask
+
+
+def unpack_2bit(two, mask, start, end):
+    """Inverse of pack_2bit on the window [start, end) (host)."""
+    i = np.arange(start, end, dtype=np.int64)
+    c = (two[i >> 2] >> ((i & 3) * 2).astype(np.uint8)) & 3
+    isn = (mask[i >> 3] >> (i & 7).astype(np.uint8)) & 1
+    return np.where(isn == 1, N_CODE, c).astype(np.uint8)
+
+
+class TwoBitGenome(PackedGenome):
+    """The same query API on 2 bits per base + a 1-bit N mask ('a 2-bit packing alone cannot represent
+    N'): 3/8 of the 1-byte store.  Windows are expanded to base codes on demand - on the host with numpy, in HBM by
+    the library's `orca_genome_unpack_2bit` kernel (the expanded window is what `orca_encoder_forward_codes` reads)."""
+
+    def __init__(self, chroms):
+        self._host, self._dev, self.device = {}, {}, None
+        for k, v in chroms.items():
+            v = np.asarray(v, dtype=np.uint8)
+            self._host[str(k)] = pack_2bit(v) + (int(v.shape[0]),)
+
+    @classmethod
+    def from_packed(cls, genome):
+        """From a 1-byte PackedGenome (e.g. `PackedGenome.from_fasta`)."""
+        return cls({c: genome._host[c] for c in genome.get_chrs()})
+
+    @classmethod
+    def from_fasta(cls, path, chroms=None):
+        return cls.from_packed(PackedGenome.from_fasta(path, chroms))
+
+    def nbytes(self):
+        return sum(t.nbytes + m.nbytes for t, m, _ in self._host.values())
+
+    def to(self, device):
+        self.device = torch.device(device)
+        self._dev = {k: (torch.from_numpy(t).to(self.device), torch.from_numpy(m).to(self.device)) for k, (t, m, _) in self._host.items()}
+        return self
+
+    def _length(self, chrom):
+        return self._host[chrom][2]
+
+    def _slice(self, chrom, qs, qe, on_dev):
+        if not on_dev:
+            t, m, _ = self._host[chrom]
+            return unpack_2bit(t, m, qs, qe)
+        import ctypes
+
+        from . import _lib, engine
+        t, m = self._dev[chrom]
+        out = torch.empty(qe - qs, dtype=torch.uint8, device=t.device)
+        if qe > qs:
+            ctx = engine.get_context(t.device)
+            _lib.check(_lib.load().orca_genome_unpack_2bit(ctx.handle, ctypes.c_void_p(t.data_ptr()), ctypes.c_void_p(m.data_ptr()), qs, qe - qs,
+                                                           ctypes.c_void_p(out.data_ptr())), "orca_genome_unpack_2bit")
+        return out

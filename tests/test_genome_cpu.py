@@ -76,3 +76,29 @@ def test_padded_window_outside_the_chromosome_is_all_n_and_unpadded_raises():
             g.get_codes_from_coords("c", *bad)
     with pytest.raises(ValueError):
         g.get_codes_from_coords("c", 5, 2, pad=True)
+
+
+def test_two_bit_store_is_bit_exact_with_the_one_byte_store(fasta):
+    """2 bits per base + N bit-mask, same query API; every window equals the 1-byte store's, on FASTA with
+    lower case, IUPAC codes and N runs, on both strands, with and without padding, at every alignment of the window."""
+    from orca_amd.genome import TwoBitGenome, pack_2bit, unpack_2bit
+    path, recs = fasta
+    g1 = PackedGenome.from_fasta(path)
+    g2 = TwoBitGenome.from_fasta(path)
+    assert g2.get_chr_lens() == g1.get_chr_lens()
+    assert g2.nbytes() <= sum(len(v) for v in recs.values()) * 3 / 8 + 2 * len(recs) + 2
+    rs = np.random.RandomState(3)
+    for chrom, n in g1.get_chr_lens():
+        for _ in range(40 if n else 1):
+            a, b = sorted(rs.randint(-9, n + 10, 2))
+            for strand in "+-":
+                np.testing.assert_array_equal(g2.get_codes_from_coords(chrom, a, b, strand, pad=True), g1.get_codes_from_coords(chrom, a, b, strand, pad=True))
+            a, b = max(a, 0), min(b, n)
+            if a <= b:
+                np.testing.assert_array_equal(g2.get_encoding_from_coords(chrom, a, b), g1.get_encoding_from_coords(chrom, a, b))
+    with pytest.raises(AssertionError):
+        g2.get_codes_from_coords("chr1", 5, 5000)
+    codes = rs.randint(0, 6, 1001).astype(np.uint8)          # 4 and 5: both read back as N
+    two, mask = pack_2bit(codes)
+    assert two.shape[0] == 251 and mask.shape[0] == 126
+    np.testing.assert_array_equal(unpack_2bit(two, mask, 0, 1001), np.minimum(codes, 4))
