@@ -215,6 +215,14 @@ int orca_decoder1m_forward(orca_ctx* ctx, orca_net* net, const float* x, int64_t
  * (orca_predict.py:514-523) for contiguous [n,n] maps. */
 int orca_strand_merge(orca_ctx* ctx, const float* fwd, const float* rev, float* out, int n);
 
+/* Replaces: `adaptive_coarsegrain_gpu(ar, countar, cutoff, max_levels, min_shape)` (selene_utils2.py:274-463), the
+ * 2x2-pooling smoother that `Genomic2DFeatures(cg=True)` applies to OBSERVED Hi-C matrices (:551-556) before they become
+ * output["experiments"].  ar = balanced matrix (NaN = masked), countar = raw counts, both [n][n] fp32 device arrays with
+ * row stride ld; out [n][n] (row stride ld_out), NaN at invalid pixels.  Bit-identical to the reference (same float32
+ * operation order).  The reference's defaults: cutoff 5, max_levels 8 (12 through its wrapper), min_shape 8. */
+int orca_adaptive_coarsegrain(orca_ctx* ctx, const float* ar, const float* countar, int64_t ld, int n, float cutoff,
+                              int max_levels, int min_shape, float* out, int64_t ld_out);
+
 /* Genome store, 2 bits per base + N bit-mask (replaces the float32 one-hot memmap of
  * selene_utils2.MemmapGenome, selene_utils2.py:38-272): expands the window [start, start+n) of a chromosome to the
  * 1-byte base codes orca_encoder_forward_codes reads (0..3 = A,C,G,T, 4 = N).  two_bit: base i in bits 2*(i%4).. of

@@ -20,6 +20,7 @@
 #include "conv_p16.h"
 #include "conv_ws.h"
 #include "misc_kernels.h"
+#include "coarsegrain.h"
 #include "orca_hip.h"
 
 // ---------------------------------------------------------------------------
@@ -1389,6 +1390,37 @@ extern "C" int orca_strand_merge(orca_ctx* ctx, const float* fwd, const float* r
   HIPCHECK(hipSetDevice(ctx->device));
   hipLaunchKernelGGL(strand_merge_kernel, dim3((unsigned)((n * n + 255) / 256)), dim3(256), 0, ctx->stream, fwd, rev, out, n);
   LAUNCHCHECK("strand_merge_kernel");
+  return ORCA_OK;
+}
+
+extern "C" int orca_adaptive_coarsegrain(orca_ctx* ctx, const float* ar, const float* countar, int64_t ld, int n, float cutoff, int max_levels,
+                                         int min_shape, float* out, int64_t ld_out) {
+  if (!ctx || !ar || !countar || !out) return fail(ORCA_EINVAL, "orca_adaptive_coarsegrain: NULL argument");
+  if (n <= 0 || n > 32768 || ld < n || ld_out < n || max_levels < 0 || min_shape < 1) return fail(ORCA_EINVAL, "orca_adaptive_coarsegrain: bad shape");
+  HIPCHECK(hipSetDevice(ctx->device));
+  int N = 1;
+  while (N < n) N <<= 1;
+  std::vector<int> sides{N};
+  for (int i = 0; i < max_levels; ++i)
+    if (sides.back() > min_shape) sides.push_back(sides.back() / 2);
+  size_t need = 0;
+  for (int sd : sides) need += 3 * ru256((size_t)sd * sd * 4);
+  ORCA_TRY(ws_ensure(ctx, need));
+  std::vector<float*> v(sides.size()), c(sides.size());
+  std::vector<int*> m(sides.size());
+  for (size_t l = 0; l < sides.size(); ++l) {
+    const size_t e = (size_t)sides[l] * sides[l];
+    v[l] = ws_take(ctx, e); c[l] = ws_take(ctx, e); m[l] = reinterpret_cast<int*>(ws_take(ctx, e));
+  }
+  hipStream_t s = ctx->stream;
+  auto blocks = [](long e) { return dim3((unsigned)((e + 255) / 256)); };
+  hipLaunchKernelGGL(cg_init_kernel, blocks((long)N * N), dim3(256), 0, s, ar, countar, (long)ld, n, N, v[0], c[0], m[0]);
+  for (size_t l = 1; l < sides.size(); ++l)
+    hipLaunchKernelGGL(cg_coarsen_kernel, blocks((long)sides[l] * sides[l]), dim3(256), 0, s, v[l - 1], c[l - 1], m[l - 1], sides[l], v[l], c[l], m[l]);
+  for (size_t l = sides.size() - 1; l >= 1; --l)
+    hipLaunchKernelGGL(cg_refine_kernel, blocks((long)sides[l] * sides[l]), dim3(256), 0, s, v[l], m[l], sides[l], cutoff, v[l - 1], c[l - 1], m[l - 1]);
+  hipLaunchKernelGGL(cg_finish_kernel, blocks((long)n * n), dim3(256), 0, s, v[0], m[0], N, n, out, (long)ld_out);
+  LAUNCHCHECK("adaptive coarse-graining kernels");
   return ORCA_OK;
 }
 

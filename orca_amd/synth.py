@@ -270,6 +270,25 @@ class FakeTarget256:
         return 1.0 / (1.0 + np.abs(a[:, None] - b[None, :]) / 32000.0) + 1e-9 * (a[:, None] + 2 * b[None, :])
 
 
+def synth_hic(n, seed, nan_frac=0.03, depth=3.0, m=None):
+    """Synthetic observed Hi-C block [n, m]: raw counts ~ Poisson(distance decay), balanced = counts x bin weights with a
+    fraction of masked (NaN) bins - the two matrices `cooler.matrix(balance=False/True).fetch` returns."""
+    m = n if m is None else m
+    rs = np.random.RandomState(seed)
+    k = max(n, m)
+    d = np.abs(np.arange(k)[:, None] - np.arange(k)[None, :])
+    cnt = rs.poisson(depth * 40.0 / (1.0 + d) ** 1.1)
+    cnt = np.triu(cnt) + np.triu(cnt, 1).T
+    w = rs.uniform(0.5, 1.5, k)
+    w[rs.rand(k) < nan_frac] = np.nan
+    bal = cnt * w[:, None] * w[None, :] / 200.0
+    return bal[:n, :m].astype(np.float64), cnt[:n, :m].astype(np.float64)
+
+
+COARSEGRAIN_CASES = [("sq250", 250, 250, 1), ("sq300", 300, 300, 2), ("sq17", 17, 17, 4), ("rect200x300", 200, 300, 7), ("rect300x120", 300, 120, 9),
+                     ("tiny6", 6, 6, 8), ("sq1000", 1000, 1000, 5)]
+
+
 def seq_digest(sequence, binsize=1_024_000):
     """Exact digest of a [1,L,4] float one-hot sequence or of [1,L] base codes: per `binsize` bin,
     sum over positions of (pos % 1000 + 1) * sum_c (c + 1) * x[pos, c]  (an 'N' row counts 2.5)."""

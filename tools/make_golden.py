@@ -474,8 +474,32 @@ def config3_golden(om):
     np.savez_compressed(os.path.join(GOLD, "G17_config3.npz"), **d)
 
 
+def coarsegrain_golden():
+    """G18: the reference's own `_adaptive_coarsegrain(cuda=True)` -> `adaptive_coarsegrain_gpu` (selene_utils2.py:274-504) on
+    synthetic observed Hi-C blocks.  The function hard-codes the CUDA default tensor type (:346) and uses `np.int`
+    (:397, removed from numpy >= 1.24): both are patched IN THIS PROCESS ONLY so that it runs on the CPU here."""
+    _stub_third_party()
+    np.int = int
+    torch.set_default_tensor_type = lambda *a, **k: None
+    import selene_utils2 as su
+    d = {}
+    for name, n, m, seed in synth.COARSEGRAIN_CASES:
+        a, c = synth.synth_hic(n, seed, m=m)
+        out = su._adaptive_coarsegrain(a.copy(), c.copy(), cuda=True).astype(np.float32)
+        if n * m > 100000:      # large case: moments + a corner + the NaN pattern's size
+            fin = np.isfinite(out)
+            d[name + "_stats"] = np.array([out[fin].astype(np.float64).sum(), (out[fin].astype(np.float64) ** 2).sum(), float((~fin).sum())])
+            d[name + "_corner"] = out[:64, :64].copy()
+        else:
+            d[name] = out
+        print("G18", name, out.shape, int(np.isnan(out).sum()), flush=True)
+    np.savez_compressed(os.path.join(GOLD, "G18_coarsegrain.npz"), **d)
+
+
 if __name__ == "__main__":
-    if "--config3" in sys.argv:
+    if "--coarsegrain" in sys.argv:
+        coarsegrain_golden()
+    elif "--config3" in sys.argv:
         _stub_third_party()
         import orca_modules as _om
         torch.set_num_threads(os.cpu_count())
