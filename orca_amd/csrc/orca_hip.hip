@@ -17,6 +17,7 @@
 #include "conv_kernels.h"
 #include "conv_bf16s.h"
 #include "conv2d_f16s.h"
+#include "conv2d_dblock.h"
 #include "conv_p16.h"
 #include "conv_ws.h"
 #include "misc_kernels.h"
@@ -1244,8 +1245,25 @@ static int decoder_nhwc(orca_ctx* ctx, orca_net* net, const float* x, long sx_b,
     }
     float* cur = Df;
     float* oth = Cf;
+    static const bool no_dblock = getenv("ORCA_NO_DBLOCK") != nullptr;   // A/B switch
+    const bool bf16 = net->precision == ORCA_PRECISION_BF16;
     for (int i = 1; i < npairs; ++i) {
       const ConvLayer* p = pairs + 4 * i;
+      const int dil = p[0].dil;
+      if (!no_dblock && (dil == 16 || dil == 32 || dil == 64) && p[1].dil == dil && p[2].dil == dil && p[3].dil == dil) {
+        // the whole block (oth = lm(cur) + cur; cur = m(oth) + oth) in one launch, in place (conv2d_dblock.h)
+        DBlockArgs da;
+        da.cur = cur; da.bs = sz64; da.cs = (long)n * ORCA_LDW * 16; da.H = n; da.W = n; da.dil = dil; da.flag = ctx->d_flag;
+        for (int k = 0; k < 4; ++k) {
+          if (!bf16 && !p[k].f16_ok) return fail(ORCA_EINVAL, "layer weights exceed the fp16 range");
+          da.w[k] = bf16 ? p[k].d_wb16p : p[k].d_wf16;
+          da.bias[k] = p[k].d_bias;
+        }
+        if (bf16) hipLaunchKernelGGL((conv2d_dblock_kernel<1, 0>), dim3(256, (unsigned)nb), dim3(512), 0, ctx->stream, da);
+        else hipLaunchKernelGGL((conv2d_dblock_kernel<2, 1>), dim3(256, (unsigned)nb), dim3(512), 0, ctx->stream, da);
+        LAUNCHCHECK("conv2d_dblock_kernel");
+        continue;
+      }
       C2(p[0], cur, sz64, 64, T, sz32, 32, nullptr, 0, 0, 0);
       C2(p[1], T, sz32, 32, oth, sz64, 64, cur, sz64, 64, 0);
       C2(p[2], oth, sz64, 64, T, sz32, 32, nullptr, 0, 0, 1);
