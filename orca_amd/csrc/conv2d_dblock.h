@@ -38,7 +38,7 @@ __device__ __forceinline__ void dblock_wait(f16x8 (&x)[NS], f16x8 (&w)[NS]) {
 }
 
 template <int NS, int DT>
-__global__ __launch_bounds__(512) void conv2d_dblock_kernel(DBlockArgs a) {
+__global__ __launch_bounds__(512, NS == 1 ? 4 : 2) void conv2d_dblock_kernel(DBlockArgs a) {   // bf16: 77 KB of LDS, two workgroups per CU if <= 128 VGPRs
   constexpr int NT = 512, PXW = 257;                 // 256 pixels + the zero unit
   constexpr int AU = NS * 8 * PXW, BU = NS * 4 * PXW; // operand images (16-byte units)
   constexpr int WP = NS * 9 * 2 * 32;                // one weight piece: 16 input channels x 32 couts

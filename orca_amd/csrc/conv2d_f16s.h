@@ -36,7 +36,7 @@ struct Conv2dF16Args {
 // NS / DT: operand splits and 16-bit type (conv_bf16s.h).  <2, 1> = fp32-class f16x2 (3 products); <1, 0> = plain bf16
 // operands, ONE product (the throughput mode of BASELINE config 3; a.w is then the bf16 pack [nchunks][9][2][COUT][8]).
 template <int COUT, int NS = 2, int DT = 1>
-__global__ __launch_bounds__(512) void conv2d_3x3_f16s_kernel(Conv2dF16Args a) {
+__global__ __launch_bounds__(512, (NS == 1 && COUT == 64) ? 4 : 2) void conv2d_3x3_f16s_kernel(Conv2dF16Args a) {   // bf16, 64 couts: 70 KB of LDS - two workgroups per CU need <= 128 VGPRs
   static_assert((NS == 2 && DT == 1) || (NS == 1 && DT == 0), "f16x2 or plain bf16");
   constexpr int NT = 512, NW = COUT / 32, PX = 256;
   constexpr int XU = NS * 2 * 3 * PX;     // 16-byte units of the X image (6144)
