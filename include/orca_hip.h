@@ -207,6 +207,18 @@ int orca_decoder_forward_mt(orca_ctx* ctx, orca_net* net, const float* x, int64_
 /* T (num_2d) of a Decoder / Decoder_1m net; 1 for every other kind. */
 int orca_net_num_targets(orca_net* net, int* num_2d);
 
+/* orca_decoder_forward_mt / orca_decoder1m_forward with ONE DEVICE POINTER PER BATCH ROW (host arrays of B pointers;
+ * y_rows may be NULL) instead of a batch stride: the rows of a batch need not be slices of one tensor.  genomepredict
+ * crops every strand's encoding (`[:, :, s:s+250]`) and coarse prediction (`[:, :, i:i+125, i:i+125]`) at the strand's
+ * own offset (orca_predict.py:356-379); with row pointers the two strands go through every decoder level as one batch
+ * without being copied next to each other first.  The pointer arrays are read during the call only. */
+int orca_decoder_forward_rows(orca_ctx* ctx, orca_net* net, const float* const* x_rows, int64_t sx_c, int64_t sx_l,
+                              const float* const* distenc_rows, int64_t sd_c, int64_t sd_h, int64_t sd_w,
+                              const float* const* y_rows, int64_t sy_c, int64_t sy_h, int64_t sy_w, int B, int n,
+                              float* out, int accumulate);
+int orca_decoder1m_forward_rows(orca_ctx* ctx, orca_net* net, const float* const* x_rows, int64_t sx_c, int64_t sx_l,
+                                int B, int n, float* out, int accumulate);
+
 /* Replaces: model.denet_1_pt.forward(x) = Decoder_1m.forward (orca_modules.py:782-800); out [B,T,n,n]. */
 int orca_decoder1m_forward(orca_ctx* ctx, orca_net* net, const float* x, int64_t sx_b, int64_t sx_c,
                            int64_t sx_l, int B, int n, float* out, int accumulate);

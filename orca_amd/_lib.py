@@ -58,6 +58,9 @@ SIGNATURES = {
                                      c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_void_p, c_int]),
     "orca_decoder_forward_mt": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64,
                                         c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_void_p, c_int]),
+    "orca_decoder_forward_rows": (c_int, [c_void_p, c_void_p, POINTER(c_void_p), c_int64, c_int64, POINTER(c_void_p), c_int64, c_int64, c_int64,
+                                          POINTER(c_void_p), c_int64, c_int64, c_int64, c_int, c_int, c_void_p, c_int]),
+    "orca_decoder1m_forward_rows": (c_int, [c_void_p, c_void_p, POINTER(c_void_p), c_int64, c_int64, c_int, c_int, c_void_p, c_int]),
     "orca_net_num_targets": (c_int, [c_void_p, POINTER(c_int)]),
     "orca_decoder1m_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_void_p, c_int]),
     "orca_strand_merge": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int]),

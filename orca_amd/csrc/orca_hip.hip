@@ -1166,6 +1166,15 @@ extern "C" int orca_unet_forward(orca_ctx* ctx, orca_net* net, const float* x, i
 // ---------------------------------------------------------------------------
 // Decoder / Decoder_1m (orca_modules.py:461-488, :782-800)
 // ---------------------------------------------------------------------------
+// batch rows of a Decoder input: slices of one strided tensor (base + b*bs) or one device pointer per row
+struct RowSrc {
+  const float* base = nullptr;
+  long bs = 0;
+  const float* const* rows = nullptr;
+  const float* at(int b) const { return rows ? rows[b] : (base ? base + (long)b * bs : nullptr); }
+  explicit operator bool() const { return rows || base; }
+};
+
 static int launch_final(orca_ctx* ctx, orca_net* net, const float* cur, long cur_bs, float* out, int B, int n, int accumulate) {
   const ConvLayer& fa = net->convs[net->convs.size() - 2];
   const ConvLayer& fb = net->convs[net->convs.size() - 1];
@@ -1179,8 +1188,8 @@ static int launch_final(orca_ctx* ctx, orca_net* net, const float* cur, long cur
 }
 
 // Decoder / Decoder_1m on the fp16 matrix cores, channel-last feature maps [n][256 px][C]
-static int decoder_nhwc(orca_ctx* ctx, orca_net* net, const float* x, long sx_b, long sx_c, long sx_l, const float* de, long sd_b,
-                        long sd_c, long sd_h, long sd_w, const float* y, long sy_b, long sy_c, long sy_h, long sy_w, int B, int n,
+static int decoder_nhwc(orca_ctx* ctx, orca_net* net, const RowSrc& x, long sx_c, long sx_l, const RowSrc& de,
+                        long sd_c, long sd_h, long sd_w, const RowSrc& y, long sy_c, long sy_h, long sy_w, int B, int n,
                         float* out, int accumulate) {
   const int nt2 = net->num_2d;
   const bool is1m = net->kind == ORCA_NET_DECODER_1M;
@@ -1205,8 +1214,8 @@ static int decoder_nhwc(orca_ctx* ctx, orca_net* net, const float* x, long sx_b,
     float* T = T0 + b0 * sz32;
     hipStream_t s = ctx->stream;
     for (int b = 0; b < nb; ++b) {
-      hipLaunchKernelGGL(outer_sum_nhwc_kernel, dim3(32, (unsigned)n), dim3(cIN / 4, 8), 0, s, x + (long)(b0 + b) * sx_b, sx_c, sx_l,
-                         de ? de + (long)(b0 + b) * sd_b : nullptr, sd_c, sd_h, sd_w, nt2, IN + b * szIN, n, cIN);
+      hipLaunchKernelGGL(outer_sum_nhwc_kernel, dim3(32, (unsigned)n), dim3(cIN / 4, 8), 0, s, x.at(b0 + b), sx_c, sx_l,
+                         de.at(b0 + b), sd_c, sd_h, sd_w, nt2, IN + b * szIN, n, cIN);
       LAUNCHCHECK("outer_sum_nhwc_kernel");
     }
     const ConvLayer* L = net->convs.data();
@@ -1222,7 +1231,7 @@ static int decoder_nhwc(orca_ctx* ctx, orca_net* net, const float* x, long sx_b,
       pairs = L + 8; npairs = 28;
       if (y) {
         for (int b = 0; b < nb; ++b) {
-          hipLaunchKernelGGL(upsample2d_nhwc_kernel, dim3((unsigned)n), dim3(256), 0, s, y + (long)(b0 + b) * sy_b, sy_c, sy_h, sy_w, nt2,
+          hipLaunchKernelGGL(upsample2d_nhwc_kernel, dim3((unsigned)n), dim3(256), 0, s, y.at(b0 + b), sy_c, sy_h, sy_w, nt2,
                              A + b * szA, n, cA, 64, net->upsample_mode == ORCA_UPSAMPLE_BILINEAR ? 1 : 0);
           LAUNCHCHECK("upsample2d_nhwc_kernel");
         }
@@ -1301,15 +1310,15 @@ static int decoder_nhwc(orca_ctx* ctx, orca_net* net, const float* x, long sx_b,
   return rc2;
 }
 
-static int decoder_common(orca_ctx* ctx, orca_net* net, const float* x, long sx_b, long sx_c, long sx_l, const float* de,
-                          long sd_b, long sd_c, long sd_h, long sd_w, const float* y, long sy_b, long sy_c, long sy_h, long sy_w,
+static int decoder_common(orca_ctx* ctx, orca_net* net, const RowSrc& x, long sx_c, long sx_l, const RowSrc& de,
+                          long sd_c, long sd_h, long sd_w, const RowSrc& y, long sy_c, long sy_h, long sy_w,
                           int B, int n, float* out, int accumulate) {
   const int nt2 = net->num_2d;
   if (n <= 0 || n > ORCA_LDW || (n & 1)) return fail(ORCA_EINVAL, "map size %d unsupported (even, <=256)", n);
   if (B <= 0) return ORCA_OK;
   HIPCHECK(hipSetDevice(ctx->device));
   if (net->precision == ORCA_PRECISION_F16X2 || net->precision == ORCA_PRECISION_BF16)
-    return decoder_nhwc(ctx, net, x, sx_b, sx_c, sx_l, de, sd_b, sd_c, sd_h, sd_w, y, sy_b, sy_c, sy_h, sy_w, B, n, out, accumulate);
+    return decoder_nhwc(ctx, net, x, sx_c, sx_l, de, sd_c, sd_h, sd_w, y, sy_c, sy_h, sy_w, B, n, out, accumulate);
   const bool is1m = net->kind == ORCA_NET_DECODER_1M;
   const size_t plane = (size_t)n * ORCA_LDW;
   const int cin0 = is1m ? 128 : 136;
@@ -1324,8 +1333,8 @@ static int decoder_common(orca_ctx* ctx, orca_net* net, const float* x, long sx_
   float* T = ws_take(ctx, B * sz32);
   hipStream_t s = ctx->stream;
   for (int b = 0; b < B; ++b) {
-    hipLaunchKernelGGL(outer_sum_kernel, dim3((unsigned)n, (unsigned)cin0), dim3(64), 0, s, x + (long)b * sx_b, sx_c, sx_l,
-                       de ? de + (long)b * sd_b : nullptr, sd_c, sd_h, sd_w, nt2, IN + b * szIN, n, cin0);
+    hipLaunchKernelGGL(outer_sum_kernel, dim3((unsigned)n, (unsigned)cin0), dim3(64), 0, s, x.at(b), sx_c, sx_l,
+                       de.at(b), sd_c, sd_h, sd_w, nt2, IN + b * szIN, n, cin0);
     LAUNCHCHECK("outer_sum_kernel");
   }
   const ConvLayer* L = net->convs.data();
@@ -1339,7 +1348,7 @@ static int decoder_common(orca_ctx* ctx, orca_net* net, const float* x, long sx_
     pairs = L + 8; npairs = 28;
     if (y) {
       for (int b = 0; b < B; ++b) {
-        hipLaunchKernelGGL(upsample2d_x2_kernel, dim3((unsigned)n, 8), dim3(ORCA_LDW), 0, s, y + (long)b * sy_b, sy_c, sy_h, sy_w, nt2,
+        hipLaunchKernelGGL(upsample2d_x2_kernel, dim3((unsigned)n, 8), dim3(ORCA_LDW), 0, s, y.at(b), sy_c, sy_h, sy_w, nt2,
                            A + b * szA + 64 * plane, n, net->upsample_mode == ORCA_UPSAMPLE_BILINEAR ? 1 : 0, 8);
         LAUNCHCHECK("upsample2d_x2_kernel");
       }
@@ -1378,7 +1387,9 @@ extern "C" int orca_decoder_forward(orca_ctx* ctx, orca_net* net, const float* x
   if (!ctx || !net || !x || !distenc || !out) return fail(ORCA_EINVAL, "orca_decoder_forward: NULL argument");
   if (net->kind != ORCA_NET_DECODER) return fail(ORCA_EINVAL, "orca_decoder_forward: net is not a Decoder");
   if (net->num_2d != 1) return fail(ORCA_EINVAL, "orca_decoder_forward: net predicts %d maps, use orca_decoder_forward_mt", net->num_2d);
-  return decoder_common(ctx, net, x, sx_b, sx_c, sx_l, distenc, sd_b, 0, sd_h, sd_w, y, sy_b, 0, sy_h, sy_w, B, n, out, accumulate);
+  RowSrc xs, ds, ys;
+  xs.base = x; xs.bs = sx_b; ds.base = distenc; ds.bs = sd_b; ys.base = y; ys.bs = sy_b;
+  return decoder_common(ctx, net, xs, sx_c, sx_l, ds, 0, sd_h, sd_w, ys, 0, sy_h, sy_w, B, n, out, accumulate);
 }
 
 extern "C" int orca_decoder_forward_mt(orca_ctx* ctx, orca_net* net, const float* x, int64_t sx_b, int64_t sx_c, int64_t sx_l,
@@ -1387,14 +1398,42 @@ extern "C" int orca_decoder_forward_mt(orca_ctx* ctx, orca_net* net, const float
                                        int accumulate) {
   if (!ctx || !net || !x || !distenc || !out) return fail(ORCA_EINVAL, "orca_decoder_forward_mt: NULL argument");
   if (net->kind != ORCA_NET_DECODER) return fail(ORCA_EINVAL, "orca_decoder_forward_mt: net is not a Decoder");
-  return decoder_common(ctx, net, x, sx_b, sx_c, sx_l, distenc, sd_b, sd_c, sd_h, sd_w, y, sy_b, sy_c, sy_h, sy_w, B, n, out, accumulate);
+  RowSrc xs, ds, ys;
+  xs.base = x; xs.bs = sx_b; ds.base = distenc; ds.bs = sd_b; ys.base = y; ys.bs = sy_b;
+  return decoder_common(ctx, net, xs, sx_c, sx_l, ds, sd_c, sd_h, sd_w, ys, sy_c, sy_h, sy_w, B, n, out, accumulate);
+}
+
+extern "C" int orca_decoder_forward_rows(orca_ctx* ctx, orca_net* net, const float* const* x_rows, int64_t sx_c, int64_t sx_l,
+                                         const float* const* distenc_rows, int64_t sd_c, int64_t sd_h, int64_t sd_w,
+                                         const float* const* y_rows, int64_t sy_c, int64_t sy_h, int64_t sy_w, int B, int n, float* out,
+                                         int accumulate) {
+  if (!ctx || !net || !x_rows || !distenc_rows || !out) return fail(ORCA_EINVAL, "orca_decoder_forward_rows: NULL argument");
+  if (net->kind != ORCA_NET_DECODER) return fail(ORCA_EINVAL, "orca_decoder_forward_rows: net is not a Decoder");
+  for (int b = 0; b < B; ++b)
+    if (!x_rows[b] || !distenc_rows[b] || (y_rows && !y_rows[b])) return fail(ORCA_EINVAL, "orca_decoder_forward_rows: NULL row pointer %d", b);
+  RowSrc xs, ds, ys;
+  xs.rows = x_rows; ds.rows = distenc_rows; ys.rows = y_rows;
+  return decoder_common(ctx, net, xs, sx_c, sx_l, ds, sd_c, sd_h, sd_w, ys, sy_c, sy_h, sy_w, B, n, out, accumulate);
+}
+
+extern "C" int orca_decoder1m_forward_rows(orca_ctx* ctx, orca_net* net, const float* const* x_rows, int64_t sx_c, int64_t sx_l, int B, int n,
+                                           float* out, int accumulate) {
+  if (!ctx || !net || !x_rows || !out) return fail(ORCA_EINVAL, "orca_decoder1m_forward_rows: NULL argument");
+  if (net->kind != ORCA_NET_DECODER_1M) return fail(ORCA_EINVAL, "orca_decoder1m_forward_rows: net is not a Decoder_1m");
+  for (int b = 0; b < B; ++b)
+    if (!x_rows[b]) return fail(ORCA_EINVAL, "orca_decoder1m_forward_rows: NULL row pointer %d", b);
+  RowSrc xs, none;
+  xs.rows = x_rows;
+  return decoder_common(ctx, net, xs, sx_c, sx_l, none, 0, 0, 0, none, 0, 0, 0, B, n, out, accumulate);
 }
 
 extern "C" int orca_decoder1m_forward(orca_ctx* ctx, orca_net* net, const float* x, int64_t sx_b, int64_t sx_c, int64_t sx_l,
                                       int B, int n, float* out, int accumulate) {
   if (!ctx || !net || !x || !out) return fail(ORCA_EINVAL, "orca_decoder1m_forward: NULL argument");
   if (net->kind != ORCA_NET_DECODER_1M) return fail(ORCA_EINVAL, "orca_decoder1m_forward: net is not a Decoder_1m");
-  return decoder_common(ctx, net, x, sx_b, sx_c, sx_l, nullptr, 0, 0, 0, 0, nullptr, 0, 0, 0, 0, B, n, out, accumulate);
+  RowSrc xs, none;
+  xs.base = x; xs.bs = sx_b;
+  return decoder_common(ctx, net, xs, sx_c, sx_l, none, 0, 0, 0, none, 0, 0, 0, B, n, out, accumulate);
 }
 
 extern "C" int orca_net_num_targets(orca_net* net, int* num_2d) {

@@ -251,7 +251,7 @@ def pack_sequence(x):
     return codes, ok
 
 
-def encoder_forward_codes(net, codes, reverse=False, bin_lo=0, bin_hi=0, chunk_bp=0):
+def encoder_forward_codes(net, codes, reverse=False, bin_lo=0, bin_hi=0, chunk_bp=0, out=None):
     if not (isinstance(codes, torch.Tensor) and codes.is_cuda and codes.dtype == torch.uint8 and codes.dim() == 2):
         raise ValueError("codes must be a [B,L] uint8 ROCm tensor")
     if codes.stride(1) != 1:
@@ -259,7 +259,10 @@ def encoder_forward_codes(net, codes, reverse=False, bin_lo=0, bin_hi=0, chunk_b
     B, L = codes.shape
     total = encoder_num_bins(L)
     hi = total if bin_hi <= 0 else bin_hi
-    out = torch.empty((B, 128, hi - bin_lo), dtype=torch.float32, device=codes.device)
+    if out is None:
+        out = torch.empty((B, 128, hi - bin_lo), dtype=torch.float32, device=codes.device)
+    elif tuple(out.shape) != (B, 128, hi - bin_lo) or out.stride(2) != 1:
+        raise ValueError(f"out must be a [{B},128,{hi - bin_lo}] view with unit stride along the bins")
     net.ctx.sync_stream()
     check(_lib.load().orca_encoder_forward_codes(net.ctx.handle, net.handle, _p(codes), codes.stride(0), 1 if reverse else 0, B, L,
                                                  bin_lo, hi, _p(out), out.stride(0), out.stride(1), chunk_bp), "orca_encoder_forward_codes")
@@ -314,6 +317,56 @@ def decoder_forward(net, x, distenc, y=None, out=None, accumulate=False):
                                                   _p(distenc), sd_b, distenc.stride(1), distenc.stride(2), distenc.stride(3), yp,
                                                   sy[0], sy[1], sy[2], sy[3], B, n, _p(out), 1 if accumulate else 0),
               "orca_decoder_forward_mt")
+    return out
+
+
+def _row_ptrs(rows):
+    return (ctypes.c_void_p * len(rows))(*[r.data_ptr() for r in rows])
+
+
+def _same_strides(rows, name):
+    st = rows[0].stride()
+    if any(r.stride() != st or r.shape != rows[0].shape for r in rows):
+        raise ValueError(f"{name}: the rows of a batch must share one shape and one set of strides")
+    return st
+
+
+def decoder_forward_rows(net, xs, des, ys=None, out=None, accumulate=False):
+    """Decoder on a batch given ROW BY ROW: xs = B views [128,n], des = B views [T,n,n] (the same view may repeat),
+    ys = None or B views [T,n/2,n/2] - any strides, no copies (orca_decoder_forward_rows)."""
+    xs = [_f32_cuda(t, "x") for t in xs]
+    des = [_f32_cuda(t, "distenc") for t in des]
+    B, T = len(xs), net.num_targets()
+    C, n = xs[0].shape
+    if C != 128 or tuple(des[0].shape) != (T, n, n) or len(des) != B:
+        raise ValueError(f"decoder rows: x [128,n] and distenc [{T},n,n] per row, got {tuple(xs[0].shape)} / {tuple(des[0].shape)}")
+    sx, sd = _same_strides(xs, "x"), _same_strides(des, "distenc")
+    yp, sy = None, (0, 0, 0)
+    if ys is not None:
+        ys = [_f32_cuda(t, "y") for t in ys]
+        if len(ys) != B or tuple(ys[0].shape) != (T, n // 2, n // 2):
+            raise ValueError(f"coarse prediction rows must be [{T},{n // 2},{n // 2}]")
+        yp, sy = _row_ptrs(ys), _same_strides(ys, "y")
+    if out is None:
+        out = torch.empty((B, T, n, n), dtype=torch.float32, device=xs[0].device)
+        accumulate = False
+    net.ctx.sync_stream()
+    check(_lib.load().orca_decoder_forward_rows(net.ctx.handle, net.handle, _row_ptrs(xs), sx[0], sx[1], _row_ptrs(des), sd[0], sd[1], sd[2],
+                                                yp, sy[0], sy[1], sy[2], B, n, _p(out), 1 if accumulate else 0), "orca_decoder_forward_rows")
+    return out
+
+
+def decoder1m_forward_rows(net, xs, out=None, accumulate=False):
+    xs = [_f32_cuda(t, "x") for t in xs]
+    B, T = len(xs), net.num_targets()
+    C, n = xs[0].shape
+    sx = _same_strides(xs, "x")
+    if out is None:
+        out = torch.empty((B, T, n, n), dtype=torch.float32, device=xs[0].device)
+        accumulate = False
+    net.ctx.sync_stream()
+    check(_lib.load().orca_decoder1m_forward_rows(net.ctx.handle, net.handle, _row_ptrs(xs), sx[0], sx[1], B, n, _p(out), 1 if accumulate else 0),
+          "orca_decoder1m_forward_rows")
     return out
 
 

@@ -165,11 +165,11 @@ class Encoder(_HipModule):
         return self._run_guarded(net, lambda: engine.encoder_forward(net, x, bin_lo, bin_hi, chunk_bp), "bf16x3")
 
 
-    def forward_codes(self, codes, reverse=False, bin_lo=0, bin_hi=0, chunk_bp=0):
+    def forward_codes(self, codes, reverse=False, bin_lo=0, bin_hi=0, chunk_bp=0, out=None):
         """Encoder straight from packed bases: ``codes`` [B,L] uint8 on the MI355X (0..3 = A,C,G,T, 4 = N, see
         engine.pack_sequence).  ``reverse=True`` encodes the reverse complement of the same buffer."""
         net = self._net(codes.device)
-        return self._run_guarded(net, lambda: engine.encoder_forward_codes(net, codes, reverse, bin_lo, bin_hi, chunk_bp), "bf16x3")
+        return self._run_guarded(net, lambda: engine.encoder_forward_codes(net, codes, reverse, bin_lo, bin_hi, chunk_bp, out), "bf16x3")
 
     forward_codes.__doc__ += "  (Replaces the float [B,4,L] input of orca_predict.py:334.)"
 
@@ -308,6 +308,11 @@ class Decoder(_HipModule):
             return self._run_guarded(net, lambda: engine.decoder_forward(net, x, distenc, y, out=out.copy_(base), accumulate=True), "f32")
         return self._run_guarded(net, lambda: engine.decoder_forward(net, x, distenc, y, out=out, accumulate=accumulate), "f32")
 
+    def forward_rows(self, xs, distencs, ys=None):
+        """forward() on a batch given row by row (lists of views [128,n] / [T,n,n] / [T,n/2,n/2]): no stacking copies."""
+        net = self._net(xs[0].device)
+        return self._run_guarded(net, lambda: engine.decoder_forward_rows(net, xs, distencs, ys), "f32")
+
 
 class Decoder_1m(_HipModule):
     """Decoder of the 1 Mb module (orca_modules.py:491-800)."""
@@ -343,6 +348,13 @@ class Decoder_1m(_HipModule):
             base = out.clone()   # a retry must not accumulate twice
             return self._run_guarded(net, lambda: engine.decoder1m_forward(net, x, out=out.copy_(base), accumulate=True), "f32")
         return self._run_guarded(net, lambda: engine.decoder1m_forward(net, x, out=out, accumulate=accumulate), "f32")
+
+    def forward_rows_into(self, out, xs, accumulate=False):
+        net = self._net(xs[0].device)
+        if accumulate and self.precision == "f16x2":
+            base = out.clone()
+            return self._run_guarded(net, lambda: engine.decoder1m_forward_rows(net, xs, out=out.copy_(base), accumulate=True), "f32")
+        return self._run_guarded(net, lambda: engine.decoder1m_forward_rows(net, xs, out=out, accumulate=accumulate), "f32")
 
 
 class Net(nn.Module):

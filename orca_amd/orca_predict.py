@@ -118,6 +118,12 @@ class _StrandInputs:
         if self.seq is None and not isinstance(net0, (Encoder, ShardedEncoder)):
             raise TypeError("packed (uint8) input needs an orca_amd Encoder as model.net0")
         if self.use_cuda and isinstance(net0, (Encoder, ShardedEncoder)) and self._pack():
+            if isinstance(net0, Encoder):     # both strands straight into the halves of one [2B,128,bins] tensor
+                B, L = self._codes.shape
+                enc0 = torch.empty((2 * B, 128, engine.encoder_num_bins(L)), dtype=torch.float32, device=self._codes.device)
+                net0.forward_codes(self._codes, reverse=False, out=enc0[:B])
+                net0.forward_codes(self._codes, reverse=True, out=enc0[B:])
+                return enc0
             return torch.cat([net0.forward_codes(self._codes, reverse=False), net0.forward_codes(self._codes, reverse=True)], dim=0)
         return torch.cat([net0(self.fwd), net0(self.rev)], dim=0)
 
@@ -220,8 +226,20 @@ def zoom_index_256m(level, start, mpos, wpos, chrlen, reverse):
     return 250 - (i + 125) if reverse else i
 
 
+def _rows(t, B, idx, width, dims):
+    """Per-strand crops of a [nstrands*B, ...] tensor (strand k uses offset idx[k]) as a list of nstrands*B row VIEWS."""
+    out = []
+    for k, i in enumerate(idx):
+        for b in range(B):
+            sl = t[k * B + b]
+            for d in dims:
+                sl = sl.narrow(d - 1, i, width)
+            out.append(sl)
+    return out
+
+
 def _gather(t, B, idx, width, dims):
-    """Per-strand crops of a [nstrands*B, ...] tensor (strand k uses offset idx[k]) restacked along the batch axis."""
+    """The same crops restacked along the batch axis (a copy; used for models that are not orca_amd modules)."""
     parts = []
     for k, i in enumerate(idx):
         sl = t[k * B:(k + 1) * B]
@@ -248,14 +266,25 @@ def run_cascade(model, encodings, levels, unit, B, reverse_flags, background, zo
     for j, level in enumerate(levels):
         u = unit(level)
         sl = [int(starts[k][j] / u) for k in range(S)]
-        enc = _gather(encodings[level], B, sl, 250, (2,))
         bgs = [background(level, k, starts[k][j]) for k in range(S)]
-        if all(b is bgs[0] for b in bgs):
-            distenc = bgs[0].expand(S * B, -1, -1, -1)
+        dec = model.denets[level]
+        if hasattr(dec, "forward_rows") and encodings[level].is_cuda:
+            # orca_amd Decoders take the batch row by row: every strand's crops stay views (no torch.cat on the path)
+            xs = _rows(encodings[level], B, sl, 250, (2,))
+            des = [bgs[k][b if bgs[k].shape[0] > 1 else 0] for k in range(S) for b in range(B)]
+            ys = _rows(preds[j - 1], B, zoom_idx, 125, (2, 3)) if j > 0 else None
+            pred = dec.forward_rows(xs, des, ys)
+            if level == add_1m_level:
+                model.denet_1_pt.forward_rows_into(pred, xs, accumulate=True)     # fused `+ denet_1_pt(x)`
+            preds.append(pred)
         else:
-            distenc = torch.cat([b.expand(B, -1, -1, -1) for b in bgs], dim=0)
-        coarse = _gather(preds[j - 1], B, zoom_idx, 125, (2, 3)) if j > 0 else None
-        preds.append(_decode(model, level, enc, distenc, coarse, level == add_1m_level))
+            enc = _gather(encodings[level], B, sl, 250, (2,))
+            if all(b is bgs[0] for b in bgs):
+                distenc = bgs[0].expand(S * B, -1, -1, -1)
+            else:
+                distenc = torch.cat([b.expand(B, -1, -1, -1) for b in bgs], dim=0)
+            coarse = _gather(preds[j - 1], B, zoom_idx, 125, (2, 3)) if j > 0 else None
+            preds.append(_decode(model, level, enc, distenc, coarse, level == add_1m_level))
         if on_level is not None:
             on_level(j, level, [starts[k][j] for k in range(S)])
         for k in range(S):
@@ -281,9 +310,15 @@ def cascade_32m(model, xs, mpos, wpos, reverse_flags, distencs=None):
         return cache[level]
 
     def forward():
-        def encode(x, rev):
-            return model.net0.forward_codes(x, reverse=rev) if x.dtype == torch.uint8 else model.net0(x)
-        enc0 = torch.cat([encode(x, r) for x, r in zip(xs, reverse_flags)], dim=0) if len(xs) > 1 else encode(xs[0], reverse_flags[0])
+        def encode(x, rev, out=None):
+            return model.net0.forward_codes(x, reverse=rev, out=out) if x.dtype == torch.uint8 else model.net0(x)
+        if len(xs) > 1 and all(x.dtype == torch.uint8 for x in xs) and hasattr(model.net0, "_net"):
+            # packed strands: each is encoded straight into its rows of one [S*B,128,bins] tensor
+            enc0 = torch.empty((len(xs) * B, 128, engine.encoder_num_bins(xs[0].shape[1])), dtype=torch.float32, device=xs[0].device)
+            for k, (x, r) in enumerate(zip(xs, reverse_flags)):
+                encode(x, r, enc0[k * B:(k + 1) * B])
+        else:
+            enc0 = torch.cat([encode(x, r) for x, r in zip(xs, reverse_flags)], dim=0) if len(xs) > 1 else encode(xs[0], reverse_flags[0])
         encodings = dict(zip([1, 2, 4, 8, 16, 32], model.net(enc0)))
         return run_cascade(model, encodings, [32, 16, 8, 4, 2, 1], lambda lv: lv, B, list(reverse_flags), background,
                            lambda lv, st, rev: zoom_index_32m(lv, st, mpos, wpos, rev), add_1m_level=1)

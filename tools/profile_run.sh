@@ -1,0 +1,25 @@
+#!/bin/bash
+# Profiles of one round, run ON THE GPU BOX (gpurun -- 'bash tools/profile_run.sh r02'): kernel trace + stats of the default
+# bench command, then separate rocprofv3 --pmc passes (SQ / FETCH_SIZE / WRITE_SIZE: one pass each, MI355X_MICROARCH.md
+# "rocprofv3 PMC slots") over one 32 Mb Encoder forward in both arithmetic modes and over one Decoder forward.
+# Everything lands in gpurun_out/<tag>/; tools/profile_collect.py turns it into the summaries committed under profiles/.
+TAG=${1:-r02}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -o bench -- python $ROOT/bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
+python $ROOT/bench.py > $OUT/bench.json 2> $OUT/bench.err
+SQ="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"
+for mode in f16x2 bf16; do
+  rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $OUT/pmc_enc_${mode}_sq -o p -- python $ROOT/tools/prof_encoder.py 32 $mode 1 codes > $OUT/pmc_enc_${mode}_sq.log 2>&1
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_enc_${mode}_fetch -o p -- python $ROOT/tools/prof_encoder.py 32 $mode 1 codes > $OUT/pmc_enc_${mode}_fetch.log 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_enc_${mode}_write -o p -- python $ROOT/tools/prof_encoder.py 32 $mode 1 codes > $OUT/pmc_enc_${mode}_write.log 2>&1
+done
+rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $OUT/pmc_dec_sq -o p -- python $ROOT/tools/prof_decoder.py > $OUT/pmc_dec_sq.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_enc_bf16_lds -o p -- python $ROOT/tools/prof_encoder.py 32 bf16 1 codes > $OUT/pmc_enc_bf16_lds.log 2>&1
+( rocm-smi --showpower --showclocks --showtemp > $OUT/rocm_smi_idle.txt 2>&1 ) || true
+find $OUT -name "*.csv" | head -40 > $OUT/files.txt
+# keep the merge-back under 64 MiB: drop the per-dispatch traces of the counter passes (the collected counters stay)
+find $OUT -path "*pmc_*" -name "*kernel_trace.csv" -delete
+du -sh $OUT > $OUT/size.txt
