@@ -13,40 +13,8 @@
 // Kernel: persistent workgroups, 8 waves, (tile, chunk) stream as in conv_bf16s.h, but with TWO LDS buffers:
 // the DMA of step s+1 is issued inside the MFMA block of step s and lands underneath it; one barrier per step.
 // Arithmetic: 3 fp16 MFMA products per fp32 product (hi*hi + hi*lo + lo*hi), fp32 accumulate.
-// Tried and dropped (tools/microbench_p16.hip has the per-wave s_memtime stamp harness that judged them):
-//   * de-phased two-group variant (waves 0-3 / 4-7 on different tiles, rotated K-chunk order): 15 % slower with the
-//     first epilogue; re-checked against the current kernel by moving the epilogues of waves 4-7 half a tile later
-//     (ABL 512, timing only): no gain either;
-//   * epilogue software-pipelined into the next step's MFMA block from a parked accumulator copy: 256 VGPRs are
-//     not enough (acc 64 + copy 64 + fragments 64 + ...), the spill reloads are VMEM loads whose vmcnt(0)
-//     serialises against the in-flight DMA - 40 % slower;
-//   * LDS-DMA issued by the younger wave of each SIMD only, 16 waves of 32x64 per workgroup, inter-workgroup
-//     start stagger: all within +-1 %.  The part runs this kernel at 1.70-1.82 GHz (s_memtime / s_memrealtime),
-//     rising to 1.93 GHz with DMA, stores and LDS reads ablated: it is power-limited, not issue-limited;
-//   * residual units of the finishing tile fetched during the last taps of its last MFMA block instead of at the head of
-//     the epilogue (64 more live registers, 244 VGPRs, no spills): same-box A/B 42.25 vs 41.90 ms per 32 Mb Encoder -
-//     slower, although the epilogue no longer waits for the loads.
-//   * ONE wave per SIMD (4 waves of 128 x 64, accumulators in AGPRs - 184 VGPRs + 128 AGPRs, no spills; parity green):
-//     42.4 vs 41.0 ms per 32 Mb Encoder.  With the upper half of a finished tile parked in 64 more AGPRs (asm "a"
-//     operands: left alone the compiler moves the parked copy to VGPRs and spills; parking all 128 leaves no AGPR for
-//     the spills - scratch traffic, 70 ms) and its epilogue issued piece by piece BETWEEN the MFMAs of the next tile's
-//     first step (sched_barrier after every MFMA): 42.7 ms.  The epilogue overlap buys nothing because the 4-wave form
-//     pays elsewhere: every wave issues 18 instead of 9 LDS-DMA pieces per step (100-180 cycles each, in order, with no
-//     second wave on the SIMD to issue MFMAs meanwhile).
-//   * two dedicated DMA waves per workgroup (10 waves: waves 8-9 issue all 70 pieces of a step, piece addresses computed
-//     on the fly; parity green): three waves on two of the SIMDs cap the kernel at 168 VGPRs, the matrix waves' path
-//     then spills (170-500 bytes of scratch per lane) - 58 vs 40 ms.  Needs a register diet of the matrix path first.
-// Power: with all-zero operands (the micro-benchmarks' inputs) the plain 64->64 launch at n = 32 M takes 4.3 ms, with
-// real activations and weights 6.2 ms - same instruction stream, the matrix pipe's switching power sets the clock
-// (issuing the MFMAs so that the W operand stays unchanged for 2*MW consecutive instructions: no difference).
-// The clock follows the operands' bit density: a 32 Mb Encoder takes 40.6 ms as is, 39.75 ms with the 5 low mantissa
-// bits of every lo half cleared (17 significant bits), 40.2 / 39.75 ms with 3 / 5 low bits of every hi half cleared (the
-// exact residual in lo: 19 / 17 bits), 37.9 ms with lo reduced to sign and exponent.  Not used: 2 % for 4-5 bits of
-// the fp32-class precision the parity claim rests on.
-// Fused first layer (F1), cost split on zero data (`tools/microbench_f1.hip`; ABL 1024 / 2048 / 4096 / 8192 = no halo tail / no image writes / no
-// table reads / no in-loop producer): fused 5.36 ms vs 4.11 without the producer; tail 0.15, table reads 0.20, image
-// writes 0.03 - the remaining 0.8 ms is the producer's VALU stream itself (window decode, 36 adds, range guard, split,
-// zero-select per position and quad).
+// Measured dead ends of this kernel (de-phased wave groups, parked-accumulator epilogue, one wave per SIMD, dedicated DMA
+// waves, residual prefetch, segmented planes, ...) and the power-limit measurements are logged in DESIGN.md section 7.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
