@@ -108,7 +108,7 @@ def sharded_256mb(args, rank, world, dev, dist):
     codes = torch.from_numpy(synth.synth_base_codes(L256, seed=2)[None]).to(dev)      # the SAME sequence on every rank
     comm, collective = None, "none (single rank)"
     if world > 1:
-        collective = "torch.distributed all_gather_into_tensor (RCCL)"
+        collective = f"torch.distributed all_gather_into_tensor ({'RCCL' if dist.get_backend() == 'nccl' else dist.get_backend()})"
         if not args.torch_collective:
             ok = 1
             try:
@@ -204,13 +204,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    if os.environ.get("ORCA_BENCH_ONE_DEVICE"):      # test hook: all ranks on cuda:0 (control-flow check of the N > 1 path on a 1-GPU box;
+        local_rank = 0                               # needs ORCA_BENCH_BACKEND=gloo - RCCL refuses two ranks on one device)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("ORCA_BENCH_BACKEND", "nccl")
+        dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
 
     from orca_amd import engine, orca_models, orca_predict, synth
     engine_pack = engine.pack_sequence
