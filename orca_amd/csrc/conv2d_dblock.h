@@ -37,7 +37,9 @@ __device__ __forceinline__ void dblock_wait(f16x8 (&x)[NS], f16x8 (&w)[NS]) {
   else asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(x[0]), "+v"(w[0]) : "n"(N));
 }
 
-template <int NS, int DT>
+// ABL (tools/microbench_dblock.hip only, 0 in the library): 1 = no MFMAs, 2 = weight pieces fetched once (no DMA in the loop),
+// 4 = no gather / residual loads, 8 = no operand reads, 16 = no piece barriers (timing only: races)
+template <int NS, int DT, int ABL = 0>
 __global__ __launch_bounds__(512, NS == 1 ? 4 : 2) void conv2d_dblock_kernel(DBlockArgs a) {   // bf16: 77 KB of LDS, two workgroups per CU if <= 128 VGPRs
   constexpr int NT = 512, PXW = 257;                 // 256 pixels + the zero unit
   constexpr int AU = NS * 8 * PXW, BU = NS * 4 * PXW; // operand images (16-byte units)
@@ -60,14 +62,18 @@ __global__ __launch_bounds__(512, NS == 1 ? 4 : 2) void conv2d_dblock_kernel(DBl
   float* const cur = a.cur + (long)blockIdx.y * a.bs;
 
   // pixel p of the workgroup -> (sub-image, r, c) -> map (row, col)
+  // Workgroups go to the XCDs round-robin (b % 8).  At d = 16 a workgroup is ONE sub-image and the sub-images (i0, 2m) and
+  // (i0, 2m + 1) interleave their pixels inside every 128-byte line: blocks b and b + 8 take such a pair, so that the line is
+  // fetched into one XCD's L2 only.  (At d = 32 / 64 a workgroup holds 4 / 16 consecutive j0 itself.)
+  const int bx = (G == 1 && !(ABL & 64)) ? (int)((blockIdx.x & ~15u) | ((blockIdx.x & 7u) << 1) | ((blockIdx.x >> 3) & 1u)) : (int)blockIdx.x;
   auto pix = [&](int p, int& row, int& col, int& r, int& c) {
-    const int sid = ((int)blockIdx.x << lG) + (p >> (2 * lS)), q = p & ((1 << (2 * lS)) - 1);
+    const int sid = (bx << lG) + (p >> (2 * lS)), q = p & ((1 << (2 * lS)) - 1);
     r = q >> lS; c = q & (S - 1);
     row = (sid >> ld) + (r << ld);
     col = (sid & (d - 1)) + (c << ld);
   };
   {   // workgroup-uniform early exit (small maps): its sub-images start at row i0, columns j0 .. j0 + G - 1
-    const int sid0 = (int)blockIdx.x << lG;
+    const int sid0 = bx << lG;
     if ((sid0 >> ld) >= H || (sid0 & (d - 1)) >= W) return;
   }
 
@@ -104,15 +110,6 @@ __global__ __launch_bounds__(512, NS == 1 ? 4 : 2) void conv2d_dblock_kernel(DBl
   int prow, pcol, pr, pc;
   pix(p, prow, pcol, pr, pc);
   const bool pvalid = prow < H && pcol < W;
-  const long poff = ((long)prow * 256 + pcol) * 16;
-  f32x4 res[2][4];                                  // cur (later oth) at couts h*32 + 8q + 4g .. +3
-#pragma unroll
-  for (int h = 0; h < 2; ++h)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int co = h * 32 + 8 * q + 4 * g;
-      res[h][q] = pvalid ? *reinterpret_cast<const f32x4*>(cur + (long)(co >> 4) * a.cs + poff + (co & 15)) : (f32x4)(0.f);
-    }
   unsigned nb16[9];                                 // byte offset of the tap's source unit within a plane (256 = the zero unit)
 #pragma unroll
   for (int t = 0; t < 9; ++t) {
@@ -121,34 +118,47 @@ __global__ __launch_bounds__(512, NS == 1 ? 4 : 2) void conv2d_dblock_kernel(DBl
     nb16[t] = (in ? (unsigned)(p + dy * S + dx) : 256u) * 16u;
   }
 
-  // ---- gather cur into A: thread -> (pixel, 32-channel half) ---------------------------------------------------
+  // ---- gather cur into A.  A pixel's 16 channels of one chunk are 64 contiguous bytes, pixels of a sub-image are d columns
+  // (>= 1 KB) apart: FOUR consecutive lanes fetch the four 16-byte pieces of one (pixel, chunk) segment, so a wave-level load
+  // touches 16 segments instead of 64 (measured: the gather was 15 of the kernel's 38 us with one lane per pixel).
   bool overflow = false;
-  {
-    const int gp = tid & 255, half = tid >> 8;
+  const int piece4 = tid & 3, gpl = tid >> 2;         // 128 pixels per round
+  f32x4 gv[8];                                        // cur, later oth: the fp32 residual stream, (pixel gpx[rnd], channels 16k + 4 piece4 .. +3)
+  int gpx[2];
+  bool gok[2];
+  long goff[2];
+#pragma unroll
+  for (int rnd = 0; rnd < 2; ++rnd) {
+    gpx[rnd] = rnd * 128 + gpl;
     int row, col, r_, c_;
-    pix(gp, row, col, r_, c_);
-    const bool ok = row < H && col < W;
-    const float* src = cur + ((long)row * 256 + col) * 16;
+    pix(gpx[rnd], row, col, r_, c_);
+    gok[rnd] = row < H && col < W;
+    goff[rnd] = ((long)row * 256 + col) * 16 + 4 * piece4;
 #pragma unroll
-    for (int o = 0; o < 4; ++o) {                  // channel octet 4*half + o = chunk 2*half + o/2, offset 8*(o&1)
-      const int ch = half * 32 + o * 8;
-      f32x4 v0 = (f32x4)(0.f), v1 = (f32x4)(0.f);
-      if (ok) {
-        const float* q_ = src + (long)(ch >> 4) * a.cs + (ch & 15);
-        v0 = *reinterpret_cast<const f32x4*>(q_);
-        v1 = *reinterpret_cast<const f32x4*>(q_ + 4);
-      }
-      u32x2 s0[NS], s1[NS];
-      split4<NS, DT>(v0, s0, overflow);
-      split4<NS, DT>(v1, s1, overflow);
-#pragma unroll
-      for (int s = 0; s < NS; ++s) {
-        u32x4_t unit = {s0[s].x, s0[s].y, s1[s].x, s1[s].y};
-        *reinterpret_cast<u32x4_t*>(As + (s * 8 + (ch >> 3)) * PXW + gp) = unit;
-      }
-    }
+    for (int k = 0; k < 4; ++k) gv[rnd * 4 + k] = (gok[rnd] && !(ABL & 4)) ? *reinterpret_cast<const f32x4*>(cur + goff[rnd] + (long)k * a.cs) : (f32x4)(0.f);
   }
-
+  // (pixel, channels 16k + 4 piece4 .. +3) -> octet 2k + piece4/2 of the 64-channel operand image, 8-byte half piece4 & 1
+  auto to_A = [&]() {
+#pragma unroll
+    for (int rnd = 0; rnd < 2; ++rnd)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        u32x2 sp[NS];
+        split4<NS, DT>(gv[rnd * 4 + k], sp, overflow);
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+          *reinterpret_cast<u32x2*>(reinterpret_cast<char*>(As + (s * 8 + 2 * k + (piece4 >> 1)) * PXW + gpx[rnd]) + 8 * (piece4 & 1)) = sp[s];
+      }
+  };
+  to_A();
+  // Epilogue of a 64-cout layer: the accumulators (MFMA layout: lane = pixel, 4 couts per register group) go through a
+  // 64 KB fp32 staging tile in the (then idle) A region back to the GATHER layout, where the residual stream lives in
+  // registers and a (pixel, chunk) segment is 4 consecutive lanes: no second, scattered read of the map for the residual
+  // (it cost 9 of 34 us) and 64-byte-coalesced final stores.  16-byte granule c of pixel p sits at granule c ^ f(p),
+  // f(p) = 4 (p & 3) + ((p >> 2) & 3): conflict-free both for the writes (16 consecutive pixels, one granule) and for the
+  // reads (4 consecutive pixels x 4 granules).
+  float* const stage = reinterpret_cast<float*>(As);
+  const int fsw_p = 4 * (p & 3) + ((p >> 2) & 3);
   f32x16 acc[2];
   int piece = 0;
   constexpr int EXTRA = (WP - (WIT - 1) * NT + 63) / 64;     // waves that issue WIT (the others WIT - 1) DMA instructions per piece
@@ -173,26 +183,74 @@ __global__ __launch_bounds__(512, NS == 1 ? 4 : 2) void conv2d_dblock_kernel(DBl
         if (wave < EXTRA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WIT) : "memory");                             \
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WIT - 1) : "memory");                                      \
       } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                     \
-      __syncthreads();   /* ... for every wave, and everyone is done with the buffer piece + 2 goes into */      \
-      if (piece + 2 < NPIECE) issue_piece(piece + 2);                                                             \
+      if (!(ABL & 16) || j == 0) __syncthreads();   /* ... for every wave, and everyone is done with the buffer piece + 2 goes into */ \
+      if (piece + 2 < NPIECE && !(ABL & 2)) issue_piece(piece + 2);                                               \
       const unsigned wrow = ws_lds + (unsigned)((piece % 3) * WP * 16);                                           \
       const unsigned xrow = (XLDS) + (unsigned)((2 * k + g) * PXW * 16);                                          \
       f16x8 xv[2][NS], wv[2][NS];                                                                                 \
       DB_READ(0, 0);                                                                                              \
       _Pragma("unroll") for (int t = 0; t < 9; ++t) {                                                             \
         const int fb = t & 1;                                                                                     \
-        if (t + 1 < 9) { DB_READ(fb ^ 1, t + 1); dblock_wait<2 * NS, NS>(xv[fb], wv[fb]); }                       \
+        if (t + 1 < 9) { if (!(ABL & 8)) { DB_READ(fb ^ 1, t + 1); dblock_wait<2 * NS, NS>(xv[fb], wv[fb]); } }   \
         else dblock_wait<0, NS>(xv[fb], wv[fb]);                                                                  \
         typedef typename Op16<DT>::vec V_;                                                                        \
+        if constexpr ((ABL & 1) != 0) { asm volatile("" ::"v"(xv[fb][0]), "v"(wv[fb][0])); } else                \
         if constexpr (NS == 2) {                                                                                  \
           acc[h] = Op16<DT>::mfma(__builtin_bit_cast(V_, wv[fb][0]), __builtin_bit_cast(V_, xv[fb][NS - 1]), acc[h]); \
           acc[h] = Op16<DT>::mfma(__builtin_bit_cast(V_, wv[fb][NS - 1]), __builtin_bit_cast(V_, xv[fb][0]), acc[h]); \
         }                                                                                                         \
-        acc[h] = Op16<DT>::mfma(__builtin_bit_cast(V_, wv[fb][0]), __builtin_bit_cast(V_, xv[fb][0]), acc[h]);   \
+        if constexpr ((ABL & 1) == 0) acc[h] = Op16<DT>::mfma(__builtin_bit_cast(V_, wv[fb][0]), __builtin_bit_cast(V_, xv[fb][0]), acc[h]); \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
       }                                                                                                           \
     }                                                                                                             \
   }
+  auto acc_to_gather = [&](int boff, bool relu, f32x4 (&out)[8]) {
+    if constexpr (NS == 2) {   // the A region (65.8 KB) holds the whole 64 KB tile
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int gr = (h * 32 + 8 * q + 4 * g) >> 2;
+          f32x4 v;
+          v.x = acc[h][4 * q + 0]; v.y = acc[h][4 * q + 1]; v.z = acc[h][4 * q + 2]; v.w = acc[h][4 * q + 3];
+          *reinterpret_cast<f32x4*>(stage + p * 64 + ((gr ^ fsw_p) << 2)) = v;
+        }
+      __syncthreads();
+#pragma unroll
+      for (int rnd = 0; rnd < 2; ++rnd) {
+        const int px = gpx[rnd], fsw = 4 * (px & 3) + ((px >> 2) & 3);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) out[rnd * 4 + k] = *reinterpret_cast<const f32x4*>(stage + px * 64 + (((4 * k + piece4) ^ fsw) << 2));
+      }
+    } else {                   // bf16: the A region is 32.9 KB - one 32-cout half (32 KB) at a time; granule c of pixel p at
+                               // c ^ f8(p), f8(p) = 4 ((p >> 1) & 1) + ((p >> 2) & 3), pixel pitch 128 bytes
+      const int f8_p = 4 * ((p >> 1) & 1) + ((p >> 2) & 3);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        if (h) __syncthreads();                    // the first half has been read
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x4 v;
+          v.x = acc[h][4 * q + 0]; v.y = acc[h][4 * q + 1]; v.z = acc[h][4 * q + 2]; v.w = acc[h][4 * q + 3];
+          *reinterpret_cast<f32x4*>(stage + p * 32 + (((2 * q + g) ^ f8_p) << 2)) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rnd = 0; rnd < 2; ++rnd) {
+          const int px = gpx[rnd], f8 = 4 * ((px >> 1) & 1) + ((px >> 2) & 3);
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk) out[rnd * 4 + 2 * h + kk] = *reinterpret_cast<const f32x4*>(stage + px * 32 + (((4 * kk + piece4) ^ f8) << 2));
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const f32x4 b = *reinterpret_cast<const f32x4*>(bias_s + boff + 4 * (4 * (i & 3) + piece4));
+      f32x4 v = out[i] + b;
+      if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      out[i] = v;
+    }
+  };
   // epilogue of a 32-cout layer: bias (+ReLU), invalid pixels -> 0, split, into B
   auto to_B = [&](int boff, bool relu) {
 #pragma unroll
@@ -222,21 +280,15 @@ __global__ __launch_bounds__(512, NS == 1 ? 4 : 2) void conv2d_dblock_kernel(DBl
   // ---- lm.b: 32 -> 64, linear, + cur -> oth (registers) -> A ----------------------------------------------------
   zero_acc();
   DB_LAYER(bs_lds, 4, true);
+  {
+    f32x4 t[8];
+    acc_to_gather(32, false, t);
 #pragma unroll
-  for (int h = 0; h < 2; ++h)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const f32x4 b = *reinterpret_cast<const f32x4*>(bias_s + 32 + h * 32 + 8 * q + 4 * g);
-      f32x4 v;
-      v.x = acc[h][4 * q + 0] + b.x; v.y = acc[h][4 * q + 1] + b.y; v.z = acc[h][4 * q + 2] + b.z; v.w = acc[h][4 * q + 3] + b.w;
-      v += res[h][q];
-      if (!pvalid) v = (f32x4)(0.f);
-      res[h][q] = v;                                 // oth
-      u32x2 sp[NS];
-      split4<NS, DT>(v, sp, overflow);
-#pragma unroll
-      for (int s = 0; s < NS; ++s) *reinterpret_cast<u32x2*>(reinterpret_cast<char*>(As + (s * 8 + h * 4 + q) * PXW + p) + 8 * g) = sp[s];
-    }
+    for (int i = 0; i < 8; ++i) gv[i] = gok[i >> 2] ? (f32x4)(t[i] + gv[i]) : (f32x4)(0.f);      // oth (invalid pixels stay zero)
+    __syncthreads();                              // every thread has read the staging tile: A becomes the operand image of oth
+    if (tid < NS * 8) As[tid * PXW + 256] = (f32x4)(0.f);   // the staging tile covered the zero units
+    to_A();
+  }
   // ---- m.a: 64 -> 32, ReLU --------------------------------------------------------------------------------------
   zero_acc();
   DB_LAYER(as_lds, 8, false);
@@ -246,18 +298,14 @@ __global__ __launch_bounds__(512, NS == 1 ? 4 : 2) void conv2d_dblock_kernel(DBl
   DB_LAYER(bs_lds, 4, true);
 #undef DB_LAYER
 #undef DB_READ
-  if (pvalid) {
+  {
+    f32x4 t[8];
+    acc_to_gather(128, true, t);
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+    for (int rnd = 0; rnd < 2; ++rnd)
+      if (gok[rnd]) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int co = h * 32 + 8 * q + 4 * g;
-        const f32x4 b = *reinterpret_cast<const f32x4*>(bias_s + 128 + co);
-        f32x4 v;
-        v.x = fmaxf(acc[h][4 * q + 0] + b.x, 0.f); v.y = fmaxf(acc[h][4 * q + 1] + b.y, 0.f);
-        v.z = fmaxf(acc[h][4 * q + 2] + b.z, 0.f); v.w = fmaxf(acc[h][4 * q + 3] + b.w, 0.f);
-        v += res[h][q];
-        *reinterpret_cast<f32x4*>(cur + (long)(co >> 4) * a.cs + poff + (co & 15)) = v;
+        for (int k = 0; k < 4; ++k) *reinterpret_cast<f32x4*>(cur + goff[rnd] + (long)k * a.cs) = t[rnd * 4 + k] + gv[rnd * 4 + k];
       }
   }
   if (DT == 1 && overflow && a.flag) *a.flag = 1u;

@@ -103,17 +103,18 @@ class Genomic2DFeatures:
         return cooler.Cooler(src)
 
     def get_feature_data(self, chrom, start, end, chrom2=None, start2=None, end2=None):
+        """[n_features, rows, cols] float32 (2-D for a single dataset) for the window, or for the rectangle between two
+        windows when the second one is given; `cg=True` smooths every dataset with its own raw counts."""
         if not self._initialized:
-            self.data = [self._open(p) for p in self.input_paths]
-            self._initialized = True
+            self.data, self._initialized = [self._open(src) for src in self.input_paths], True
         self.chrom, self.start, self.end = chrom, start, end
-        if chrom2 is not None and start2 is not None and end2 is not None:
-            query = ((chrom, start, end), (chrom2, start2, end2))
-        else:
-            query = ((chrom, start, end),)
-        if self.cg:
-            out = [_adaptive_coarsegrain(c.matrix(balance=True).fetch(*query), c.matrix(balance=False).fetch(*query), cuda=self.cuda).astype(np.float32)
-                   for c in self.data]
-        else:
-            out = [np.asarray(c.matrix(balance=True).fetch(*query)).astype(np.float32) for c in self.data]
-        return out[0] if len(out) == 1 else np.concatenate([o[None, :, :] for o in out], axis=0)
+        regions = [(chrom, start, end)]
+        if None not in (chrom2, start2, end2):
+            regions.append((chrom2, start2, end2))
+        mats = []
+        for source in self.data:
+            balanced = np.asarray(source.matrix(balance=True).fetch(*regions))
+            if self.cg:
+                balanced = _adaptive_coarsegrain(balanced, np.asarray(source.matrix(balance=False).fetch(*regions)), cuda=self.cuda)
+            mats.append(balanced.astype(np.float32))
+        return mats[0] if len(mats) == 1 else np.stack(mats, axis=0)
