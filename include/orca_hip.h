@@ -136,6 +136,9 @@ int orca_net_free(orca_net* net);
  *                         fp32 accumulate: ~2^-22 relative error (fp32-class end to end) at 5.3x the
  *                         fp32-MFMA rate; requires |activation|, |weight| < 65504 (fp16 range). */
 #define ORCA_PRECISION_F16X2 4
+/*  ORCA_PRECISION_F16   : Decoder / Decoder_1m nets only - ONE fp16 plane per feature map and one MFMA product (the rate and
+ *                         traffic of _BF16, 11 instead of 8 significant bits; fp16 range guard as _F16X2). */
+#define ORCA_PRECISION_F16 5
 int orca_net_set_precision(orca_net* net, int precision);
 /* ORCA_PRECISION_F16X2 only: the kernels raise a device flag when an activation leaves the fp16
  * range (the result of that forward is then invalid).  This call waits for the context's stream,

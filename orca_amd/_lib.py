@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "liborca_hip.so")
 
 ORCA_NET_ENCODER, ORCA_NET_ENCODER2, ORCA_NET_ENCODER3, ORCA_NET_DECODER, ORCA_NET_DECODER_1M, ORCA_NET_ENCODER2B = 1, 2, 3, 4, 5, 6
 ORCA_UPSAMPLE_NEAREST, ORCA_UPSAMPLE_BILINEAR = 0, 1
-PRECISIONS = {"f32": 0, "bf16": 1, "bf16x2": 2, "bf16x3": 3, "f16x2": 4}
+PRECISIONS = {"f32": 0, "bf16": 1, "bf16x2": 2, "bf16x3": 3, "f16x2": 4, "f16": 5}
 
 
 class OrcaHipError(RuntimeError):

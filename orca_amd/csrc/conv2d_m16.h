@@ -1,0 +1,391 @@
+// conv2d_m16.h - the Decoders' feature maps in "M16" and the dilated 3x3 Conv2d on them (dilations 1-8; the blocks with
+// dilation 16-64 run in conv2d_dblock.h).
+//
+// M16 = the 2-D analogue of the Encoder's P16 / B16: a map [C][H][W] is stored as planes of 16-byte units, one unit = the 8
+// channels 8o..8o+7 of one pixel in 16-bit form; plane (octet o, split s) = [H rows][256 pixels] units (row pitch padded
+// 250 -> 256, pad pixels kept ZERO by every producer):
+//     unit(o, s, y, x) at base + (((o * NS + s) * H + y) * 256 + x) * 16 bytes
+//   NS = 2, fp16: value = hi + lo (22 significant bits, the fp32-class default: 4 bytes per element as fp32);
+//   NS = 1: one 16-bit plane, 2 bytes per element - bf16 (the throughput mode of BASELINE config 3) or fp16 ("f16": the same
+//           rate and traffic, 11 instead of 8 significant bits, fp16 range guard as in the default mode).
+// A plane row IS the MFMA operand image of that row: a conv's K-chunk (16 channels x 3 source rows x 256 pixels) is
+// 12 (6) contiguous 4 KB runs that LDS-DMA drops into LDS - no staging registers, no split in the consumer (the per-layer
+// kernel of round 1 re-split every fp32 row three times, once per reader, behind a load -> split -> ds_write -> barrier
+// chain per chunk: 18-20 us per conv against ~8 us in the fused block, which had no such chain).  Producers split once,
+// in their epilogue, with the P16 recipe (v_cvt_pk + fma_mix, v_permlane32_swap): every lane stores whole 16-byte units,
+// 512 contiguous bytes per half wave - the LDS transposition of the fp32 layout is gone too.
+//
+// conv2d_3x3_m16_kernel: one workgroup = one output row (8 waves x 32 pixels, all couts); the work is a stream of pieces
+// (K-chunk k, 32-cout half h): X image of chunk k double-buffered ([split][2][3 rows][8 + 256 + 8] units, zero margins
+// for the taps that leave the row), weight pieces [split][9][2][32] in a 3-deep ring, both by LDS-DMA issued one / two
+// pieces ahead and retired by counted s_waitcnt vmcnt; one barrier per piece; operand reads in inline asm with counted
+// lgkmcnt waits (as conv_p16.h).
+#pragma once
+#include "conv_p16.h"
+#include "misc_kernels.h"
+
+#define M16_PX 256
+
+__device__ __forceinline__ long m16_plane(int o, int s, int NS, int H) { return (long)(o * NS + s) * H * M16_PX; }   // in units
+
+// 8 consecutive channels of one pixel -> NS units
+template <int NS, int DT>
+__device__ __forceinline__ void m16_pack8(const f32x4 lo4, const f32x4 hi4, u32x4_t (&out)[NS], bool& ovf) {
+  u32x2 a[NS], b[NS];
+  split4<NS, DT>(lo4, a, ovf);
+  split4<NS, DT>(hi4, b, ovf);
+#pragma unroll
+  for (int s = 0; s < NS; ++s) { out[s].x = a[s].x; out[s].y = a[s].y; out[s].z = b[s].x; out[s].w = b[s].y; }
+}
+// two floats -> packed 16-bit pair (round to nearest even)
+template <int DT>
+__device__ __forceinline__ unsigned m16_pk2(float a, float b) {
+  if (DT == 1) { const f16x2 h = {(_Float16)a, (_Float16)b}; return __builtin_bit_cast(unsigned, h); }
+  return cvt_pk_bf16(a, b);
+}
+// two packed 16-bit values -> floats
+template <int DT>
+__device__ __forceinline__ void m16_pair(unsigned pk, float& a, float& b) {
+  if (DT == 1) { const f16x2 h = __builtin_bit_cast(f16x2, pk); a = (float)h.x; b = (float)h.y; }
+  else { a = bf16lo_f32(pk); b = bf16hi_f32(pk); }
+}
+template <int NS, int DT>
+__device__ __forceinline__ void m16_unpack8(const u32x4_t (&u)[NS], float (&v)[8]) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float a, b;
+    m16_pair<DT>(u[0][e], a, b);
+    if (NS == 2) { float c, d; m16_pair<DT>(u[NS - 1][e], c, d); a += c; b += d; }
+    v[2 * e] = a; v[2 * e + 1] = b;
+  }
+}
+
+// ---- producers / consumers at the ends of a Decoder ---------------------------------------------------------------
+// mat[c][i][j] = x[c][i] + x[c][j] (c < 128); channels 128..128+nt-1 = distenc[t][i][j]; other channels and pad pixels 0.
+// grid n (row i), block 256 (pixel j); `noct` octets.
+template <int NS, int DT>
+__global__ void outer_sum_m16_kernel(const float* __restrict__ x, long sx_c, long sx_l, const float* __restrict__ de, long sd_c, long sd_h,
+                                     long sd_w, int nt, f32x4* __restrict__ out, int n, int noct, unsigned* flag) {
+  const int j = threadIdx.x, i = blockIdx.x;
+  bool ovf = false;
+  for (int o = 0; o < noct; ++o) {
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = 8 * o + e;
+      float t = 0.f;
+      if (j < n) {
+        if (c < 128) t = x[c * sx_c + i * sx_l] + x[c * sx_c + j * sx_l];
+        else if (c < 128 + nt && de) t = de[(c - 128) * sd_c + i * sd_h + j * sd_w];
+      }
+      v[e] = t;
+    }
+    f32x4 a, b;
+    a.x = v[0]; a.y = v[1]; a.z = v[2]; a.w = v[3]; b.x = v[4]; b.y = v[5]; b.z = v[6]; b.w = v[7];
+    u32x4_t u[NS];
+    m16_pack8<NS, DT>(a, b, u, ovf);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) reinterpret_cast<u32x4_t*>(out)[m16_plane(o, s, NS, n) + (long)i * M16_PX + j] = u[s];
+  }
+  if (DT == 1 && ovf && flag) *flag = 1u;
+}
+
+// bilinear / nearest x2 upsample of y [nt][n/2][n/2] into octet o0 (channels 8*o0 .. +nt-1; the rest of the octet and octet
+// o0 + 1 = 0) of an M16 map.  grid n, block 256
+template <int NS, int DT>
+__global__ void upsample2d_m16_kernel(const float* __restrict__ y, long sy_c, long sy_h, long sy_w, int nt, f32x4* __restrict__ out, int n,
+                                      int o0, int bilinear, unsigned* flag) {
+  const int j = threadIdx.x, i = blockIdx.x, h = n / 2;
+  float v[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) v[t] = 0.f;
+  if (j < n) {
+    const float fy = fmaxf(0.5f * (i + 0.5f) - 0.5f, 0.f), fx = fmaxf(0.5f * (j + 0.5f) - 0.5f, 0.f);
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < h - 1 ? 1 : 0);
+    const float ly = fy - y0, lx = fx - x0, hy = 1.f - ly, hx = 1.f - lx;
+#pragma unroll
+    for (int t = 0; t < ORCA_MAX_TARGETS; ++t) {
+      if (t >= nt) break;
+      const float* yt = y + t * sy_c;
+      if (!bilinear) v[t] = yt[(i >> 1) * sy_h + (j >> 1) * sy_w];
+      else
+        v[t] = hy * (hx * yt[y0 * sy_h + x0 * sy_w] + lx * yt[y0 * sy_h + x1 * sy_w]) +
+               ly * (hx * yt[y1 * sy_h + x0 * sy_w] + lx * yt[y1 * sy_h + x1 * sy_w]);
+    }
+  }
+  bool ovf = false;
+  f32x4 a, b;
+  a.x = v[0]; a.y = v[1]; a.z = v[2]; a.w = v[3]; b.x = v[4]; b.y = v[5]; b.z = v[6]; b.w = v[7];
+  u32x4_t u[NS];
+  m16_pack8<NS, DT>(a, b, u, ovf);
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    reinterpret_cast<u32x4_t*>(out)[m16_plane(o0, s, NS, n) + (long)i * M16_PX + j] = u[s];
+    reinterpret_cast<u32x4_t*>(out)[m16_plane(o0 + 1, s, NS, n) + (long)i * M16_PX + j] = (u32x4_t)(0u);
+  }
+  if (DT == 1 && ovf && flag) *flag = 1u;
+}
+
+// `final` head + symmetrisation on a 64-channel M16 map (see final_sym_kernel); a.cur = the map's units, a.cur_bs in units
+template <int NS, int DT>
+__global__ void final_sym_m16_kernel(FinalArgs a) {
+  ORCA_FINAL_LOAD_HEAD();
+  const int j = threadIdx.x, i = blockIdx.x, b = blockIdx.y, n = a.n;
+  if (j >= n) return;
+  const u32x4_t* cur = reinterpret_cast<const u32x4_t*>(a.cur) + (long)b * a.cur_bs;
+  float h1[ORCA_MAX_TARGETS], h2[ORCA_MAX_TARGETS];
+#pragma unroll
+  for (int o = 0; o < ORCA_MAX_TARGETS; ++o) { h1[o] = b1s[o]; h2[o] = b1s[o]; }
+  for (int oc = 0; oc < 8; ++oc) {
+    u32x4_t uu[NS], vv[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      uu[s] = cur[m16_plane(oc, s, NS, n) + (long)i * M16_PX + j];
+      vv[s] = cur[m16_plane(oc, s, NS, n) + (long)j * M16_PX + i];
+    }
+    float u[8], v[8];
+    m16_unpack8<NS, DT>(uu, u);
+    m16_unpack8<NS, DT>(vv, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+#pragma unroll
+      for (int o = 0; o < ORCA_MAX_TARGETS; ++o)
+        if (o < a.F) { h1[o] = fmaf(w1s[o * 64 + 8 * oc + e], u[e], h1[o]); h2[o] = fmaf(w1s[o * 64 + 8 * oc + e], v[e], h2[o]); }
+  }
+  final_head_store(a, h1, h2, w2s, b2s, b, i, j);
+}
+
+// ---- the conv ---------------------------------------------------------------------------------------------------------
+struct ConvM16Args {
+  const f32x4* x;     // M16 map with >= 2*nchunks octets
+  const void* w;      // pack [nchunks][NS][9][2][cout][8]
+  const float* bias;
+  f32x4* y;           // M16 map, octets 0 .. cout/8-1 written
+  const f32x4* r;     // optional residual map (64 channels)
+  long x_bs, y_bs, r_bs;   // batch strides in units
+  int H, W, dil, nchunks, relu;
+  int banded;
+  unsigned* flag;
+};
+
+template <int N, int NS>
+__device__ __forceinline__ void m16_wait(f16x8 (&x)[NS], f16x8 (&w)[NS]) {
+  if constexpr (NS == 2) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(x[0]), "+v"(x[1]), "+v"(w[0]), "+v"(w[1]) : "n"(N));
+  else asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(x[0]), "+v"(w[0]) : "n"(N));
+}
+
+template <int COUT, int NS, int DT>
+__global__ __launch_bounds__(512, 2) void conv2d_3x3_m16_kernel(ConvM16Args a) {
+  static_assert(NS == 1 || DT == 1, "f16x2, plain fp16 or plain bf16");
+  constexpr int WNS = DT == 1 ? 2 : 1;              // splits in the weight pack (the fp16 pack always carries hi and lo)
+  constexpr int NT = 512, NH = COUT / 32, ROWP = 8 + M16_PX + 8;
+  constexpr int XROWS = NS * 2 * 3;                 // rows of an X image: [s][g][ky]
+  constexpr int XB = XROWS * ROWP;                  // units per X buffer
+  constexpr int WP = NS * 9 * 2 * 32;               // units per weight piece
+  constexpr int XIT = XROWS * M16_PX / NT;          // X DMA instructions per thread and chunk (6 / 3): the same for every wave
+  constexpr int WIT = (WP + NT - 1) / NT;
+  constexpr int EXTRA = (WP - (WIT - 1) * NT + 63) / 64;   // waves that issue WIT weight DMAs per piece (the others WIT - 1)
+  static_assert(XROWS * M16_PX % NT == 0, "X image rows per DMA round");
+  __shared__ f32x4 smem[2 * XB + 3 * WP + COUT / 4];
+  f32x4* const Xs = smem;
+  f32x4* const Ws = smem + 2 * XB;
+  float* const bias_s = reinterpret_cast<float*>(smem + 2 * XB + 3 * WP);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, g = lane >> 5;
+  const int b = blockIdx.y, H = a.H, W = a.W, d = a.dil;
+  int y0 = blockIdx.x;
+  if (a.banded) {   // XCD-banded row order for small dilations: the three readers of a source row share an XCD's L2
+    y0 = (int)(blockIdx.x & 7) * ((H + 7) >> 3) + (int)(blockIdx.x >> 3);
+    if (y0 >= H) return;
+  }
+  const int NP = a.nchunks * NH;
+
+  // zero margins of both X buffers, bias - BEFORE the first DMA (a visible LDS store behind a pending DMA makes the compiler wait for it)
+  for (int i = tid; i < 2 * XROWS * 16; i += NT) {
+    const int row = i >> 4, m = i & 15;
+    Xs[row * ROWP + (m < 8 ? m : M16_PX + m)] = (f32x4)(0.f);
+  }
+  if (tid < COUT) bias_s[tid] = a.bias[tid];
+
+  bool rowok[3];
+  int ysrc[3];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int ys = y0 + (ky - 1) * d;
+    rowok[ky] = ys >= 0 && ys < H;
+    ysrc[ky] = rowok[ky] ? ys : y0;      // out-of-map rows are fetched from a valid row (uniform DMA counts) and never read
+  }
+  const f32x4* const xb = a.x + (long)b * a.x_bs;
+  auto issue_x = [&](int k, int buf) {
+#pragma unroll
+    for (int it = 0; it < XIT; ++it) {
+      const int row = 2 * it + (wave >> 2), px = tid & 255;     // row = (s*2 + g)*3 + ky: one wave = 64 pixels of one row
+      const int s = row / 6, gg = (row / 3) & 1, ky = row % 3;
+      p16_glds16(xb + m16_plane(2 * k + gg, s, NS, H) + (long)ysrc[ky] * M16_PX + px, Xs + buf * XB + row * ROWP + 8 + (wave & 3) * 64);
+    }
+  };
+  auto issue_w = [&](int i) {      // piece i = (k, h) = (i / NH, i % NH)
+    const int k = i / NH, h = i - k * NH;
+    f32x4* dst = Ws + (i % 3) * WP;
+#pragma unroll
+    for (int it = 0; it < WIT; ++it) {
+      const int u = tid + it * NT;
+      if (u < WP) p16_glds16(reinterpret_cast<const f32x4*>(a.w) + ((long)k * (WNS * 9 * 2) + (u >> 5)) * COUT + h * 32 + (u & 31), dst + it * NT + wave * 64);
+    }
+  };
+  __syncthreads();                     // margins and bias are in before anything else touches LDS
+  issue_x(0, 0);
+  issue_w(0);
+  if (NP > 1) issue_w(1);
+
+  f32x16 acc[NH];
+#pragma unroll
+  for (int h = 0; h < NH; ++h)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[h][r] = 0.f;
+  const bool allrows = rowok[0] && rowok[2];
+  const unsigned ws_lds = p16_lds_addr(Ws + g * 32 + l31);
+  const unsigned xs_lds = p16_lds_addr(Xs + g * 3 * ROWP + 8 + wave * 32 + l31);
+
+#define M16_READ(buf_, t_)                                                                                          \
+  _Pragma("unroll") for (int s = 0; s < NS; ++s) {                                                                  \
+    xv[buf_][s] = p16_lds_read16(xcol[(t_) % 3], (s * 6 + (t_) / 3) * ROWP * 16);                                   \
+    wv[buf_][s] = p16_lds_read16(wrow, ((s * 9 + (t_)) * 2) * 32 * 16);                                             \
+  }
+#define M16_MFMA(fb_, h_)                                                                                           \
+  {                                                                                                                 \
+    typedef typename Op16<DT>::vec V_;                                                                              \
+    if constexpr (NS == 2) {                                                                                        \
+      acc[h_] = Op16<DT>::mfma(__builtin_bit_cast(V_, wv[fb_][0]), __builtin_bit_cast(V_, xv[fb_][NS - 1]), acc[h_]); \
+      acc[h_] = Op16<DT>::mfma(__builtin_bit_cast(V_, wv[fb_][NS - 1]), __builtin_bit_cast(V_, xv[fb_][0]), acc[h_]); \
+    }                                                                                                               \
+    acc[h_] = Op16<DT>::mfma(__builtin_bit_cast(V_, wv[fb_][0]), __builtin_bit_cast(V_, xv[fb_][0]), acc[h_]);     \
+  }
+
+  for (int k = 0; k < a.nchunks; ++k) {
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      const int i = k * NH + h;
+      // what was issued at the top of piece i-1 may stay in flight: weight piece i+1 and - 64 couts, second half of a chunk -
+      // the next chunk's X image; everything older (this piece's weights, this chunk's X image) has landed
+      if (i + 1 >= NP) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (NH == 2 && h == 1 && k + 1 < a.nchunks) {
+        if (wave < EXTRA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WIT + XIT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WIT - 1 + XIT) : "memory");
+      } else {
+        if (wave < EXTRA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WIT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WIT - 1) : "memory");
+      }
+      __syncthreads();                 // ... for every wave; everyone is done with the buffers the next DMAs go into
+      if (h == 0 && k + 1 < a.nchunks) issue_x(k + 1, (k + 1) & 1);
+      if (i + 2 < NP) issue_w(i + 2);
+      const unsigned wrow = ws_lds + (unsigned)((i % 3) * WP * 16);
+      unsigned xcol[3];
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) xcol[kx] = xs_lds + (unsigned)(((k & 1) * XB + (kx - 1) * d) * 16);
+      f16x8 xv[2][NS], wv[2][NS];
+      if (allrows) {                   // interior rows: all nine taps, fragments double-buffered across taps
+        M16_READ(0, 0);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int fb = t & 1;
+          if (t + 1 < 9) { M16_READ(fb ^ 1, t + 1); m16_wait<2 * NS, NS>(xv[fb], wv[fb]); }
+          else m16_wait<0, NS>(xv[fb], wv[fb]);
+          M16_MFMA(fb, h);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {                         // rows near the top / bottom edge: taps of out-of-map source rows are skipped
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          if (!rowok[t / 3]) continue;
+          M16_READ(0, t);
+          m16_wait<0, NS>(xv[0], wv[0]);
+          M16_MFMA(0, h);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+  }
+#undef M16_READ
+#undef M16_MFMA
+
+  // ---- epilogue: bias, ReLU, residual, back to M16 units (the P16 / B16 recipe: after v_permlane32_swap every lane holds
+  // one whole 16-byte unit - g = 0 the hi (or even-octet) one, g = 1 the lo (or odd-octet) one; 512 contiguous bytes per half wave)
+  const int px = wave * 32 + l31;
+  const bool pxok = px < W;
+  const long rowoff = (long)y0 * M16_PX + px;
+  f32x4* const yb = a.y + (long)b * a.y_bs;
+  const f32x4* const rb = a.r ? a.r + (long)b * a.r_bs : nullptr;
+  float vmax = 0.f;
+  if constexpr (NS == 2) {
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int o = h * 4 + q;
+        const f32x4 bs4 = *reinterpret_cast<const f32x4*>(bias_s + h * 32 + 8 * q + 4 * g);
+        f32x4 v;
+        v.x = acc[h][4 * q + 0] + bs4.x; v.y = acc[h][4 * q + 1] + bs4.y; v.z = acc[h][4 * q + 2] + bs4.z; v.w = acc[h][4 * q + 3] + bs4.w;
+        if (a.relu) { v.x = p16_vmax(v.x, 0.f); v.y = p16_vmax(v.y, 0.f); v.z = p16_vmax(v.z, 0.f); v.w = p16_vmax(v.w, 0.f); }
+        if (rb) {
+          const u32x4_t u_ = reinterpret_cast<const u32x4_t*>(rb)[m16_plane(o, g, NS, H) + rowoff];   // g = 0: the hi unit, g = 1: the lo unit
+          unsigned ux_ = u_.x, uy_ = u_.y, uz_ = u_.z, uw_ = u_.w;
+          p16_swap32(ux_, uz_);
+          p16_swap32(uy_, uw_);
+          const f16x2 h0_ = __builtin_bit_cast(f16x2, ux_), h1_ = __builtin_bit_cast(f16x2, uy_);
+          const f16x2 l0_ = __builtin_bit_cast(f16x2, uz_), l1_ = __builtin_bit_cast(f16x2, uw_);
+          v.x += (float)h0_.x + (float)l0_.x; v.y += (float)h0_.y + (float)l0_.y;
+          v.z += (float)h1_.x + (float)l1_.x; v.w += (float)h1_.y + (float)l1_.y;
+        }
+        if (!pxok) v = (f32x4)(0.f);
+        vmax = p16_vmax3_abs(p16_vmax3_abs(vmax, v.x, v.y), v.z, v.w);
+        unsigned h0_, h1_, l0_, l1_;
+        p16_split_hl(v, h0_, h1_, l0_, l1_);
+        p16_swap32(h0_, l0_);
+        p16_swap32(h1_, l1_);
+        u32x4_t unit_;
+        unit_.x = h0_; unit_.y = h1_; unit_.z = l0_; unit_.w = l1_;
+        reinterpret_cast<u32x4_t*>(yb)[m16_plane(o, g, NS, H) + rowoff] = unit_;
+      }
+    if (vmax > 65504.f && a.flag) *a.flag = 1u;
+  } else {
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+      for (int qp = 0; qp < 2; ++qp) {
+        const int o = h * 4 + 2 * qp;                 // octets o (q0 = 2 qp) and o + 1
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias_s + h * 32 + 16 * qp + 4 * g);
+        const f32x4 b1 = *reinterpret_cast<const f32x4*>(bias_s + h * 32 + 16 * qp + 8 + 4 * g);
+        f32x4 v0, v1;
+        v0.x = acc[h][8 * qp + 0] + b0.x; v0.y = acc[h][8 * qp + 1] + b0.y; v0.z = acc[h][8 * qp + 2] + b0.z; v0.w = acc[h][8 * qp + 3] + b0.w;
+        v1.x = acc[h][8 * qp + 4] + b1.x; v1.y = acc[h][8 * qp + 5] + b1.y; v1.z = acc[h][8 * qp + 6] + b1.z; v1.w = acc[h][8 * qp + 7] + b1.w;
+        if (a.relu) {
+          v0.x = p16_vmax(v0.x, 0.f); v0.y = p16_vmax(v0.y, 0.f); v0.z = p16_vmax(v0.z, 0.f); v0.w = p16_vmax(v0.w, 0.f);
+          v1.x = p16_vmax(v1.x, 0.f); v1.y = p16_vmax(v1.y, 0.f); v1.z = p16_vmax(v1.z, 0.f); v1.w = p16_vmax(v1.w, 0.f);
+        }
+        if (rb) {                                     // the lane loads the whole unit of octet o + g
+          const u32x4_t u_ = reinterpret_cast<const u32x4_t*>(rb)[m16_plane(o + g, 0, NS, H) + rowoff];
+          unsigned ux_ = u_.x, uy_ = u_.y, uz_ = u_.z, uw_ = u_.w;
+          p16_swap32(ux_, uz_);
+          p16_swap32(uy_, uw_);
+          float t0, t1;
+          m16_pair<DT>(ux_, t0, t1); v0.x += t0; v0.y += t1;
+          m16_pair<DT>(uy_, t0, t1); v0.z += t0; v0.w += t1;
+          m16_pair<DT>(uz_, t0, t1); v1.x += t0; v1.y += t1;
+          m16_pair<DT>(uw_, t0, t1); v1.z += t0; v1.w += t1;
+        }
+        if (!pxok) { v0 = (f32x4)(0.f); v1 = (f32x4)(0.f); }
+        if (DT == 1) vmax = p16_vmax3_abs(p16_vmax3_abs(p16_vmax3_abs(p16_vmax3_abs(vmax, v0.x, v0.y), v0.z, v0.w), v1.x, v1.y), v1.z, v1.w);
+        unsigned a0_ = m16_pk2<DT>(v0.x, v0.y), a1_ = m16_pk2<DT>(v0.z, v0.w), b0_ = m16_pk2<DT>(v1.x, v1.y), b1_ = m16_pk2<DT>(v1.z, v1.w);
+        p16_swap32(a0_, b0_);
+        p16_swap32(a1_, b1_);
+        u32x4_t unit_;
+        unit_.x = a0_; unit_.y = a1_; unit_.z = b0_; unit_.w = b1_;
+        reinterpret_cast<u32x4_t*>(yb)[m16_plane(o + g, 0, NS, H) + rowoff] = unit_;
+      }
+    if (DT == 1 && vmax > 65504.f && a.flag) *a.flag = 1u;
+  }
+}

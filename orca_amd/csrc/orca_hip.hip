@@ -16,7 +16,7 @@
 
 #include "conv_kernels.h"
 #include "conv_bf16s.h"
-#include "conv2d_f16s.h"
+#include "conv2d_m16.h"
 #include "conv2d_dblock.h"
 #include "conv_p16.h"
 #include "conv_ws.h"
@@ -266,7 +266,7 @@ static int make_layer(const orca_conv_desc& d, ConvLayer* out) {
     if (e1 != hipSuccess) { free_layer(L); return fail(ORCA_EHIP, "bf16 plain weight upload failed: %s", hipGetErrorString(e1)); }
   }
   if (d.ksize == 3) {
-    // fp16 2-way split pack for conv2d_f16s.h: [cin_pad16/16][2][9][2][cout][8], pad channels = 0
+    // fp16 2-way split pack for conv2d_m16.h / conv2d_dblock.h: [cin_pad16/16][2][9][2][cout][8], pad channels = 0
     const int nc = (d.cin + 15) / 16;
     std::vector<uint16_t> pf((size_t)nc * 2 * 9 * 2 * d.cout * 8, 0);
     for (int co = 0; co < d.cout; ++co)
@@ -372,27 +372,33 @@ static int launch_conv2d(orca_ctx* ctx, const ConvLayer& L, const float* x, long
   return ORCA_OK;
 }
 
-// channel-last fp16-split conv2d (conv2d_f16s.h): x [B][n][256][xc], y [B][n][256][yc], r [B][n][256][rc]
-static int launch_conv2d_f16(orca_ctx* ctx, const ConvLayer& L, const float* x, long x_bs, int xc, float* y, long y_bs, int yc,
-                             const float* r, long r_bs, int rc, int B, int n, int relu, bool bf16 = false) {
-  if (L.ksize != 3 || !L.d_wf16 || !L.d_wb16p) return fail(ORCA_EINVAL, "launch_conv2d_f16 on a layer without a 16-bit pack");
+// dilated 3x3 conv on M16 maps (conv2d_m16.h); maps are unit arrays [octets][NS][n][256]; strides in units
+// mode: 0 = f16x2 (two fp16 planes, 3 products), 1 = bf16 (one plane, 1 product), 2 = f16 (one fp16 plane, 1 product)
+static int launch_conv2d_m16(orca_ctx* ctx, const ConvLayer& L, const f32x4* x, long x_bs, int x_oct, f32x4* y, long y_bs, int y_oct,
+                             const f32x4* r, long r_bs, int B, int n, int relu, int mode) {
+  const bool bf16 = mode == 1;
+  if (L.ksize != 3 || !L.d_wf16 || !L.d_wb16p) return fail(ORCA_EINVAL, "launch_conv2d_m16 on a layer without a 16-bit pack");
   if (!bf16 && !L.f16_ok) return fail(ORCA_EINVAL, "layer weights exceed the fp16 range");
-  Conv2dF16Args a;
-  const long cs = (long)n * ORCA_LDW * 16;   // chunk stride of every chunk-planar map [C/16][n][256][16]
+  if (L.dil > 8) return fail(ORCA_EINVAL, "conv2d_3x3_m16_kernel handles dilations 1-8 (got %d); larger ones run as fused blocks", L.dil);
+  ConvM16Args a;
   a.x = x; a.w = bf16 ? L.d_wb16p : L.d_wf16; a.bias = L.d_bias; a.y = y; a.r = r; a.x_bs = x_bs; a.y_bs = y_bs; a.r_bs = r_bs;
-  a.x_cs = cs; a.y_cs = cs; a.r_cs = cs; a.H = n; a.W = n; a.dil = L.dil; a.nchunks = (L.cin + 15) / 16; a.relu = relu; a.flag = ctx->d_flag; a.stamps = nullptr;
-  if (a.nchunks * 16 > xc) return fail(ORCA_EINVAL, "conv2d_f16: input has %d channels per pixel, layer needs %d", xc, a.nchunks * 16);
-  if (L.cout > yc || (r && L.cout > rc)) return fail(ORCA_EINVAL, "conv2d_f16: output / residual map narrower than the layer");
+  a.H = n; a.W = n; a.dil = L.dil; a.nchunks = (L.cin + 15) / 16; a.relu = relu; a.flag = ctx->d_flag;
+  if (a.nchunks * 2 > x_oct) return fail(ORCA_EINVAL, "conv2d_m16: input map has %d channel octets, layer needs %d", x_oct, a.nchunks * 2);
+  if (L.cout / 8 > y_oct) return fail(ORCA_EINVAL, "conv2d_m16: output map narrower than the layer");
   static const bool no_banded = getenv("ORCA_NO_BANDED") != nullptr;   // A/B switch
-  a.banded = (L.dil < 8 && n >= 64 && !no_banded) ? 1 : 0;
+  a.banded = (n >= 64 && !no_banded) ? 1 : 0;
   dim3 grid((unsigned)(a.banded ? 8 * ((n + 7) / 8) : n), (unsigned)B);
   if (bf16) {
-    if (L.cout == 64) hipLaunchKernelGGL((conv2d_3x3_f16s_kernel<64, 1, 0>), grid, dim3(512), 0, ctx->stream, a);
-    else hipLaunchKernelGGL((conv2d_3x3_f16s_kernel<32, 1, 0>), grid, dim3(512), 0, ctx->stream, a);
-  } else
-  if (L.cout == 64) hipLaunchKernelGGL((conv2d_3x3_f16s_kernel<64>), grid, dim3(512), 0, ctx->stream, a);
-  else hipLaunchKernelGGL((conv2d_3x3_f16s_kernel<32>), grid, dim3(512), 0, ctx->stream, a);
-  LAUNCHCHECK("conv2d_3x3_f16s_kernel");
+    if (L.cout == 64) hipLaunchKernelGGL((conv2d_3x3_m16_kernel<64, 1, 0>), grid, dim3(512), 0, ctx->stream, a);
+    else hipLaunchKernelGGL((conv2d_3x3_m16_kernel<32, 1, 0>), grid, dim3(512), 0, ctx->stream, a);
+  } else if (mode == 2) {
+    if (L.cout == 64) hipLaunchKernelGGL((conv2d_3x3_m16_kernel<64, 1, 1>), grid, dim3(512), 0, ctx->stream, a);
+    else hipLaunchKernelGGL((conv2d_3x3_m16_kernel<32, 1, 1>), grid, dim3(512), 0, ctx->stream, a);
+  } else {
+    if (L.cout == 64) hipLaunchKernelGGL((conv2d_3x3_m16_kernel<64, 2, 1>), grid, dim3(512), 0, ctx->stream, a);
+    else hipLaunchKernelGGL((conv2d_3x3_m16_kernel<32, 2, 1>), grid, dim3(512), 0, ctx->stream, a);
+  }
+  LAUNCHCHECK("conv2d_3x3_m16_kernel");
   return ORCA_OK;
 }
 
@@ -852,9 +858,10 @@ extern "C" int orca_net_create(orca_ctx* ctx, int kind, const orca_conv_desc* co
 
 extern "C" int orca_net_set_precision(orca_net* net, int precision) {
   if (!net) return fail(ORCA_EINVAL, "net is NULL");
-  if (precision < ORCA_PRECISION_F32 || precision > ORCA_PRECISION_F16X2) return fail(ORCA_EINVAL, "unknown precision %d", precision);
+  if (precision < ORCA_PRECISION_F32 || precision > ORCA_PRECISION_F16) return fail(ORCA_EINVAL, "unknown precision %d", precision);
   const bool dec = net->kind == ORCA_NET_DECODER || net->kind == ORCA_NET_DECODER_1M;
-  if (precision != ORCA_PRECISION_F32 && !(net->kind == ORCA_NET_ENCODER || (dec && (precision == ORCA_PRECISION_F16X2 || precision == ORCA_PRECISION_BF16))))
+  if (precision != ORCA_PRECISION_F32 && !((net->kind == ORCA_NET_ENCODER && precision != ORCA_PRECISION_F16) ||
+                                           (dec && (precision == ORCA_PRECISION_F16X2 || precision == ORCA_PRECISION_BF16 || precision == ORCA_PRECISION_F16))))
     return fail(ORCA_EINVAL, "precision %d is not implemented for net kind %d", precision, net->kind);
   net->precision = precision;
   return ORCA_OK;
@@ -1187,110 +1194,111 @@ static int launch_final(orca_ctx* ctx, orca_net* net, const float* cur, long cur
   return ORCA_OK;
 }
 
-// Decoder / Decoder_1m on the fp16 matrix cores, channel-last feature maps [n][256 px][C]
-static int decoder_nhwc(orca_ctx* ctx, orca_net* net, const RowSrc& x, long sx_c, long sx_l, const RowSrc& de,
-                        long sd_c, long sd_h, long sd_w, const RowSrc& y, long sy_c, long sy_h, long sy_w, int B, int n,
-                        float* out, int accumulate) {
+// Decoder / Decoder_1m on the 16-bit matrix cores, feature maps in M16 (conv2d_m16.h)
+template <int NS, int DT>
+static int decoder_m16(orca_ctx* ctx, orca_net* net, const RowSrc& x, long sx_c, long sx_l, const RowSrc& de,
+                       long sd_c, long sd_h, long sd_w, const RowSrc& y, long sy_c, long sy_h, long sy_w, int B, int n,
+                       float* out, int accumulate) {
   const int nt2 = net->num_2d;
-  const bool is1m = net->kind == ORCA_NET_DECODER_1M;
-  const size_t px = (size_t)n * 256;
-  const int cIN = is1m ? 128 : 144, cA = 80;
-  const size_t szIN = px * cIN, szA = px * cA, sz64 = px * 64, sz32 = px * 32;
-  const size_t need = ru256(B * szIN * 4) + ru256(B * szA * 4) + 3 * ru256(B * sz64 * 4) + ru256(B * sz32 * 4);
+  const bool is1m = net->kind == ORCA_NET_DECODER_1M, bf16 = DT == 0;
+  const int mode = DT == 0 ? 1 : (NS == 1 ? 2 : 0);
+  const int oIN = is1m ? 16 : 18, oA = 10;                  // channel octets: 128 / 144 (128 + distenc, padded), 80 (64 + coarse prediction)
+  const size_t upo = (size_t)NS * n * ORCA_LDW;              // units per octet and map
+  const size_t szIN = upo * oIN, szA = upo * oA, sz64 = upo * 8, sz32 = upo * 4;   // units
+  const size_t need = ru256(B * szIN * 16) + ru256(B * szA * 16) + 3 * ru256(B * sz64 * 16) + ru256(B * sz32 * 16);
   ORCA_TRY(ws_ensure(ctx, need));
-  float* const IN0 = ws_take(ctx, B * szIN);
-  float* const A0 = ws_take(ctx, B * szA);
-  float* const Bf0 = ws_take(ctx, B * sz64);
-  float* const Cf0 = ws_take(ctx, B * sz64);
-  float* const Df0 = ws_take(ctx, B * sz64);
-  float* const T0 = ws_take(ctx, B * sz32);
+  auto take = [&](size_t units) { return reinterpret_cast<f32x4*>(ws_take(ctx, units * 4)); };
+  f32x4* const IN0 = take(B * szIN);
+  f32x4* const A0 = take(B * szA);
+  f32x4* const Bf0 = take(B * sz64);
+  f32x4* const Cf0 = take(B * sz64);
+  f32x4* const Df0 = take(B * sz64);
+  f32x4* const T0 = take(B * sz32);
   // maps [b0, b0 + nb) of the batch, on ctx->stream
   auto run = [&](int b0, int nb) -> int {
-    float* IN = IN0 + b0 * szIN;
-    float* A = A0 + b0 * szA;
-    float* Bf = Bf0 + b0 * sz64;
-    float* Cf = Cf0 + b0 * sz64;
-    float* Df = Df0 + b0 * sz64;
-    float* T = T0 + b0 * sz32;
+    f32x4* IN = IN0 + b0 * szIN;
+    f32x4* A = A0 + b0 * szA;
+    f32x4* Bf = Bf0 + b0 * sz64;
+    f32x4* Cf = Cf0 + b0 * sz64;
+    f32x4* Df = Df0 + b0 * sz64;
+    f32x4* T = T0 + b0 * sz32;
     hipStream_t s = ctx->stream;
     for (int b = 0; b < nb; ++b) {
-      hipLaunchKernelGGL(outer_sum_nhwc_kernel, dim3(32, (unsigned)n), dim3(cIN / 4, 8), 0, s, x.at(b0 + b), sx_c, sx_l,
-                         de.at(b0 + b), sd_c, sd_h, sd_w, nt2, IN + b * szIN, n, cIN);
-      LAUNCHCHECK("outer_sum_nhwc_kernel");
+      hipLaunchKernelGGL((outer_sum_m16_kernel<NS, DT>), dim3((unsigned)n), dim3(ORCA_LDW), 0, s, x.at(b0 + b), sx_c, sx_l, de.at(b0 + b), sd_c, sd_h,
+                         sd_w, nt2, IN + b * szIN, n, oIN, ctx->d_flag);
+      LAUNCHCHECK("outer_sum_m16_kernel");
     }
     const ConvLayer* L = net->convs.data();
     const ConvLayer* pairs;
     int npairs;
-#define C2(layer, src, sbs, sc, dst, dbs, dc, res, rbs, rc, relu) \
-  ORCA_TRY(launch_conv2d_f16(ctx, layer, src, sbs, sc, dst, dbs, dc, res, rbs, rc, nb, n, relu, net->precision == ORCA_PRECISION_BF16))
+#define C2(layer, src, sbs, so, dst, dbs, dso, res, rbs, relu) \
+  ORCA_TRY(launch_conv2d_m16(ctx, layer, src, sbs, so, dst, dbs, dso, res, rbs, nb, n, relu, mode))
     if (!is1m) {
-      C2(L[0], IN, szIN, cIN, Bf, sz64, 64, nullptr, 0, 0, 0);
-      C2(L[1], Bf, sz64, 64, Cf, sz64, 64, nullptr, 0, 0, 0);
-      C2(L[2], Cf, sz64, 64, Bf, sz64, 64, nullptr, 0, 0, 1);
-      C2(L[3], Bf, sz64, 64, A, szA, cA, Cf, sz64, 64, 1);           // A[..., 0:64] = combinerD(.) + .
+      C2(L[0], IN, szIN, oIN, Bf, sz64, 8, nullptr, 0, 0);
+      C2(L[1], Bf, sz64, 8, Cf, sz64, 8, nullptr, 0, 0);
+      C2(L[2], Cf, sz64, 8, Bf, sz64, 8, nullptr, 0, 1);
+      C2(L[3], Bf, sz64, 8, A, szA, oA, Cf, sz64, 1);           // A[octets 0..7] = combinerD(.) + .
       pairs = L + 8; npairs = 28;
       if (y) {
-        for (int b = 0; b < nb; ++b) {
-          hipLaunchKernelGGL(upsample2d_nhwc_kernel, dim3((unsigned)n), dim3(256), 0, s, y.at(b0 + b), sy_c, sy_h, sy_w, nt2,
-                             A + b * szA, n, cA, 64, net->upsample_mode == ORCA_UPSAMPLE_BILINEAR ? 1 : 0);
-          LAUNCHCHECK("upsample2d_nhwc_kernel");
+        for (int b = 0; b < nb; ++b) {                            // octets 8, 9 of A: the coarse prediction
+          hipLaunchKernelGGL((upsample2d_m16_kernel<NS, DT>), dim3((unsigned)n), dim3(ORCA_LDW), 0, s, y.at(b0 + b), sy_c, sy_h, sy_w, nt2,
+                             A + b * szA, n, 8, net->upsample_mode == ORCA_UPSAMPLE_BILINEAR ? 1 : 0, ctx->d_flag);
+          LAUNCHCHECK("upsample2d_m16_kernel");
         }
-        C2(L[4], A, szA, cA, Bf, sz64, 64, nullptr, 0, 0, 0);
-        C2(L[5], Bf, sz64, 64, Cf, sz64, 64, nullptr, 0, 0, 0);
-        C2(L[6], Cf, sz64, 64, Bf, sz64, 64, nullptr, 0, 0, 1);
-        C2(L[7], Bf, sz64, 64, Df, sz64, 64, Cf, sz64, 64, 1);
+        C2(L[4], A, szA, oA, Bf, sz64, 8, nullptr, 0, 0);
+        C2(L[5], Bf, sz64, 8, Cf, sz64, 8, nullptr, 0, 0);
+        C2(L[6], Cf, sz64, 8, Bf, sz64, 8, nullptr, 0, 1);
+        C2(L[7], Bf, sz64, 8, Df, sz64, 8, Cf, sz64, 1);
       } else {
-        C2(pairs[0], A, szA, cA, T, sz32, 32, nullptr, 0, 0, 0);
-        C2(pairs[1], T, sz32, 32, Cf, sz64, 64, nullptr, 0, 0, 0);
-        C2(pairs[2], Cf, sz64, 64, T, sz32, 32, nullptr, 0, 0, 1);
-        C2(pairs[3], T, sz32, 32, Df, sz64, 64, Cf, sz64, 64, 1);
+        C2(pairs[0], A, szA, oA, T, sz32, 4, nullptr, 0, 0);
+        C2(pairs[1], T, sz32, 4, Cf, sz64, 8, nullptr, 0, 0);
+        C2(pairs[2], Cf, sz64, 8, T, sz32, 4, nullptr, 0, 1);
+        C2(pairs[3], T, sz32, 4, Df, sz64, 8, Cf, sz64, 1);
       }
     } else {
       pairs = L; npairs = 19;
-      C2(pairs[0], IN, szIN, cIN, T, sz32, 32, nullptr, 0, 0, 0);
-      C2(pairs[1], T, sz32, 32, Cf, sz64, 64, nullptr, 0, 0, 0);
-      C2(pairs[2], Cf, sz64, 64, T, sz32, 32, nullptr, 0, 0, 1);
-      C2(pairs[3], T, sz32, 32, Df, sz64, 64, Cf, sz64, 64, 1);
+      C2(pairs[0], IN, szIN, oIN, T, sz32, 4, nullptr, 0, 0);
+      C2(pairs[1], T, sz32, 4, Cf, sz64, 8, nullptr, 0, 0);
+      C2(pairs[2], Cf, sz64, 8, T, sz32, 4, nullptr, 0, 1);
+      C2(pairs[3], T, sz32, 4, Df, sz64, 8, Cf, sz64, 1);
     }
-    float* cur = Df;
-    float* oth = Cf;
-    static const bool no_dblock = getenv("ORCA_NO_DBLOCK") != nullptr;   // A/B switch
-    const bool bf16 = net->precision == ORCA_PRECISION_BF16;
+    f32x4* cur = Df;
+    f32x4* oth = Cf;
     for (int i = 1; i < npairs; ++i) {
       const ConvLayer* p = pairs + 4 * i;
       const int dil = p[0].dil;
-      if (!no_dblock && (dil == 16 || dil == 32 || dil == 64) && p[1].dil == dil && p[2].dil == dil && p[3].dil == dil) {
+      if (dil >= 16) {
         // the whole block (oth = lm(cur) + cur; cur = m(oth) + oth) in one launch, in place (conv2d_dblock.h)
+        if (!(dil == 16 || dil == 32 || dil == 64) || p[1].dil != dil || p[2].dil != dil || p[3].dil != dil)
+          return fail(ORCA_EINVAL, "decoder block %d: dilation %d unsupported", i, dil);
         DBlockArgs da;
-        da.cur = cur; da.bs = sz64; da.cs = (long)n * ORCA_LDW * 16; da.H = n; da.W = n; da.dil = dil; da.flag = ctx->d_flag;
+        da.cur = cur; da.bs = sz64; da.H = n; da.W = n; da.dil = dil; da.flag = ctx->d_flag;
         for (int k = 0; k < 4; ++k) {
           if (!bf16 && !p[k].f16_ok) return fail(ORCA_EINVAL, "layer weights exceed the fp16 range");
           da.w[k] = bf16 ? p[k].d_wb16p : p[k].d_wf16;
           da.bias[k] = p[k].d_bias;
         }
-        if (bf16) hipLaunchKernelGGL((conv2d_dblock_kernel<1, 0>), dim3(256, (unsigned)nb), dim3(512), 0, ctx->stream, da);
-        else hipLaunchKernelGGL((conv2d_dblock_kernel<2, 1>), dim3(256, (unsigned)nb), dim3(512), 0, ctx->stream, da);
+        hipLaunchKernelGGL((conv2d_dblock_kernel<NS, DT>), dim3(256, (unsigned)nb), dim3(512), 0, ctx->stream, da);
         LAUNCHCHECK("conv2d_dblock_kernel");
         continue;
       }
-      C2(p[0], cur, sz64, 64, T, sz32, 32, nullptr, 0, 0, 0);
-      C2(p[1], T, sz32, 32, oth, sz64, 64, cur, sz64, 64, 0);
-      C2(p[2], oth, sz64, 64, T, sz32, 32, nullptr, 0, 0, 1);
-      C2(p[3], T, sz32, 32, cur, sz64, 64, oth, sz64, 64, 1);
+      C2(p[0], cur, sz64, 8, T, sz32, 4, nullptr, 0, 0);
+      C2(p[1], T, sz32, 4, oth, sz64, 8, cur, sz64, 0);
+      C2(p[2], oth, sz64, 8, T, sz32, 4, nullptr, 0, 1);
+      C2(p[3], T, sz32, 4, cur, sz64, 8, oth, sz64, 1);
     }
 #undef C2
     const ConvLayer& fa = net->convs[net->convs.size() - 2];
     const ConvLayer& fb = net->convs[net->convs.size() - 1];
     FinalArgs fa_;
-    fa_.cur = cur; fa_.w1 = fa.d_w; fa_.b1 = fa.d_bias; fa_.w2 = fb.d_w; fa_.b2 = fb.d_bias; fa_.out = out + (size_t)b0 * nt2 * n * n;
+    fa_.cur = reinterpret_cast<const float*>(cur); fa_.w1 = fa.d_w; fa_.b1 = fa.d_bias; fa_.w2 = fb.d_w; fa_.b2 = fb.d_bias; fa_.out = out + (size_t)b0 * nt2 * n * n;
     fa_.cur_bs = sz64; fa_.out_bs = (long)nt2 * n * n; fa_.n = n; fa_.accumulate = accumulate; fa_.T = nt2; fa_.F = fa.cout;
-    hipLaunchKernelGGL(final_sym_nhwc_kernel, dim3((unsigned)n, (unsigned)nb), dim3(256), 0, s, fa_);
-    LAUNCHCHECK("final_sym_nhwc_kernel");
+    hipLaunchKernelGGL((final_sym_m16_kernel<NS, DT>), dim3((unsigned)n, (unsigned)nb), dim3(256), 0, s, fa_);
+    LAUNCHCHECK("final_sym_m16_kernel");
     return ORCA_OK;
   };
-  // A Decoder is a chain of ~120 dependent launches of 250 workgroups per map, each launch with a dispatch ramp and a
-  // tail in which most CUs idle.  The maps of a batch are independent, so an even batch runs as two half-batches on
-  // two streams: one half's ramps and tails are filled by the other half's workgroups.
+  // A Decoder is a chain of ~90 dependent launches per map.  The maps of a batch are independent, so an even batch runs as
+  // two half-batches on two streams: one half's ramps and tails are filled by the other half's workgroups.
   static const bool one_stream = getenv("ORCA_DECODER_ONE_STREAM") != nullptr;   // A/B switch
   if (B < 2 || (B & 1) || one_stream) return run(0, B);
   if (!ctx->aux) {
@@ -1317,8 +1325,12 @@ static int decoder_common(orca_ctx* ctx, orca_net* net, const RowSrc& x, long sx
   if (n <= 0 || n > ORCA_LDW || (n & 1)) return fail(ORCA_EINVAL, "map size %d unsupported (even, <=256)", n);
   if (B <= 0) return ORCA_OK;
   HIPCHECK(hipSetDevice(ctx->device));
-  if (net->precision == ORCA_PRECISION_F16X2 || net->precision == ORCA_PRECISION_BF16)
-    return decoder_nhwc(ctx, net, x, sx_c, sx_l, de, sd_c, sd_h, sd_w, y, sy_c, sy_h, sy_w, B, n, out, accumulate);
+  if (net->precision == ORCA_PRECISION_F16X2)
+    return decoder_m16<2, 1>(ctx, net, x, sx_c, sx_l, de, sd_c, sd_h, sd_w, y, sy_c, sy_h, sy_w, B, n, out, accumulate);
+  if (net->precision == ORCA_PRECISION_BF16)
+    return decoder_m16<1, 0>(ctx, net, x, sx_c, sx_l, de, sd_c, sd_h, sd_w, y, sy_c, sy_h, sy_w, B, n, out, accumulate);
+  if (net->precision == ORCA_PRECISION_F16)
+    return decoder_m16<1, 1>(ctx, net, x, sx_c, sx_l, de, sd_c, sd_h, sd_w, y, sy_c, sy_h, sy_w, B, n, out, accumulate);
   const bool is1m = net->kind == ORCA_NET_DECODER_1M;
   const size_t plane = (size_t)n * ORCA_LDW;
   const int cin0 = is1m ? 128 : 136;

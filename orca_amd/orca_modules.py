@@ -114,10 +114,11 @@ class _HipModule(nn.Module):
     def _run_guarded(self, net, fn, fallback):
         """Run fn() in self.precision; in the fp16-split mode check the device range flag and redo the
         forward in the range-safe ``fallback`` arithmetic if an activation left the fp16 range."""
-        prec = fallback if (engine._guard["force_safe"] and self.precision == "f16x2") else self.precision
+        ranged = ("f16x2", "f16")          # the modes with fp16 operands: device range guard
+        prec = fallback if (engine._guard["force_safe"] and self.precision in ranged) else self.precision
         self._apply_precision(net, prec)
         out = fn()
-        if prec == "f16x2" and not engine._guard["defer"] and net.ctx.take_overflow():
+        if prec in ranged and not engine._guard["defer"] and net.ctx.take_overflow():
             import warnings
             warnings.warn(f"orca_amd.{type(self).__name__}: an activation left the fp16 range; recomputing this forward "
                           f"with precision='{fallback}' (set .precision='{fallback}' to avoid the retry)")
@@ -265,15 +266,16 @@ class Decoder(_HipModule):
     def __init__(self, upsample_mode="nearest", precision=None, num_2d=1):
         """precision: "f16x2" (dilated 3x3 convs on the fp16 matrix cores with 2-way split fp32 operands,
         ~2^-22 relative error, device range guard with automatic "f32" retry; default), "f32" (fp32 MFMA) or
-        "bf16" (plain bf16 operands, one product, fp32 accumulate and fp32 feature maps: the throughput mode).
+        "bf16" / "f16" (ONE bf16 / fp16 plane per feature map, one product, fp32 accumulate: the throughput modes - "bf16" is
+        BASELINE config 3 as named, "f16" the same rate with 11 instead of 8 significant bits and the fp16 range guard).
         Default: $ORCA_DECODER_PRECISION or "f16x2".
         num_2d: maps per prediction (the multi-target decoders of orca_leukemia.py:512-990): distenc and the
         coarse prediction y then carry num_2d channels, and so does the output."""
         super().__init__()
         self.num_2d = _check_num_2d(num_2d)
         self.precision = precision or os.environ.get("ORCA_DECODER_PRECISION", "f16x2")
-        if self.precision not in ("f16x2", "f32", "bf16"):
-            raise ValueError("Decoder precision must be 'f16x2', 'f32' or 'bf16'")
+        if self.precision not in ("f16x2", "f32", "bf16", "f16"):
+            raise ValueError("Decoder precision must be 'f16x2', 'f32', 'bf16' or 'f16'")
         if upsample_mode not in ("nearest", "bilinear"):
             raise ValueError("upsample_mode must be 'nearest' or 'bilinear'")
         self._upsample = _lib.ORCA_UPSAMPLE_BILINEAR if upsample_mode == "bilinear" else _lib.ORCA_UPSAMPLE_NEAREST
@@ -303,7 +305,7 @@ class Decoder(_HipModule):
 
     def forward_into(self, out, x, distenc, y=None, accumulate=False):
         net = self._net(x.device)
-        if accumulate and self.precision == "f16x2":
+        if accumulate and self.precision in ("f16x2", "f16"):
             base = out.clone()   # a retry must not accumulate twice
             return self._run_guarded(net, lambda: engine.decoder_forward(net, x, distenc, y, out=out.copy_(base), accumulate=True), "f32")
         return self._run_guarded(net, lambda: engine.decoder_forward(net, x, distenc, y, out=out, accumulate=accumulate), "f32")
@@ -323,8 +325,8 @@ class Decoder_1m(_HipModule):
         super().__init__()
         self.num_2d = _check_num_2d(num_2d)
         self.precision = precision or os.environ.get("ORCA_DECODER_PRECISION", "f16x2")
-        if self.precision not in ("f16x2", "f32", "bf16"):
-            raise ValueError("Decoder_1m precision must be 'f16x2', 'f32' or 'bf16'")
+        if self.precision not in ("f16x2", "f32", "bf16", "f16"):
+            raise ValueError("Decoder_1m precision must be 'f16x2', 'f32', 'bf16' or 'f16'")
         self.lconvtwos = nn.ModuleList([
             _linear_pair(nn.Conv2d, nn.BatchNorm2d, 128 if i == 0 else 64, 32, 64, nn.Dropout(p=0.1) if i == 0 else None, **_c2(d))
             for i, d in enumerate(DECODER1M_DILATIONS)])
@@ -344,14 +346,14 @@ class Decoder_1m(_HipModule):
 
     def forward_into(self, out, x, accumulate=False):
         net = self._net(x.device)
-        if accumulate and self.precision == "f16x2":
+        if accumulate and self.precision in ("f16x2", "f16"):
             base = out.clone()   # a retry must not accumulate twice
             return self._run_guarded(net, lambda: engine.decoder1m_forward(net, x, out=out.copy_(base), accumulate=True), "f32")
         return self._run_guarded(net, lambda: engine.decoder1m_forward(net, x, out=out, accumulate=accumulate), "f32")
 
     def forward_rows_into(self, out, xs, accumulate=False):
         net = self._net(xs[0].device)
-        if accumulate and self.precision == "f16x2":
+        if accumulate and self.precision in ("f16x2", "f16"):
             base = out.clone()
             return self._run_guarded(net, lambda: engine.decoder1m_forward_rows(net, xs, out=out.copy_(base), accumulate=True), "f32")
         return self._run_guarded(net, lambda: engine.decoder1m_forward_rows(net, xs, out=out, accumulate=accumulate), "f32")

@@ -4,9 +4,12 @@ batch > 1 is a module-level mode, train_h1esc_b.py:170) - against rows 0 and 5 c
 nn.Modules on CPU (tests/golden/G17_config3.npz, tools/make_golden.py --config3).
 
   * default arithmetic (fp32-class f16x2): north-star tolerance, 1e-4 max-abs per level;
-  * "bf16" throughput mode (Encoder stages 1-3 on single-plane bf16 activations, bf16 operands everywhere, one MFMA
-    product, fp32 accumulate): bf16 keeps 8 significant bits, so through ~150 layers the maps agree to ~2 decimal
-    digits - stated tolerance: max-abs 0.2 on maps of range ~+-3 (measured 0.134), Pearson r >= 0.9995 per level (measured 0.99995)."""
+  * "bf16" throughput mode (2-byte activations end to end: Encoder stages 1-3 on single-plane bf16 activations, Decoder
+    feature maps - residual stream included - as single bf16 planes, bf16 operands, one MFMA product, fp32 accumulate): bf16
+    keeps 8 significant bits and the Decoders round their residual stream 56 times, so the maps agree to 1-2 decimal digits -
+    stated tolerance: max-abs 0.6 on maps of range ~+-3 (measured 0.40), Pearson r >= 0.999 per level (measured 0.9998);
+  * the same with the Decoders on single fp16 planes ("f16": same traffic and rate, 11 significant bits, fp16 range guard) -
+    stated tolerance max-abs 0.2, Pearson r >= 0.9995 (the Encoder's bf16 rounding dominates)."""
 import numpy as np
 import pytest
 import torch
@@ -26,11 +29,12 @@ def setup(cuda):
     return model, codes, de
 
 
-def _forward(model, codes, de, precision):
+def _forward(model, codes, de, precision, dec_precision=None):
+    dec_precision = dec_precision or precision
     model.net0.precision = precision
     for lv in model.levels:
-        model.denets[lv].precision = precision
-    model.denet_1_pt.precision = precision
+        model.denets[lv].precision = dec_precision
+    model.denet_1_pt.precision = dec_precision
     enc0 = model.net0.forward_codes(codes)
     encs = dict(zip([1, 2, 4, 8, 16, 32], model.net(enc0)))
     preds, starts = P.run_cascade(model, encs, [32, 16, 8, 4, 2, 1], lambda lv: lv, codes.shape[0], [False], lambda lv, k, st: de[lv],
@@ -56,16 +60,17 @@ def test_config3_default_arithmetic_vs_reference(setup):
     assert max(maxabs(m[0], m[5]) for m in maps) > 1e-3
 
 
-def test_config3_bf16_throughput_mode_vs_reference(setup):
+@pytest.mark.parametrize("dec_precision,tol,rmin", [("bf16", 0.6, 0.999), ("f16", 0.2, 0.9995)])
+def test_config3_bf16_throughput_mode_vs_reference(setup, dec_precision, tol, rmin):
     model, codes, de = setup
     g = golden("G17_config3.npz")
-    enc0, maps, starts = _forward(model, codes, de, "bf16")
+    enc0, maps, starts = _forward(model, codes, de, "bf16", dec_precision)
     worst = (0.0, 1.0)
     for b in CFG["rows"]:
         assert list(starts) == list(g[f"starts_row{b}"])
         for j in range(6):
             err, r = maxabs(maps[j][b], g[f"maps_row{b}"][j]), pearson(maps[j][b], g[f"maps_row{b}"][j])
             worst = (max(worst[0], err), min(worst[1], r))
-            assert err < 0.2 and r > 0.9995, (b, j, err, r)
-    print(f"config 3 bf16 vs reference: worst max-abs {worst[0]:.4g}, worst Pearson {worst[1]:.6f}")
+            assert err < tol and r > rmin, (b, j, err, r)
+    print(f"config 3, Encoder bf16 / Decoders {dec_precision} vs reference: worst max-abs {worst[0]:.4g}, worst Pearson {worst[1]:.6f}")
     _forward(model, codes, de, "f16x2")   # leave the module-scoped model in its default arithmetic

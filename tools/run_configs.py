@@ -16,24 +16,26 @@ hff = M.Hff(synthetic_seed=7)
 codes = torch.from_numpy(np.stack([synth.synth_base_codes(32_000_000, seed=10 + b) for b in range(8)])).to(dev)
 de = {lv: torch.log(torch.from_numpy(hff.normmats[lv][None, None].astype(np.float32))).to(dev) for lv in hff.levels}
 def fwd8(prec, enc_only=False):
-    hff.net0.precision = prec
-    for lv in hff.levels: hff.denets[lv].precision = prec
-    hff.denet_1_pt.precision = prec
+    dprec = {"bf16+f16": "f16"}.get(prec, prec)
+    hff.net0.precision = prec.split("+")[0]
+    for lv in hff.levels: hff.denets[lv].precision = dprec
+    hff.denet_1_pt.precision = dprec
     enc0 = hff.net0.forward_codes(codes)
     if enc_only: return enc0
     encs = dict(zip([1, 2, 4, 8, 16, 32], hff.net(enc0)))
     return P.run_cascade(hff, encs, [32, 16, 8, 4, 2, 1], lambda lv: lv, 8, [False], lambda lv, k, st: de[lv],
                          lambda lv, st, rev: P.zoom_index_32m(lv, st, 17_234_567, 16_000_000, rev), add_1m_level=1)[0]
 out = {}
-for prec in ("bf16", "f16x2"):
+for prec in ("bf16", "bf16+f16", "f16x2"):
     fwd8(prec); sync(); t = time.perf_counter(); p = fwd8(prec); sync(); dt = time.perf_counter() - t
     t = time.perf_counter(); fwd8(prec, True); sync(); dte = time.perf_counter() - t
     out[prec] = [x.cpu().numpy() for x in p]
     res[f"config3_{prec}_B8_single_strand"] = {"s": round(dt, 4), "Mb_per_s": round(8 * 32 / dt, 1), "maps_per_s": round(48 / dt, 1),
                                                 "encoder_s": round(dte, 4), "encoder_Mb_per_s": round(8 * 32 / dte, 1)}
-err = max(float(np.abs(a - b).max()) for a, b in zip(out["bf16"], out["f16x2"]))
-r = min(float(np.corrcoef(a.ravel(), b.ravel())[0, 1]) for a, b in zip(out["bf16"], out["f16x2"]))
-res["config3_bf16_vs_f16x2"] = {"max_abs": round(err, 4), "min_pearson_r": round(r, 6)}
+for m in ("bf16", "bf16+f16"):
+    err = max(float(np.abs(a - b).max()) for a, b in zip(out[m], out["f16x2"]))
+    r = min(float(np.corrcoef(a.ravel(), b.ravel())[0, 1]) for a, b in zip(out[m], out["f16x2"]))
+    res[f"config3_{m}_vs_f16x2"] = {"max_abs": round(err, 4), "min_pearson_r": round(r, 6)}
 print(json.dumps(res), flush=True)
 if len(sys.argv) > 1 and sys.argv[1] == "config3": sys.exit(0)
 del codes, hff, out; engine.get_context(dev).release_workspace(); torch.cuda.empty_cache()
