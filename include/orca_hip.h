@@ -295,6 +295,11 @@ int orca_conv1d_b16_forward(orca_ctx* ctx, const orca_conv_desc* conv, const flo
 /* y = [relu](conv2d_3x3_dilated(x) + b) [+ r]; x: contiguous [B,cin,n,n], y/r: [B,cout,n,n]. */
 int orca_conv2d_forward(orca_ctx* ctx, const orca_conv_desc* conv, const float* x, float* y, const float* r,
                         int B, int n, int relu);
+/* The Decoders' 16-bit conv (conv2d_m16.h; precision ORCA_PRECISION_F16X2 / _BF16 / _F16; dilation 1..8), wrapped for
+ * tests: contiguous [B,cin,n,n] in, [B,cout,n,n] out / residual; the maps make a round trip through the M16 storage
+ * (two fp16 planes, or one bf16 / fp16 plane). */
+int orca_conv2d_m16_forward(orca_ctx* ctx, const orca_conv_desc* conv, int precision, const float* x, float* y,
+                            const float* r, int B, int n, int relu);
 /* y[c][m] = max_{j<k} x[c][k*m+j]  (nn.MaxPool1d(k,k)); x: [rows][ldx], y: [rows][ldy]. */
 int orca_maxpool1d_forward(orca_ctx* ctx, const float* x, int64_t ldx, float* y, int64_t ldy, int64_t rows,
                            int64_t n_out, int k);

@@ -76,6 +76,7 @@ SIGNATURES = {
     "orca_conv1d_p16_forward": (c_int, [c_void_p, POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int]),
     "orca_conv1d_b16_forward": (c_int, [c_void_p, POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int]),
     "orca_conv2d_forward": (c_int, [c_void_p, POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_int, c_int, c_int]),
+    "orca_conv2d_m16_forward": (c_int, [c_void_p, POINTER(ConvDesc), c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int]),
     "orca_maxpool1d_forward": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int]),
     "orca_pointwise1d_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int64, c_int64, c_void_p, c_int64,
                                           c_int64, c_int, c_int64, c_int]),

@@ -156,6 +156,38 @@ __global__ void final_sym_m16_kernel(FinalArgs a) {
   final_head_store(a, h1, h2, w2s, b2s, b, i, j);
 }
 
+// converters for the single-layer test entry point: [C][n][n] fp32 <-> M16 (`noct` octets; channels >= C and pad pixels zero)
+template <int NS, int DT>
+__global__ void nchw_to_m16_kernel(const float* __restrict__ x, int C, int n, f32x4* __restrict__ out, int noct) {
+  const int j = threadIdx.x, i = blockIdx.x;
+  bool ovf = false;
+  for (int o = 0; o < noct; ++o) {
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const int c = 8 * o + e; v[e] = (j < n && c < C) ? x[((long)c * n + i) * n + j] : 0.f; }
+    f32x4 a, b;
+    a.x = v[0]; a.y = v[1]; a.z = v[2]; a.w = v[3]; b.x = v[4]; b.y = v[5]; b.z = v[6]; b.w = v[7];
+    u32x4_t u[NS];
+    m16_pack8<NS, DT>(a, b, u, ovf);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) reinterpret_cast<u32x4_t*>(out)[m16_plane(o, s, NS, n) + (long)i * M16_PX + j] = u[s];
+  }
+}
+template <int NS, int DT>
+__global__ void m16_to_nchw_kernel(const f32x4* __restrict__ in, int C, int n, float* __restrict__ y) {
+  const int j = threadIdx.x, i = blockIdx.x;
+  if (j >= n) return;
+  for (int o = 0; o < C / 8; ++o) {
+    u32x4_t u[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) u[s] = reinterpret_cast<const u32x4_t*>(in)[m16_plane(o, s, NS, n) + (long)i * M16_PX + j];
+    float v[8];
+    m16_unpack8<NS, DT>(u, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) y[((long)(8 * o + e) * n + i) * n + j] = v[e];
+  }
+}
+
 // ---- the conv ---------------------------------------------------------------------------------------------------------
 struct ConvM16Args {
   const f32x4* x;     // M16 map with >= 2*nchunks octets

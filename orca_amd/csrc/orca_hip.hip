@@ -1716,6 +1716,44 @@ extern "C" int orca_conv2d_forward(orca_ctx* ctx, const orca_conv_desc* conv, co
   return rc;
 }
 
+// single dilated 3x3 layer on M16 maps (conv2d_m16.h; dilations 1-8) - or, for dilation 16 / 32 / 64, a whole residual block
+template <int NS, int DT>
+static int conv2d_m16_test(orca_ctx* ctx, const ConvLayer& L, int mode, const float* x, float* y, const float* r, int B, int n, int relu) {
+  const int xo = 2 * ((L.cin + 15) / 16), yo = L.cout / 8;
+  const size_t upo = (size_t)NS * n * ORCA_LDW;
+  ORCA_TRY(ws_ensure(ctx, ru256(B * upo * xo * 16) + 2 * ru256(B * upo * yo * 16)));
+  f32x4* xp = reinterpret_cast<f32x4*>(ws_take(ctx, B * upo * xo * 4));
+  f32x4* yp = reinterpret_cast<f32x4*>(ws_take(ctx, B * upo * yo * 4));
+  f32x4* rp = reinterpret_cast<f32x4*>(ws_take(ctx, B * upo * yo * 4));
+  hipStream_t s = ctx->stream;
+  for (int b = 0; b < B; ++b) {
+    hipLaunchKernelGGL((nchw_to_m16_kernel<NS, DT>), dim3((unsigned)n), dim3(ORCA_LDW), 0, s, x + (size_t)b * L.cin * n * n, L.cin, n, xp + b * upo * xo, xo);
+    if (r) hipLaunchKernelGGL((nchw_to_m16_kernel<NS, DT>), dim3((unsigned)n), dim3(ORCA_LDW), 0, s, r + (size_t)b * L.cout * n * n, L.cout, n, rp + b * upo * yo, yo);
+  }
+  ORCA_TRY(launch_conv2d_m16(ctx, L, xp, upo * xo, xo, yp, upo * yo, yo, r ? rp : nullptr, upo * yo, B, n, relu, mode));
+  for (int b = 0; b < B; ++b)
+    hipLaunchKernelGGL((m16_to_nchw_kernel<NS, DT>), dim3((unsigned)n), dim3(ORCA_LDW), 0, s, yp + b * upo * yo, L.cout, n, y + (size_t)b * L.cout * n * n);
+  LAUNCHCHECK("conv2d_m16 test path");
+  return ORCA_OK;
+}
+
+extern "C" int orca_conv2d_m16_forward(orca_ctx* ctx, const orca_conv_desc* conv, int precision, const float* x, float* y, const float* r,
+                                       int B, int n, int relu) {
+  if (!ctx || !conv || !x || !y) return fail(ORCA_EINVAL, "orca_conv2d_m16_forward: NULL argument");
+  if (n <= 0 || n > ORCA_LDW) return fail(ORCA_EINVAL, "map size %d unsupported", n);
+  HIPCHECK(hipSetDevice(ctx->device));
+  ConvLayer L;
+  ORCA_TRY(make_layer(*conv, &L));
+  int rc;
+  if (precision == ORCA_PRECISION_F16X2) rc = conv2d_m16_test<2, 1>(ctx, L, 0, x, y, r, B, n, relu);
+  else if (precision == ORCA_PRECISION_BF16) rc = conv2d_m16_test<1, 0>(ctx, L, 1, x, y, r, B, n, relu);
+  else if (precision == ORCA_PRECISION_F16) rc = conv2d_m16_test<1, 1>(ctx, L, 2, x, y, r, B, n, relu);
+  else rc = fail(ORCA_EINVAL, "orca_conv2d_m16_forward: precision %d has no M16 kernel", precision);
+  (void)hipStreamSynchronize(ctx->stream);
+  free_layer(L);
+  return rc;
+}
+
 extern "C" int orca_pointwise1d_forward(orca_ctx* ctx, const float* w_dev, const float* bias_dev, int cout, int cin, const float* x,
                                         int64_t x_bs, int64_t ldx, float* y, int64_t y_bs, int64_t ldy, int B, int64_t n, int act) {
   if (!ctx || !w_dev || !bias_dev || !x || !y) return fail(ORCA_EINVAL, "orca_pointwise1d_forward: NULL argument");

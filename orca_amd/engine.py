@@ -464,6 +464,22 @@ def conv2d(x, w, b, dilation=1, relu=False, r=None):
     return y
 
 
+def conv2d_m16(x, w, b, dilation=1, relu=False, r=None, precision="f16x2"):
+    """The Decoders' 16-bit 3x3 conv on M16 maps (test wrapper): x [B,cin,n,n] -> [B,cout,n,n]; dilation 1..8."""
+    x = _f32_cuda(x, "x").contiguous()
+    B, cin, n, _ = x.shape
+    w = np.ascontiguousarray(w, dtype=np.float32)
+    b = np.ascontiguousarray(b, dtype=np.float32)
+    cout = w.shape[0]
+    d = make_descs([{"w": w, "b": b, "cout": cout, "cin": cin, "k": 3, "dil": dilation}])
+    y = torch.empty((B, cout, n, n), dtype=torch.float32, device=x.device)
+    ctx = get_context(x.device)
+    r = r.contiguous() if r is not None else None
+    check(_lib.load().orca_conv2d_m16_forward(ctx.handle, d, _lib.PRECISIONS[precision], _p(x), _p(y), _p(r) if r is not None else None, B, n,
+                                              1 if relu else 0), "orca_conv2d_m16_forward")
+    return y
+
+
 def maxpool1d(x, k):
     x = _f32_cuda(x, "x").contiguous()
     B, C, n = x.shape

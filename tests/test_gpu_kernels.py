@@ -158,3 +158,43 @@ def test_conv1d_b16_dma(cuda, cin, cout, n, out_mode):
         d = (y.cpu().t()[None] - ref).abs()
         bound = 2e-5 + (ref.abs() * 2.0 ** -8 if out_mode != 2 else 0.0)
         assert bool((d <= bound).all()), (cin, cout, n, out_mode, relu, float(d.max()))
+
+
+@pytest.mark.parametrize("cin,cout,dil,n", [(64, 32, 1, 250), (32, 64, 2, 250), (64, 64, 1, 250), (64, 32, 8, 250), (32, 64, 4, 250), (129, 64, 1, 250),
+                                            (65, 64, 1, 250), (128, 32, 1, 250), (64, 32, 8, 126), (32, 64, 8, 64), (64, 64, 2, 256), (64, 32, 4, 30)])
+def test_conv2d_m16_dilated(cuda, cin, cout, dil, n):
+    """conv2d_m16.h: the Decoders' conv on M16 maps (two fp16 planes, LDS-DMA'd operands, 3 products) vs torch fp32.  The
+    maps make a round trip through the 22-bit storage (inputs, residual and output each rounded once: 2^-22 relative)."""
+    rs = np.random.RandomState(cin * 100 + cout + dil + n)
+    B = 2 if n < 250 else 1
+    x = torch.from_numpy(rs.randn(B, cin, n, n).astype(np.float32))
+    w = (rs.randn(cout, cin, 3, 3) / np.sqrt(cin * 9)).astype(np.float32)
+    b = rs.randn(cout).astype(np.float32) * 0.1
+    r = torch.from_numpy(rs.randn(B, cout, n, n).astype(np.float32))
+    for relu, rr in [(False, None), (True, r)]:
+        y = engine.conv2d_m16(x.to(cuda), w, b, dil, relu, None if rr is None else rr.to(cuda)).cpu()
+        ref = F.conv2d(x, torch.from_numpy(w), torch.from_numpy(b), padding=dil, dilation=dil)
+        if relu:
+            ref = F.relu(ref)
+        if rr is not None:
+            ref = ref + rr
+        err = float((y - ref).abs().max())
+        assert err < TOL, (cin, cout, dil, n, relu, err)
+
+
+@pytest.mark.parametrize("precision,ulp", [("bf16", 2.0 ** -8), ("f16", 2.0 ** -11)])
+@pytest.mark.parametrize("cin,cout,dil,n", [(64, 32, 1, 250), (32, 64, 8, 250), (144, 64, 1, 126), (64, 64, 4, 64)])
+def test_conv2d_m16_single_plane(cuda, cin, cout, dil, n, precision, ulp):
+    """The single-plane modes: on operands that are exactly representable the only differences from torch fp32 are the
+    summation order and ONE final rounding of the output to the plane's 16-bit type."""
+    rs = np.random.RandomState(cin + cout + dil + n)
+    dt = torch.bfloat16 if precision == "bf16" else torch.float16
+    q = lambda t: t.to(dt).to(torch.float32)
+    x = q(torch.from_numpy(rs.randn(1, cin, n, n).astype(np.float32)))
+    w = q(torch.from_numpy((rs.randn(cout, cin, 3, 3) / np.sqrt(cin * 9)).astype(np.float32))).numpy()
+    b = rs.randn(cout).astype(np.float32) * 0.1
+    r = q(torch.from_numpy(rs.randn(1, cout, n, n).astype(np.float32)))
+    y = engine.conv2d_m16(x.to(cuda), w, b, dil, True, r.to(cuda), precision=precision).cpu()
+    ref = F.relu(F.conv2d(x, torch.from_numpy(w), torch.from_numpy(b), padding=dil, dilation=dil)) + r
+    d = (y - ref).abs()
+    assert bool((d <= 2e-5 + ref.abs() * ulp).all()), (cin, cout, dil, n, precision, float(d.max()))
