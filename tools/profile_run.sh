@@ -17,6 +17,9 @@ for mode in f16x2 bf16; do
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_enc_${mode}_write -o p -- python $ROOT/tools/prof_encoder.py 32 $mode 1 codes > $OUT/pmc_enc_${mode}_write.log 2>&1
 done
 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $OUT/pmc_dec_sq -o p -- python $ROOT/tools/prof_decoder.py > $OUT/pmc_dec_sq.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_dec_fetch -o p -- python $ROOT/tools/prof_decoder.py > $OUT/pmc_dec_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_dec_write -o p -- python $ROOT/tools/prof_decoder.py > $OUT/pmc_dec_write.log 2>&1
+python $ROOT/tools/run_configs.py config3 > $OUT/configs.json 2> $OUT/configs.err
 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_enc_bf16_lds -o p -- python $ROOT/tools/prof_encoder.py 32 bf16 1 codes > $OUT/pmc_enc_bf16_lds.log 2>&1
 ( rocm-smi --showpower --showclocks --showtemp > $OUT/rocm_smi_idle.txt 2>&1 ) || true
 find $OUT -name "*.csv" | head -40 > $OUT/files.txt
