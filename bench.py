@@ -28,7 +28,7 @@ Also measured in the same run, OUTSIDE the timed region, and reported in the sam
 Prints ONE JSON line (rank 0).  value = strand-Mb of sequence encoded AND decoded per second over the whole job
 (2 strands x 32 Mb per step per rank).
 """
-import argparse
+import argparse, threading
 import json
 import os
 import sys
@@ -195,6 +195,7 @@ def main():
     ap.add_argument("--seq-mb", type=int, default=32, help="debug only: shorter sequence (invalidates the metric)")
     ap.add_argument("--float-input", action="store_true", help="keep the strands as float32 [1,4,L] views (the reference's input form)")
     ap.add_argument("--no-sharded", action="store_true", help="skip the 256 Mb sharded-encoder section")
+    ap.add_argument("--sharded-timeout", type=float, default=420.0, help="N > 1: seconds the 256 Mb sharded section (and the final barrier) may take before the line is printed without it")
     ap.add_argument("--sharded-steps", type=int, default=3)
     ap.add_argument("--torch-collective", action="store_true", help="256 Mb section: torch.distributed all-gather instead of the C ABI's RCCL communicator")
     args = ap.parse_args()
@@ -364,16 +365,38 @@ def main():
     torch.cuda.empty_cache()
 
     # ---- north star / config 4: 256 Mb model, Encoder bins sharded over the ranks + one RCCL all-gather per strand
+    #      (N > 1: under a watchdog - a collective that never completes must not take the replica-mode line above down with it)
+    printed = threading.Event()
+
+    def emit():
+        if rank == 0 and not printed.is_set():
+            printed.set()
+            print(json.dumps(res), flush=True)
+
+    def bail():
+        res.setdefault("sharded_256mb", {"error": f"no completion within {args.sharded_timeout} s (rank {rank}); the replica-mode figures of this line are unaffected"})
+        emit()
+        os._exit(0)
+
+    dog = None
+    if world > 1:
+        dog = threading.Timer(args.sharded_timeout, bail)
+        dog.daemon = True
+        dog.start()
     if not args.no_sharded and Lbp == L_BP:
-        res["sharded_256mb"] = sharded_256mb(args, rank, world, dev, dist)
+        try:
+            res["sharded_256mb"] = sharded_256mb(args, rank, world, dev, dist)
+        except Exception as e:      # reported, not fatal: the ranks may be out of step now, the watchdog covers the final barrier
+            res["sharded_256mb"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(0)
         res["speedup_vs_cpu"] = round(res["value"] / world / res["cpu_baseline"]["value"], 1)
-    if rank == 0:
-        print(json.dumps(res))
+    emit()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if dog is not None:
+        dog.cancel()
 
 
 if __name__ == "__main__":

@@ -62,31 +62,30 @@ __device__ __forceinline__ void m16_unpack8(const u32x4_t (&u)[NS], float (&v)[8
 
 // ---- producers / consumers at the ends of a Decoder ---------------------------------------------------------------
 // mat[c][i][j] = x[c][i] + x[c][j] (c < 128); channels 128..128+nt-1 = distenc[t][i][j]; other channels and pad pixels 0.
-// grid n (row i), block 256 (pixel j); `noct` octets.
+// grid (n rows, noct octets), block 256 (pixel j): 4 500 independent workgroups per map (one row of ALL octets per workgroup was a serial
+// chain of 18 load -> pack -> store rounds on 1 000 waves: 59 us per map).
 template <int NS, int DT>
 __global__ void outer_sum_m16_kernel(const float* __restrict__ x, long sx_c, long sx_l, const float* __restrict__ de, long sd_c, long sd_h,
                                      long sd_w, int nt, f32x4* __restrict__ out, int n, int noct, unsigned* flag) {
-  const int j = threadIdx.x, i = blockIdx.x;
+  const int j = threadIdx.x, i = blockIdx.x, o = blockIdx.y;
   bool ovf = false;
-  for (int o = 0; o < noct; ++o) {
-    float v[8];
+  float v[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int c = 8 * o + e;
-      float t = 0.f;
-      if (j < n) {
-        if (c < 128) t = x[c * sx_c + i * sx_l] + x[c * sx_c + j * sx_l];
-        else if (c < 128 + nt && de) t = de[(c - 128) * sd_c + i * sd_h + j * sd_w];
-      }
-      v[e] = t;
+  for (int e = 0; e < 8; ++e) {
+    const int c = 8 * o + e;
+    float t = 0.f;
+    if (j < n) {
+      if (c < 128) t = x[c * sx_c + i * sx_l] + x[c * sx_c + j * sx_l];
+      else if (c < 128 + nt && de) t = de[(c - 128) * sd_c + i * sd_h + j * sd_w];
     }
-    f32x4 a, b;
-    a.x = v[0]; a.y = v[1]; a.z = v[2]; a.w = v[3]; b.x = v[4]; b.y = v[5]; b.z = v[6]; b.w = v[7];
-    u32x4_t u[NS];
-    m16_pack8<NS, DT>(a, b, u, ovf);
-#pragma unroll
-    for (int s = 0; s < NS; ++s) reinterpret_cast<u32x4_t*>(out)[m16_plane(o, s, NS, n) + (long)i * M16_PX + j] = u[s];
+    v[e] = t;
   }
+  f32x4 a, b;
+  a.x = v[0]; a.y = v[1]; a.z = v[2]; a.w = v[3]; b.x = v[4]; b.y = v[5]; b.z = v[6]; b.w = v[7];
+  u32x4_t u[NS];
+  m16_pack8<NS, DT>(a, b, u, ovf);
+#pragma unroll
+  for (int s = 0; s < NS; ++s) reinterpret_cast<u32x4_t*>(out)[m16_plane(o, s, NS, n) + (long)i * M16_PX + j] = u[s];
   if (DT == 1 && ovf && flag) *flag = 1u;
 }
 
@@ -127,13 +126,22 @@ __global__ void upsample2d_m16_kernel(const float* __restrict__ y, long sy_c, lo
   if (DT == 1 && ovf && flag) *flag = 1u;
 }
 
-// `final` head + symmetrisation on a 64-channel M16 map (see final_sym_kernel); a.cur = the map's units, a.cur_bs in units
+// `final` head + symmetrisation on a 64-channel M16 map (see final_sym_kernel); a.cur = the map's units, a.cur_bs in units.
+// One workgroup per PAIR of 16 x 16 pixel tiles (I, J), (J, I), I <= J: grid (136, B), block 256 = one pixel of each tile per thread.
+// Both tiles are read along rows (16 px = 256 contiguous bytes per octet and split); the transposed partner of a pixel is taken from
+// LDS (a thread per output row reading column i of the map, 64 lines per wave instruction and 16 of those in a row, was 33 us per map).
 template <int NS, int DT>
 __global__ void final_sym_m16_kernel(FinalArgs a) {
   ORCA_FINAL_LOAD_HEAD();
-  const int j = threadIdx.x, i = blockIdx.x, b = blockIdx.y, n = a.n;
-  if (j >= n) return;
+  __shared__ float ft[2][ORCA_MAX_TARGETS][16][17];
+  const int n = a.n, b = blockIdx.y, r = threadIdx.x >> 4, c = threadIdx.x & 15;
+  int I = 0, p = blockIdx.x;                       // pair index -> (I, J), rows of the upper triangle have 16 - I entries
+  while (p >= 16 - I) { p -= 16 - I; ++I; }
+  const int J = I + p;
   const u32x4_t* cur = reinterpret_cast<const u32x4_t*>(a.cur) + (long)b * a.cur_bs;
+  const int i1 = I * 16 + r, j1 = J * 16 + c;      // this thread's pixel of tile (I, J)
+  const int i2 = J * 16 + r, j2 = I * 16 + c;      // ... and of tile (J, I)
+  const bool in1 = i1 < n && j1 < n, in2 = i2 < n && j2 < n;
   float h1[ORCA_MAX_TARGETS], h2[ORCA_MAX_TARGETS];
 #pragma unroll
   for (int o = 0; o < ORCA_MAX_TARGETS; ++o) { h1[o] = b1s[o]; h2[o] = b1s[o]; }
@@ -141,8 +149,8 @@ __global__ void final_sym_m16_kernel(FinalArgs a) {
     u32x4_t uu[NS], vv[NS];
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-      uu[s] = cur[m16_plane(oc, s, NS, n) + (long)i * M16_PX + j];
-      vv[s] = cur[m16_plane(oc, s, NS, n) + (long)j * M16_PX + i];
+      uu[s] = in1 ? cur[m16_plane(oc, s, NS, n) + (long)i1 * M16_PX + j1] : (u32x4_t)(0u);
+      vv[s] = in2 ? cur[m16_plane(oc, s, NS, n) + (long)i2 * M16_PX + j2] : (u32x4_t)(0u);
     }
     float u[8], v[8];
     m16_unpack8<NS, DT>(uu, u);
@@ -153,7 +161,28 @@ __global__ void final_sym_m16_kernel(FinalArgs a) {
       for (int o = 0; o < ORCA_MAX_TARGETS; ++o)
         if (o < a.F) { h1[o] = fmaf(w1s[o * 64 + 8 * oc + e], u[e], h1[o]); h2[o] = fmaf(w1s[o * 64 + 8 * oc + e], v[e], h2[o]); }
   }
-  final_head_store(a, h1, h2, w2s, b2s, b, i, j);
+  for (int t = 0; t < a.T; ++t) {
+    float f1 = b2s[t], f2 = b2s[t];
+#pragma unroll
+    for (int o = 0; o < ORCA_MAX_TARGETS; ++o)
+      if (o < a.F) { f1 = fmaf(w2s[t * ORCA_MAX_TARGETS + o], fmaxf(h1[o], 0.f), f1); f2 = fmaf(w2s[t * ORCA_MAX_TARGETS + o], fmaxf(h2[o], 0.f), f2); }
+    ft[0][t][r][c] = f1;
+    ft[1][t][r][c] = f2;
+  }
+  __syncthreads();
+  for (int t = 0; t < a.T; ++t) {
+    // out(i1, j1) = (f(i1, j1) + f(j1, i1)) / 2, f(j1, i1) = tile (J, I) at (c, r); the (J, I) pixel likewise from tile (I, J)
+    if (in1) {
+      float* op = a.out + (long)b * a.out_bs + ((long)t * n + i1) * n + j1;
+      const float v1 = 0.5f * ft[0][t][r][c] + 0.5f * ft[1][t][c][r];
+      *op = a.accumulate ? (*op + v1) : v1;
+    }
+    if (in2 && I != J) {
+      float* op = a.out + (long)b * a.out_bs + ((long)t * n + i2) * n + j2;
+      const float v2 = 0.5f * ft[1][t][r][c] + 0.5f * ft[0][t][c][r];
+      *op = a.accumulate ? (*op + v2) : v2;
+    }
+  }
 }
 
 // converters for the single-layer test entry point: [C][n][n] fp32 <-> M16 (`noct` octets; channels >= C and pad pixels zero)

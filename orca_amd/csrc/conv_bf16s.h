@@ -313,20 +313,27 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv1d_k9_bf16s_kernel(ConvB16
   if (DT == 1 && overflow && a.flag) *a.flag = 1u;
 }
 
-// nn.MaxPool1d(k,k) on channel-last data: y[m][c] = max_j x[k*m+j][c]; one thread = 4 channels
+// nn.MaxPool1d(k,k) on channel-last data: y[m][c] = max_j x[k*m+j][c]; one thread = 4 channels of TWO outputs (2K independent
+// 16-byte loads in flight per thread), 32-bit index arithmetic (C / 4 divides the block: grid = ceil(n_out / (2 * 256 / (C/4)))).
 template <int K>
 __global__ void maxpool1d_nlc_kernel(const float* __restrict__ x, float* __restrict__ y, long n_out, int C) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const int c4n = C / 4;
-  if (idx >= n_out * c4n) return;
-  const long m = idx / c4n;
-  const int c4 = (int)(idx - m * c4n);
-  const f32x4* p = reinterpret_cast<const f32x4*>(x + ((long)K * m) * C) + c4;
-  f32x4 v = p[0];
+  const int c4n = C / 4, per = 256 / c4n;
+  const int c4 = threadIdx.x % c4n, r = threadIdx.x / c4n;
+  if (r >= per) return;
+  const long m0 = ((long)blockIdx.x * 2) * per + r, m1 = m0 + per;
+  if (m0 >= n_out) return;
+  const bool two = m1 < n_out;
+  const f32x4* p = reinterpret_cast<const f32x4*>(x + ((long)K * m0) * C) + c4;
+  const f32x4* q = reinterpret_cast<const f32x4*>(x + ((long)K * (two ? m1 : m0)) * C) + c4;
+  f32x4 a[K], b[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) { a[j] = p[(long)j * c4n]; b[j] = q[(long)j * c4n]; }
+  f32x4 v = a[0], w = b[0];
 #pragma unroll
   for (int j = 1; j < K; ++j) {
-    const f32x4 q = p[(long)j * c4n];
-    v.x = fmaxf(v.x, q.x); v.y = fmaxf(v.y, q.y); v.z = fmaxf(v.z, q.z); v.w = fmaxf(v.w, q.w);
+    v.x = fmaxf(v.x, a[j].x); v.y = fmaxf(v.y, a[j].y); v.z = fmaxf(v.z, a[j].z); v.w = fmaxf(v.w, a[j].w);
+    w.x = fmaxf(w.x, b[j].x); w.y = fmaxf(w.y, b[j].y); w.z = fmaxf(w.z, b[j].z); w.w = fmaxf(w.w, b[j].w);
   }
-  reinterpret_cast<f32x4*>(y + m * C)[c4] = v;
+  reinterpret_cast<f32x4*>(y + m0 * C)[c4] = v;
+  if (two) reinterpret_cast<f32x4*>(y + m1 * C)[c4] = w;
 }

@@ -621,7 +621,8 @@ __global__ __launch_bounds__(WM * 64, WM / 4) void conv1d_k9_p16_kernel(ConvP16A
       if (F1) p16_lds_wait<15, MW, NW>(av[fb], bv[fb]);                      // already retired above: ordering only
       else if (tap + 1 < 9) p16_lds_wait<2 * (MW + NW), MW, NW>(av[fb], bv[fb]);   // this tap's fragments are in, the next tap's stay in flight
       else p16_lds_wait<0, MW, NW>(av[fb], bv[fb]);
-      if constexpr (FMT == 1) {
+      if ((ABL & 16384) && tap >= 6) { /* micro-benchmark: 2/3 of the MFMA work (timing only) */ }
+      else if constexpr (FMT == 1) {
 #pragma unroll
         for (int p = 0; p < 2; ++p)   // the two k-pairs of the step's 32 input channels
 #pragma unroll

@@ -634,8 +634,9 @@ static int launch_conv1d_p16(orca_ctx* ctx, const ConvLayer& L, const float* x, 
 
 static int launch_pool_nlc(orca_ctx* ctx, const float* x, float* y, long n_out, int C, int k) {
   if (n_out <= 0) return ORCA_OK;
-  const long total = n_out * (C / 4);
-  dim3 grid((unsigned)((total + 255) / 256));
+  if (C % 4 || C / 4 > 256) return fail(ORCA_EINVAL, "maxpool (channel-last): %d channels unsupported", C);
+  const long per_block = 2 * (256 / (C / 4));
+  dim3 grid((unsigned)((n_out + per_block - 1) / per_block));
   switch (k) {
     case 2: hipLaunchKernelGGL((maxpool1d_nlc_kernel<2>), grid, dim3(256), 0, ctx->stream, x, y, n_out, C); break;
     case 4: hipLaunchKernelGGL((maxpool1d_nlc_kernel<4>), grid, dim3(256), 0, ctx->stream, x, y, n_out, C); break;
@@ -1224,7 +1225,7 @@ static int decoder_m16(orca_ctx* ctx, orca_net* net, const RowSrc& x, long sx_c,
     f32x4* T = T0 + b0 * sz32;
     hipStream_t s = ctx->stream;
     for (int b = 0; b < nb; ++b) {
-      hipLaunchKernelGGL((outer_sum_m16_kernel<NS, DT>), dim3((unsigned)n), dim3(ORCA_LDW), 0, s, x.at(b0 + b), sx_c, sx_l, de.at(b0 + b), sd_c, sd_h,
+      hipLaunchKernelGGL((outer_sum_m16_kernel<NS, DT>), dim3((unsigned)n, (unsigned)oIN), dim3(ORCA_LDW), 0, s, x.at(b0 + b), sx_c, sx_l, de.at(b0 + b), sd_c, sd_h,
                          sd_w, nt2, IN + b * szIN, n, oIN, ctx->d_flag);
       LAUNCHCHECK("outer_sum_m16_kernel");
     }
@@ -1293,7 +1294,7 @@ static int decoder_m16(orca_ctx* ctx, orca_net* net, const RowSrc& x, long sx_c,
     FinalArgs fa_;
     fa_.cur = reinterpret_cast<const float*>(cur); fa_.w1 = fa.d_w; fa_.b1 = fa.d_bias; fa_.w2 = fb.d_w; fa_.b2 = fb.d_bias; fa_.out = out + (size_t)b0 * nt2 * n * n;
     fa_.cur_bs = sz64; fa_.out_bs = (long)nt2 * n * n; fa_.n = n; fa_.accumulate = accumulate; fa_.T = nt2; fa_.F = fa.cout;
-    hipLaunchKernelGGL((final_sym_m16_kernel<NS, DT>), dim3((unsigned)n, (unsigned)nb), dim3(256), 0, s, fa_);
+    hipLaunchKernelGGL((final_sym_m16_kernel<NS, DT>), dim3(136u, (unsigned)nb), dim3(256), 0, s, fa_);   // 16 x 16 tile pairs of the upper triangle
     LAUNCHCHECK("final_sym_m16_kernel");
     return ORCA_OK;
   };

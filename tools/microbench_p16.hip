@@ -59,6 +59,10 @@ int main(int argc, char** argv) {
   a.out_mode = 0;
   run<64, 2, 2, 8, 0, false, 0>(a, "warm");
   run<64, 2, 2, 8, 0, false, 0>(a, "plain");
+  run<64, 2, 2, 8, 0, false, 128>(a, "plain, stamped"); report(st);
+  run<64, 2, 2, 8, 0, false, 16384>(a, "6 of 9 taps' MFMAs");
+  run<64, 2, 2, 8, 0, false, 16384 + 128>(a, "6 of 9 taps' MFMAs, stamped"); report(st);
+  if (argc > 3) return 0;
   run<64, 2, 2, 8, 0, false, 512>(a, "epilogues of waves 4-7 half a tile late (timing only)");
   run<64, 2, 2, 8, 0, false, 0>(a, "plain");
   run<64, 2, 2, 8, 0, false, 512>(a, "epilogues of waves 4-7 half a tile late (timing only)");
