@@ -248,7 +248,10 @@ __global__ __launch_bounds__(512, 2) void conv2d_3x3_m16_kernel(ConvM16Args a) {
   constexpr int WIT = (WP + NT - 1) / NT;
   constexpr int EXTRA = (WP - (WIT - 1) * NT + 63) / 64;   // waves that issue WIT weight DMAs per piece (the others WIT - 1)
   static_assert(XROWS * M16_PX % NT == 0, "X image rows per DMA round");
-  __shared__ f32x4 smem[2 * XB + 3 * WP + COUT / 4];
+#ifndef M16_LDS_PAD_UNITS
+#define M16_LDS_PAD_UNITS 0   // experiment hook: extra LDS per workgroup (forces one workgroup per CU for the single-plane kernels)
+#endif
+  __shared__ f32x4 smem[2 * XB + 3 * WP + COUT / 4 + (NS == 1 ? M16_LDS_PAD_UNITS : 0)];
   f32x4* const Xs = smem;
   f32x4* const Ws = smem + 2 * XB;
   float* const bias_s = reinterpret_cast<float*>(smem + 2 * XB + 3 * WP);
