@@ -9,7 +9,9 @@ The reference's only multi-GPU mechanism is nn.DataParallel's batch split
   via the C ABI's bin_lo/bin_hi and ONE all-gather per strand assembles the
   [B,128,n_bins] encoding (32.8 MB for 256 Mb on 8 ranks - latency-bound on
   xGMI, ~0.2 % of the encoder time).  Everything after it (Encoder2/Encoder3 +
-  decoder cascade, ~1 % of the FLOPs) runs replicated on every rank.
+  decoder cascade, ~1 % of the FLOPs) runs replicated - or, for the 256 Mb model,
+  one strand per rank parity with a 1 MB all-gather of the maps
+  (`strand_parallel_cascade_256m`).
 * independent 32 Mb windows (structural-variant screens, batches) are plain
   replicas: `shard_indices` deals them out, no data-path collective.
 """
@@ -155,6 +157,43 @@ class ShardedEncoder(torch.nn.Module):
         total = engine.encoder_num_bins(codes.shape[1])
         return sharded_encode(lambda t, lo, hi: self._local(lambda: self.encoder.forward_codes(t, reverse=reverse, bin_lo=lo, bin_hi=hi)),
                               codes, total, self.group, self.comm)
+
+
+def strand_tail_256m(model, enc0, strand, mpos, wpos, chrlen, distencs):
+    """One strand's share of the 256 Mb tail: rows [strand*B, (strand+1)*B) of ``enc0`` [2B,128,64000] through
+    Encoder2 -> Encoder3 -> the four Decoders (orca_predict.cascade_256m).  Returns [4, C, 250, 250] (batch row 0)."""
+    from . import orca_predict
+    B = enc0.shape[0] // 2
+    preds, _ = orca_predict.cascade_256m(model, enc0[strand * B: (strand + 1) * B], mpos, wpos, chrlen, distencs, reverse_flags=(bool(strand),))
+    return torch.stack([p[0] for p in preds]).contiguous()
+
+
+def strand_parallel_cascade_256m(model, enc0, mpos, wpos, chrlen, distencs, group=None, comm=None):
+    """The part of genomepredict_256Mb after the Encoder (orca_predict.py:675-838 + the strand merge :866-877), with the
+    two strands' tails on different ranks: the strands are independent until the merge, so even ranks run the forward
+    strand, odd ranks the reverse strand, and ONE all-gather of the [4,C,250,250] maps (1 MB per rank) replaces the
+    second half of the replicated work.  Returns the four merged [C,250,250] maps, identical on every rank.
+    With one rank (or no process group) both strands run here, batched, exactly as cascade_256m does."""
+    from . import engine, orca_predict
+    if comm is not None:
+        world, rank = comm.world, comm.rank
+    elif dist.is_initialized():
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+    else:
+        world, rank = 1, 0
+    B = enc0.shape[0] // 2
+    if world == 1:
+        preds, _ = orca_predict.cascade_256m(model, enc0, mpos, wpos, chrlen, distencs)
+        fwd, rev = torch.stack([p[0] for p in preds]), torch.stack([p[B] for p in preds])
+    else:
+        slab = strand_tail_256m(model, enc0, rank & 1, mpos, wpos, chrlen, distencs)
+        if comm is not None:
+            allm = comm.all_gather(slab)
+        else:
+            allm = torch.empty((world,) + tuple(slab.shape), dtype=slab.dtype, device=slab.device)
+            dist.all_gather_into_tensor(allm.view(-1), slab.view(-1), group=group)
+        fwd, rev = allm[0], allm[1]      # ranks 0 and 1 hold one strand each; the other ranks' slabs are copies of these
+    return [torch.stack([engine.strand_merge(fwd[j, c], rev[j, c]) for c in range(fwd.shape[1])]) for j in range(fwd.shape[0])]
 
 
 def max_over_ranks(value, device):

@@ -39,6 +39,16 @@ def _worker(rank, world, port, L, q):
         x = torch.from_numpy(synth.synth_sequence(L, seed=5)).transpose(1, 2)
         out = D.sharded_encode(_oracle_range(synth_sd("Encoder", 0)), x, L // 4000)
         t = D.max_over_ranks(float(rank + 1), dev)
+        # strand-parallel 256 Mb tail: rank parity picks the strand, ONE all-gather of the maps, merge on every rank.  The device work
+        # (strand_tail_256m, engine.strand_merge) is replaced by stand-ins: what is tested is the exchange.
+        from orca_amd import engine
+        seen = []
+        D.strand_tail_256m = lambda model, enc0, strand, *a: (seen.append(strand), torch.full((4, 1, 6, 6), float(10 + strand)) + torch.arange(36.).view(6, 6))[1]
+        engine.strand_merge = lambda f, r: 0.5 * f + 0.5 * torch.flip(r, [0, 1])
+        maps = D.strand_parallel_cascade_256m(None, torch.zeros(2, 128, 8), 0, 0, 0, {})
+        assert seen == [rank & 1] and len(maps) == 4 and maps[0].shape == (1, 6, 6)
+        want = 0.5 * (10 + torch.arange(36.).view(6, 6)) + 0.5 * torch.flip(11 + torch.arange(36.).view(6, 6), [0, 1])
+        assert all(torch.equal(m[0], want) for m in maps)
         q.put((rank, out.numpy(), t))
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

@@ -25,6 +25,35 @@ def test_abi_communicator_single_rank(cuda):
     comm.close()
 
 
+def _tail_inputs(cuda):
+    from orca_amd import orca_models, orca_predict, synth
+    model = orca_models.H1esc_256M(synthetic_seed=0)
+    enc0 = torch.from_numpy(np.random.RandomState(3).randn(2, 128, 64000).astype(np.float32)).to(cuda)
+    chrlen = 138_368_000
+    nm = synth.synth_normmat_256m(chrlen, seed=0)
+    de = {}
+    for lv in (256, 128, 64, 32):
+        w = 250 * (lv // 8)
+        de[lv] = torch.log(torch.from_numpy(orca_predict._coarse_grain(nm[None, :w, :w], lv // 8, 1).astype(np.float32))[None]).to(cuda)
+    return model, enc0, chrlen, de
+
+
+def test_strand_parallel_tail_single_process(cuda):
+    """The per-rank share of the 256 Mb tail (one strand, dist.strand_tail_256m) against the batched two-strand cascade:
+    what ranks 0 and 1 of a world would all-gather, merged, must BE the single-rank result (same kernels per map)."""
+    from orca_amd import dist as D
+    from orca_amd import engine
+    model, enc0, chrlen, de = _tail_inputs(cuda)
+    mpos, wpos = 70_000_000, 128_000_000
+    whole = D.strand_parallel_cascade_256m(model, enc0, mpos, wpos, chrlen, de)          # no process group: both strands here
+    fwd = D.strand_tail_256m(model, enc0, 0, mpos, wpos, chrlen, de)
+    rev = D.strand_tail_256m(model, enc0, 1, mpos, wpos, chrlen, de)
+    assert fwd.shape == (4, 1, 250, 250) and len(whole) == 4
+    assert float((fwd - rev).abs().max()) > 1e-3                                        # the strands do differ
+    for j in range(4):
+        assert torch.equal(engine.strand_merge(fwd[j, 0], rev[j, 0]), whole[j][0]), j
+
+
 def test_sharded_encoder_world2_rccl(cuda):
     if torch.cuda.device_count() < 2:
         pytest.skip("needs 2 GPUs (the driver's 8-GPU node); the partition / reassembly logic is covered on CPU by tests/test_dist_cpu.py")
