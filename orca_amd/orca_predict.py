@@ -490,5 +490,5 @@ def genomepredict_256Mb(sequence, mchr, normmats, chrlen, mpos=-1, wpos=-1, mode
 
 
 # structural-variant drivers (orca_predict.py:983-3057) live in sv_drivers.py; re-exported under the reference's names
-from .sv_drivers import (process_custom, process_del, process_dup, process_ins, process_inv, process_region,  # noqa: E402,F401
-                         process_single_breakpoint)
+from .sv_drivers import (predict_sequence_string, process_custom, process_del, process_dup, process_ins, process_inv,  # noqa: E402,F401
+                         process_region, process_seqstr, process_single_breakpoint)

@@ -1,6 +1,6 @@
 """Structural-variant drivers with the reference's signatures: `process_region / process_dup /
-process_del / process_inv / process_ins / process_custom / process_single_breakpoint`
-(/root/reference/orca_predict.py:983-3057), for the 32 Mb (`window_radius=16000000`) and the 256 Mb models.
+process_del / process_inv / process_ins / process_custom / process_single_breakpoint / process_seqstr`
+(/root/reference/orca_predict.py:983-3161), for the 32 Mb (`window_radius=16000000`) and the 256 Mb models.
 
 Each driver is a list of VIEWS of a reference or mutated chromosome: (allele, anchor position, chromosome length
 used for window clipping, annotation).  A view is materialised as the 32 Mb window sequence and handed to
@@ -436,3 +436,39 @@ def process_single_breakpoint(chr1, pos1, chr2, pos2, orientation1, orientation2
     anno = process_anno([[first_len, "double"]], base=0, window_radius=window_radius)
     alt = _predict(seq, fused, breakpos, wpos, models, anno, None, use_cuda)
     return ref_1, ref_2, alt
+
+
+def predict_sequence_string(sequence_str, mpos=None, models=("h1esc", "hff"), use_cuda=True):
+    """The body of `process_seqstr` after the Seqstr lookup (orca_predict.py:3113-3148): the middle 32 Mb of a DNA string
+    (ValueError below 32 Mb), window centre = its midpoint, zoom position ``mpos`` (default: the midpoint), chromosome
+    label "customized seq", no targets.  With ``use_cuda`` the string becomes 1 byte/base codes that go straight into the
+    Encoder's packed-input path (the reference builds the 512 MB float one-hot array with `Genome.sequence_to_encoding`)."""
+    from . import orca_predict
+    midpoint = int(len(sequence_str) / 2)
+    if midpoint < _R32:
+        raise ValueError("Sequence length needs to be at least 32Mb long.\n" + " Current length is " + str(len(sequence_str)))
+    if midpoint > _R32:
+        print("Sequence length is longer than 32Mb. Only the middle 32Mb will be used.")
+        sequence_str = sequence_str[midpoint - _R32: midpoint + _R32]
+    midpoint = int(len(sequence_str) / 2)
+    wpos = midpoint
+    if mpos is None:
+        mpos = midpoint
+    codes = _genome.sequence_to_codes(sequence_str)
+    if use_cuda:
+        sequence = torch.from_numpy(codes)[None].cuda()
+    else:
+        sequence = _genome.codes_to_encoding(codes)[None, :, :]
+    return orca_predict.genomepredict(sequence, "customized seq", mpos, wpos, models=list(models), targets=False, use_cuda=use_cuda)
+
+
+def process_seqstr(seqstr_input, file=None, mpos=None, custom_models=None, model_labels=None, use_cuda=True):
+    """`process_region` for a Seqstr specification, e.g. '[hg38]chr9:94904000-126904000 +' (orca_predict.py:3060-3161):
+    the first sequence the `seqstr` package returns for the one-line input, then `predict_sequence_string`.
+    ImportError when `seqstr` is not installed, as in the reference; `file=` (plotting) is not part of orca_amd."""
+    try:
+        from seqstr import seqstr
+    except ImportError:
+        raise ImportError("Seqstr is not installed. Please install it first.\n" + "pip install seqstr")
+    models, _ = _setup(custom_models, _R32, model_labels, file)
+    return predict_sequence_string(seqstr(seqstr_input)[0].Seq, mpos=mpos, models=models, use_cuda=use_cuda)

@@ -227,6 +227,32 @@ def summarize_outputs(outputs):
     return d
 
 
+# ---- process_seqstr (orca_predict.py:3060-3161): a stand-in for the `seqstr` package (absent here) and the cases both the
+# fixture generator (the reference's function) and the tests (orca_amd's) run
+def seqstr_string(n, seed):
+    """n bases of ACGT with a short N run (deterministic)."""
+    codes = synth_base_codes(n, seed=seed).copy()
+    codes[n // 3: n // 3 + 57] = 4
+    return np.array(list("ACGTN"), dtype="S1")[codes].tobytes().decode("ascii")
+
+
+class FakeSeqstr:
+    """`seqstr(spec)` -> list of records with `.Seq`; the spec names a (length, seed) pair."""
+
+    class _Rec:
+        def __init__(self, seq):
+            self.Seq = seq
+
+    def __call__(self, spec):
+        n, seed = (int(v) for v in spec.strip("[]").split(","))
+        return [self._Rec(seqstr_string(n, seed)), self._Rec("ACGT")]      # only the first record is used (:3113)
+
+
+def seqstr_cases():
+    # (name, spec, mpos): exactly 32 Mb with the default zoom; an odd 33 000 001 bp string (chopped to the middle 32 Mb) with a zoom position
+    return [("exact", "[32000000,41]", None), ("chopped", "[33000001,42]", 15_000_000)]
+
+
 # ---- 256 Mb structural-variant drivers: the views are pinned WITHOUT running a model (a 256 Mb CPU forward of even a
 # stand-in model costs minutes): both sides replace `genomepredict_256Mb` by this recorder and the fixtures keep what
 # each view would have been called with - an exact position-weighted digest of the 256 Mb sequence, digests of the

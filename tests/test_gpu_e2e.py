@@ -153,6 +153,20 @@ def test_sv_screen_packed_genome(cuda):
         assert maxabs(a, b) < 1e-6
 
 
+def test_predict_sequence_string_packed_route(cuda):
+    """`process_seqstr`'s body (orca_predict.py:3113-3148) on the MI355X: the DNA string becomes 1-byte codes and takes the
+    packed-input path; same dictionary as `genomepredict` on the explicit one-hot float window."""
+    from orca_amd import genome, synth
+    model = M.H1esc(synthetic_seed=0)
+    s = synth.seqstr_string(32_000_000, seed=41)
+    out = P.predict_sequence_string(s, mpos=14_321_000, models=[model])
+    seq = genome.sequence_to_encoding(s)[None]
+    ref = P.genomepredict(seq, "customized seq", 14_321_000, 16_000_000, models=[model], targets=False, use_cuda=True)
+    assert out["chr"] == "customized seq" and out["start_coords"] == ref["start_coords"] and out["end_coords"] == ref["end_coords"]
+    for a, b in zip(out["predictions"][0], ref["predictions"][0]):
+        assert a.shape == (250, 250) and maxabs(a, b) < 1e-6
+
+
 def test_sv_drivers_device_genome_equals_host_route(cuda):
     """`process_*` on the MI355X with the real-architecture model: a PackedGenome resident in HBM
     (windows gathered as 1-byte codes on the device) gives the same dictionaries as the reference's host route (float

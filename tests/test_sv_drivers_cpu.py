@@ -152,3 +152,33 @@ def test_sv_drivers_256mb_unsupported_forms():
     for fn, a in (("process_ins", ("chrS", 5, "ACGT")), ("process_custom", ([], [], 0))):
         with pytest.raises(NotImplementedError):
             getattr(orca_predict, fn)(*a, g, custom_models=[object()], window_radius=128000000, use_cuda=False)
+
+
+def test_process_seqstr_matches_reference(monkeypatch):
+    """`process_seqstr` (orca_predict.py:3060-3161) against G19 = the reference's function run with the same stand-in for
+    the absent `seqstr` package and the same stand-in model: exactly 32 Mb with the default zoom, and an odd-length longer
+    string chopped to its middle 32 Mb with a zoom position.  Error behaviour as the reference's."""
+    import sys
+    import types
+    gold = np.load(os.path.join(GOLD, "G19_seqstr.npz"))
+    monkeypatch.setitem(sys.modules, "seqstr", None)                     # not installed
+    with pytest.raises(ImportError, match="Seqstr is not installed"):
+        orca_predict.process_seqstr("[32000000,41]")
+    monkeypatch.setitem(sys.modules, "seqstr", types.SimpleNamespace(seqstr=synth.FakeSeqstr()))
+    with pytest.raises(ValueError, match="at least 32Mb"):
+        orca_predict.process_seqstr("[31999999,1]", custom_models=[synth.FakeModel32(0)], use_cuda=False)
+    with pytest.raises(NotImplementedError):
+        orca_predict.process_seqstr("[32000000,41]", file="x", custom_models=[synth.FakeModel32(0)], use_cuda=False)
+    h1 = synth.FakeModel32(0)
+    for name, spec, mpos in synth.seqstr_cases():
+        got = synth.summarize_outputs(orca_predict.process_seqstr(spec, mpos=mpos, custom_models=[h1], use_cuda=False))
+        keys = [k for k in gold.files if k.startswith(name + ".")]
+        assert len(keys) == len(got) and len(keys) > 0
+        for k in keys:
+            want, have = gold[k], got[k[len(name) + 1:]]
+            if want.dtype.kind in "US":
+                assert str(want[0]) == str(have[0]), k
+            elif want.dtype.kind == "i":
+                np.testing.assert_array_equal(want, have, err_msg=k)
+            else:
+                np.testing.assert_allclose(have, want, rtol=2e-5, atol=2e-5, err_msg=k)

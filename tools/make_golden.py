@@ -275,6 +275,21 @@ def main():
             np.savez_compressed(os.path.join(GOLD, "G11_sv_drivers.npz"), **d)
             print("G11 done")
 
+        # ---- G19: process_seqstr through the REAL orca_predict.process_seqstr (the `seqstr` package replaced by a stand-in) ----
+        if want("G19"):
+            import orca_predict as op
+            op.seqstr = synth.FakeSeqstr()
+            h1 = synth.FakeModel32(0)
+            d = {}
+            for name, spec, mpos in synth.seqstr_cases():
+                t = time.time()
+                out = op.process_seqstr(spec, mpos=mpos, custom_models=[h1], use_cuda=False)
+                for k, v in synth.summarize_outputs(out).items():
+                    d[f"{name}.{k}"] = v
+                print("G19", name, "%.1fs" % (time.time() - t))
+            np.savez_compressed(os.path.join(GOLD, "G19_seqstr.npz"), **d)
+            print("G19 done")
+
         # ---- G15: Encoder2b (orca_modules.py:1173-1276), the HCTnoc variant of Encoder2 ----------------------
         if want("G15"):
             e2b = load_synth(om.Encoder2b(), seed=0)
