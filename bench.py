@@ -239,8 +239,7 @@ def main():
     ctx = engine.get_context(dev)
 
     def step():
-        preds, _ = orca_predict.cascade_32m(model, strands, mpos, wpos, [False, True], distencs)
-        return [engine.strand_merge(p[0, 0], p[1, 0]) for p in preds]
+        return [m[0] for m in orca_predict.cascade_32m(model, strands, mpos, wpos, [False, True], distencs, merge=True)[2]]
 
     def sync():
         torch.cuda.synchronize(dev)

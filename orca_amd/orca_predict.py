@@ -295,12 +295,13 @@ def run_cascade(model, encodings, levels, unit, B, reverse_flags, background, zo
     return preds, [st[:-1] for st in starts]
 
 
-def cascade_32m(model, xs, mpos, wpos, reverse_flags, distencs=None):
+def cascade_32m(model, xs, mpos, wpos, reverse_flags, distencs=None, merge=False):
     """32 Mb model on device-resident strands: ``xs`` = list of [B,4,L] tensors (e.g. forward strand and reverse
     complement), ``reverse_flags`` the matching booleans.  net0 per strand, then Encoder2 and the six decoder
     levels batched over the strands.  Returns (preds[6] each [S*B,1,250,250], starts[k][6] in 4 kb bins).
     A strand may also be given as packed bases - a uint8 [B,L] tensor of the FORWARD strand (engine.pack_sequence);
-    its flag then also tells the Encoder to read it as the reverse complement (no second copy exists)."""
+    its flag then also tells the Encoder to read it as the reverse complement (no second copy exists).
+    ``merge=True`` (two strands): also returns the strand-merged maps (`_merge_device`), enqueued before the guard's sync."""
     B = xs[0].shape[0]
     cache = {}
 
@@ -322,8 +323,9 @@ def cascade_32m(model, xs, mpos, wpos, reverse_flags, distencs=None):
         else:
             enc0 = torch.cat([encode(x, r) for x, r in zip(xs, reverse_flags)], dim=0) if len(xs) > 1 else encode(xs[0], reverse_flags[0])
         encodings = dict(zip([1, 2, 4, 8, 16, 32], model.net(enc0)))
-        return run_cascade(model, encodings, [32, 16, 8, 4, 2, 1], lambda lv: lv, B, list(reverse_flags), background,
-                           lambda lv, st, rev: zoom_index_32m(lv, st, mpos, wpos, rev), add_1m_level=1)
+        preds, starts = run_cascade(model, encodings, [32, 16, 8, 4, 2, 1], lambda lv: lv, B, list(reverse_flags), background,
+                                    lambda lv, st, rev: zoom_index_32m(lv, st, mpos, wpos, rev), add_1m_level=1)
+        return (preds, starts, _merge_device(preds, B)) if merge else (preds, starts)
 
     return engine.run_with_overflow_retry(forward, xs[0].device)
 
@@ -358,6 +360,26 @@ def _merge(preds, B):
         else:
             merged.append(f[:, :, :] * 0.5 + r[:, ::-1, ::-1] * 0.5)
     return merged
+
+
+def _merge_device(preds, B):
+    """`_merge` on the MI355X, without leaving it: per level a [C,250,250] tensor.  Called INSIDE the guarded forward, i.e.
+    enqueued before the host waits for the fp16-range flag (the merges used to start 0.6 ms after the last Decoder: flag
+    read-back, host wake-up, then six launches each followed by its own blocking copy)."""
+    merged = []
+    for p in preds:
+        fwd, rev = p[0], p[B]
+        if p.shape[1] == 1:
+            merged.append(engine.strand_merge(fwd[0], rev[0])[None])
+        else:
+            merged.append(fwd * 0.5 + torch.flip(rev, [1, 2]) * 0.5)
+    return merged
+
+
+def _merged_to_host(merged):
+    """One device -> host copy for all levels; [250,250] per level for single-target models, [C,250,250] otherwise (:510-523)."""
+    a = torch.stack(merged).cpu().numpy()
+    return [m[0] if m.shape[0] == 1 else m for m in a]
 
 
 def genomepredict(sequence, mchr, mpos=-1, wpos=-1, models=["h1esc", "hff"], targets=None, annotation=None,
@@ -397,12 +419,13 @@ def genomepredict(sequence, mchr, mpos=-1, wpos=-1, models=["h1esc", "hff"], tar
                 del ts[:], annos[:]
                 enc0 = strands.encode(model.net0)
                 encodings = dict(zip([1, 2, 4, 8, 16, 32], model.net(enc0)))
-                return run_cascade(model, encodings, levels, lambda lv: lv, batch, [False, True], background,
-                                   lambda lv, st, rev: zoom_index_32m(lv, st, mpos, wpos, rev), add_1m_level=1,
-                                   on_level=on_level)
+                preds, starts = run_cascade(model, encodings, levels, lambda lv: lv, batch, [False, True], background,
+                                            lambda lv, st, rev: zoom_index_32m(lv, st, mpos, wpos, rev), add_1m_level=1,
+                                            on_level=on_level)
+                return preds, starts, (_merge_device(preds, batch) if preds[0].is_cuda else None)
 
-            preds, starts = engine.run_with_overflow_retry(forward, strands.device)
-            predictions.append(_merge(preds, batch))
+            preds, starts, merged = engine.run_with_overflow_retry(forward, strands.device)
+            predictions.append(_merged_to_host(merged) if merged is not None else _merge(preds, batch))
             allstarts.append(starts[0])
             if targets:
                 alltargets.append(ts)
@@ -466,11 +489,12 @@ def genomepredict_256Mb(sequence, mchr, normmats, chrlen, mpos=-1, wpos=-1, mode
                 del ts[:], annos[:]
                 enc0 = strands.encode(model.net0)
                 encodings = dict(zip([32, 64, 128, 256], model.net(model.net1(enc0)[-1])))
-                return run_cascade(model, encodings, levels, lambda lv: lv // 8, batch, [False, True], background, zoom,
-                                   add_1m_level=None, on_level=on_level)
+                preds, starts = run_cascade(model, encodings, levels, lambda lv: lv // 8, batch, [False, True], background, zoom,
+                                            add_1m_level=None, on_level=on_level)
+                return preds, starts, (_merge_device(preds, batch) if preds[0].is_cuda else None)
 
-            preds, starts = engine.run_with_overflow_retry(forward, strands.device)
-            predictions.append(_merge(preds, batch))
+            preds, starts, merged = engine.run_with_overflow_retry(forward, strands.device)
+            predictions.append(_merged_to_host(merged) if merged is not None else _merge(preds, batch))
             allstarts.append(starts[0])
             allnormmats.append({lv: v[1] for lv, v in ns[0].items()})
             allnormmats_rev.append({lv: v[1] for lv, v in ns[1].items()})
