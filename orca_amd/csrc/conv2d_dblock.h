@@ -76,14 +76,16 @@ __global__ __launch_bounds__(512, NS == 1 ? 4 : 2) void conv2d_dblock_kernel(DBl
     if ((sid0 >> ld) >= H || (sid0 & (d - 1)) >= W) return;
   }
 
-  // ---- biases, zero units: BEFORE the first DMA (a visible LDS store behind a pending DMA makes the compiler wait for it) ----
-  if (tid < 192) {
-    const int L = tid < 32 ? 0 : (tid < 96 ? 1 : (tid < 128 ? 2 : 3)), o = tid - (tid < 32 ? 0 : (tid < 96 ? 32 : (tid < 128 ? 96 : 128)));
-    bias_s[tid] = a.bias[L][o];
-  }
+  // ---- zero units: BEFORE the first DMA (a visible LDS store behind a pending DMA makes the compiler wait for it) ----
   if (tid >= 256 && tid < 256 + NS * 8) As[(tid - 256) * PXW + 256] = (f32x4)(0.f);
   if (tid >= 320 && tid < 320 + NS * 4) Bs[(tid - 320) * PXW + 256] = (f32x4)(0.f);
   __syncthreads();
+  // ---- the four biases [32 | 64 | 32 | 64] by ONE DMA instruction of wave 0 (48 lanes x 16 bytes, per-lane sources): a register-staged
+  // copy put a global-load round trip in front of the gather.  It is the wave's oldest transfer: every counted wait below covers it ----
+  if (wave == 0 && lane < 48) {
+    const float* src = lane < 8 ? a.bias[0] + 4 * lane : (lane < 24 ? a.bias[1] + 4 * (lane - 8) : (lane < 32 ? a.bias[2] + 4 * (lane - 24) : a.bias[3] + 4 * (lane - 32)));
+    p16_glds16(reinterpret_cast<const f32x4*>(src), smem + AU + BU + 3 * WP);
+  }
 
   // ---- gather: the units of the workgroup's 256 pixels, all 8 octets x NS planes, by LDS-DMA; a pixel outside the map is
   // fetched from pad pixel 255 of row 0 (zero; maps with W = 256 have no outside pixels) ----

@@ -267,12 +267,11 @@ __global__ __launch_bounds__(512, 2) void conv2d_3x3_m16_kernel(ConvM16Args a) {
   }
   const int NP = a.nchunks * NH;
 
-  // zero margins of both X buffers, bias - BEFORE the first DMA (a visible LDS store behind a pending DMA makes the compiler wait for it)
+  // zero margins of both X buffers - BEFORE the first DMA (a visible LDS store behind a pending DMA makes the compiler wait for it)
   for (int i = tid; i < 2 * XROWS * 16; i += NT) {
     const int row = i >> 4, m = i & 15;
     Xs[row * ROWP + (m < 8 ? m : M16_PX + m)] = (f32x4)(0.f);
   }
-  if (tid < COUT) bias_s[tid] = a.bias[tid];
 
   bool rowok[3];
   int ysrc[3];
@@ -300,7 +299,10 @@ __global__ __launch_bounds__(512, 2) void conv2d_3x3_m16_kernel(ConvM16Args a) {
       if (u < WP) p16_glds16(reinterpret_cast<const f32x4*>(a.w) + ((long)k * (WNS * 9 * 2) + (u >> 5)) * COUT + h * 32 + (u & 31), dst + it * NT + wave * 64);
     }
   };
-  __syncthreads();                     // margins and bias are in before anything else touches LDS
+  __syncthreads();                     // margins are in before anything else touches LDS
+  // the bias goes in by DMA as well, ahead of the first pieces (a register-staged copy put a global-load round trip and a
+  // barrier in front of the first DMA of every workgroup); it is this wave's OLDEST transfer, so every counted wait below covers it
+  if (wave == 0 && lane < COUT / 4) p16_glds16(reinterpret_cast<const f32x4*>(a.bias) + lane, smem + 2 * XB + 3 * WP);
   issue_x(0, 0);
   issue_w(0);
   if (NP > 1) issue_w(1);
@@ -315,12 +317,25 @@ __global__ __launch_bounds__(512, 2) void conv2d_3x3_m16_kernel(ConvM16Args a) {
   const unsigned xs_lds = p16_lds_addr(Xs + g * 3 * ROWP + 8 + wave * 32 + l31);
 
 #define M16_READ(buf_, t_)                                                                                          \
-  _Pragma("unroll") for (int s = 0; s < NS; ++s) {                                                                  \
+  if constexpr (!(M16_ABL & 2)) _Pragma("unroll") for (int s = 0; s < NS; ++s) {                                                                  \
     xv[buf_][s] = p16_lds_read16(xcol[(t_) % 3], (s * 6 + (t_) / 3) * ROWP * 16);                                   \
     wv[buf_][s] = p16_lds_read16(wrow, ((s * 9 + (t_)) * 2) * 32 * 16);                                             \
   }
+#define M16_READ_XK(t_)                                                                                             \
+  if constexpr (!(M16_ABL & 2)) _Pragma("unroll") for (int s = 0; s < NS; ++s) xk[t_][s] = p16_lds_read16(xcol[(t_) % 3], (s * 6 + (t_) / 3) * ROWP * 16);
+#define M16_READ_W(buf_, t_)                                                                                        \
+  if constexpr (!(M16_ABL & 2)) _Pragma("unroll") for (int s = 0; s < NS; ++s) wv[buf_][s] = p16_lds_read16(wrow, ((s * 9 + (t_)) * 2) * 32 * 16);
+#define M16_MFMA_XK(t_, fb_, h_)                                                                                    \
+  if constexpr (!(M16_ABL & 1)) {                                                                                   \
+    typedef typename Op16<DT>::vec V_;                                                                              \
+    if constexpr (NS == 2) {                                                                                        \
+      acc[h_] = Op16<DT>::mfma(__builtin_bit_cast(V_, wv[fb_][0]), __builtin_bit_cast(V_, xk[t_][NS - 1]), acc[h_]); \
+      acc[h_] = Op16<DT>::mfma(__builtin_bit_cast(V_, wv[fb_][NS - 1]), __builtin_bit_cast(V_, xk[t_][0]), acc[h_]); \
+    }                                                                                                               \
+    acc[h_] = Op16<DT>::mfma(__builtin_bit_cast(V_, wv[fb_][0]), __builtin_bit_cast(V_, xk[t_][0]), acc[h_]);     \
+  }
 #define M16_MFMA(fb_, h_)                                                                                           \
-  {                                                                                                                 \
+  if constexpr (!(M16_ABL & 1)) {                                                                                   \
     typedef typename Op16<DT>::vec V_;                                                                              \
     if constexpr (NS == 2) {                                                                                        \
       acc[h_] = Op16<DT>::mfma(__builtin_bit_cast(V_, wv[fb_][0]), __builtin_bit_cast(V_, xv[fb_][NS - 1]), acc[h_]); \
@@ -329,7 +344,22 @@ __global__ __launch_bounds__(512, 2) void conv2d_3x3_m16_kernel(ConvM16Args a) {
     acc[h_] = Op16<DT>::mfma(__builtin_bit_cast(V_, wv[fb_][0]), __builtin_bit_cast(V_, xv[fb_][0]), acc[h_]);     \
   }
 
+  // residual units of this lane (see the epilogue), requested when the LAST piece starts: their round trip runs under its MFMAs
+  const int px = wave * 32 + l31;
+  const long rowoff = (long)y0 * M16_PX + px;
+  const f32x4* const rb = a.r ? a.r + (long)b * a.r_bs : nullptr;
+  // (f16x2 only: one workgroup per CU there anyway; the single-plane <64> kernel sits exactly on the 128 VGPRs that two workgroups per CU allow)
+  constexpr int NRU = NS == 2 ? NH * 4 : 1;
+  u32x4_t ru[NRU];
+#ifndef M16_XKEEP
+#define M16_XKEEP 1
+#endif
+#ifndef M16_ABL
+#define M16_ABL 0   // timing-only ablations (tools/exp): 1 no MFMA, 2 no fragment reads, 4 no epilogue loads / stores, 8 / 16 X / W DMA of the first pieces only
+#endif
   for (int k = 0; k < a.nchunks; ++k) {
+    f16x8 xk[NH == 2 && NS == 2 ? 9 : 1][NS];     // see M16_XKEEP below (f16x2 only: the single-plane kernels must stay under 128 VGPRs for two workgroups per CU)
+    if constexpr (M16_ABL & 2) { _Pragma("unroll") for (int t = 0; t < (NH == 2 && NS == 2 ? 9 : 1); ++t) _Pragma("unroll") for (int s = 0; s < NS; ++s) xk[t][s] = (f16x8)(0); }
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
       const int i = k * NH + h;
@@ -344,14 +374,46 @@ __global__ __launch_bounds__(512, 2) void conv2d_3x3_m16_kernel(ConvM16Args a) {
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WIT - 1) : "memory");
       }
       __syncthreads();                 // ... for every wave; everyone is done with the buffers the next DMAs go into
-      if (h == 0 && k + 1 < a.nchunks) issue_x(k + 1, (k + 1) & 1);
-      if (i + 2 < NP) issue_w(i + 2);
+      if constexpr (NS == 2) {
+        if (i + 1 == NP && rb && !(M16_ABL & 4)) {
+#pragma unroll
+          for (int j = 0; j < NRU; ++j) ru[j] = reinterpret_cast<const u32x4_t*>(rb)[m16_plane(j, g, NS, H) + rowoff];      // j = octet h*4 + q
+        }
+      }
+      if (h == 0 && k + 1 < a.nchunks && !(M16_ABL & 8)) issue_x(k + 1, (k + 1) & 1);
+      if (i + 2 < NP && !(M16_ABL & 16)) issue_w(i + 2);
       const unsigned wrow = ws_lds + (unsigned)((i % 3) * WP * 16);
       unsigned xcol[3];
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx) xcol[kx] = xs_lds + (unsigned)(((k & 1) * XB + (kx - 1) * d) * 16);
       f16x8 xv[2][NS], wv[2][NS];
-      if (allrows) {                   // interior rows: all nine taps, fragments double-buffered across taps
+      if constexpr (M16_ABL & 2) { _Pragma("unroll") for (int q = 0; q < 2; ++q) _Pragma("unroll") for (int s = 0; s < NS; ++s) { xv[q][s] = (f16x8)(0); wv[q][s] = (f16x8)(0); } }
+      if (allrows && NH == 2 && NS == 2 && M16_XKEEP) {
+        // 64 couts, interior rows: the X fragments of a chunk are the same for both cout halves - read for the first half, kept in
+        // registers (9 taps x NS x 4 VGPRs) for the second, which then issues weight reads only.  The workgroup is LDS-read bound
+        // (4 ds_read_b128 per 3 MFMAs and wave, 8 waves on one 128 B/clk port): 54 instead of 72 reads per chunk and wave.
+        if (h == 0) {
+          M16_READ_XK(0); M16_READ_W(0, 0);
+#pragma unroll
+          for (int t = 0; t < 9; ++t) {
+            const int fb = t & 1;
+            if (t + 1 < 9) { M16_READ_XK(t + 1); M16_READ_W(fb ^ 1, t + 1); m16_wait<2 * NS, NS>(xk[t], wv[fb]); }
+            else m16_wait<0, NS>(xk[t], wv[fb]);
+            M16_MFMA_XK(t, fb, h);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        } else {
+          M16_READ_W(0, 0);
+#pragma unroll
+          for (int t = 0; t < 9; ++t) {
+            const int fb = t & 1;
+            if (t + 1 < 9) { M16_READ_W(fb ^ 1, t + 1); m16_wait<NS, NS>(xk[t], wv[fb]); }
+            else m16_wait<0, NS>(xk[t], wv[fb]);
+            M16_MFMA_XK(t, fb, h);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      } else if (allrows) {            // interior rows: all nine taps, fragments double-buffered across taps
         M16_READ(0, 0);
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
@@ -375,14 +437,14 @@ __global__ __launch_bounds__(512, 2) void conv2d_3x3_m16_kernel(ConvM16Args a) {
   }
 #undef M16_READ
 #undef M16_MFMA
+#undef M16_READ_XK
+#undef M16_READ_W
+#undef M16_MFMA_XK
 
   // ---- epilogue: bias, ReLU, residual, back to M16 units (the P16 / B16 recipe: after v_permlane32_swap every lane holds
   // one whole 16-byte unit - g = 0 the hi (or even-octet) one, g = 1 the lo (or odd-octet) one; 512 contiguous bytes per half wave)
-  const int px = wave * 32 + l31;
   const bool pxok = px < W;
-  const long rowoff = (long)y0 * M16_PX + px;
   f32x4* const yb = a.y + (long)b * a.y_bs;
-  const f32x4* const rb = a.r ? a.r + (long)b * a.r_bs : nullptr;
   float vmax = 0.f;
   if constexpr (NS == 2) {
 #pragma unroll
@@ -394,8 +456,8 @@ __global__ __launch_bounds__(512, 2) void conv2d_3x3_m16_kernel(ConvM16Args a) {
         f32x4 v;
         v.x = acc[h][4 * q + 0] + bs4.x; v.y = acc[h][4 * q + 1] + bs4.y; v.z = acc[h][4 * q + 2] + bs4.z; v.w = acc[h][4 * q + 3] + bs4.w;
         if (a.relu) { v.x = p16_vmax(v.x, 0.f); v.y = p16_vmax(v.y, 0.f); v.z = p16_vmax(v.z, 0.f); v.w = p16_vmax(v.w, 0.f); }
-        if (rb) {
-          const u32x4_t u_ = reinterpret_cast<const u32x4_t*>(rb)[m16_plane(o, g, NS, H) + rowoff];   // g = 0: the hi unit, g = 1: the lo unit
+        if (rb && !(M16_ABL & 4)) {
+          const u32x4_t u_ = ru[o];                                                                    // g = 0: the hi unit, g = 1: the lo unit
           unsigned ux_ = u_.x, uy_ = u_.y, uz_ = u_.z, uw_ = u_.w;
           p16_swap32(ux_, uz_);
           p16_swap32(uy_, uw_);
@@ -412,7 +474,7 @@ __global__ __launch_bounds__(512, 2) void conv2d_3x3_m16_kernel(ConvM16Args a) {
         p16_swap32(h1_, l1_);
         u32x4_t unit_;
         unit_.x = h0_; unit_.y = h1_; unit_.z = l0_; unit_.w = l1_;
-        reinterpret_cast<u32x4_t*>(yb)[m16_plane(o, g, NS, H) + rowoff] = unit_;
+        if (!(M16_ABL & 4) || unit_.x == 0x12345u) reinterpret_cast<u32x4_t*>(yb)[m16_plane(o, g, NS, H) + rowoff] = unit_;
       }
     if (vmax > 65504.f && a.flag) *a.flag = 1u;
   } else {
