@@ -236,6 +236,12 @@ __device__ __forceinline__ void m16_wait(f16x8 (&x)[NS], f16x8 (&w)[NS]) {
   else asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(x[0]), "+v"(w[0]) : "n"(N));
 }
 
+#ifdef M16_STAMPS   // tools/microbench_m16.hip: s_memtime stamps of every wave of ONE workgroup [wave][16]
+__device__ unsigned long long m16_stamp_buf[8 * 16];
+#define M16_STAMP(n_) { if (blockIdx.x == M16_STAMPS && lane == 0) m16_stamp_buf[wave * 16 + (n_)] = __builtin_readcyclecounter(); }
+#else
+#define M16_STAMP(n_)
+#endif
 template <int COUT, int NS, int DT>
 __global__ __launch_bounds__(512, 2) void conv2d_3x3_m16_kernel(ConvM16Args a) {
   static_assert(NS == 1 || DT == 1, "f16x2, plain fp16 or plain bf16");
@@ -267,6 +273,7 @@ __global__ __launch_bounds__(512, 2) void conv2d_3x3_m16_kernel(ConvM16Args a) {
   }
   const int NP = a.nchunks * NH;
 
+  M16_STAMP(0);
   // zero margins of both X buffers - BEFORE the first DMA (a visible LDS store behind a pending DMA makes the compiler wait for it)
   for (int i = tid; i < 2 * XROWS * 16; i += NT) {
     const int row = i >> 4, m = i & 15;
@@ -282,22 +289,23 @@ __global__ __launch_bounds__(512, 2) void conv2d_3x3_m16_kernel(ConvM16Args a) {
     ysrc[ky] = rowok[ky] ? ys : y0;      // out-of-map rows are fetched from a valid row (uniform DMA counts) and never read
   }
   const f32x4* const xb = a.x + (long)b * a.x_bs;
+  auto issue_x1 = [&](int k, int buf, int it) {      // one of the XIT transfers of chunk k's X image
+    const int row = 2 * it + (wave >> 2), px = tid & 255;       // row = (s*2 + g)*3 + ky: one wave = 64 pixels of one row
+    const int s = row / 6, gg = (row / 3) & 1, ky = row % 3;
+    p16_glds16(xb + m16_plane(2 * k + gg, s, NS, H) + (long)ysrc[ky] * M16_PX + px, Xs + buf * XB + row * ROWP + 8 + (wave & 3) * 64);
+  };
+  auto issue_w1 = [&](int i, int it) {               // one of the WIT transfers of weight piece i = (k, h) = (i / NH, i % NH)
+    const int k = i / NH, h = i - k * NH;
+    const int u = tid + it * NT;
+    if (u < WP) p16_glds16(reinterpret_cast<const f32x4*>(a.w) + ((long)k * (WNS * 9 * 2) + (u >> 5)) * COUT + h * 32 + (u & 31), Ws + (i % 3) * WP + it * NT + wave * 64);
+  };
   auto issue_x = [&](int k, int buf) {
 #pragma unroll
-    for (int it = 0; it < XIT; ++it) {
-      const int row = 2 * it + (wave >> 2), px = tid & 255;     // row = (s*2 + g)*3 + ky: one wave = 64 pixels of one row
-      const int s = row / 6, gg = (row / 3) & 1, ky = row % 3;
-      p16_glds16(xb + m16_plane(2 * k + gg, s, NS, H) + (long)ysrc[ky] * M16_PX + px, Xs + buf * XB + row * ROWP + 8 + (wave & 3) * 64);
-    }
+    for (int it = 0; it < XIT; ++it) issue_x1(k, buf, it);
   };
-  auto issue_w = [&](int i) {      // piece i = (k, h) = (i / NH, i % NH)
-    const int k = i / NH, h = i - k * NH;
-    f32x4* dst = Ws + (i % 3) * WP;
+  auto issue_w = [&](int i) {
 #pragma unroll
-    for (int it = 0; it < WIT; ++it) {
-      const int u = tid + it * NT;
-      if (u < WP) p16_glds16(reinterpret_cast<const f32x4*>(a.w) + ((long)k * (WNS * 9 * 2) + (u >> 5)) * COUT + h * 32 + (u & 31), dst + it * NT + wave * 64);
-    }
+    for (int it = 0; it < WIT; ++it) issue_w1(i, it);
   };
   __syncthreads();                     // margins are in before anything else touches LDS
   // the bias goes in by DMA as well, ahead of the first pieces (a register-staged copy put a global-load round trip and a
@@ -306,6 +314,7 @@ __global__ __launch_bounds__(512, 2) void conv2d_3x3_m16_kernel(ConvM16Args a) {
   issue_x(0, 0);
   issue_w(0);
   if (NP > 1) issue_w(1);
+  M16_STAMP(1);
 
   f32x16 acc[NH];
 #pragma unroll
@@ -354,6 +363,9 @@ __global__ __launch_bounds__(512, 2) void conv2d_3x3_m16_kernel(ConvM16Args a) {
 #ifndef M16_XKEEP
 #define M16_XKEEP 1
 #endif
+#ifndef M16_DMA_SPREAD
+#define M16_DMA_SPREAD 0   // 1: one transfer per tap between the MFMA groups instead of a block at the top of the piece.  Measured: no gain for
+#endif                     // f16x2 (pieces stay ~3 800 cycles), 8-15 % slower single-plane: a piece waits for its DATA
 #ifndef M16_ABL
 #define M16_ABL 0   // timing-only ablations (tools/exp): 1 no MFMA, 2 no fragment reads, 4 no epilogue loads / stores, 8 / 16 X / W DMA of the first pieces only
 #endif
@@ -373,15 +385,27 @@ __global__ __launch_bounds__(512, 2) void conv2d_3x3_m16_kernel(ConvM16Args a) {
         if (wave < EXTRA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WIT) : "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WIT - 1) : "memory");
       }
+      M16_STAMP(2 + 2 * i);            // this piece's transfers have landed (this wave)
       __syncthreads();                 // ... for every wave; everyone is done with the buffers the next DMAs go into
+      M16_STAMP(3 + 2 * i);
       if constexpr (NS == 2) {
         if (i + 1 == NP && rb && !(M16_ABL & 4)) {
 #pragma unroll
           for (int j = 0; j < NRU; ++j) ru[j] = reinterpret_cast<const u32x4_t*>(rb)[m16_plane(j, g, NS, H) + rowoff];      // j = octet h*4 + q
         }
       }
-      if (h == 0 && k + 1 < a.nchunks && !(M16_ABL & 8)) issue_x(k + 1, (k + 1) & 1);
-      if (i + 2 < NP && !(M16_ABL & 16)) issue_w(i + 2);
+      // the next chunk's X image and weight piece i + 2: in a block here, or (M16_DMA_SPREAD) one transfer per tap between the MFMA groups
+      const bool dox = h == 0 && k + 1 < a.nchunks && !(M16_ABL & 8), dow = i + 2 < NP && !(M16_ABL & 16);
+      static_assert(XIT + WIT <= 9, "one transfer per tap");
+#define M16_DMA_SLOT(t_)                                                                       \
+  {                                                                                            \
+    if ((t_) < XIT) { if (dox) issue_x1(k + 1, (k + 1) & 1, (t_)); }                           \
+    else if ((t_) - XIT < WIT) { if (dow) issue_w1(i + 2, (t_) - XIT); }                       \
+  }
+      if (!allrows || !M16_DMA_SPREAD) {      // edge rows skip taps: everything up front
+        if (dox) issue_x(k + 1, (k + 1) & 1);
+        if (dow) issue_w(i + 2);
+      }
       const unsigned wrow = ws_lds + (unsigned)((i % 3) * WP * 16);
       unsigned xcol[3];
 #pragma unroll
@@ -397,6 +421,7 @@ __global__ __launch_bounds__(512, 2) void conv2d_3x3_m16_kernel(ConvM16Args a) {
 #pragma unroll
           for (int t = 0; t < 9; ++t) {
             const int fb = t & 1;
+            if (M16_DMA_SPREAD) M16_DMA_SLOT(t);
             if (t + 1 < 9) { M16_READ_XK(t + 1); M16_READ_W(fb ^ 1, t + 1); m16_wait<2 * NS, NS>(xk[t], wv[fb]); }
             else m16_wait<0, NS>(xk[t], wv[fb]);
             M16_MFMA_XK(t, fb, h);
@@ -407,6 +432,7 @@ __global__ __launch_bounds__(512, 2) void conv2d_3x3_m16_kernel(ConvM16Args a) {
 #pragma unroll
           for (int t = 0; t < 9; ++t) {
             const int fb = t & 1;
+            if (M16_DMA_SPREAD) M16_DMA_SLOT(t);
             if (t + 1 < 9) { M16_READ_W(fb ^ 1, t + 1); m16_wait<NS, NS>(xk[t], wv[fb]); }
             else m16_wait<0, NS>(xk[t], wv[fb]);
             M16_MFMA_XK(t, fb, h);
@@ -418,6 +444,7 @@ __global__ __launch_bounds__(512, 2) void conv2d_3x3_m16_kernel(ConvM16Args a) {
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
           const int fb = t & 1;
+          if (M16_DMA_SPREAD) M16_DMA_SLOT(t);
           if (t + 1 < 9) { M16_READ(fb ^ 1, t + 1); m16_wait<2 * NS, NS>(xv[fb], wv[fb]); }
           else m16_wait<0, NS>(xv[fb], wv[fb]);
           M16_MFMA(fb, h);
@@ -437,12 +464,14 @@ __global__ __launch_bounds__(512, 2) void conv2d_3x3_m16_kernel(ConvM16Args a) {
   }
 #undef M16_READ
 #undef M16_MFMA
+#undef M16_DMA_SLOT
 #undef M16_READ_XK
 #undef M16_READ_W
 #undef M16_MFMA_XK
 
   // ---- epilogue: bias, ReLU, residual, back to M16 units (the P16 / B16 recipe: after v_permlane32_swap every lane holds
   // one whole 16-byte unit - g = 0 the hi (or even-octet) one, g = 1 the lo (or odd-octet) one; 512 contiguous bytes per half wave)
+  M16_STAMP(10);                       // MFMAs of the last piece issued
   const bool pxok = px < W;
   f32x4* const yb = a.y + (long)b * a.y_bs;
   float vmax = 0.f;
@@ -514,4 +543,5 @@ __global__ __launch_bounds__(512, 2) void conv2d_3x3_m16_kernel(ConvM16Args a) {
       }
     if (DT == 1 && vmax > 65504.f && a.flag) *a.flag = 1u;
   }
+  M16_STAMP(11);                       // epilogue stores issued
 }
