@@ -317,7 +317,7 @@ def main():
         "value": round(mb_per_s, 3), "unit": "Mb/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": f"Encoder Conv1d stages 1-7: {enc_prec} = {ARITH[enc_prec]}; Decoder / Decoder_1m Conv2d: {dec_prec} = {ARITH[dec_prec]}; "
-                 "Encoder2 Conv1d, 1x1 heads, pools, upsampling, merges: fp32",
+                 f"Encoder2 Conv1d: {getattr(model.net, 'precision', 'f32')}; 1x1 heads, pools, upsampling, merges: fp32",
         "data": "synthetic",
         "config": {"workload": f"H1-ESC 32Mb model forward, single random {args.seq_mb}Mb sequence, fp32-class ({enc_prec} split operands on the 16-bit matrix "
                                "cores, see dtype; parity vs the reference's fp32 in `parity`), both strands (genomepredict-equivalent, 1 model): "
@@ -346,7 +346,7 @@ def main():
 
     # ---- exact fp32 MFMA everywhere: short second loop (N = 1)
     if world == 1 and Lbp == L_BP:
-        mods = [model.net0] + [model.denets[lv] for lv in model.levels] + [model.denet_1_pt]
+        mods = [model.net0, model.net] + [model.denets[lv] for lv in model.levels] + [model.denet_1_pt]
         old = [m.precision for m in mods]
         for m in mods:
             m.precision = "f32"

@@ -181,7 +181,10 @@ int64_t orca_encoder_num_bins(int64_t L);
  * x: [B,128,n] (strides in elements), n divisible by 2^nlev (nlev = 5 / 3).
  * An ORCA_NET_ENCODER2B net (Encoder2b.forward, :1262-1276; 5 levels) returns the contracting path's encodings.
  * outs: HOST array of nlev+1 device pointers; outs[i] receives the
- * contiguous [B,128,n>>i] encoding (fine -> coarse, as the reference returns). */
+ * contiguous [B,128,n>>i] encoding (fine -> coarse, as the reference returns).
+ * Arithmetic: orca_net_set_precision (F32, F16X2, BF16X3, BF16X2, BF16).  The split-operand modes run on channel-last
+ * activations from B*n >= 32000 positions on (the 256 Mb model's 64 000 bins); smaller problems use the exact fp32 kernels,
+ * which are faster there, whatever the precision asked for ($ORCA_UNET_NLC_MIN overrides the threshold). */
 int orca_unet_forward(orca_ctx* ctx, orca_net* net, const float* x, int64_t sx_b, int64_t sx_c,
                       int64_t sx_l, int B, int n, float* const* outs_host, int n_outs);
 

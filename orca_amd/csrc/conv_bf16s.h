@@ -50,6 +50,7 @@ struct ConvB16Args {
   const float* bias;
   float* y;         // [B][n][COUT]
   const float* r1;  // optional residual, layout of y
+  const float* r2;  // optional second residual (the U-net's skip connection), same layout and batch stride
   long x_bs, y_bs;  // batch strides (elements)
   long r_bs;        // batch stride of r1
   long n;
@@ -259,6 +260,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv1d_k9_bf16s_kernel(ConvB16
       const long m0 = (tile - tb * a.tiles_per_row) * MT;
       float* yb = a.y + tb * a.y_bs;
       const float* rb = a.r1 ? a.r1 + tb * a.r_bs : nullptr;
+      const float* rb2 = a.r2 ? a.r2 + tb * a.r_bs : nullptr;
 #pragma unroll
       for (int i = 0; i < MW; ++i) {
         const long pos = m0 + wm * (MW * 32) + i * 32 + l31;
@@ -279,6 +281,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv1d_k9_bf16s_kernel(ConvB16
               if (pos < a.n) {
                 const long o = pos * COUT + co;
                 if (rb) v += *reinterpret_cast<const f32x4*>(rb + o);
+                if (rb2) v += *reinterpret_cast<const f32x4*>(rb2 + o);     // may alias y: read before this lane's own store
                 if (!(ABL & 16) || v.x == 12345.678f) *reinterpret_cast<f32x4*>(yb + o) = v;
               }
             } else {

@@ -77,6 +77,37 @@ __global__ void upsample1d_x2_kernel(const float* __restrict__ x, long ldx, floa
   y[r * ldy + m] = x[r * ldx + (m >> 1)];
 }
 
+// nn.Upsample(scale_factor=2) (nearest) on channel-last rows: y[m][:] = x[m >> 1][:]; one thread = 4 channels.  grid ceil(n_out*C/4 / 256)
+__global__ void upsample1d_x2_nlc_kernel(const float* __restrict__ x, float* __restrict__ y, long n_out, int C) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c4n = C / 4;
+  if (idx >= n_out * c4n) return;
+  const long m = idx / c4n;
+  const int c4 = (int)(idx - m * c4n);
+  reinterpret_cast<f32x4*>(y + m * C)[c4] = reinterpret_cast<const f32x4*>(x + (m >> 1) * C)[c4];
+}
+
+// [rows][cols] <-> its transpose through a 32 x 33 LDS tile, both sides coalesced: dst[c * ldd + r] = src[r * lds_ + c]
+// (channel-last [n][128] <-> channel-major [128][n] hand-overs of the U-net encoders).  grid (ceil(cols/32), ceil(rows/32), batch), block (32, 8)
+__global__ void transpose2d_kernel(const float* __restrict__ src, long lds_, long src_bs, float* __restrict__ dst, long ldd, long dst_bs,
+                                   long rows, long cols) {
+  __shared__ float tile[32][33];
+  src += (long)blockIdx.z * src_bs;
+  dst += (long)blockIdx.z * dst_bs;
+  const long r0 = (long)blockIdx.y * 32, c0 = (long)blockIdx.x * 32;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const long r = r0 + threadIdx.y + 8 * k, c = c0 + threadIdx.x;
+    if (r < rows && c < cols) tile[threadIdx.y + 8 * k][threadIdx.x] = src[r * lds_ + c];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const long c = c0 + threadIdx.y + 8 * k, r = r0 + threadIdx.x;
+    if (r < rows && c < cols) dst[c * ldd + r] = tile[threadIdx.x][threadIdx.y + 8 * k];
+  }
+}
+
 // generic strided 2-D copy: dst[r*ldd + c] = src[r*lds_ + c*scol]
 __global__ void copy2d_kernel(const float* __restrict__ src, long lds_, long scol, float* __restrict__ dst, long ldd, long cols) {
   const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;

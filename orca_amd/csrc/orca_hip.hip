@@ -449,11 +449,11 @@ static int launch_conv1d_b16_ns(orca_ctx* ctx, const ConvLayer& L, const ConvB16
 
 // x [B][n][cin], y/r1 [B][n][cout] channel-last.  precision: ORCA_PRECISION_BF16 / _BF16X2 / _BF16X3
 static int launch_conv1d_b16(orca_ctx* ctx, const ConvLayer& L, int precision, const float* x, long x_bs, float* y, long y_bs,
-                             const float* r1, int B, long n, int relu, int pool4 = 0) {
+                             const float* r1, int B, long n, int relu, int pool4 = 0, const float* r2 = nullptr) {
   if (!L.d_wb16) return fail(ORCA_EINVAL, "layer has no bf16 split pack (cin %d)", L.cin);
   if (n <= 0 || B <= 0) return ORCA_OK;
   ConvB16Args a;
-  a.x = x; a.w = L.d_wb16; a.bias = L.d_bias; a.y = y; a.r1 = r1; a.x_bs = x_bs; a.y_bs = y_bs; a.n = n;
+  a.x = x; a.w = L.d_wb16; a.bias = L.d_bias; a.y = y; a.r1 = r1; a.r2 = r2; a.x_bs = x_bs; a.y_bs = y_bs; a.n = n;
   a.pool4 = pool4; a.r_bs = (long)n * L.cout;
   a.cin = L.cin; a.nchunks = L.cin / 16; a.relu = relu; a.stagger = 2;
   a.flag = ctx->d_flag;
@@ -861,7 +861,8 @@ extern "C" int orca_net_set_precision(orca_net* net, int precision) {
   if (!net) return fail(ORCA_EINVAL, "net is NULL");
   if (precision < ORCA_PRECISION_F32 || precision > ORCA_PRECISION_F16) return fail(ORCA_EINVAL, "unknown precision %d", precision);
   const bool dec = net->kind == ORCA_NET_DECODER || net->kind == ORCA_NET_DECODER_1M;
-  if (precision != ORCA_PRECISION_F32 && !((net->kind == ORCA_NET_ENCODER && precision != ORCA_PRECISION_F16) ||
+  const bool unet = net->kind == ORCA_NET_ENCODER2 || net->kind == ORCA_NET_ENCODER3 || net->kind == ORCA_NET_ENCODER2B;
+  if (precision != ORCA_PRECISION_F32 && !(((net->kind == ORCA_NET_ENCODER || unet) && precision != ORCA_PRECISION_F16) ||
                                            (dec && (precision == ORCA_PRECISION_F16X2 || precision == ORCA_PRECISION_BF16 || precision == ORCA_PRECISION_F16))))
     return fail(ORCA_EINVAL, "precision %d is not implemented for net kind %d", precision, net->kind);
   net->precision = precision;
@@ -1114,6 +1115,67 @@ extern "C" int orca_pack_sequence(orca_ctx* ctx, const float* x, int64_t sx_c, i
 // ---------------------------------------------------------------------------
 // Encoder2 / Encoder3 (orca_modules.py:1151-1169, :1388-1406)
 // ---------------------------------------------------------------------------
+static int launch_transpose(orca_ctx* ctx, const float* src, long lds_, long src_bs, float* dst, long ldd, long dst_bs, long rows, long cols, int B) {
+  if (rows <= 0 || cols <= 0 || B <= 0) return ORCA_OK;
+  dim3 grid((unsigned)((cols + 31) / 32), (unsigned)((rows + 31) / 32), (unsigned)B);
+  hipLaunchKernelGGL(transpose2d_kernel, grid, dim3(32, 8), 0, ctx->stream, src, lds_, src_bs, dst, ldd, dst_bs, rows, cols);
+  LAUNCHCHECK("transpose2d_kernel");
+  return ORCA_OK;
+}
+
+// The U-net encoders on the 16-bit matrix cores (conv_bf16s.h: channel-last fp32 activations [B][n][128], split operands).  Same graph as
+// the fp32 path below; the skip connection of the expanding path is the kernel's second residual and the result of a level overwrites the
+// contracting-path encoding it consumed.  The outputs are handed over channel-major ([B][128][n], the C ABI's layout) by tiled transposes.
+static int unet_forward_nlc(orca_ctx* ctx, orca_net* net, const float* x, int64_t sx_b, int64_t sx_c, int64_t sx_l, int B, int n,
+                            float* const* outs, int nlev, bool up_only) {
+  const int prec = net->precision;
+  const size_t full = (size_t)B * 128 * n;
+  size_t need = 3 * ru256(full * sizeof(float));
+  for (int i = 0; i <= nlev; ++i) need += ru256((full >> i) * sizeof(float));
+  ORCA_TRY(ws_ensure(ctx, need));
+  std::vector<float*> encs(nlev + 1);
+  for (int i = 0; i <= nlev; ++i) encs[i] = ws_take(ctx, full >> i);
+  float* t0 = ws_take(ctx, full);
+  float* t1 = ws_take(ctx, full);
+  float* t2 = ws_take(ctx, full);
+  hipStream_t s = ctx->stream;
+  // the (possibly strided) channel-major input -> [B][n][128]
+  if (sx_l == 1) ORCA_TRY(launch_transpose(ctx, x, sx_c, sx_b, encs[0], 128, (long)n * 128, 128, n, B));
+  else
+    for (int b = 0; b < B; ++b) ORCA_TRY(launch_copy2d(ctx, x + (long)b * sx_b, sx_l, sx_c, encs[0] + (size_t)b * n * 128, 128, n, 128));
+  const ConvLayer* L = net->convs.data();
+  for (int i = 0; i < nlev; ++i) {      // contracting path
+    const long no = n >> (i + 1), bs = 128 * no;
+    ORCA_TRY(launch_pool_nlc(ctx, encs[i], t0, (long)B * no, 128, 2));          // rows of all batch entries in one pass (n >> i is even)
+    ORCA_TRY(launch_conv1d_b16(ctx, L[4 * i + 0], prec, t0, bs, t1, bs, nullptr, B, no, 0));
+    ORCA_TRY(launch_conv1d_b16(ctx, L[4 * i + 1], prec, t1, bs, t2, bs, nullptr, B, no, 0));   // lout
+    ORCA_TRY(launch_conv1d_b16(ctx, L[4 * i + 2], prec, t2, bs, t1, bs, nullptr, B, no, 1));
+    ORCA_TRY(launch_conv1d_b16(ctx, L[4 * i + 3], prec, t1, bs, encs[i + 1], bs, t2, B, no, 1));
+  }
+  auto hand_over = [&](int lev) { const long nl = n >> lev; return launch_transpose(ctx, encs[lev], 128, nl * 128, outs[lev], nl, 128 * nl, nl, 128, B); };
+  ORCA_TRY(hand_over(nlev));
+  if (up_only) {
+    for (int lev = 0; lev < nlev; ++lev) ORCA_TRY(hand_over(lev));
+    return ORCA_OK;
+  }
+  const float* cur = encs[nlev];
+  for (int i = 0; i < nlev; ++i) {      // expanding path
+    const int lev = nlev - 1 - i;
+    const long no = n >> lev, bs = 128 * no;
+    const long total = (long)B * no * 32;
+    hipLaunchKernelGGL(upsample1d_x2_nlc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, cur, t0, (long)B * no, 128);
+    LAUNCHCHECK("upsample1d_x2_nlc_kernel");
+    const ConvLayer* D = L + 4 * nlev + 4 * i;
+    ORCA_TRY(launch_conv1d_b16(ctx, D[0], prec, t0, bs, t1, bs, nullptr, B, no, 0));
+    ORCA_TRY(launch_conv1d_b16(ctx, D[1], prec, t1, bs, t2, bs, nullptr, B, no, 0));           // lout
+    ORCA_TRY(launch_conv1d_b16(ctx, D[2], prec, t2, bs, t1, bs, nullptr, B, no, 1));
+    ORCA_TRY(launch_conv1d_b16(ctx, D[3], prec, t1, bs, encs[lev], bs, t2, B, no, 1, 0, encs[lev]));   // + lout + skip, in place of the skip
+    ORCA_TRY(hand_over(lev));
+    cur = encs[lev];
+  }
+  return ORCA_OK;
+}
+
 extern "C" int orca_unet_forward(orca_ctx* ctx, orca_net* net, const float* x, int64_t sx_b, int64_t sx_c, int64_t sx_l, int B,
                                  int n, float* const* outs, int n_outs) {
   if (!ctx || !net || !x || !outs) return fail(ORCA_EINVAL, "orca_unet_forward: NULL argument");
@@ -1125,6 +1187,12 @@ extern "C" int orca_unet_forward(orca_ctx* ctx, orca_net* net, const float* x, i
   if (n_outs != nlev + 1) return fail(ORCA_EINVAL, "expected %d output pointers, got %d", nlev + 1, n_outs);
   if (n <= 0 || (n % (1 << nlev))) return fail(ORCA_EINVAL, "length %d not divisible by %d", n, 1 << nlev);
   if (B <= 0) return ORCA_OK;
+  // The split-operand path pays off from ~32 K positions per launch (256 Mb model: 2 x 64 000 bins, tail 14.6 -> 13.1 ms); below that the
+  // 128-position tiles of conv_bf16s.h leave most CUs idle and the exact fp32 kernels with their small tiles are faster (32 Mb model,
+  // 2 x 8 000 bins: 94.8 vs 95.4 ms per bench step) - and at least as accurate, so they serve every precision there.
+  const char* nlc_env = getenv("ORCA_UNET_NLC_MIN");      // read per call: the tests force the split-operand path at small sizes
+  const long nlc_min = nlc_env ? atol(nlc_env) : 32000;
+  if (net->precision != ORCA_PRECISION_F32 && (long)B * n >= nlc_min) return unet_forward_nlc(ctx, net, x, sx_b, sx_c, sx_l, B, n, outs, nlev, up_only);
   const size_t full = (size_t)B * 128 * n;
   size_t need = 0;
   for (int i = 0; i < nlev; ++i) need += ru256((full >> i) * sizeof(float));  // encs[0..nlev-1]

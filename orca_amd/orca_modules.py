@@ -175,11 +175,21 @@ class Encoder(_HipModule):
     forward_codes.__doc__ += "  (Replaces the float [B,4,L] input of orca_predict.py:334.)"
 
 
+def _unet_precision(precision):
+    p = precision or os.environ.get("ORCA_ENCODER2_PRECISION", "f16x2")
+    if p not in ("f32", "f16x2", "bf16x3", "bf16x2", "bf16"):
+        raise ValueError("precision must be one of ['bf16', 'bf16x2', 'bf16x3', 'f16x2', 'f32']")
+    return p
+
+
 class _UNetEncoder(_HipModule):
     _nlev = 0
 
-    def __init__(self):
+    def __init__(self, precision=None):
+        """precision: as Encoder's ("f16x2" default - split fp16 operands under the device range guard, fp32-class results; "f32" = the
+        exact fp32-MFMA kernels).  Default: $ORCA_ENCODER2_PRECISION or "f16x2"."""
         super().__init__()
+        self.precision = _unet_precision(precision)
         n = self._nlev
         c1 = dict(kernel_size=9, padding=4)
         self.lblocks = nn.ModuleList(
@@ -200,7 +210,8 @@ class _UNetEncoder(_HipModule):
 
     def forward(self, x):
         """x: [B,128,n] -> list of nlev+1 encodings [B,128,n>>i], fine to coarse."""
-        return engine.unet_forward(self._net(x.device), x, self._nlev)
+        net = self._net(x.device)
+        return self._run_guarded(net, lambda: engine.unet_forward(net, x, self._nlev), "bf16x3")
 
 
 class Encoder2(_UNetEncoder):
@@ -215,8 +226,9 @@ class Encoder2b(_HipModule):
     _kind = _lib.ORCA_NET_ENCODER2B
     _nlev = 5
 
-    def __init__(self):
+    def __init__(self, precision=None):
         super().__init__()
+        self.precision = _unet_precision(precision)
         c1 = dict(kernel_size=9, padding=4)
         self.lblocks = nn.ModuleList(
             [_linear_pair(nn.Conv1d, nn.BatchNorm1d, 128, 128, 128, nn.MaxPool1d(kernel_size=2, stride=2), **c1) for _ in range(5)])
@@ -229,7 +241,8 @@ class Encoder2b(_HipModule):
         return items
 
     def forward(self, x):
-        return engine.unet_forward(self._net(x.device), x, 5)
+        net = self._net(x.device)
+        return self._run_guarded(net, lambda: engine.unet_forward(net, x, 5), "bf16x3")
 
 
 class Encoder3(_UNetEncoder):

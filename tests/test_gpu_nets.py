@@ -47,9 +47,11 @@ def test_encoder_ragged_length_and_batch_vs_oracle(cuda):
     assert maxabs(y, ref) < TOL
 
 
-def test_encoder2_encoder3_vs_golden(cuda):
+@pytest.mark.parametrize("precision", ["f16x2", "f32", "bf16x3"])
+def test_encoder2_encoder3_vs_golden(cuda, precision, monkeypatch):
+    monkeypatch.setenv("ORCA_UNET_NLC_MIN", "0")     # the split-operand path also below its pay-off size (default: >= 32 000 positions)
     g = golden("G3_encoder23.npz")
-    e2 = product_module("Encoder2", 0)
+    e2 = product_module("Encoder2", 0, precision=precision)
     x = torch.from_numpy((np.random.RandomState(21).rand(1, 128, 800) * 0.5).astype(np.float32)).to(cuda)
     ys = e2(x)
     for i, y in enumerate(ys):
@@ -58,20 +60,27 @@ def test_encoder2_encoder3_vs_golden(cuda):
     for i, y in enumerate(e2(xl)):
         assert maxabs(y[0, :, :16].cpu().numpy(), g[f"e2L_head_{i}"]) < TOL
         np.testing.assert_allclose(stats(y.cpu().numpy()), g[f"e2L_stats_{i}"], rtol=1e-4)
-    e3 = product_module("Encoder3", 0)
+    e3 = product_module("Encoder3", 0, precision=precision)
     x3 = torch.from_numpy((np.random.RandomState(23).rand(1, 128, 2000) * 0.5).astype(np.float32)).to(cuda)
     for i, y in enumerate(e3(x3)):
         assert maxabs(y[0, :, ::5].cpu().numpy(), g[f"e3_{i}"]) < TOL
 
 
-def test_encoder2_batch_and_strided_input_vs_oracle(cuda):
-    e2 = product_module("Encoder2", 1)
+@pytest.mark.parametrize("precision", ["f16x2", "f32"])
+def test_encoder2_batch_and_strided_input_vs_oracle(cuda, precision, monkeypatch):
+    monkeypatch.setenv("ORCA_UNET_NLC_MIN", "0")
+    e2 = product_module("Encoder2", 1, precision=precision)
     sd = synth_sd("Encoder2", 1)
     big = torch.from_numpy((np.random.RandomState(7).rand(2, 128, 700) * 0.5).astype(np.float32))
     x = big[:, :, 30:670]  # non-contiguous, 640 bins
     ref = O.encoder2_forward(sd, x)
     ys = e2(big.to(cuda)[:, :, 30:670])
     for a, b in zip(ys, ref):
+        assert maxabs(a.cpu().numpy(), b.numpy()) < TOL
+    # position-strided input (every second bin of a longer tensor): the other staging route of the channel-last path
+    xs = torch.from_numpy((np.random.RandomState(8).rand(2, 128, 1280) * 0.5).astype(np.float32))
+    ref2 = O.encoder2_forward(sd, xs[:, :, ::2])
+    for a, b in zip(e2(xs.to(cuda)[:, :, ::2]), ref2):
         assert maxabs(a.cpu().numpy(), b.numpy()) < TOL
 
 
@@ -204,10 +213,12 @@ def test_net_1mb_model_vs_reference_and_oracle(cuda):
     assert maxabs(net2.to(cuda)(x)[0].cpu().numpy(), pred.cpu().numpy()) == 0.0
 
 
-def test_encoder2b_vs_reference_and_hctnoc_container(cuda):
+@pytest.mark.parametrize("nlc_min", ["0", "32000"])
+def test_encoder2b_vs_reference_and_hctnoc_container(cuda, nlc_min, monkeypatch):
     """Encoder2b (the HCTnoc variant: contracting path only) vs the reference fixture G15 and, batched and strided,
     vs the oracle; the HCTnoc container exposes the reference's attributes (no denet_1_pt, nearest-upsampling decoders)."""
     from orca_amd import orca_models as M
+    monkeypatch.setenv("ORCA_UNET_NLC_MIN", nlc_min)     # split-operand channel-last path / exact fp32 kernels
     g = golden("G15_encoder2b.npz")
     e2b = product_module("Encoder2b", 0, device=cuda)
     x = torch.from_numpy((np.random.RandomState(33).rand(1, 128, 2048) * 0.5).astype(np.float32))
