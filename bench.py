@@ -28,14 +28,17 @@ Also measured in the same run, OUTSIDE the timed region, and reported in the sam
 Prints ONE JSON line (rank 0).  value = strand-Mb of sequence encoded AND decoded per second over the whole job
 (2 strands x 32 Mb per step per rank).
 """
-import argparse, threading
+import argparse
 import json
 import os
 import sys
+import threading
 import time
 
-import numpy as np
-import torch
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # multi-process GPU work on this driver needs dmabuf IPC (before the HIP runtime starts)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)

@@ -24,6 +24,7 @@ import torch.distributed as dist
 def init_from_env(backend=None):
     """Initialise the default process group from torchrun's env (RANK, WORLD_SIZE,
     LOCAL_RANK, MASTER_ADDR/PORT).  Returns (rank, world, device)."""
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # RCCL across processes on this driver: dmabuf IPC only
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
