@@ -158,7 +158,10 @@ __global__ __launch_bounds__(512, NS == 1 ? 4 : 2) void conv2d_dblock_kernel(DBl
         if (wave < EXTRA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WIT) : "memory");                             \
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WIT - 1) : "memory");                                      \
       } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                     \
-      if (!(ABL & 16) || j == 0) __syncthreads();   /* ... for every wave, and everyone is done with the buffer piece + 2 goes into */ \
+      /* ... for every wave, and everyone is done with the buffer piece + 2 goes into.  A bare barrier behind the wave's own LDS   */ \
+      /* traffic (the `put`s of the previous layer): __syncthreads() compiles to s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier and   */ \
+      /* retired the weight piece in flight at every piece (conv2d_m16.h)                                                          */ \
+      if (!(ABL & 16) || j == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                   \
       if (piece + 2 < NPIECE && !(ABL & 2)) issue_piece(piece + 2);                                               \
       const unsigned wrow = ws_lds + (unsigned)((piece % 3) * WP * 16);                                           \
       const unsigned xrow = (XLDS) + (unsigned)((2 * k + g) * PXW * 16);                                          \

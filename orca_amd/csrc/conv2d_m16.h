@@ -236,6 +236,23 @@ __device__ __forceinline__ void m16_wait(f16x8 (&x)[NS], f16x8 (&w)[NS]) {
   else asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(x[0]), "+v"(w[0]) : "n"(N));
 }
 
+#ifndef M16_RAW_BARRIER
+#define M16_RAW_BARRIER 1
+#endif
+#if M16_RAW_BARRIER
+#define M16_BARRIER() asm volatile("s_barrier" ::: "memory")
+#else
+#define M16_BARRIER() __syncthreads()
+#endif
+#ifndef M16_XKEEP
+#define M16_XKEEP 1
+#endif
+#ifndef M16_DMA_SPREAD
+#define M16_DMA_SPREAD 0   // 1: one transfer per tap between the MFMA groups instead of a block at the top of the piece.  Measured: no gain for
+#endif                     // f16x2 (pieces stay ~3 800 cycles), 8-15 % slower single-plane: a piece waits for its DATA (see DESIGN.md section 7)
+#ifndef M16_ABL
+#define M16_ABL 0   // timing-only ablations (tools/exp): 1 no MFMA, 2 no fragment reads, 4 no epilogue loads / stores, 8 / 16 X / W DMA of the first pieces only, 32 two distinct source rows
+#endif
 #ifdef M16_STAMPS   // tools/microbench_m16.hip: s_memtime stamps of every wave of ONE workgroup [wave][16]
 __device__ unsigned long long m16_stamp_buf[8 * 16];
 #define M16_STAMP(n_) { if (blockIdx.x == M16_STAMPS && lane == 0) m16_stamp_buf[wave * 16 + (n_)] = __builtin_readcyclecounter(); }
@@ -287,6 +304,7 @@ __global__ __launch_bounds__(512, 2) void conv2d_3x3_m16_kernel(ConvM16Args a) {
     const int ys = y0 + (ky - 1) * d;
     rowok[ky] = ys >= 0 && ys < H;
     ysrc[ky] = rowok[ky] ? ys : y0;      // out-of-map rows are fetched from a valid row (uniform DMA counts) and never read
+    if ((M16_ABL & 32) && ky == 2) ysrc[ky] = y0;   // timing only: two distinct source rows instead of three
   }
   const f32x4* const xb = a.x + (long)b * a.x_bs;
   auto issue_x1 = [&](int k, int buf, int it) {      // one of the XIT transfers of chunk k's X image
@@ -360,15 +378,6 @@ __global__ __launch_bounds__(512, 2) void conv2d_3x3_m16_kernel(ConvM16Args a) {
   // (f16x2 only: one workgroup per CU there anyway; the single-plane <64> kernel sits exactly on the 128 VGPRs that two workgroups per CU allow)
   constexpr int NRU = NS == 2 ? NH * 4 : 1;
   u32x4_t ru[NRU];
-#ifndef M16_XKEEP
-#define M16_XKEEP 1
-#endif
-#ifndef M16_DMA_SPREAD
-#define M16_DMA_SPREAD 0   // 1: one transfer per tap between the MFMA groups instead of a block at the top of the piece.  Measured: no gain for
-#endif                     // f16x2 (pieces stay ~3 800 cycles), 8-15 % slower single-plane: a piece waits for its DATA (see DESIGN.md section 7)
-#ifndef M16_ABL
-#define M16_ABL 0   // timing-only ablations (tools/exp): 1 no MFMA, 2 no fragment reads, 4 no epilogue loads / stores, 8 / 16 X / W DMA of the first pieces only
-#endif
   for (int k = 0; k < a.nchunks; ++k) {
     f16x8 xk[NH == 2 && NS == 2 ? 9 : 1][NS];     // see M16_XKEEP below (f16x2 only: the single-plane kernels must stay under 128 VGPRs for two workgroups per CU)
     if constexpr (M16_ABL & 2) { _Pragma("unroll") for (int t = 0; t < (NH == 2 && NS == 2 ? 9 : 1); ++t) _Pragma("unroll") for (int s = 0; s < NS; ++s) xk[t][s] = (f16x8)(0); }
@@ -386,7 +395,11 @@ __global__ __launch_bounds__(512, 2) void conv2d_3x3_m16_kernel(ConvM16Args a) {
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WIT - 1) : "memory");
       }
       M16_STAMP(2 + 2 * i);            // this piece's transfers have landed (this wave)
-      __syncthreads();                 // ... for every wave; everyone is done with the buffers the next DMAs go into
+      // ... for every wave; everyone is done with the buffers the next DMAs go into.  A bare s_barrier: __syncthreads() is a fence, and the
+      // compiler implements it as s_waitcnt vmcnt(0) lgkmcnt(0) - which retired EVERY transfer in flight at every piece and turned the two
+      // pieces of weight lookahead (and the counted waits above) into one.  All LDS traffic of this loop is inline asm or DMA whose
+      // completion the counted waits establish, so the barrier itself is all that is needed.
+      M16_BARRIER();
       M16_STAMP(3 + 2 * i);
       if constexpr (NS == 2) {
         if (i + 1 == NP && rb && !(M16_ABL & 4)) {
