@@ -131,7 +131,7 @@ __global__ void upsample2d_m16_kernel(const float* __restrict__ y, long sy_c, lo
 // Both tiles are read along rows (16 px = 256 contiguous bytes per octet and split); the transposed partner of a pixel is taken from
 // LDS (a thread per output row reading column i of the map, 64 lines per wave instruction and 16 of those in a row, was 33 us per map).
 template <int NS, int DT>
-__global__ void final_sym_m16_kernel(FinalArgs a) {
+__global__ __launch_bounds__(256) void final_sym_m16_kernel(FinalArgs a) {
   ORCA_FINAL_LOAD_HEAD();
   __shared__ float ft[2][ORCA_MAX_TARGETS][16][17];
   const int n = a.n, b = blockIdx.y, r = threadIdx.x >> 4, c = threadIdx.x & 15;
@@ -145,16 +145,20 @@ __global__ void final_sym_m16_kernel(FinalArgs a) {
   float h1[ORCA_MAX_TARGETS], h2[ORCA_MAX_TARGETS];
 #pragma unroll
   for (int o = 0; o < ORCA_MAX_TARGETS; ++o) { h1[o] = b1s[o]; h2[o] = b1s[o]; }
-  for (int oc = 0; oc < 8; ++oc) {
-    u32x4_t uu[NS], vv[NS];
+  // all 16 x NS units of the two pixels are requested before the first is used: one memory round trip per thread instead of eight
+  u32x4_t ua[8][NS], va[8][NS];
+#pragma unroll
+  for (int oc = 0; oc < 8; ++oc)
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-      uu[s] = in1 ? cur[m16_plane(oc, s, NS, n) + (long)i1 * M16_PX + j1] : (u32x4_t)(0u);
-      vv[s] = in2 ? cur[m16_plane(oc, s, NS, n) + (long)i2 * M16_PX + j2] : (u32x4_t)(0u);
+      ua[oc][s] = in1 ? cur[m16_plane(oc, s, NS, n) + (long)i1 * M16_PX + j1] : (u32x4_t)(0u);
+      va[oc][s] = in2 ? cur[m16_plane(oc, s, NS, n) + (long)i2 * M16_PX + j2] : (u32x4_t)(0u);
     }
+#pragma unroll
+  for (int oc = 0; oc < 8; ++oc) {
     float u[8], v[8];
-    m16_unpack8<NS, DT>(uu, u);
-    m16_unpack8<NS, DT>(vv, v);
+    m16_unpack8<NS, DT>(ua[oc], u);
+    m16_unpack8<NS, DT>(va[oc], v);
 #pragma unroll
     for (int e = 0; e < 8; ++e)
 #pragma unroll
