@@ -1,5 +1,6 @@
+"""cProfile of one genomepredict_256Mb call on the MI355X (host time vs GPU time; quoted in DESIGN.md section 6)."""
 import os, sys, time, cProfile, pstats
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from orca_amd import engine, orca_models as M, orca_predict as P, synth
 dev = torch.device("cuda:0")
