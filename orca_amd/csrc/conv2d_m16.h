@@ -255,7 +255,7 @@ __device__ __forceinline__ void m16_wait(f16x8 (&x)[NS], f16x8 (&w)[NS]) {
 #define M16_DMA_SPREAD 0   // 1: one transfer per tap between the MFMA groups instead of a block at the top of the piece.  Measured: no gain for
 #endif                     // f16x2 (pieces stay ~3 800 cycles), 8-15 % slower single-plane: a piece waits for its DATA
 #ifndef M16_ABL
-#define M16_ABL 0   // timing-only ablations (tools/exp): 1 no MFMA, 2 no fragment reads, 4 no epilogue loads / stores, 8 / 16 X / W DMA of the first pieces only, 32 two distinct source rows
+#define M16_ABL 0   // timing-only ablations (tools/microbench_m16.hip, tools/time_decoder.py): 1 no MFMA, 2 no fragment reads, 4 no epilogue loads / stores, 8 / 16 X / W DMA of the first pieces only, 32 two distinct source rows
 #endif
 #ifdef M16_STAMPS   // tools/microbench_m16.hip: s_memtime stamps of every wave of ONE workgroup [wave][16]
 __device__ unsigned long long m16_stamp_buf[8 * 16];
