@@ -68,3 +68,27 @@ def test_sharded_encoder_world2_rccl(cuda):
         for k, v in r.items():
             if k not in ("rank", "world"):
                 assert v == 0.0, (k, v, r)     # same kernels on the same bins: bit-identical to the unsharded encoding
+
+
+def test_bench_two_ranks_on_one_gpu_over_gloo(cuda):
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one process per rank), with both ranks on cuda:0 and gloo as
+    the process group (ORCA_BENCH_ONE_DEVICE / ORCA_BENCH_BACKEND test hooks): the whole N > 1 control flow - replica mode with the
+    max-over-ranks clock, the 256 Mb section with bin-sharded Encoders, the all-gathers, one strand's tail per rank parity and the map
+    gather - runs on a 1-GPU box.  The sharded maps must be the single-rank ones (checksum of the four merged maps)."""
+    env = dict(os.environ, ORCA_BENCH_ONE_DEVICE="1", ORCA_BENCH_BACKEND="gloo")
+    base = [os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--sharded-steps", "1", "--no-cpu-baseline"]
+    p1 = subprocess.run([sys.executable] + base + ["--gpus", "1"], env=env, capture_output=True, text=True, timeout=900)
+    assert p1.returncode == 0, p1.stderr[-2000:]
+    one = json.loads([l for l in p1.stdout.splitlines() if l.startswith("{")][-1])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29300 + os.getpid() % 300)] + base + ["--gpus", "2"]
+    p2 = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert p2.returncode == 0, p2.stdout[-1500:] + p2.stderr[-1500:]
+    lines = [l for l in p2.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                            # ONE JSON line, from rank 0
+    two = json.loads(lines[0])
+    assert two["n_gpus"] == 2 and two["scaling"] == "weak" and two["metric"] == one["metric"]
+    s1, s2 = one["sharded_256mb"], two["sharded_256mb"]
+    assert "error" not in s2, s2
+    assert s2["n_gpus"] == 2 and s2["bins_this_rank"] == [0, 32000] and s1["bins_this_rank"] == [0, 64000]
+    assert abs(s2["maps_checksum"] - s1["maps_checksum"]) <= 1e-6 * abs(s1["maps_checksum"]), (s1["maps_checksum"], s2["maps_checksum"])
