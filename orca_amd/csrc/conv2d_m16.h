@@ -62,12 +62,13 @@ __device__ __forceinline__ void m16_unpack8(const u32x4_t (&u)[NS], float (&v)[8
 
 // ---- producers / consumers at the ends of a Decoder ---------------------------------------------------------------
 // mat[c][i][j] = x[c][i] + x[c][j] (c < 128); channels 128..128+nt-1 = distenc[t][i][j]; other channels and pad pixels 0.
+// `o0`: first channel octet produced (the Decoder only materialises octets 16, 17 = distenc + padding; octet o lands in plane o - o0).
 // grid (n rows, noct octets), block 256 (pixel j): 4 500 independent workgroups per map (one row of ALL octets per workgroup was a serial
 // chain of 18 load -> pack -> store rounds on 1 000 waves: 59 us per map).
 template <int NS, int DT>
 __global__ void outer_sum_m16_kernel(const float* __restrict__ x, long sx_c, long sx_l, const float* __restrict__ de, long sd_c, long sd_h,
-                                     long sd_w, int nt, f32x4* __restrict__ out, int n, int noct, unsigned* flag) {
-  const int j = threadIdx.x, i = blockIdx.x, o = blockIdx.y;
+                                     long sd_w, int nt, f32x4* __restrict__ out, int n, int o0, unsigned* flag) {
+  const int j = threadIdx.x, i = blockIdx.x, o = blockIdx.y + o0;
   bool ovf = false;
   float v[8];
 #pragma unroll
@@ -85,8 +86,37 @@ __global__ void outer_sum_m16_kernel(const float* __restrict__ x, long sx_c, lon
   u32x4_t u[NS];
   m16_pack8<NS, DT>(a, b, u, ovf);
 #pragma unroll
-  for (int s = 0; s < NS; ++s) reinterpret_cast<u32x4_t*>(out)[m16_plane(o, s, NS, n) + (long)i * M16_PX + j] = u[s];
+  for (int s = 0; s < NS; ++s) reinterpret_cast<u32x4_t*>(out)[m16_plane(o - o0, s, NS, n) + (long)i * M16_PX + j] = u[s];
   if (DT == 1 && ovf && flag) *flag = 1u;
+}
+
+// The separable part of the Decoder's first conv (lcombinerD.a on mat = x_i + x_j, orca_modules.py:462-465), exact fp32:
+//   tab[which][cls][pos][co] = sum_k sum_c wsep[which][cls][k][c][co] * x[c][pos + k - 1]       (taps inside [0, n) only)
+// which = 0: the row term, indexed by the pixel's row, one table per COLUMN class (0: first column, 1: interior, 2: last column - the
+// classes differ in which kx taps were summed into wsep); which = 1: the column term per ROW class.
+__global__ __launch_bounds__(256) void sep_tables_kernel(const float* __restrict__ x, long sx_c, long sx_l, const float* __restrict__ wsep,
+                                                         float* __restrict__ tab, int n) {
+  // grid (n, 6), block 256 = 64 couts x 4 groups of 32 input channels (partials reduced through LDS): 96 independent-load FMAs per thread.
+  // 15 us per map (the weights come from L2 once per position: 150 MB).  Measured alternatives: ten positions per workgroup 28 us (150
+  // workgroups of serial loads); one-wave workgroups without LDS (to run beside the other stream's conv workgroups) 22 us.
+  __shared__ float part[4][64];
+  const int pos = blockIdx.x, wc = blockIdx.y, co = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const float* w = wsep + (size_t)wc * 3 * 128 * 64;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int k = 0; k < 3; ++k) {
+    const int p = pos + k - 1;
+    if (p < 0 || p >= n) continue;
+    const float* wk = w + ((size_t)k * 128 + grp * 32) * 64 + co;
+    const float* xk = x + (long)(grp * 32) * sx_c + (long)p * sx_l;
+#pragma unroll
+    for (int c = 0; c < 32; c += 4) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc[u] = fmaf(wk[(c + u) * 64], xk[(c + u) * sx_c], acc[u]);
+    }
+  }
+  part[grp][co] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+  __syncthreads();
+  if (grp == 0) tab[((size_t)wc * n + pos) * 64 + co] = (part[0][co] + part[1][co]) + (part[2][co] + part[3][co]);
 }
 
 // bilinear / nearest x2 upsample of y [nt][n/2][n/2] into octet o0 (channels 8*o0 .. +nt-1; the rest of the octet and octet
@@ -232,6 +262,8 @@ struct ConvM16Args {
   int H, W, dil, nchunks, relu;
   int banded;
   unsigned* flag;
+  const float* tab;   // optional [2][3][H][64] fp32 added to the conv (sep_tables_kernel; 64-cout layers only)
+  long tab_bs;        // floats per map
 };
 
 template <int N, int NS>
@@ -491,6 +523,15 @@ __global__ __launch_bounds__(512, 2) void conv2d_3x3_m16_kernel(ConvM16Args a) {
   M16_STAMP(10);                       // MFMAs of the last piece issued
   const bool pxok = px < W;
   f32x4* const yb = a.y + (long)b * a.y_bs;
+  // separable-part tables: row term [column class of px][y0][co], column term [row class of y0][px][co]
+  const float* tabr = nullptr;
+  const float* tabc = nullptr;
+  if (a.tab && pxok) {
+    const float* tb = a.tab + (long)b * a.tab_bs;
+    const int xc = px == 0 ? 0 : (px == W - 1 ? 2 : 1), yc = y0 == 0 ? 0 : (y0 == H - 1 ? 2 : 1);
+    tabr = tb + ((long)xc * H + y0) * 64;
+    tabc = tb + ((long)(3 + yc) * H + px) * 64;
+  }
   float vmax = 0.f;
   if constexpr (NS == 2) {
 #pragma unroll
@@ -501,6 +542,10 @@ __global__ __launch_bounds__(512, 2) void conv2d_3x3_m16_kernel(ConvM16Args a) {
         const f32x4 bs4 = *reinterpret_cast<const f32x4*>(bias_s + h * 32 + 8 * q + 4 * g);
         f32x4 v;
         v.x = acc[h][4 * q + 0] + bs4.x; v.y = acc[h][4 * q + 1] + bs4.y; v.z = acc[h][4 * q + 2] + bs4.z; v.w = acc[h][4 * q + 3] + bs4.w;
+        if (tabr) {
+          const f32x4 tr = *reinterpret_cast<const f32x4*>(tabr + h * 32 + 8 * q + 4 * g), tc = *reinterpret_cast<const f32x4*>(tabc + h * 32 + 8 * q + 4 * g);
+          v.x += tr.x + tc.x; v.y += tr.y + tc.y; v.z += tr.z + tc.z; v.w += tr.w + tc.w;
+        }
         if (a.relu) { v.x = p16_vmax(v.x, 0.f); v.y = p16_vmax(v.y, 0.f); v.z = p16_vmax(v.z, 0.f); v.w = p16_vmax(v.w, 0.f); }
         if (rb && !(M16_ABL & 4)) {
           const u32x4_t u_ = ru[o];                                                                    // g = 0: the hi unit, g = 1: the lo unit
@@ -534,6 +579,13 @@ __global__ __launch_bounds__(512, 2) void conv2d_3x3_m16_kernel(ConvM16Args a) {
         f32x4 v0, v1;
         v0.x = acc[h][8 * qp + 0] + b0.x; v0.y = acc[h][8 * qp + 1] + b0.y; v0.z = acc[h][8 * qp + 2] + b0.z; v0.w = acc[h][8 * qp + 3] + b0.w;
         v1.x = acc[h][8 * qp + 4] + b1.x; v1.y = acc[h][8 * qp + 5] + b1.y; v1.z = acc[h][8 * qp + 6] + b1.z; v1.w = acc[h][8 * qp + 7] + b1.w;
+        if (tabr) {
+          const int co_ = h * 32 + 16 * qp + 4 * g;
+          const f32x4 r0 = *reinterpret_cast<const f32x4*>(tabr + co_), c0 = *reinterpret_cast<const f32x4*>(tabc + co_);
+          const f32x4 r1 = *reinterpret_cast<const f32x4*>(tabr + co_ + 8), c1 = *reinterpret_cast<const f32x4*>(tabc + co_ + 8);
+          v0.x += r0.x + c0.x; v0.y += r0.y + c0.y; v0.z += r0.z + c0.z; v0.w += r0.w + c0.w;
+          v1.x += r1.x + c1.x; v1.y += r1.y + c1.y; v1.z += r1.z + c1.z; v1.w += r1.w + c1.w;
+        }
         if (a.relu) {
           v0.x = p16_vmax(v0.x, 0.f); v0.y = p16_vmax(v0.y, 0.f); v0.z = p16_vmax(v0.z, 0.f); v0.w = p16_vmax(v0.w, 0.f);
           v1.x = p16_vmax(v1.x, 0.f); v1.y = p16_vmax(v1.y, 0.f); v1.z = p16_vmax(v1.z, 0.f); v1.w = p16_vmax(v1.w, 0.f);

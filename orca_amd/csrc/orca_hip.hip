@@ -136,6 +136,7 @@ struct orca_net {
   float* d_first_tab = nullptr; // same as a per-base-code table [9 taps][6 codes][64] (fused first layer of conv1d_k9_p16_kernel)
   int upsample_mode = ORCA_UPSAMPLE_BILINEAR;
   int num_2d = 1;               // Decoder / Decoder_1m: target maps per prediction (orca_leukemia.py:512-990); 1 = the Orca models
+  float* d_sep = nullptr;       // Decoder: tap-summed weights of lcombinerD.a for the separable part of the first conv (sep_tables_kernel)
   std::vector<ConvLayer> convs;
 };
 
@@ -374,15 +375,20 @@ static int launch_conv2d(orca_ctx* ctx, const ConvLayer& L, const float* x, long
 
 // dilated 3x3 conv on M16 maps (conv2d_m16.h); maps are unit arrays [octets][NS][n][256]; strides in units
 // mode: 0 = f16x2 (two fp16 planes, 3 products), 1 = bf16 (one plane, 1 product), 2 = f16 (one fp16 plane, 1 product)
+// chunk0 / nchunks_: a sub-range of the layer's 16-channel input chunks (x then starts at channel octet 0 of THAT range); tab: per-map
+// tables [2][3][n][64] added in the epilogue (row term by column class, column term by row class - see sep_tables_kernel)
 static int launch_conv2d_m16(orca_ctx* ctx, const ConvLayer& L, const f32x4* x, long x_bs, int x_oct, f32x4* y, long y_bs, int y_oct,
-                             const f32x4* r, long r_bs, int B, int n, int relu, int mode) {
+                             const f32x4* r, long r_bs, int B, int n, int relu, int mode, int chunk0 = 0, int nchunks_ = 0,
+                             const float* tab = nullptr, long tab_bs = 0) {
   const bool bf16 = mode == 1;
   if (L.ksize != 3 || !L.d_wf16 || !L.d_wb16p) return fail(ORCA_EINVAL, "launch_conv2d_m16 on a layer without a 16-bit pack");
   if (!bf16 && !L.f16_ok) return fail(ORCA_EINVAL, "layer weights exceed the fp16 range");
   if (L.dil > 8) return fail(ORCA_EINVAL, "conv2d_3x3_m16_kernel handles dilations 1-8 (got %d); larger ones run as fused blocks", L.dil);
   ConvM16Args a;
   a.x = x; a.w = bf16 ? L.d_wb16p : L.d_wf16; a.bias = L.d_bias; a.y = y; a.r = r; a.x_bs = x_bs; a.y_bs = y_bs; a.r_bs = r_bs;
-  a.H = n; a.W = n; a.dil = L.dil; a.nchunks = (L.cin + 15) / 16; a.relu = relu; a.flag = ctx->d_flag;
+  a.H = n; a.W = n; a.dil = L.dil; a.nchunks = nchunks_ > 0 ? nchunks_ : (L.cin + 15) / 16; a.relu = relu; a.flag = ctx->d_flag;
+  a.tab = tab; a.tab_bs = tab_bs;
+  if (chunk0 > 0) a.w = static_cast<const char*>(a.w) + (size_t)chunk0 * (bf16 ? 1 : 2) * 9 * 2 * L.cout * 8 * 2;   // pack [chunk][splits][9][2][cout][8] halves
   if (a.nchunks * 2 > x_oct) return fail(ORCA_EINVAL, "conv2d_m16: input map has %d channel octets, layer needs %d", x_oct, a.nchunks * 2);
   if (L.cout / 8 > y_oct) return fail(ORCA_EINVAL, "conv2d_m16: output map narrower than the layer");
   static const bool no_banded = getenv("ORCA_NO_BANDED") != nullptr;   // A/B switch
@@ -814,6 +820,28 @@ extern "C" int orca_net_create(orca_ctx* ctx, int kind, const orca_conv_desc* co
     int rc = make_layer(convs[i], &net->convs[i]);
     if (rc != ORCA_OK) { orca_net_free(net); return rc; }
   }
+  if (kind == ORCA_NET_DECODER) {
+    // lcombinerD.a on mat[c][i][j] = x[c][i] + x[c][j] (c < 128) is separable:
+    //   sum_{ky,kx valid} w[ky][kx] (x[i+ky-1] + x[j+kx-1]) = sum_ky (sum_{kx valid at j} w[ky][kx]) x[i+ky-1] + sum_kx (sum_{ky valid at i} w[ky][kx]) x[j+kx-1]
+    // - two 3-tap 1-D convs of the encoding per border class (first / interior / last column resp. row).  wsep[which][class][k][c][co]:
+    // which 0 = row term (k = ky, summed over the kx valid in column class), 1 = column term (k = kx, summed over the ky valid in row class).
+    const orca_conv_desc& d0 = convs[0];
+    std::vector<float> ws((size_t)2 * 3 * 3 * 128 * 64);
+    for (int which = 0; which < 2; ++which)
+      for (int cls = 0; cls < 3; ++cls)
+        for (int k = 0; k < 3; ++k)
+          for (int c = 0; c < 128; ++c)
+            for (int co = 0; co < 64; ++co) {
+              double acc = 0.0;
+              for (int o = (cls == 0 ? 1 : 0); o <= (cls == 2 ? 1 : 2); ++o) {   // the other axis' taps that stay inside the map
+                const int ky = which == 0 ? k : o, kx = which == 0 ? o : k;
+                acc += d0.weight_host[(((size_t)co * d0.cin + c) * 3 + ky) * 3 + kx];
+              }
+              ws[((((size_t)which * 3 + cls) * 3 + k) * 128 + c) * 64 + co] = (float)acc;
+            }
+    int rc = upload(ws, &net->d_sep);
+    if (rc != ORCA_OK) { orca_net_free(net); return rc; }
+  }
   if (kind == ORCA_NET_ENCODER) {
     std::vector<float> w0(convs[0].weight_host, convs[0].weight_host + 64 * 4 * 9);
     int rc = upload(w0, &net->d_first_w);
@@ -876,6 +904,7 @@ extern "C" int orca_net_free(orca_net* net) {
   if (net->d_first_w) (void)hipFree(net->d_first_w);
   if (net->d_first_w16) (void)hipFree(net->d_first_w16);
   if (net->d_first_tab) (void)hipFree(net->d_first_tab);
+  if (net->d_sep) (void)hipFree(net->d_sep);
   delete net;
   return ORCA_OK;
 }
@@ -1271,12 +1300,16 @@ static int decoder_m16(orca_ctx* ctx, orca_net* net, const RowSrc& x, long sx_c,
   const int nt2 = net->num_2d;
   const bool is1m = net->kind == ORCA_NET_DECODER_1M, bf16 = DT == 0;
   const int mode = DT == 0 ? 1 : (NS == 1 ? 2 : 0);
-  const int oIN = is1m ? 16 : 18, oA = 10;                  // channel octets: 128 / 144 (128 + distenc, padded), 80 (64 + coarse prediction)
+  // channel octets: Decoder_1m 128 channels of outer sum; Decoder: ONLY the distenc chunk (16 channels) - the 128 outer-sum channels of
+  // lcombinerD.a never exist as a map (separable, see orca_net_create); A: 80 (64 + coarse prediction)
+  const int oIN = is1m ? 16 : 2, oA = 10;
+  const size_t tabsz = (size_t)2 * 3 * n * 64;               // floats per map
   const size_t upo = (size_t)NS * n * ORCA_LDW;              // units per octet and map
   const size_t szIN = upo * oIN, szA = upo * oA, sz64 = upo * 8, sz32 = upo * 4;   // units
-  const size_t need = ru256(B * szIN * 16) + ru256(B * szA * 16) + 3 * ru256(B * sz64 * 16) + ru256(B * sz32 * 16);
+  const size_t need = ru256(B * szIN * 16) + ru256(B * szA * 16) + 3 * ru256(B * sz64 * 16) + ru256(B * sz32 * 16) + ru256(B * tabsz * 4);
   ORCA_TRY(ws_ensure(ctx, need));
   auto take = [&](size_t units) { return reinterpret_cast<f32x4*>(ws_take(ctx, units * 4)); };
+  float* const TAB0 = is1m ? nullptr : ws_take(ctx, B * tabsz);
   f32x4* const IN0 = take(B * szIN);
   f32x4* const A0 = take(B * szA);
   f32x4* const Bf0 = take(B * sz64);
@@ -1292,10 +1325,15 @@ static int decoder_m16(orca_ctx* ctx, orca_net* net, const RowSrc& x, long sx_c,
     f32x4* Df = Df0 + b0 * sz64;
     f32x4* T = T0 + b0 * sz32;
     hipStream_t s = ctx->stream;
+    float* TAB = is1m ? nullptr : TAB0 + b0 * tabsz;
     for (int b = 0; b < nb; ++b) {
       hipLaunchKernelGGL((outer_sum_m16_kernel<NS, DT>), dim3((unsigned)n, (unsigned)oIN), dim3(ORCA_LDW), 0, s, x.at(b0 + b), sx_c, sx_l, de.at(b0 + b), sd_c, sd_h,
-                         sd_w, nt2, IN + b * szIN, n, oIN, ctx->d_flag);
+                         sd_w, nt2, IN + b * szIN, n, is1m ? 0 : 16, ctx->d_flag);
       LAUNCHCHECK("outer_sum_m16_kernel");
+      if (!is1m) {
+        hipLaunchKernelGGL(sep_tables_kernel, dim3((unsigned)n, 6u), dim3(256), 0, s, x.at(b0 + b), sx_c, sx_l, net->d_sep, TAB + b * tabsz, n);
+        LAUNCHCHECK("sep_tables_kernel");
+      }
     }
     const ConvLayer* L = net->convs.data();
     const ConvLayer* pairs;
@@ -1303,7 +1341,8 @@ static int decoder_m16(orca_ctx* ctx, orca_net* net, const RowSrc& x, long sx_c,
 #define C2(layer, src, sbs, so, dst, dbs, dso, res, rbs, relu) \
   ORCA_TRY(launch_conv2d_m16(ctx, layer, src, sbs, so, dst, dbs, dso, res, rbs, nb, n, relu, mode))
     if (!is1m) {
-      C2(L[0], IN, szIN, oIN, Bf, sz64, 8, nullptr, 0, 0);
+      // lcombinerD.a = (MFMA conv over the distenc chunk) + (separable outer-sum part from the tables, added in the epilogue)
+      ORCA_TRY(launch_conv2d_m16(ctx, L[0], IN, szIN, oIN, Bf, sz64, 8, nullptr, 0, nb, n, 0, mode, 8, 1, TAB, (long)tabsz));
       C2(L[1], Bf, sz64, 8, Cf, sz64, 8, nullptr, 0, 0);
       C2(L[2], Cf, sz64, 8, Bf, sz64, 8, nullptr, 0, 1);
       C2(L[3], Bf, sz64, 8, A, szA, oA, Cf, sz64, 1);           // A[octets 0..7] = combinerD(.) + .
