@@ -501,6 +501,17 @@ static int launch_p16_zero_pads(orca_ctx* ctx, float* base, int C, long n_valid,
   return ORCA_OK;
 }
 
+// MaxPool1d(5) between planar stages: x [C] planes of n_in positions -> y of n_in / 5 (conv2d_m16.h: p16_maxpool_kernel)
+static int launch_p16_pool5(orca_ctx* ctx, const float* x, float* y, int C, long n_in, int fmt) {
+  const long n_out = n_in / 5;
+  if (n_out <= 0) return ORCA_OK;
+  dim3 grid((unsigned)((n_out + 255) / 256), (unsigned)(C / 8));
+  if (fmt == 1) hipLaunchKernelGGL((p16_maxpool_kernel<5, 1, 0>), grid, dim3(256), 0, ctx->stream, reinterpret_cast<const f32x4*>(x), p16_plen(n_in), reinterpret_cast<f32x4*>(y), p16_plen(n_out), n_out);
+  else hipLaunchKernelGGL((p16_maxpool_kernel<5, 2, 1>), grid, dim3(256), 0, ctx->stream, reinterpret_cast<const f32x4*>(x), p16_plen(n_in), reinterpret_cast<f32x4*>(y), p16_plen(n_out), n_out);
+  LAUNCHCHECK("p16_maxpool_kernel");
+  return ORCA_OK;
+}
+
 template <int CT, int MW, int NW, int WM, int OM, bool R1, int FMT = 0>
 static void launch_p16_k(hipStream_t s, ConvP16Args a) {
   constexpr int MT = WM * MW * 32;
@@ -1004,9 +1015,17 @@ static int encoder_chunk(orca_ctx* ctx, orca_net* net, const SeqSource& src, lon
       if (!fuse1) ORCA_TRY(launch_p16_zero_pads(ctx, buf[1], 64, n1, fmt));
       int T = 1, LO = 2, S = 0;   // buffer roles: T holds the current input
       n = n1;
-      for (st0 = 0; st0 < 3; ++st0) {
+      static const bool no_st4 = getenv("ORCA_NO_P16_STAGE4") != nullptr;   // A/B switch: stage 4 on the register-staged kernel again
+      const int nplanar = no_st4 ? 3 : 4;                                   // stages on the planar kernels (pools 4, 4 fused; 5 as a planar pass)
+      for (st0 = 0; st0 < nplanar; ++st0) {
         const ConvLayer* Ls = L + 4 * st0;
         const int C = Ls[3].cout;
+        if (kEncPools[st0] == 5) {   // MaxPool1d(5) in front of this stage: previous output buf[S] (n positions) -> buf[LO] -> becomes S
+          ORCA_TRY(launch_p16_pool5(ctx, buf[S], buf[LO], Ls[0].cin, n, fmt));
+          n /= 5;
+          ORCA_TRY(launch_p16_zero_pads(ctx, buf[LO], Ls[0].cin, n, fmt));
+          const int t_ = S; S = LO; LO = t_;
+        }
         if (st0 > 0) {  // first conv of the stage: previous (pooled) output in buf[S] -> buf[T]
           ORCA_TRY(launch_conv1d_p16(ctx, Ls[0], buf[S], buf[T], nullptr, n, 0, 0, nullptr, fmt));
           ORCA_TRY(launch_p16_zero_pads(ctx, buf[T], C, n, fmt));
@@ -1015,10 +1034,13 @@ static int encoder_chunk(orca_ctx* ctx, orca_net* net, const SeqSource& src, lon
         ORCA_TRY(launch_p16_zero_pads(ctx, buf[LO], C, n, fmt));
         ORCA_TRY(launch_conv1d_p16(ctx, Ls[2], buf[LO], buf[T], nullptr, n, 1, 0, nullptr, fmt));
         ORCA_TRY(launch_p16_zero_pads(ctx, buf[T], C, n, fmt));
-        if (st0 < 2) {
+        if (st0 + 1 < nplanar && kEncPools[st0 + 1] == 4) {
           ORCA_TRY(launch_conv1d_p16(ctx, Ls[3], buf[T], buf[S], buf[LO], n, 1, 1, nullptr, fmt));          // relu(.)+lout, MaxPool1d(4)
           ORCA_TRY(launch_p16_zero_pads(ctx, buf[S], C, n / 4, fmt));
           n /= 4;
+        } else if (st0 + 1 < nplanar) {
+          ORCA_TRY(launch_conv1d_p16(ctx, Ls[3], buf[T], buf[S], buf[LO], n, 1, 0, nullptr, fmt));          // relu(.)+lout, planar; pooled by the next stage
+          ORCA_TRY(launch_p16_zero_pads(ctx, buf[S], C, n, fmt));
         } else {
           ORCA_TRY(launch_conv1d_p16(ctx, Ls[3], buf[T], buf[S], buf[LO], n, 1, 2, nullptr, fmt));          // fp32 channel-last hand-over
         }
