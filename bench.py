@@ -268,11 +268,13 @@ def main():
 
     # ---- dominant kernel: per-instantiation HIP-event timings collected in the timed region
     groups = {}
-    for cout, cin, tile, batch, n, ms in recs:
-        g = groups.setdefault((cout, cin, tile), {"ms": 0.0, "launches": 0, "flop": 0.0})
+    for cout, cin, tile, batch, n, ms, ksize in recs:
+        g = groups.setdefault((cout, cin, tile, ksize), {"ms": 0.0, "launches": 0, "flop": 0.0})
         g["ms"] += ms
         g["launches"] += 1
-        g["flop"] += 2.0 * 9 * cin * cout * n * batch
+        # a 17-tap launch is a composed linear pair Conv(cin->cout) - BN - Conv(cout->cout) - BN (orca_modules.py:811-816):
+        # its ALGORITHMIC work is the pair's (SURVEY 8d counts the reference's convolutions)
+        g["flop"] += 2.0 * 9 * (cin * cout + (cout * cout if ksize == 17 else 0)) * n * batch
     # kernel instantiation = (cout, arithmetic); records of the 16-bit split kernels carry tile = -precision
     PREC = {0: ("f32", "conv1d_k9_kernel", PEAK_F32_MFMA_TFLOPS, 1), 1: ("bf16", "conv1d_k9_bf16s_kernel", PEAK_16BIT_MFMA_TFLOPS, 1),
             2: ("bf16x2", "conv1d_k9_bf16s_kernel", PEAK_16BIT_MFMA_TFLOPS, 3), 3: ("bf16x3", "conv1d_k9_bf16s_kernel", PEAK_16BIT_MFMA_TFLOPS, 6),
@@ -280,9 +282,11 @@ def main():
             5: ("f16x2", "conv1d_k9_p16_kernel", PEAK_16BIT_MFMA_TFLOPS, 3), 6: ("bf16", "conv1d_k9_p16_kernel", PEAK_16BIT_MFMA_TFLOPS, 1),
             7: ("f16x2", "conv1d_k9_ws_kernel", PEAK_16BIT_MFMA_TFLOPS, 3), 8: ("bf16", "conv1d_k9_ws_kernel", PEAK_16BIT_MFMA_TFLOPS, 1)}
     inst = {}
-    for (cout, cin, tile), g in groups.items():
+    for (cout, cin, tile, ksize), g in groups.items():
         prec = -tile if tile < 0 else 0
         pname, kname, peak, nprod = PREC[prec]
+        if ksize == 17:
+            kname = "conv1d_first_mfma_p16_kernel[17 taps: composed lconv1]" if cin == 4 else kname + "[17 taps: composed pair]"
         key = f"{kname}<cout={cout},{pname}>" if prec else f"{kname}<cout={cout},kc={4 if cin == 4 else 8},tile={tile}>"
         d = inst.setdefault(key, {"ms": 0.0, "launches": 0, "flop": 0.0, "peak": peak, "nprod": nprod, "arith": pname})
         for k in ("ms", "launches", "flop"):

@@ -103,7 +103,7 @@ typedef struct orca_kernel_time {
   int32_t cout, cin, tile, batch;
   int64_t n;      /* positions per batch row            */
   float ms;       /* elapsed between the two HIP events */
-  int32_t pad_;
+  int32_t ksize;  /* taps of the launch: 9, or 17 = a composed linear pair (its algorithmic FLOPs are the pair's) */
 } orca_kernel_time;
 int orca_ctx_set_timing(orca_ctx* ctx, int enable);
 int orca_ctx_get_timing(orca_ctx* ctx, orca_kernel_time* out, int max, int* n);

@@ -27,7 +27,7 @@ class ConvDesc(ctypes.Structure):
 
 class KernelTime(ctypes.Structure):
     _fields_ = [("cout", c_int32), ("cin", c_int32), ("tile", c_int32), ("batch", c_int32), ("n", c_int64),
-                ("ms", ctypes.c_float), ("pad_", c_int32)]
+                ("ms", ctypes.c_float), ("ksize", c_int32)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/orca_hip.h

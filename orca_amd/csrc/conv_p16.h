@@ -3,7 +3,7 @@
 // P16 = planar 2-way-split fp16 storage of an fp32 activation tensor [n][C]:
 //     value(pos, ch) = hi + lo,   hi = fp16(v), lo = fp16(v - hi)            (22 significant bits)
 //     plane (p = ch/8, s in {hi,lo}) is a contiguous array of 16-byte units, one unit per position holding the
-//     8 channels 8p..8p+7;  unit(p, s, pos) at  base + ((2p + s) * PLEN + 4 + pos) * 16 bytes.
+//     8 channels 8p..8p+7;  unit(p, s, pos) at  base + ((2p + s) * PLEN + P16_GUARD + pos) * 16 bytes.
 //   Same 4 bytes per element as fp32, but it IS the MFMA operand image: a conv's input tile is a set of
 //   contiguous 16-byte runs that `global_load_lds` (LDS-DMA) drops straight into the LDS operand image - no
 //   staging registers, no VALU conversion, no ds_write pass.  Each plane carries 4 guard units on the left and
@@ -21,7 +21,8 @@
 
 #include "conv_bf16s.h"
 
-#define P16_GUARD 4
+#define P16_GUARD 8   // zero guard units on the left of every plane (>= 8 + 16 on the right): covers the 17-tap composed convs
+#define P16_HALO 4    // half width of a k9 conv: image column i of a tile at m0 is position m0 + i - P16_HALO
 
 struct ConvP16Args {
   const f32x4* x;      // P16 input, cin channels
@@ -36,6 +37,8 @@ struct ConvP16Args {
   int cout;            // total output channels (multiple of CT)
   int relu;
   int out_mode;        // 0: P16 same length; 1: P16 with MaxPool1d(4) fused (length n/4); 2: fp32 [n][cout]
+  int k17;             // 17-tap conv (a composed linear pair, see orca_hip.hip: compose_pair) run as 2 * cin/16 k9 steps: step 2c + h
+                       // covers taps 9h .. 9h+8 (tap 17 has zero weights) on the input shifted by 9h - 4 positions
   unsigned* flag;      // raised when a value written to P16 leaves the fp16 range
   unsigned long long* stamps;   // micro-benchmark only (ABL & 128): s_memtime stamps of workgroup 0 / wave 0
   // fused first layer (template flag F1): x is not read; the input tiles are PRODUCED from the packed bases
@@ -278,7 +281,7 @@ __global__ __launch_bounds__(WM * 64, WM / 4) void conv1d_k9_p16_kernel(ConvP16A
       const unsigned code_ = (unsigned)((t_ < 4 ? lo_ >> (8 * t_) : hi_ >> (8 * (t_ - 4))) & 0xff);                \
       f1_off[t_] = f1_tab_lds + (unsigned)(((t_ * 4 + (kc_)) * 6) * 64) + code_ * 64;                              \
     }                                                                                                              \
-    const long p_ = (m0_) + ii_ - P16_GUARD;                                                                       \
+    const long p_ = (m0_) + ii_ - P16_HALO;                                                                       \
     f1_in = p_ >= 0 && p_ < a.n;                     /* else: this conv's own zero padding / ragged tail */         \
   }
 #define P16_F1_QUAD(i_, quad_, kc_, buf_)                                                                          \
@@ -362,7 +365,9 @@ __global__ __launch_bounds__(WM * 64, WM / 4) void conv1d_k9_p16_kernel(ConvP16A
   const f32x4 *xsrc = nullptr, *wsrc = nullptr;            // uniform sources of the (tile, chunk) being fetched
 #define P16_SRC(cb, pos, c)                                                            \
   {                                                                                    \
-    xsrc = a.x + (long)(c) * 4 * a.x_plen + (pos) * MT;                                \
+    const int cx_ = a.k17 ? ((c) >> 1) : (c);                                          \
+    const int xo_ = a.k17 ? (((c) & 1) ? 9 : 0) : (P16_GUARD - P16_HALO);              \
+    xsrc = a.x + (long)cx_ * 4 * a.x_plen + (pos) * MT + xo_;                          \
     wsrc = a.w + (long)(c) * wchunk + (cb) * CT;                                       \
   }
 #define P16_DMA_ONE(it, buf) \
@@ -770,10 +775,17 @@ struct FirstMfmaArgs {
 
 // ABL (tools/microbench_first.hip only): 1 = no MFMA, 16 = no stores, 32 = input not re-fetched per tile
 // FMT = 1: the output is B16 (one bf16 plane per 8 channels) instead of P16; the arithmetic is unchanged.
-template <int ABL = 0, int FMT = 0>
+// NTAP = 9: the first layer alone (lconv1.a).  NTAP = 17: the COMPOSED linear pair lconv1 = Conv(4,64,k9)-BN-Conv(64,64,k9)-BN
+//   (orca_modules.py:811-816 has no nonlinearity between the two) as ONE 17-tap conv from the bases, K = 68 -> 80: the
+//   64 -> 64 launch at full resolution that used to follow the first layer is gone.  The 4 positions next to each end of
+//   the chunk are redone by lconv_edge_fix_kernel (the intermediate is zero-padded there, which a single conv cannot express).
+//   With packed input the X operand is exactly representable in fp16 (0, 0.25, 1): its lo plane is zero and the lo*hi product is skipped.
+template <int ABL = 0, int FMT = 0, int NTAP = 9>
 __global__ __launch_bounds__(256, 2) void conv1d_first_mfma_p16_kernel(FirstMfmaArgs a) {
-  constexpr int MT = 256, WIN = MT + 12;          // positions m0-4 .. m0+MT+7 (9-tap window + k padding overrun)
-  constexpr int WU = 2 * 3 * 2 * 64;              // 768 units
+  constexpr int H = (NTAP - 1) / 2;               // conv half width
+  constexpr int KS = (4 * NTAP + 15) / 16;        // k16 steps (K = 4 NTAP padded; the pad weights are zero)
+  constexpr int MT = 256, WIN = MT + 4 * KS;      // positions m0-H .. (9-tap window + k padding overrun)
+  constexpr int WU = 2 * KS * 2 * 64;             // weight units
   __shared__ f32x4 wsm[WU];
   __shared__ u32x2 xsm[2][WIN];                   // [split][position] -> 4 halves (the 4 channels)
   __shared__ float bias_s[64];
@@ -785,6 +797,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_first_mfma_p16_kernel(FirstMfma
   if (tid < 64) bias_s[tid] = a.bias[tid];
   bool overflow = false;
   float vmax = 0.f;
+  const bool exact_x = a.codes != nullptr;        // uniform
 
   f32x4 xr[2];
   auto fetch = [&](long p) -> f32x4 {
@@ -798,7 +811,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_first_mfma_p16_kernel(FirstMfma
     return v;
   };
   auto load_win = [&](long t, f32x4& r0, f32x4& r1) {
-    const long p0 = t * MT - 4 + tid;
+    const long p0 = t * MT - H + tid;
     r0 = fetch(p0);
     r1 = (tid < WIN - 256) ? fetch(p0 + 256) : (f32x4)(0.f);
   };
@@ -829,7 +842,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_first_mfma_p16_kernel(FirstMfma
         for (int i = 0; i < 2; ++i) { acc[i][j][4 * q + 0] = b_.x; acc[i][j][4 * q + 1] = b_.y; acc[i][j][4 * q + 2] = b_.z; acc[i][j][4 * q + 3] = b_.w; }
       }
 #pragma unroll
-    for (int kk = 0; kk < 3; ++kk) {
+    for (int kk = 0; kk < KS; ++kk) {
       f16x8 xv[2][2], wv[2][2];
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
@@ -841,11 +854,12 @@ __global__ __launch_bounds__(256, 2) void conv1d_first_mfma_p16_kernel(FirstMfma
           xv[s][i] = __builtin_bit_cast(f16x8, q);
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) wv[s][j] = __builtin_bit_cast(f16x8, wsm[((s * 3 + kk) * 2 + g) * 64 + j * 32 + l31]);
+        for (int j = 0; j < 2; ++j) wv[s][j] = __builtin_bit_cast(f16x8, wsm[((s * KS + kk) * 2 + g) * 64 + j * 32 + l31]);
       }
 #pragma unroll
       for (int p = 0; p < 3; ++p) {
         constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
+        if (p == 0 && exact_x) continue;   // x lo plane is all zero
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -984,4 +998,81 @@ __global__ void p16_to_nlc_kernel(const f32x4* __restrict__ x, float* __restrict
   const int c4 = (int)(idx - pos * c4n);
   *reinterpret_cast<f32x4*>(y + pos * C + 4 * c4) =
       p16_load4(reinterpret_cast<const char*>(x) + (long)(c4 >> 1) * 2 * plen * 16 + (P16_GUARD + pos) * 16 + (c4 & 1) * 8, plen * 16);
+}
+
+// ---- composed linear pairs: exact ends -------------------------------------------------------------------------------
+// lconv_i = [MaxPool] Conv k9 - BN - Conv k9 - BN has no nonlinearity (orca_modules.py:811-816, 829-835, 846-852), so the
+// library runs it as ONE 17-tap conv with weights composed on the host in fp64 (orca_hip.hip: compose_pair).  The single
+// conv differs from the pair in the 4 outputs next to each end of the chunk: PyTorch zero-pads the INTERMEDIATE there,
+// while the composed conv sees the intermediate's virtual values b1 + (partial window).  This kernel recomputes those
+// 8 positions with the two-step formula in fp32 and overwrites them; one workgroup per position.  (Ends that are halo
+// seams of a longer sequence are discarded by the caller anyway; ends of the true sequence are what this is for.)
+struct EdgeFixArgs {
+  int in_mode;                 // 0: float rows (x, sc, sl; 4 channels)  1: base codes (4 channels)  2: P16 planes  3: B16 planes
+  const float* x; long sc, sl;
+  const unsigned char* codes; long codes_L, codes_off; int reverse;
+  const f32x4* xp; long x_plen;
+  long n;
+  int cin, cmid, cout;
+  const float* w1; const float* b1; int kc1;   // fp32 pack [cin/kc1][9][kc1][cmid]  (make_layer)
+  const float* w2; const float* b2; int kc2;   // fp32 pack [cmid/kc2][9][kc2][cout]
+  f32x4* y; long y_plen; int out_fmt;          // 0: P16, 1: B16
+};
+
+__global__ __launch_bounds__(256) void lconv_edge_fix_kernel(EdgeFixArgs a) {
+  __shared__ float xs[17][128];
+  __shared__ float mid[9][128];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const long p = b < 4 ? b : a.n - 8 + b;
+  if (p < 0 || p >= a.n || (b >= 4 && p < 4)) return;     // short chunks: every position once
+  for (int idx = tid; idx < 17 * a.cin; idx += 256) {
+    const int j = idx / a.cin, ci = idx - j * a.cin;
+    const long pos = p - 8 + j;
+    float v = 0.f;
+    if (pos >= 0 && pos < a.n) {
+      if (a.in_mode == 0) v = a.x[pos * a.sl + ci * a.sc];
+      else if (a.in_mode == 1) {
+        const long P = a.codes_off + pos;
+        int c = a.reverse ? a.codes[a.codes_L - 1 - P] : a.codes[P];
+        if (a.reverse && c < 4) c = 3 - c;
+        v = c == 4 ? 0.25f : (c == ci ? 1.f : 0.f);
+      } else if (a.in_mode == 2) {
+        const _Float16* u = reinterpret_cast<const _Float16*>(a.xp + (long)(ci >> 3) * 2 * a.x_plen + P16_GUARD + pos);
+        const _Float16* l = reinterpret_cast<const _Float16*>(a.xp + ((long)(ci >> 3) * 2 + 1) * a.x_plen + P16_GUARD + pos);
+        v = (float)u[ci & 7] + (float)l[ci & 7];
+      } else {
+        const unsigned short* u = reinterpret_cast<const unsigned short*>(a.xp + (long)(ci >> 3) * a.x_plen + P16_GUARD + pos);
+        v = __builtin_bit_cast(float, (unsigned)u[ci & 7] << 16);
+      }
+    }
+    xs[j][ci] = v;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < 9 * a.cmid; idx += 256) {
+    const int jq = idx / a.cmid, m = idx - jq * a.cmid;
+    const long q = p - 4 + jq;
+    float acc = 0.f;
+    if (q >= 0 && q < a.n) {
+      acc = a.b1[m];
+      for (int t = 0; t < 9; ++t)
+        for (int ci = 0; ci < a.cin; ++ci)
+          acc = fmaf(a.w1[(((long)(ci / a.kc1) * 9 + t) * a.kc1 + ci % a.kc1) * a.cmid + m], xs[jq + t][ci], acc);
+    }
+    mid[jq][m] = acc;
+  }
+  __syncthreads();
+  for (int co = tid; co < a.cout; co += 256) {
+    float acc = a.b2[co];
+    for (int t = 0; t < 9; ++t)
+      for (int m = 0; m < a.cmid; ++m)
+        acc = fmaf(a.w2[(((long)(m / a.kc2) * 9 + t) * a.kc2 + m % a.kc2) * a.cout + co], mid[t][m], acc);
+    if (a.out_fmt == 0) {
+      const _Float16 h = (_Float16)acc;
+      const _Float16 l = (_Float16)(acc - (float)h);
+      reinterpret_cast<_Float16*>(a.y + (long)(co >> 3) * 2 * a.y_plen + P16_GUARD + p)[co & 7] = h;
+      reinterpret_cast<_Float16*>(a.y + ((long)(co >> 3) * 2 + 1) * a.y_plen + P16_GUARD + p)[co & 7] = l;
+    } else {
+      reinterpret_cast<unsigned short*>(a.y + (long)(co >> 3) * a.y_plen + P16_GUARD + p)[co & 7] = (unsigned short)(cvt_pk_bf16(acc, 0.f) & 0xffffu);
+    }
+  }
 }

@@ -80,7 +80,7 @@ __global__ __launch_bounds__(512, 2) void conv1d_k9_ws_kernel(ConvP16Args a) {
     xrel[p] = (int)((FMT == 1 ? (s * 2 + gg) : (gg * 2 + s)) * a.x_plen) + col;
   }
   const f32x4* xsrc = nullptr;
-#define WS_SRC(t, c) { xsrc = a.x + (long)(c) * 4 * a.x_plen + (t) * MTW; }
+#define WS_SRC(t, c) { xsrc = a.x + (long)(c) * 4 * a.x_plen + (t) * MTW + (P16_GUARD - P16_HALO); }
 #define WS_DMA_ONE(p, slot) if (act[p]) p16_glds16(xsrc + xrel[p], ring + (slot) * SLOT + (p) * 64);
 
   f32x16 acc[MW][NW];

@@ -137,6 +137,11 @@ struct orca_net {
   int upsample_mode = ORCA_UPSAMPLE_BILINEAR;
   int num_2d = 1;               // Decoder / Decoder_1m: target maps per prediction (orca_leukemia.py:512-990); 1 = the Orca models
   float* d_sep = nullptr;       // Decoder: tap-summed weights of lcombinerD.a for the separable part of the first conv (sep_tables_kernel)
+  // Encoder: composed linear pairs (compose_pair).  lconv1 as ONE 17-tap first layer (K = 68 -> 80 fp16 split pack + bias),
+  // lconv2 / lconv3 as 17-tap planar convs (comp[1], comp[2]; ksize 17)
+  void* d_l1_w16 = nullptr;
+  float* d_l1_bias = nullptr;
+  ConvLayer comp[3];
   std::vector<ConvLayer> convs;
 };
 
@@ -303,6 +308,77 @@ static int make_layer(const orca_conv_desc& d, ConvLayer* out) {
   return ORCA_OK;
 }
 
+// A linear pair Conv(k9, W1, b1) -> Conv(k9, W2, b2) (BatchNorms folded; no nonlinearity in between: the Encoder's lconv_i,
+// orca_modules.py:811-816, 829-835, 846-852) is ONE affine 17-tap conv:
+//   out[p] = b2 + sum_t2 W2[t2] (b1 + sum_t1 W1[t1] x[p + t1 + t2 - 8])  =>  W17[co][ci][t] = sum_m sum_{t1+t2=t} W2[co][m][t2] W1[m][ci][t1],
+//   b17[co] = b2[co] + sum_m sum_t2 W2[co][m][t2] b1[m]        (composed in fp64)
+// exact wherever the intermediate is not zero-padded, i.e. everywhere but the 4 outputs next to each end (lconv_edge_fix_kernel).
+static void compose_pair(const orca_conv_desc& c1, const orca_conv_desc& c2, std::vector<double>* w17, std::vector<double>* b17) {
+  const int cin = c1.cin, cm = c1.cout, cout = c2.cout;
+  w17->assign((size_t)cout * cin * 17, 0.0);
+  b17->assign(cout, 0.0);
+  std::vector<double> w1t((size_t)cm * cin * 9);
+  for (size_t i = 0; i < w1t.size(); ++i) w1t[i] = c1.weight_host[i];
+  for (int co = 0; co < cout; ++co) {
+    double bb = c2.bias_host[co];
+    double* wo = w17->data() + (size_t)co * cin * 17;
+    for (int m = 0; m < cm; ++m) {
+      const float* w2 = c2.weight_host + ((size_t)co * cm + m) * 9;
+      double s2 = 0.0;
+      for (int t2 = 0; t2 < 9; ++t2) s2 += w2[t2];
+      bb += s2 * (double)c1.bias_host[m];
+      const double* w1 = w1t.data() + (size_t)m * cin * 9;
+      for (int ci = 0; ci < cin; ++ci)
+        for (int t2 = 0; t2 < 9; ++t2) {
+          const double v2 = w2[t2];
+          for (int t1 = 0; t1 < 9; ++t1) wo[ci * 17 + t1 + t2] += v2 * w1[ci * 9 + t1];
+        }
+    }
+    (*b17)[co] = bb;
+  }
+}
+
+// 17-tap planar conv layer: packs in the layout of the k9 kernels with TWICE the K-chunks - chunk 2c + h holds taps 9h .. 9h+8
+// of input channels 16c .. 16c+15 (32c .. in the bf16 pack); tap 17 does not exist: zero weights
+static int make_layer17(int cin, int cout, const std::vector<double>& w17, const std::vector<double>& b17, ConvLayer* out) {
+  ConvLayer L;
+  L.cin = cin; L.cout = cout; L.ksize = 17; L.kc = 16; L.nchunks = 2 * (cin / 16);
+  if (cin % 32 || !(cout == 64 || cout == 96 || cout == 128)) return fail(ORCA_EINVAL, "composed conv %d -> %d unsupported", cin, cout);
+  std::vector<float> bias(cout);
+  for (int i = 0; i < cout; ++i) bias[i] = (float)b17[i];
+  ORCA_TRY(upload(bias, &L.d_bias));
+  std::vector<uint16_t> pf((size_t)L.nchunks * 2 * 9 * 2 * cout * 8, 0), pb((size_t)2 * (cin / 32) * 2 * 9 * 2 * cout * 8, 0);
+  for (int co = 0; co < cout; ++co)
+    for (int ci = 0; ci < cin; ++ci)
+      for (int t = 0; t < 17; ++t) {
+        const double wd = w17[((size_t)co * cin + ci) * 17 + t];
+        float v = (float)wd;
+        if (!(v > -65504.f && v < 65504.f)) L.f16_ok = false;
+        const int h = t / 9, tt = t % 9;
+        {
+          const int c = ci / 16, gg = (ci % 16) / 8, e = ci % 8;
+          for (int sp = 0; sp < 2; ++sp) {
+            const _Float16 hh = (_Float16)v;
+            v -= (float)hh;
+            uint16_t bits;
+            memcpy(&bits, &hh, 2);
+            pf[((((((size_t)c * 2 + h) * 2 + sp) * 9 + tt) * 2 + gg) * cout + co) * 8 + e] = bits;
+          }
+        }
+        {
+          const int c = ci / 32, kp = (ci % 32) / 16, gg = (ci % 16) / 8, e = ci % 8;
+          pb[((((((size_t)c * 2 + h) * 2 + kp) * 9 + tt) * 2 + gg) * cout + co) * 8 + e] = bf16_rne((float)wd);
+        }
+      }
+  hipError_t e1 = hipMalloc(&L.d_wf16, pf.size() * 2);
+  if (e1 == hipSuccess) e1 = hipMemcpy(L.d_wf16, pf.data(), pf.size() * 2, hipMemcpyHostToDevice);
+  if (e1 == hipSuccess) e1 = hipMalloc(&L.d_wb16p, pb.size() * 2);
+  if (e1 == hipSuccess) e1 = hipMemcpy(L.d_wb16p, pb.data(), pb.size() * 2, hipMemcpyHostToDevice);
+  if (e1 != hipSuccess) { free_layer(L); return fail(ORCA_EHIP, "composed weight upload failed: %s", hipGetErrorString(e1)); }
+  *out = L;
+  return ORCA_OK;
+}
+
 // ---------------------------------------------------------------------------
 // kernel launch helpers
 // ---------------------------------------------------------------------------
@@ -354,7 +430,7 @@ static int launch_conv1d(orca_ctx* ctx, const ConvLayer& L, const float* x, long
   LAUNCHCHECK("conv1d_k9_kernel");
   if (timed) {
     HIPCHECK(hipEventRecord(tl.e1, s));
-    tl.rec.cout = L.cout; tl.rec.cin = L.cin; tl.rec.tile = used_tile; tl.rec.batch = B; tl.rec.n = n; tl.rec.ms = 0.f; tl.rec.pad_ = 0;
+    tl.rec.cout = L.cout; tl.rec.cin = L.cin; tl.rec.tile = used_tile; tl.rec.batch = B; tl.rec.n = n; tl.rec.ms = 0.f; tl.rec.ksize = 9;
     ctx->timed.push_back(tl);
   }
   return ORCA_OK;
@@ -483,16 +559,17 @@ static int launch_conv1d_b16(orca_ctx* ctx, const ConvLayer& L, int precision, c
   LAUNCHCHECK("conv1d_k9_bf16s_kernel");
   if (timed) {
     HIPCHECK(hipEventRecord(tl.e1, ctx->stream));
-    tl.rec.cout = L.cout; tl.rec.cin = L.cin; tl.rec.tile = -precision; tl.rec.batch = B; tl.rec.n = n; tl.rec.ms = 0.f; tl.rec.pad_ = 0;
+    tl.rec.cout = L.cout; tl.rec.cin = L.cin; tl.rec.tile = -precision; tl.rec.batch = B; tl.rec.n = n; tl.rec.ms = 0.f; tl.rec.ksize = 9;
     ctx->timed.push_back(tl);
   }
   return ORCA_OK;
 }
 
 // ---- P16 (planar split fp16) conv1d with LDS-DMA staging (conv_p16.h) -------------------------------------
-// plane length in 16-byte units: 4 guard units each side; the +1 keeps the zero stores of a pooled output's ragged
-// last tile (128 * ceil(4n'/512) positions) inside the plane for every n'
-static inline long p16_plen(long n) { return ((n + 512) / 512) * 512 + 2 * P16_GUARD; }
+// plane length in 16-byte units: P16_GUARD = 8 guard units on the left, >= 24 on the right (a 17-tap conv's second tap
+// half reads 9 units past the last tile); the +1 keeps the zero stores of a pooled output's ragged last tile
+// (128 * ceil(4n'/512) positions) inside the plane for every n'
+static inline long p16_plen(long n) { return ((n + 512) / 512) * 512 + 32; }
 
 static int launch_p16_zero_pads(orca_ctx* ctx, float* base, int C, long n_valid, int fmt = 0) {
   hipLaunchKernelGGL(p16_zero_pads_kernel, dim3((unsigned)(fmt == 1 ? C / 8 : C / 8 * 2)), dim3(256), 0, ctx->stream, reinterpret_cast<f32x4*>(base),
@@ -602,13 +679,15 @@ struct FusedFirst {   // packed bases + first-layer table: the conv's input is p
 // fmt 0: P16 activations (fp32-class f16x2 arithmetic); fmt 1: B16 activations (plain bf16, BASELINE config 3)
 static int launch_conv1d_p16(orca_ctx* ctx, const ConvLayer& L, const float* x, void* y, const float* r1, long n, int relu,
                              int out_mode, const FusedFirst* f1 = nullptr, int fmt = 0) {
-  if (L.ksize != 9 || (fmt == 0 ? !L.d_wf16 : !L.d_wb16p)) return fail(ORCA_EINVAL, "layer has no %s pack", fmt == 0 ? "fp16 split" : "bf16");
+  const bool k17 = L.ksize == 17;
+  if ((L.ksize != 9 && !k17) || (fmt == 0 ? !L.d_wf16 : !L.d_wb16p)) return fail(ORCA_EINVAL, "layer has no %s pack", fmt == 0 ? "fp16 split" : "bf16");
   if (fmt == 0 && !L.f16_ok) return fail(ORCA_EINVAL, "layer weights exceed the fp16 range: use ORCA_PRECISION_BF16X3");
   if (n <= 0) return ORCA_OK;
   ConvP16Args a;
   a.x = reinterpret_cast<const f32x4*>(x); a.w = reinterpret_cast<const f32x4*>(fmt == 0 ? L.d_wf16 : L.d_wb16p); a.bias = L.d_bias; a.y = y;
   a.r1 = reinterpret_cast<const f32x4*>(r1); a.x_plen = p16_plen(n); a.y_plen = p16_plen(out_mode == 1 ? n / 4 : n); a.n = n;
-  a.nchunks = fmt == 0 ? L.cin / 16 : L.cin / 32; a.cout = L.cout; a.relu = relu; a.out_mode = out_mode; a.flag = ctx->d_flag;
+  a.nchunks = (fmt == 0 ? L.cin / 16 : L.cin / 32) * (k17 ? 2 : 1); a.cout = L.cout; a.relu = relu; a.out_mode = out_mode; a.flag = ctx->d_flag;
+  a.k17 = k17 ? 1 : 0;
   const bool timed = ctx->timing && n >= 65536;
   TimedLaunch tl;
   if (timed) {
@@ -619,10 +698,10 @@ static int launch_conv1d_p16(orca_ctx* ctx, const ConvLayer& L, const float* x, 
   a.f1_codes = nullptr; a.f1_codes_L = a.f1_codes_off = 0; a.f1_reverse = 0; a.f1_table = a.f1_bias = nullptr; a.stamps = nullptr;
   static const bool no_ws = getenv("ORCA_NO_WS") != nullptr;   // A/B switch: W-stationary barrier-free kernel (conv_ws.h)
   static const bool ws_p16 = getenv("ORCA_WS_P16") != nullptr; // ... also for P16 (measured 3 % slower there: off)
-  const bool ws_ok = !no_ws && (fmt == 1 || ws_p16);
+  const bool ws_ok = !no_ws && (fmt == 1 || ws_p16) && !k17;
   int tile_tag = fmt == 1 ? -6 : -5;
   if (f1) {
-    if (L.cout != 64 || L.cin != 64 || out_mode != 0 || r1 || fmt != 0) return fail(ORCA_EINVAL, "fused first layer: only the 64 -> 64 P16 conv that follows it");
+    if (L.cout != 64 || L.cin != 64 || out_mode != 0 || r1 || fmt != 0 || k17) return fail(ORCA_EINVAL, "fused first layer: only the 64 -> 64 P16 conv that follows it");
     a.f1_codes = f1->codes; a.f1_codes_L = f1->codes_L; a.f1_codes_off = f1->codes_off; a.f1_reverse = f1->reverse;
     a.f1_table = f1->table; a.f1_bias = f1->bias;
     launch_p16_fused_first(ctx->stream, a);
@@ -643,9 +722,20 @@ static int launch_conv1d_p16(orca_ctx* ctx, const ConvLayer& L, const float* x, 
   LAUNCHCHECK("conv1d_k9_p16_kernel");
   if (timed) {
     HIPCHECK(hipEventRecord(tl.e1, ctx->stream));
-    tl.rec.cout = L.cout; tl.rec.cin = L.cin; tl.rec.tile = tile_tag; tl.rec.batch = 1; tl.rec.n = n; tl.rec.ms = 0.f; tl.rec.pad_ = 0;
+    tl.rec.cout = L.cout; tl.rec.cin = L.cin; tl.rec.tile = tile_tag; tl.rec.batch = 1; tl.rec.n = n; tl.rec.ms = 0.f; tl.rec.ksize = k17 ? 17 : 9;
     ctx->timed.push_back(tl);
   }
+  return ORCA_OK;
+}
+
+// the 4 + 4 end positions of a composed linear pair, recomputed with the two-step formula (conv_p16.h: lconv_edge_fix_kernel)
+static int launch_edge_fix(orca_ctx* ctx, const ConvLayer& A, const ConvLayer& Bl, EdgeFixArgs a, long n, float* y, int fmt) {
+  if (!A.d_w || !Bl.d_w) return fail(ORCA_EINVAL, "edge fix: layer without an fp32 pack");
+  a.n = n; a.cin = A.cin; a.cmid = A.cout; a.cout = Bl.cout;
+  a.w1 = A.d_w; a.b1 = A.d_bias; a.kc1 = A.kc; a.w2 = Bl.d_w; a.b2 = Bl.d_bias; a.kc2 = Bl.kc;
+  a.y = reinterpret_cast<f32x4*>(y); a.y_plen = p16_plen(n); a.out_fmt = fmt;
+  hipLaunchKernelGGL(lconv_edge_fix_kernel, dim3(8), dim3(256), 0, ctx->stream, a);
+  LAUNCHCHECK("lconv_edge_fix_kernel");
   return ORCA_OK;
 }
 
@@ -891,6 +981,36 @@ extern "C" int orca_net_create(orca_ctx* ctx, int kind, const orca_conv_desc* co
       }
     rc = upload(tab, &net->d_first_tab);
     if (rc != ORCA_OK) { orca_net_free(net); return rc; }
+    // composed linear pairs (compose_pair): lconv1 -> K = 68 (tap*4 + ci) fp16 split pack for conv1d_first_mfma_p16_kernel<.,.,17>
+    {
+      std::vector<double> w17, b17;
+      compose_pair(convs[0], convs[1], &w17, &b17);
+      std::vector<uint16_t> p17((size_t)2 * 5 * 2 * 64 * 8, 0);
+      for (int co = 0; co < 64; ++co)
+        for (int k = 0; k < 68; ++k) {
+          float v = (float)w17[((size_t)co * 4 + (k & 3)) * 17 + (k >> 2)];
+          const int kk = k / 16, gg = (k % 16) / 8, e = k % 8;
+          for (int sp = 0; sp < 2; ++sp) {
+            const _Float16 hh = (_Float16)v;
+            v -= (float)hh;
+            uint16_t bits;
+            memcpy(&bits, &hh, 2);
+            p17[((((size_t)sp * 5 + kk) * 2 + gg) * 64 + co) * 8 + e] = bits;
+          }
+        }
+      std::vector<float> bf(64);
+      for (int i = 0; i < 64; ++i) bf[i] = (float)b17[i];
+      if (hipMalloc(&net->d_l1_w16, p17.size() * 2) != hipSuccess ||
+          hipMemcpy(net->d_l1_w16, p17.data(), p17.size() * 2, hipMemcpyHostToDevice) != hipSuccess || upload(bf, &net->d_l1_bias) != ORCA_OK) {
+        orca_net_free(net);
+        return fail(ORCA_EHIP, "composed first-layer upload failed");
+      }
+      for (int st = 1; st <= 2; ++st) {
+        compose_pair(convs[4 * st], convs[4 * st + 1], &w17, &b17);
+        rc = make_layer17(convs[4 * st].cin, convs[4 * st + 1].cout, w17, b17, &net->comp[st]);
+        if (rc != ORCA_OK) { orca_net_free(net); return rc; }
+      }
+    }
   }
   *out = net;
   return ORCA_OK;
@@ -916,6 +1036,9 @@ extern "C" int orca_net_free(orca_net* net) {
   if (net->d_first_w16) (void)hipFree(net->d_first_w16);
   if (net->d_first_tab) (void)hipFree(net->d_first_tab);
   if (net->d_sep) (void)hipFree(net->d_sep);
+  if (net->d_l1_w16) (void)hipFree(net->d_l1_w16);
+  if (net->d_l1_bias) (void)hipFree(net->d_l1_bias);
+  for (auto& L : net->comp) free_layer(L);
   delete net;
   return ORCA_OK;
 }
@@ -978,42 +1101,66 @@ static int encoder_chunk(orca_ctx* ctx, orca_net* net, const SeqSource& src, lon
       fa.x = x; fa.sc = sx_c; fa.sl = sx_l; fa.n = n1; fa.w = nullptr; fa.bias = L[0].d_bias; fa.y = reinterpret_cast<f32x4*>(buf[1]);
       fa.y_plen = p16_plen(n1); fa.flag = ctx->d_flag;
       fa.w = net->d_first_w;
+      // Composed linear pairs (default; ORCA_NO_COMPOSE=1 = the two-conv form, kept as the in-library A/B reference): lconv1 is ONE
+      // 17-tap first layer straight into buf[LO] (K = 68 MFMA GEMM from the bases / float rows), lconv2 / lconv3 are 17-tap planar
+      // convs; the 4 + 4 end positions of each are redone exactly by lconv_edge_fix_kernel.
+      const bool no_compose = getenv("ORCA_NO_COMPOSE") != nullptr;   // read per call: the tests flip it
+      const bool compose = !no_compose && net->d_l1_w16 != nullptr;
       // packed input: the first layer is fused into the input-tile producer of the conv that follows it (conv_p16.h, F1)
       static const bool no_fuse1 = getenv("ORCA_NO_FUSE1") != nullptr;   // A/B switch
-      const bool fuse1 = src.codes && !no_fuse1 && fmt == 0;
+      const bool fuse1 = src.codes && !no_fuse1 && fmt == 0 && !compose;
       FusedFirst f1;
       f1.codes = src.codes; f1.codes_L = src.codes_L; f1.codes_off = src.codes_off; f1.reverse = src.reverse;
       f1.table = net->d_first_tab; f1.bias = L[0].d_bias;
+      int T = 1, LO = 2, S = 0;   // buffer roles: T holds the current input
       // (guards and tails of every planar tensor are zeroed by p16_zero_pads_kernel AFTER its producer: the conv kernels
       // write the units of a ragged last tile unmasked)
+      const bool flat = src.codes || (sx_c == 1 && sx_l == 4 && al16(x));
+      float* first_out = compose ? buf[LO] : buf[T];
       if (fuse1) {
         // nothing to launch: buf[1] is never materialised
-      } else if (src.codes || (sx_c == 1 && sx_l == 4 && al16(x) && (fmt == 1 || !getenv("ORCA_FIRST_VALU")))) {
-        FirstMfmaArgs fm;   // K=48 GEMM on the flat [L][4] window (or straight from the packed bases)
+      } else if (compose || flat || fmt == 1) {
+        FirstMfmaArgs fm;   // K=48 / K=80 GEMM on the flat [L][4] window (or straight from the packed bases)
+        fm.codes = src.codes; fm.codes_L = src.codes_L; fm.codes_off = src.codes_off; fm.reverse = src.reverse;
         fm.x = src.codes ? nullptr : x; fm.n = n1;
-        fm.codes = src.codes; fm.codes_L = src.codes_L; fm.codes_off = src.codes_off; fm.reverse = src.reverse; fm.w = reinterpret_cast<const f32x4*>(net->d_first_w16); fm.bias = L[0].d_bias;
-        fm.y = reinterpret_cast<f32x4*>(buf[1]); fm.y_plen = p16_plen(n1); fm.flag = ctx->d_flag;
+        if (!flat) {
+          // strided float rows: gather them into a flat [n][4] copy (buf[S] is free until the stage's last conv), then the MFMA kernel
+          hipLaunchKernelGGL(seq_to_rows_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, s, x, sx_c, sx_l, n1, buf[S]);
+          LAUNCHCHECK("seq_to_rows_kernel");
+          fm.x = buf[S];
+        }
+        fm.w = reinterpret_cast<const f32x4*>(compose ? net->d_l1_w16 : net->d_first_w16); fm.bias = compose ? net->d_l1_bias : L[0].d_bias;
+        fm.y = reinterpret_cast<f32x4*>(first_out); fm.y_plen = p16_plen(n1); fm.flag = ctx->d_flag;
         const long nt = (n1 + 255) / 256;
-        if (fmt == 1) hipLaunchKernelGGL((conv1d_first_mfma_p16_kernel<0, 1>), dim3((unsigned)(nt < 2048 ? nt : 2048)), dim3(256), 0, s, fm);
-        else hipLaunchKernelGGL((conv1d_first_mfma_p16_kernel<0, 0>), dim3((unsigned)(nt < 2048 ? nt : 2048)), dim3(256), 0, s, fm);
+        const dim3 grid((unsigned)(nt < 2048 ? nt : 2048));
+        const bool timed = ctx->timing && n1 >= 65536 && compose;
+        TimedLaunch tl;
+        if (timed) {
+          HIPCHECK(hipEventCreate(&tl.e0));
+          HIPCHECK(hipEventCreate(&tl.e1));
+          HIPCHECK(hipEventRecord(tl.e0, s));
+        }
+        if (compose && fmt == 1) hipLaunchKernelGGL((conv1d_first_mfma_p16_kernel<0, 1, 17>), grid, dim3(256), 0, s, fm);
+        else if (compose) hipLaunchKernelGGL((conv1d_first_mfma_p16_kernel<0, 0, 17>), grid, dim3(256), 0, s, fm);
+        else if (fmt == 1) hipLaunchKernelGGL((conv1d_first_mfma_p16_kernel<0, 1, 9>), grid, dim3(256), 0, s, fm);
+        else hipLaunchKernelGGL((conv1d_first_mfma_p16_kernel<0, 0, 9>), grid, dim3(256), 0, s, fm);
         LAUNCHCHECK("conv1d_first_mfma_p16_kernel");
-      } else if (fmt == 1) {
-        // strided float rows: gather them into a flat [n][4] copy (buf[2] is free until the second conv), then the MFMA kernel
-        hipLaunchKernelGGL(seq_to_rows_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, s, x, sx_c, sx_l, n1, buf[2]);
-        LAUNCHCHECK("seq_to_rows_kernel");
-        FirstMfmaArgs fm;
-        fm.x = buf[2]; fm.n = n1; fm.codes = nullptr; fm.codes_L = fm.codes_off = 0; fm.reverse = 0;
-        fm.w = reinterpret_cast<const f32x4*>(net->d_first_w16); fm.bias = L[0].d_bias;
-        fm.y = reinterpret_cast<f32x4*>(buf[1]); fm.y_plen = p16_plen(n1); fm.flag = ctx->d_flag;
-        const long nt = (n1 + 255) / 256;
-        hipLaunchKernelGGL((conv1d_first_mfma_p16_kernel<0, 1>), dim3((unsigned)(nt < 2048 ? nt : 2048)), dim3(256), 0, s, fm);
-        LAUNCHCHECK("conv1d_first_mfma_p16_kernel");
+        if (timed) {
+          HIPCHECK(hipEventRecord(tl.e1, s));
+          tl.rec.cout = 64; tl.rec.cin = 4; tl.rec.tile = fmt == 1 ? -6 : -5; tl.rec.batch = 1; tl.rec.n = n1; tl.rec.ms = 0.f; tl.rec.ksize = 17;
+          ctx->timed.push_back(tl);
+        }
       } else {
         hipLaunchKernelGGL(conv1d_first_p16_kernel, dim3((unsigned)((n1 + 255) / 256), 8), dim3(256), 0, s, fa);
         LAUNCHCHECK("conv1d_first_p16_kernel");
       }
-      if (!fuse1) ORCA_TRY(launch_p16_zero_pads(ctx, buf[1], 64, n1, fmt));
-      int T = 1, LO = 2, S = 0;   // buffer roles: T holds the current input
+      if (!fuse1) ORCA_TRY(launch_p16_zero_pads(ctx, first_out, 64, n1, fmt));
+      if (compose) {
+        EdgeFixArgs ef{};
+        if (src.codes) { ef.in_mode = 1; ef.codes = src.codes; ef.codes_L = src.codes_L; ef.codes_off = src.codes_off; ef.reverse = src.reverse; }
+        else { ef.in_mode = 0; ef.x = x; ef.sc = sx_c; ef.sl = sx_l; }
+        ORCA_TRY(launch_edge_fix(ctx, L[0], L[1], ef, n1, buf[LO], fmt));
+      }
       n = n1;
       static const bool no_st4 = getenv("ORCA_NO_P16_STAGE4") != nullptr;   // A/B switch: stage 4 on the register-staged kernel again
       const int nplanar = no_st4 ? 3 : 4;                                   // stages on the planar kernels (pools 4, 4 fused; 5 as a planar pass)
@@ -1026,12 +1173,22 @@ static int encoder_chunk(orca_ctx* ctx, orca_net* net, const SeqSource& src, lon
           ORCA_TRY(launch_p16_zero_pads(ctx, buf[LO], Ls[0].cin, n, fmt));
           const int t_ = S; S = LO; LO = t_;
         }
-        if (st0 > 0) {  // first conv of the stage: previous (pooled) output in buf[S] -> buf[T]
-          ORCA_TRY(launch_conv1d_p16(ctx, Ls[0], buf[S], buf[T], nullptr, n, 0, 0, nullptr, fmt));
-          ORCA_TRY(launch_p16_zero_pads(ctx, buf[T], C, n, fmt));
+        // the stage's linear pair: (pooled) previous output buf[S] -> lout in buf[LO]
+        const bool comp_st = compose && (st0 == 0 || (st0 <= 2 && net->comp[st0].d_wf16));
+        if (comp_st && st0 > 0) {
+          ORCA_TRY(launch_conv1d_p16(ctx, net->comp[st0], buf[S], buf[LO], nullptr, n, 0, 0, nullptr, fmt));
+          ORCA_TRY(launch_p16_zero_pads(ctx, buf[LO], C, n, fmt));
+          EdgeFixArgs ef{};
+          ef.in_mode = fmt == 1 ? 3 : 2; ef.xp = reinterpret_cast<const f32x4*>(buf[S]); ef.x_plen = p16_plen(n);
+          ORCA_TRY(launch_edge_fix(ctx, Ls[0], Ls[1], ef, n, buf[LO], fmt));
+        } else if (!comp_st) {
+          if (st0 > 0) {  // first conv of the stage: previous (pooled) output in buf[S] -> buf[T]
+            ORCA_TRY(launch_conv1d_p16(ctx, Ls[0], buf[S], buf[T], nullptr, n, 0, 0, nullptr, fmt));
+            ORCA_TRY(launch_p16_zero_pads(ctx, buf[T], C, n, fmt));
+          }
+          ORCA_TRY(launch_conv1d_p16(ctx, Ls[1], buf[T], buf[LO], nullptr, n, 0, 0, (st0 == 0 && fuse1) ? &f1 : nullptr, fmt));   // lout
+          ORCA_TRY(launch_p16_zero_pads(ctx, buf[LO], C, n, fmt));
         }
-        ORCA_TRY(launch_conv1d_p16(ctx, Ls[1], buf[T], buf[LO], nullptr, n, 0, 0, (st0 == 0 && fuse1) ? &f1 : nullptr, fmt));   // lout
-        ORCA_TRY(launch_p16_zero_pads(ctx, buf[LO], C, n, fmt));
         ORCA_TRY(launch_conv1d_p16(ctx, Ls[2], buf[LO], buf[T], nullptr, n, 1, 0, nullptr, fmt));
         ORCA_TRY(launch_p16_zero_pads(ctx, buf[T], C, n, fmt));
         if (st0 + 1 < nplanar && kEncPools[st0 + 1] == 4) {

@@ -50,11 +50,11 @@ class Context:
         check(_lib.load().orca_ctx_set_timing(self.handle, 1 if enable else 0))
 
     def get_timing(self, max_records=4096):
-        """[(cout, cin, tile, batch, n, ms)] of the conv1d launches timed since the last call."""
+        """[(cout, cin, tile, batch, n, ms, ksize)] of the conv1d launches timed since the last call."""
         buf = (_lib.KernelTime * max_records)()
         n = ctypes.c_int()
         check(_lib.load().orca_ctx_get_timing(self.handle, buf, max_records, ctypes.byref(n)))
-        return [(r.cout, r.cin, r.tile, r.batch, r.n, r.ms) for r in buf[: min(n.value, max_records)]]
+        return [(r.cout, r.cin, r.tile, r.batch, r.n, r.ms, r.ksize) for r in buf[: min(n.value, max_records)]]
 
     def release_workspace(self):
         check(_lib.load().orca_ctx_release_workspace(self.handle))

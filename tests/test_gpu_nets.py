@@ -47,6 +47,46 @@ def test_encoder_ragged_length_and_batch_vs_oracle(cuda):
     assert maxabs(y, ref) < TOL
 
 
+@pytest.mark.parametrize("precision", ["f16x2", "bf16"])
+def test_encoder_composed_linear_pairs_vs_two_conv_form_and_oracle(cuda, precision, monkeypatch):
+    """lconv1..3 run as single 17-tap convs (weights composed on the host, ends redone by lconv_edge_fix_kernel).  Against
+    (a) the CPU oracle = the reference's two-conv form, on sequences so short that the 4 + 4 end positions of every stage
+    carry weight (1 and 2 bins: 250 / 500 positions at stage 3), one-hot with N runs, reverse strand from codes, and raw
+    floats; (b) the library's own two-conv form (ORCA_NO_COMPOSE=1) on the same inputs."""
+    from orca_amd import engine
+    enc = product_module("Encoder", 5)
+    enc.precision = precision
+    sd = synth_sd("Encoder", 5)
+    tol = 1e-4 if precision == "f16x2" else 0.15
+    for L, seed in ((4000, 3), (8000, 4), (4000 * 3 + 777, 6)):
+        xs = synth.synth_sequence(L, seed=seed, n_frac=0.03)
+        x = torch.from_numpy(xs).transpose(1, 2)
+        ref = O.encoder_forward(sd, x).numpy()
+        xc = x.to(cuda)
+        y = enc(xc).cpu().numpy()
+        assert maxabs(y, ref) < tol, (L, "float rows")
+        codes, ok = engine.pack_sequence(xc)
+        assert ok
+        yc = enc.forward_codes(codes).cpu().numpy()
+        assert maxabs(yc, ref) < tol, (L, "codes")
+        xr = torch.from_numpy(np.ascontiguousarray(xs[:, ::-1, ::-1])).transpose(1, 2)
+        refr = O.encoder_forward(sd, xr).numpy()
+        yr = enc.forward_codes(codes, reverse=True).cpu().numpy()
+        assert maxabs(yr, refr) < tol, (L, "reverse codes")
+        monkeypatch.setenv("ORCA_NO_COMPOSE", "1")
+        y2 = enc(xc).cpu().numpy()
+        yc2 = enc.forward_codes(codes).cpu().numpy()
+        monkeypatch.delenv("ORCA_NO_COMPOSE")
+        assert maxabs(y2, ref) < tol and maxabs(yc2, ref) < tol
+        if precision == "f16x2":
+            assert maxabs(y, y2) < 2e-5 and maxabs(yc, yc2) < 2e-5
+    xf = torch.from_numpy(np.random.RandomState(14).rand(1, 4, 4000 * 2).astype(np.float32))     # arbitrary float rows
+    reff = O.encoder_forward(sd, xf).numpy()
+    assert maxabs(enc(xf.to(cuda)).cpu().numpy(), reff) < tol
+    big = torch.from_numpy(np.random.RandomState(15).rand(1, 8, 4000 * 2).astype(np.float32))     # strided rows: gathered first
+    assert maxabs(enc(big.to(cuda)[:, ::2, :]).cpu().numpy(), O.encoder_forward(sd, big[:, ::2, :]).numpy()) < tol
+
+
 @pytest.mark.parametrize("precision", ["f16x2", "f32", "bf16x3"])
 def test_encoder2_encoder3_vs_golden(cuda, precision, monkeypatch):
     monkeypatch.setenv("ORCA_UNET_NLC_MIN", "0")     # the split-operand path also below its pay-off size (default: >= 32 000 positions)

@@ -511,9 +511,75 @@ def coarsegrain_golden():
     np.savez_compressed(os.path.join(GOLD, "G18_coarsegrain.npz"), **d)
 
 
+FULL256 = {"seed": 0, "seq_seed": 2, "L": 256_000_000, "chrlen": 138_368_000, "mpos": 70_000_000, "wpos": 128_000_000}
+
+
+def full256_sample_bins(nb=64000):
+    """Bins of the [128, 64000] Encoder output kept in G20: both ends, every 125th, and +-8 around each multiple of
+    8000 (the product's 32 Mb chunk seams)."""
+    idx = set(range(64)) | set(range(nb - 64, nb)) | set(range(0, nb, 125))
+    for k in range(1, nb // 8000):
+        idx |= set(range(k * 8000 - 8, k * 8000 + 8))
+    return np.array(sorted(idx), dtype=np.int64)
+
+
+def full256_golden(om, threads):
+    """G20 - BASELINE.json configs[3] at FULL size through the reference's own code: `genomepredict_256Mb`
+    (orca_predict.py:543-878) with the REAL `net0` = `orca_modules.Encoder` (:803-980) on a seeded 256 Mb sequence, both
+    strands; Encoder2(64 000 bins) -> [-1] -> Encoder3 -> four Decoders.  Stored: the four maps, start/end coords, and of
+    each strand's [128, 64000] Encoder output a column sample + moments.  ~20 min of CPU on 8 cores."""
+    import orca_predict as op
+    c = FULL256
+    torch.set_num_threads(threads)
+
+    class Rec(torch.nn.Module):
+        def __init__(self, inner):
+            super().__init__()
+            self.inner, self.outs = inner, []
+
+        def forward(self, x):
+            y = self.inner(x)
+            self.outs.append(y[0].numpy().copy())
+            return y
+
+    class Ref256(torch.nn.Module):
+        def __init__(self, seed):
+            super().__init__()
+            self.net0 = Rec(load_synth(om.Encoder(), seed=seed))
+            self.net1 = load_synth(om.Encoder2(), seed=seed)
+            self.net = load_synth(om.Encoder3(), seed=seed)
+            self.denets = {lv: load_synth(om.Decoder(upsample_mode="bilinear"), seed=seed + lv) for lv in (32, 64, 128, 256)}
+
+    model = Ref256(c["seed"])
+    t = time.time()
+    seq = synth.synth_sequence(c["L"], seed=c["seq_seed"])
+    nm = synth.synth_normmat_256m(c["chrlen"], seed=0)
+    print("G20 inputs ready %.1fs" % (time.time() - t), flush=True)
+    out = op.genomepredict_256Mb(seq, "chrS", [nm], c["chrlen"], c["mpos"], c["wpos"], models=[model], padding_chr="chrP", use_cuda=False)
+    d = {"args": np.array([c["mpos"], c["wpos"], c["chrlen"], c["L"], c["seq_seed"], c["seed"]], dtype=np.int64),
+         "start": np.array(out["start_coords"], dtype=np.int64), "end": np.array([int(v) for v in out["end_coords"]], dtype=np.int64),
+         "t_total_cpu_s": np.array([time.time() - t]), "ncores": np.array([threads]), "bins": full256_sample_bins()}
+    for j, p in enumerate(out["predictions"][0]):
+        d[f"pred_{j}"] = p.astype(np.float32)
+    assert len(model.net0.outs) == 2
+    for k, e in enumerate(model.net0.outs):      # 0 = forward strand, 1 = reverse complement
+        d[f"enc_{k}_cols"] = e[:, d["bins"]].copy()
+        d[f"enc_{k}_stats"] = stats(e)
+        e64 = e.astype(np.float64)
+        d[f"enc_{k}_chan_sum"] = e64.sum(axis=1)
+        d[f"enc_{k}_chan_sq"] = (e64 * e64).sum(axis=1)
+    np.savez_compressed(os.path.join(GOLD, "G20_full256m.npz"), **d)
+    print("G20 done in %.1fs" % (time.time() - t), out["start_coords"], flush=True)
+
+
 if __name__ == "__main__":
     if "--coarsegrain" in sys.argv:
         coarsegrain_golden()
+    elif "--full256m" in sys.argv:
+        _stub_third_party()
+        import orca_modules as _om
+        with torch.no_grad():
+            full256_golden(_om, int(os.environ.get("GOLDEN_THREADS", os.cpu_count())))
     elif "--config3" in sys.argv:
         _stub_third_party()
         import orca_modules as _om
