@@ -128,14 +128,14 @@ def sharded_256mb(args, rank, world, dev, dist):
                 comm = None
     enc = odist.ShardedEncoder(model.net0, comm=comm)
     chrlen = 138_368_000
-    nm = synth.synth_normmat_256m(chrlen, seed=0)
-    de = {}
-    for lv in (256, 128, 64, 32):      # top-left window of each level: the host-side block means are not part of this measurement
-        w = 250 * (lv // 8)
-        de[lv] = torch.log(torch.from_numpy(orca_predict._coarse_grain(nm[None, :w, :w], lv // 8, 1).astype(np.float32))[None]).to(dev)
+    # the 8000 x 8000 float64 background resident in HBM: per-level, per-strand block means + log + reverse-strand flip run on the
+    # device inside the timed tail (orca_block_mean_f64), exactly what genomepredict_256Mb computes (orca_predict.py:703, :724-737)
+    de = orca_predict.Background256.to_device(synth.synth_normmat_256m(chrlen, seed=0), dev)
     mpos, wpos = 70_000_000, 128_000_000
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
     acc = np.zeros(3)
+
+    last = {}
 
     def one(timed):
         ev[0].record()
@@ -143,6 +143,7 @@ def sharded_256mb(args, rank, world, dev, dist):
         er = enc._local(lambda: model.net0.forward_codes(codes, reverse=True, **rng))
         ev[1].record()
         enc0 = torch.cat([gather(ef), gather(er)], dim=0)
+        last["enc0"] = enc0
         ev[2].record()
         # N = 1: both strands batched; N > 1: one strand per rank parity + one all-gather of the maps (dist.strand_parallel_cascade_256m)
         outs_ = [m[0] for m in odist.strand_parallel_cascade_256m(model, enc0, mpos, wpos, chrlen, de, comm=comm)]
@@ -176,6 +177,25 @@ def sharded_256mb(args, rank, world, dev, dist):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el, parts = float(t[0]), t[1:].cpu().numpy()
     chk = float(sum(float(o.double().sum()) for o in outs_))
+    # parity of THIS run's result against the reference's own genomepredict_256Mb on this sequence / these weights / this position
+    # with the REAL Encoder as net0 (tests/golden/G20_full256m.npz, tools/make_golden.py --full256m): the 4 maps and a column sample
+    # of both strands' [128, 64000] encodings.  At N > 1 this checks the sharded path end to end (every rank holds the same result).
+    parity = None
+    g20 = os.path.join(ROOT, "tests", "golden", "G20_full256m.npz")
+    if rank == 0 and os.path.exists(g20):
+        g = np.load(g20)
+        bins = torch.from_numpy(g["bins"]).to(dev)
+        e_err = [float(np.abs(last["enc0"][k][:, bins].cpu().numpy().astype(np.float64) - g[f"enc_{k}_cols"]).max()) for k in range(2)]
+        m_err, m_r = [], []
+        for j, o in enumerate(outs_):
+            a, b = o.cpu().numpy().astype(np.float64), g[f"pred_{j}"].astype(np.float64)
+            m_err.append(float(np.abs(a - b).max()))
+            m_r.append(float(np.corrcoef(a.ravel(), b.ravel())[0, 1]))
+        parity = {"against": "tests/golden/G20_full256m.npz = the reference's genomepredict_256Mb (PyTorch CPU fp32, real Encoder as net0) on this sequence",
+                  "encoder_max_abs_per_strand": [round(e, 8) for e in e_err], "encoder_columns_checked": int(bins.numel()),
+                  "map_max_abs_per_level": [round(e, 8) for e in m_err], "map_pearson_min": round(min(m_r), 9), "tolerance": 1e-4,
+                  "ok": bool(max(e_err + m_err) < 1e-4)}
+    last.clear()
     if comm is not None:
         comm.close()
     ms = el / args.sharded_steps * 1e3
@@ -186,7 +206,7 @@ def sharded_256mb(args, rank, world, dev, dist):
             "n_gpus": world, "steps": args.sharded_steps, "scaling": "strong", "collective": collective,
             "ms_per_step": round(ms, 2), "Mb_per_s": round(2 * 256 / (ms * 1e-3), 1),
             "encoder_ms_per_rank_max": round(float(parts[0]), 2), "allgather_ms_max": round(float(parts[1]), 3), "tail_ms_max": round(float(parts[2]), 2),
-            "encoder_Mb_per_s": round(2 * 256 / (float(parts[0]) * 1e-3), 1), "maps_checksum": round(chk, 4),
+            "encoder_Mb_per_s": round(2 * 256 / (float(parts[0]) * 1e-3), 1), "maps_checksum": round(chk, 4), "parity": parity,
             "bins_this_rank": [int(lo), int(hi)]}
 
 

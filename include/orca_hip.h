@@ -233,6 +233,16 @@ int orca_decoder1m_forward(orca_ctx* ctx, orca_net* net, const float* x, int64_t
  * (orca_predict.py:514-523) for contiguous [n,n] maps. */
 int orca_strand_merge(orca_ctx* ctx, const float* fwd, const float* rev, float* out, int n);
 
+/* Replaces: the per-level background of genomepredict_256Mb (orca_predict.py:724-737, :692-697, :703):
+ *   normmat_r = np.nanmean(np.nanmean(np.reshape(normmat[s : s + 250 nb, s : s + 250 nb], (1, 250, nb, 250, nb)), axis=4), axis=2)
+ *   distenc   = torch.log(torch.FloatTensor(normmat_r))        [torch.flip(distenc, [2, 3]) on the reverse strand]
+ * on an 8000 x 8000 float64 background held in HBM (row stride ld, window origin (row0, col0), nb = level // 8 entries per
+ * pixel side, npix = 250).  mean_out [npix][npix] float64 is BIT-IDENTICAL to numpy's result (same pairwise / sequential
+ * summation order); log_out [npix][npix] float32 = logf of its float32 rounding, written flipped in both axes when
+ * `flip`.  Either output may be NULL.  Device pointers. */
+int orca_block_mean_f64(orca_ctx* ctx, const double* mat, int64_t ld, int64_t row0, int64_t col0, int nb, int npix,
+                        double* mean_out, float* log_out, int flip);
+
 /* Replaces: `adaptive_coarsegrain_gpu(ar, countar, cutoff, max_levels, min_shape)` (selene_utils2.py:274-463), the
  * 2x2-pooling smoother that `Genomic2DFeatures(cg=True)` applies to OBSERVED Hi-C matrices (:551-556) before they become
  * output["experiments"].  ar = balanced matrix (NaN = masked), countar = raw counts, both [n][n] fp32 device arrays with

@@ -64,6 +64,7 @@ SIGNATURES = {
     "orca_net_num_targets": (c_int, [c_void_p, POINTER(c_int)]),
     "orca_decoder1m_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_void_p, c_int]),
     "orca_strand_merge": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int]),
+    "orca_block_mean_f64": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p, c_int]),
     "orca_adaptive_coarsegrain": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, ctypes.c_float, c_int, c_int, c_void_p, c_int64]),
     "orca_genome_unpack_2bit": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "orca_comm_unique_id": (c_int, [c_void_p]),

@@ -258,3 +258,48 @@ __global__ void pointwise1d_kernel(const float* __restrict__ w, const float* __r
   else if (act == 2) acc = 1.f / (1.f + expf(-acc));
   y[(long)b * y_bs + (long)co * ldy + m] = acc;
 }
+
+// ---- block means of the 256 Mb model's background (orca_predict.py:724-737) -------------------------------------------
+// normmat_r = nanmean(nanmean(reshape(normmat[s : s + 250 nb, s : s + 250 nb], (250, nb, 250, nb)), axis=3), axis=1) in float64,
+// then distenc = log(float32(normmat_r)) [flipped in both axes on the reverse strand, :703].  One thread per output pixel,
+// numpy's own operation order so that the float64 means are BIT-IDENTICAL to the reference's:
+//   inner axis (contiguous, n = nb): numpy's pairwise sum - n < 8 sequential from -0.0, else 8 running sums r[k] += a[i+k]
+//   combined ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) - divided by the count; outer axis: sequential sum of those nb means, divided by the count.
+// NaN entries count as missing (nanmean); an all-NaN group gives NaN.
+__global__ void block_mean_f64_kernel(const double* __restrict__ mat, long ld, long r0, long c0, int nb, int npix, double* __restrict__ mean_out,
+                                      float* __restrict__ log_out, int flip) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+  if (j >= npix) return;
+  double acc = 0.0;
+  int cnt2 = 0;
+  for (int a = 0; a < nb; ++a) {
+    const double* row = mat + (r0 + (long)i * nb + a) * ld + c0 + (long)j * nb;
+    double s;
+    int cnt = 0;
+    if (nb < 8) {
+      s = -0.0;
+      for (int k = 0; k < nb; ++k) { const double v = row[k]; const bool ok = v == v; cnt += ok; s = s + (ok ? v : 0.0); }
+    } else {
+      double r[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { const double v = row[k]; const bool ok = v == v; cnt += ok; r[k] = ok ? v : 0.0; }
+      int q = 8;
+      for (; q < nb - (nb % 8); q += 8) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const double v = row[q + k]; const bool ok = v == v; cnt += ok; r[k] = r[k] + (ok ? v : 0.0); }
+      }
+      s = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+      for (; q < nb; ++q) { const double v = row[q]; const bool ok = v == v; cnt += ok; s = s + (ok ? v : 0.0); }
+    }
+    const double m1 = s / (double)cnt;          // 0/0 = NaN for an all-NaN group, as numpy
+    const bool ok1 = m1 == m1;
+    cnt2 += ok1;
+    acc = a == 0 ? (ok1 ? m1 : 0.0) : acc + (ok1 ? m1 : 0.0);
+  }
+  const double m = acc / (double)cnt2;
+  if (mean_out) mean_out[(long)i * npix + j] = m;
+  if (log_out) {
+    const long o = flip ? (long)(npix - 1 - i) * npix + (npix - 1 - j) : (long)i * npix + j;
+    log_out[o] = logf((float)m);
+  }
+}

@@ -1749,6 +1749,16 @@ extern "C" int orca_strand_merge(orca_ctx* ctx, const float* fwd, const float* r
   return ORCA_OK;
 }
 
+extern "C" int orca_block_mean_f64(orca_ctx* ctx, const double* mat, int64_t ld, int64_t row0, int64_t col0, int nb, int npix, double* mean_out,
+                                   float* log_out, int flip) {
+  if (!ctx || !mat || nb <= 0 || npix <= 0 || (!mean_out && !log_out)) return fail(ORCA_EINVAL, "orca_block_mean_f64: bad argument");
+  HIPCHECK(hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(block_mean_f64_kernel, dim3((unsigned)((npix + 63) / 64), (unsigned)npix), dim3(64), 0, ctx->stream, mat, (long)ld, (long)row0,
+                     (long)col0, nb, npix, mean_out, log_out, flip);
+  LAUNCHCHECK("block_mean_f64_kernel");
+  return ORCA_OK;
+}
+
 extern "C" int orca_adaptive_coarsegrain(orca_ctx* ctx, const float* ar, const float* countar, int64_t ld, int n, float cutoff, int max_levels,
                                          int min_shape, float* out, int64_t ld_out) {
   if (!ctx || !ar || !countar || !out) return fail(ORCA_EINVAL, "orca_adaptive_coarsegrain: NULL argument");

@@ -160,16 +160,18 @@ class ShardedEncoder(torch.nn.Module):
                               codes, total, self.group, self.comm)
 
 
-def strand_tail_256m(model, enc0, strand, mpos, wpos, chrlen, distencs):
+def strand_tail_256m(model, enc0, strand, mpos, wpos, chrlen, normmat):
     """One strand's share of the 256 Mb tail: rows [strand*B, (strand+1)*B) of ``enc0`` [2B,128,64000] through
-    Encoder2 -> Encoder3 -> the four Decoders (orca_predict.cascade_256m).  Returns [4, C, 250, 250] (batch row 0)."""
+    Encoder2 -> Encoder3 -> the four Decoders (orca_predict.cascade_256m; strand 1 = the reverse complement: its backgrounds are
+    flipped and its zoom mirrored, orca_predict.py:703, :813-835).  ``normmat``: the 8000 x 8000 background (host array or float64
+    ROCm tensor).  Returns [4, C, 250, 250] (batch row 0)."""
     from . import orca_predict
     B = enc0.shape[0] // 2
-    preds, _ = orca_predict.cascade_256m(model, enc0[strand * B: (strand + 1) * B], mpos, wpos, chrlen, distencs, reverse_flags=(bool(strand),))
+    preds, _ = orca_predict.cascade_256m(model, enc0[strand * B: (strand + 1) * B], mpos, wpos, chrlen, normmat, reverse_flags=(bool(strand),))
     return torch.stack([p[0] for p in preds]).contiguous()
 
 
-def strand_parallel_cascade_256m(model, enc0, mpos, wpos, chrlen, distencs, group=None, comm=None):
+def strand_parallel_cascade_256m(model, enc0, mpos, wpos, chrlen, normmat, group=None, comm=None):
     """The part of genomepredict_256Mb after the Encoder (orca_predict.py:675-838 + the strand merge :866-877), with the
     two strands' tails on different ranks: the strands are independent until the merge, so even ranks run the forward
     strand, odd ranks the reverse strand, and ONE all-gather of the [4,C,250,250] maps (1 MB per rank) replaces the
@@ -184,10 +186,10 @@ def strand_parallel_cascade_256m(model, enc0, mpos, wpos, chrlen, distencs, grou
         world, rank = 1, 0
     B = enc0.shape[0] // 2
     if world == 1:
-        preds, _ = orca_predict.cascade_256m(model, enc0, mpos, wpos, chrlen, distencs)
+        preds, _ = orca_predict.cascade_256m(model, enc0, mpos, wpos, chrlen, normmat)
         fwd, rev = torch.stack([p[0] for p in preds]), torch.stack([p[B] for p in preds])
     else:
-        slab = strand_tail_256m(model, enc0, rank & 1, mpos, wpos, chrlen, distencs)
+        slab = strand_tail_256m(model, enc0, rank & 1, mpos, wpos, chrlen, normmat)
         if comm is not None:
             allm = comm.all_gather(slab)
         else:

@@ -397,6 +397,23 @@ def strand_merge(fwd, rev):
     return out
 
 
+def block_mean(normmat, start, nb, npix=250, flip=False, want_mean=True):
+    """Background of one level of the 256 Mb cascade on the device (orca_predict.py:724-737, :692-703): block means of the
+    window [start, start + npix*nb)^2 of a float64 CUDA matrix -> (float64 [npix,npix] means or None, float32 [1,1,npix,npix]
+    log-background, flipped in both axes if ``flip``).  The means are bit-identical to numpy's nanmean-of-nanmean."""
+    if not (normmat.is_cuda and normmat.dtype == torch.float64 and normmat.dim() == 2 and normmat.stride(1) == 1):
+        raise OrcaHipError("block_mean: a float64 [n,n] ROCm tensor with unit column stride is required")
+    if start < 0 or start + npix * nb > min(normmat.shape):
+        raise ValueError(f"block_mean: window [{start}, {start + npix * nb}) outside the {tuple(normmat.shape)} background")
+    ctx = get_context(normmat.device)
+    ctx.sync_stream()
+    mean = torch.empty((npix, npix), dtype=torch.float64, device=normmat.device) if want_mean else None
+    logt = torch.empty((1, 1, npix, npix), dtype=torch.float32, device=normmat.device)
+    check(_lib.load().orca_block_mean_f64(ctx.handle, _p(normmat), normmat.stride(0), int(start), int(start), int(nb), int(npix),
+                                          _p(mean) if mean is not None else None, _p(logt), 1 if flip else 0), "orca_block_mean_f64")
+    return mean, logt
+
+
 # ---- single layers (kernel unit tests) -------------------------------------
 def conv1d(x, w, b, relu=False, r1=None, r2=None, tile=0):
     """y = [relu](conv1d_k9(x, w) + b) [+ r1] [+ r2]; x [B,cin,n] contiguous cuda."""

@@ -188,6 +188,79 @@ def _coarse_grain(mat, nblock, nan_thresh):
     return mean
 
 
+class Background256:
+    """Per-level, per-strand log-background of the 256 Mb cascade (orca_predict.py:692-703, :724-737): block means of the
+    window of the 8000 x 8000 (32 kb bins) background at the strand's current start, log in float32, flipped in both axes on
+    the reverse strand.  ``normmat`` is either the reference's host array (numpy float64; block means with numpy, overlapped
+    with the Encoder's queue) or a float64 ROCm tensor RESIDENT IN HBM (`Background256.to_device`, `sv_drivers` build it there):
+    then the block means run in one kernel per level (engine.block_mean, bit-identical float64 means) and nothing of the
+    8000 x 8000 matrix crosses PCIe or the host's caches per call.  NaNs are filled with the smallest finite entry, in place,
+    exactly once (:664-667).  Callable as run_cascade's ``background(level, k, start)`` for the strands ``reverse_flags``."""
+
+    def __init__(self, normmat, reverse_flags=(False, True), use_cuda=True):
+        self.on_device = isinstance(normmat, torch.Tensor) and normmat.is_cuda
+        if self.on_device and normmat.dtype != torch.float64:
+            raise ValueError("device-resident background: float64 expected (the reference's dtype)")
+        if not self.on_device and isinstance(normmat, torch.Tensor):
+            normmat = normmat.numpy()
+        self.normmat, self.reverse_flags, self.use_cuda = normmat, [bool(r) for r in reverse_flags], use_cuda
+        self.ns = [{} for _ in self.reverse_flags]            # per strand: {level: (start, block means[, {flip: log tensor}])}
+        self._filled = False
+
+    def _fill_nan(self):
+        """`normmat[isnan] = nanmin(normmat)` in place (:664-667) - on first use, i.e. with the Encoder already enqueued."""
+        if self._filled:
+            return
+        self._filled = True
+        m = self.normmat
+        if self.on_device:
+            nan = torch.isnan(m)
+            if bool(nan.any()):
+                m[nan] = m[~nan].min()
+        else:
+            isnan = np.isnan(m)
+            if np.any(isnan):
+                m[isnan] = np.nanmin(m[~isnan])
+
+    @staticmethod
+    def to_device(normmat, device):
+        """Upload a host background once (512 MB of float64) - for callers that reuse it over many calls."""
+        return torch.from_numpy(np.ascontiguousarray(normmat, dtype=np.float64)).to(device)
+
+    def reset(self):
+        for d in self.ns:
+            d.clear()
+
+    def means(self, k, level):
+        """float64 [250,250] block means strand k used at ``level`` (host array; output["normmats"])."""
+        m = self.ns[k][level][1]
+        return m.cpu().numpy() if isinstance(m, torch.Tensor) else m
+
+    def __call__(self, level, k, start):
+        self._fill_nan()
+        nb, flip = level // 8, self.reverse_flags[k]
+        hit = self.ns[k].get(level)
+        if hit is None or hit[0] != start:
+            hit = None
+            for other in self.ns:                             # strands that start a level at the same bin share the means
+                o = other.get(level)
+                if o is not None and o[0] == start:
+                    self.ns[k][level] = hit = o
+                    break
+        if self.on_device:
+            if hit is not None and flip in hit[2]:
+                return hit[2][flip]
+            mean, logt = engine.block_mean(self.normmat, start, nb, 250, flip, want_mean=hit is None)
+            if hit is None:
+                self.ns[k][level] = hit = (start, mean, {})
+            hit[2][flip] = logt
+            return logt
+        if hit is None:
+            w = 250 * nb
+            self.ns[k][level] = hit = (start, _coarse_grain(self.normmat[None, start: start + w, start: start + w], nb, 1))
+        return _log_background(hit[1], 1, self.use_cuda, flip=flip)
+
+
 def _scale_annotation(annotation, newstart, newend):
     """Clip / rescale plot annotations into the current window (orca_predict.py:451-468)."""
     span = newend - newstart
@@ -330,17 +403,23 @@ def cascade_32m(model, xs, mpos, wpos, reverse_flags, distencs=None, merge=False
     return engine.run_with_overflow_retry(forward, xs[0].device)
 
 
-def cascade_256m(model, enc0, mpos, wpos, chrlen, distencs, reverse_flags=(False, True)):
-    """Device part of the 256 Mb cascade AFTER the Encoder (orca_predict.py:675-838): ``enc0`` [S*B,128,64000] (strand k =
-    rows k*B..) -> net1 -> [-1] -> net -> the four decoder levels.  ``distencs``: {level: log-background [1,1,250,250]}
-    (the host-side block means of the 8000 x 8000 background, :724-737, are the caller's business)."""
+def cascade_256m(model, enc0, mpos, wpos, chrlen, normmat, reverse_flags=(False, True)):
+    """Device part of genomepredict_256Mb AFTER the Encoder (orca_predict.py:675-838): ``enc0`` [S*B,128,64000] (strand k =
+    rows k*B..) -> net1 -> [-1] -> net -> the four decoder levels, numerically the same as the full call: every strand's
+    background is the block mean of ``normmat`` at THAT strand's window start, flipped on the reverse strand (:703, :724-737).
+    ``normmat``: the 8000 x 8000 background (host numpy array, or a float64 ROCm tensor for device-side block means), or a
+    ready `Background256` (its ``reverse_flags`` must be the ones given here).  Returns (preds[4], starts[k][4])."""
     S = len(reverse_flags)
     B = enc0.shape[0] // S
+    bg = normmat if isinstance(normmat, Background256) else Background256(normmat, reverse_flags, enc0.is_cuda)
+    if list(bg.reverse_flags) != [bool(r) for r in reverse_flags]:
+        raise ValueError("cascade_256m: the Background256 was built for other strands")
 
     def forward():
+        bg.reset()
         encodings = dict(zip([32, 64, 128, 256], model.net(model.net1(enc0)[-1])))
-        return run_cascade(model, encodings, [256, 128, 64, 32], lambda lv: lv // 8, B, list(reverse_flags),
-                           lambda lv, k, st: distencs[lv], lambda lv, st, rev: zoom_index_256m(lv, st, mpos, wpos, chrlen, rev))
+        return run_cascade(model, encodings, [256, 128, 64, 32], lambda lv: lv // 8, B, [bool(r) for r in reverse_flags],
+                           bg, lambda lv, st, rev: zoom_index_256m(lv, st, mpos, wpos, chrlen, rev))
 
     return engine.run_with_overflow_retry(forward, enc0.device)
 
@@ -457,36 +536,25 @@ def genomepredict_256Mb(sequence, mchr, normmats, chrlen, mpos=-1, wpos=-1, mode
     with torch.no_grad():
         strands = _StrandInputs(sequence, use_cuda)
         for ii, model in enumerate(models):
-            normmat = normmats[ii]
-            isnan = np.isnan(normmat)
-            if np.any(isnan):
-                normmat[isnan] = np.nanmin(normmat[~isnan])   # in place, as the reference (:664-667)
-            ns = [{}, {}]                                     # per strand: {level: coarse-grained background}
+            bg = Background256(normmats[ii], [False, True], use_cuda)
             ts, annos = [], []
 
-            def background(level, k, start, normmat=normmat, ns=ns):
-                w = 250 * (level // 8)
-                other = ns[1 - k].get(level)
-                if other is not None and other[0] == start:   # both strands start level 256 at 0: grain once
-                    ns[k][level] = other
-                else:
-                    ns[k][level] = (start, _coarse_grain(normmat[None, start: start + w, start: start + w], level // 8, 1))
-                return _log_background(ns[k][level][1], 1, use_cuda, flip=(k != 0))   # flipped on the reverse strand (:703)
-
-            def on_level(j, level, starts_now, ii=ii, ns=ns, ts=ts, annos=annos):
+            def on_level(j, level, starts_now, ii=ii, bg=bg, ts=ts, annos=annos):
                 s0, w = starts_now[0], 250 * (level // 8)
                 if targets:
                     tgt = targets[ii]
                     tgt = tgt.numpy() if isinstance(tgt, torch.Tensor) else np.asarray(tgt)
                     tr = _coarse_grain(tgt[:, s0: s0 + w, s0: s0 + w], level // 8, nan_thresh)
-                    eps = np.nanmin(ns[0][level][1])
-                    lf = np.log((tr + eps) / (ns[0][level][1] + eps))
+                    nm0 = bg.means(0, level)
+                    eps = np.nanmin(nm0)
+                    lf = np.log((tr + eps) / (nm0 + eps))
                     ts.append(lf[0, :, :] if tr.shape[0] == 1 else lf)
                 if annotation is not None:
                     annos.append(_scale_annotation(annotation, s0 / 8000.0, (s0 + w) / 8000.0))
 
-            def forward(model=model, background=background, on_level=on_level, ts=ts, annos=annos):
+            def forward(model=model, background=bg, on_level=on_level, ts=ts, annos=annos):
                 del ts[:], annos[:]
+                background.reset()
                 enc0 = strands.encode(model.net0)
                 encodings = dict(zip([32, 64, 128, 256], model.net(model.net1(enc0)[-1])))
                 preds, starts = run_cascade(model, encodings, levels, lambda lv: lv // 8, batch, [False, True], background, zoom,
@@ -496,8 +564,8 @@ def genomepredict_256Mb(sequence, mchr, normmats, chrlen, mpos=-1, wpos=-1, mode
             preds, starts, merged = engine.run_with_overflow_retry(forward, strands.device)
             predictions.append(_merged_to_host(merged) if merged is not None else _merge(preds, batch))
             allstarts.append(starts[0])
-            allnormmats.append({lv: v[1] for lv, v in ns[0].items()})
-            allnormmats_rev.append({lv: v[1] for lv, v in ns[1].items()})
+            allnormmats.append({lv: bg.means(0, lv) for lv in bg.ns[0]})
+            allnormmats_rev.append({lv: bg.means(1, lv) for lv in bg.ns[1]})
             if targets:
                 alltargets.append(ts)
             if annotation is not None:

@@ -30,12 +30,8 @@ def _tail_inputs(cuda):
     model = orca_models.H1esc_256M(synthetic_seed=0)
     enc0 = torch.from_numpy(np.random.RandomState(3).randn(2, 128, 64000).astype(np.float32)).to(cuda)
     chrlen = 138_368_000
-    nm = synth.synth_normmat_256m(chrlen, seed=0)
-    de = {}
-    for lv in (256, 128, 64, 32):
-        w = 250 * (lv // 8)
-        de[lv] = torch.log(torch.from_numpy(orca_predict._coarse_grain(nm[None, :w, :w], lv // 8, 1).astype(np.float32))[None]).to(cuda)
-    return model, enc0, chrlen, de
+    nm = orca_predict.Background256.to_device(synth.synth_normmat_256m(chrlen, seed=0), cuda)   # 8000 x 8000 float64 resident in HBM
+    return model, enc0, chrlen, nm
 
 
 def test_strand_parallel_tail_single_process(cuda):
@@ -52,6 +48,65 @@ def test_strand_parallel_tail_single_process(cuda):
     assert float((fwd - rev).abs().max()) > 1e-3                                        # the strands do differ
     for j in range(4):
         assert torch.equal(engine.strand_merge(fwd[j, 0], rev[j, 0]), whole[j][0]), j
+
+
+def test_strand_parallel_tail_equals_genomepredict_256mb_fixture(cuda):
+    """`strand_parallel_cascade_256m` / `cascade_256m` = the part of genomepredict_256Mb after the Encoder, NUMERICALLY: per-strand
+    backgrounds at each strand's own window start, flipped on the reverse strand (orca_predict.py:703, :724-737).  Against the maps
+    the reference's own function produced (G9, all three zoom cases), with the background on the host and resident in HBM."""
+    from orca_amd import dist as D
+    from orca_amd import orca_models, orca_predict, synth
+    from tests.util import golden, maxabs
+    g = golden("G9_cascade256.npz")
+    model = orca_models.H1esc_256M(synthetic_seed=0)
+    net0 = synth.FakeNet0(nbins=64000, seed=0).to(cuda)
+    seq = synth.synth_sequence(512000, seed=51)
+    x = torch.from_numpy(seq).to(cuda).transpose(1, 2)
+    xr = torch.from_numpy(np.ascontiguousarray(seq[:, ::-1, ::-1])).to(cuda).transpose(1, 2)
+    enc0 = torch.cat([net0(x), net0(xr)], dim=0)
+    for ci in range(3):
+        mpos, wpos, chrlen = (int(v) for v in g[f"c{ci}_args"])
+        nm = synth.synth_normmat_256m(chrlen, seed=0)
+        dnm = orca_predict.Background256.to_device(nm, cuda)
+        for bg in (nm, dnm):
+            maps = D.strand_parallel_cascade_256m(model, enc0, mpos, wpos, chrlen, bg)
+            for j, m in enumerate(maps):
+                p = m[0].cpu().numpy()
+                assert maxabs(p if ci == 0 else p[::5, ::5], g[f"c{ci}_sub_{j}"]) < 1e-4, (ci, j, type(bg))
+        # one strand at a time (what a rank of an N > 1 world runs) merges to the same maps
+        f = D.strand_tail_256m(model, enc0, 0, mpos, wpos, chrlen, dnm)
+        r = D.strand_tail_256m(model, enc0, 1, mpos, wpos, chrlen, dnm)
+        from orca_amd import engine
+        for j in range(4):
+            assert torch.equal(engine.strand_merge(f[j, 0], r[j, 0]), maps[j][0]), (ci, j)
+
+
+def test_block_mean_bit_identical_to_numpy(cuda):
+    """engine.block_mean (orca_block_mean_f64) against numpy's nanmean-of-nanmean on the same float64 background: identical BITS for
+    every level of the 256 Mb cascade, windows off the origin, NaN entries; the log-background and its reverse-strand flip."""
+    from orca_amd import engine, orca_predict, synth
+    nm = synth.synth_normmat_256m(138_368_000, seed=3)
+    rs = np.random.RandomState(0)
+    nm[rs.randint(0, 8000, 500), rs.randint(0, 8000, 500)] = np.nan
+    nm[4000:4016, :] = np.nan                      # whole groups missing
+    d = torch.from_numpy(nm).to(cuda)
+    for level, start in ((256, 0), (128, 1000), (128, 4000), (64, 5999), (32, 7000), (32, 3993)):
+        nb = level // 8
+        w = 250 * nb
+        with np.errstate(invalid="ignore", divide="ignore"):
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                ref = np.nanmean(np.nanmean(np.reshape(nm[None, start:start + w, start:start + w], (1, 250, nb, 250, nb)), axis=4), axis=2)[0]
+                lref = np.log(ref.astype(np.float32))
+        mean, logt = engine.block_mean(d, start, nb)
+        m = mean.cpu().numpy()
+        assert np.array_equal(np.isnan(m), np.isnan(ref)) and np.array_equal(m[~np.isnan(m)].view(np.int64), ref[~np.isnan(ref)].view(np.int64)), (level, start)
+        lg = logt[0, 0].cpu().numpy()
+        ok = ~np.isnan(lref)
+        assert np.abs(lg[ok] - lref[ok]).max() < 2e-6
+        _, lflip = engine.block_mean(d, start, nb, flip=True, want_mean=False)
+        assert torch.equal(lflip[0, 0].flip(0, 1).nan_to_num(7.0), logt[0, 0].nan_to_num(7.0))
 
 
 def test_sharded_encoder_world2_rccl(cuda):

@@ -89,6 +89,34 @@ def test_256mb_cascade_fixture_on_gpu(cuda):
             assert maxabs(p if ci == 0 else p[::5, ::5], ref) < TOL, (ci, j)
 
 
+def test_256mb_full_size_vs_reference_fixture(cuda):
+    """BASELINE config 4 at FULL size against the reference itself (G20 = `genomepredict_256Mb` of /root/reference with the REAL
+    `orca_modules.Encoder` as net0 on the seed-2 256 Mb sequence, tools/make_golden.py --full256m): both strands' [128, 64000]
+    Encoder outputs on a column sample that includes every 32 Mb chunk seam of the product, the four maps, start / end coordinates -
+    at the north-star 1e-4; with the background on the host (the reference's argument form) and resident in HBM."""
+    g = golden("G20_full256m.npz")
+    mpos, wpos, chrlen, L, seq_seed, seed = (int(v) for v in g["args"])
+    model = M.H1esc_256M(synthetic_seed=seed)
+    codes = torch.from_numpy(synth.synth_base_codes(L, seed=seq_seed)[None]).to(cuda)
+    bins = torch.from_numpy(g["bins"]).to(cuda)
+    for k in range(2):
+        e = model.net0.forward_codes(codes, reverse=bool(k))[0]
+        assert e.shape == (128, 64000)
+        assert maxabs(e[:, bins].cpu().numpy(), g[f"enc_{k}_cols"]) < TOL, k
+        e64 = e.double()
+        np.testing.assert_allclose(e64.sum(dim=1).cpu().numpy(), g[f"enc_{k}_chan_sum"], rtol=0, atol=0.2)       # 64 000 bins x a few 1e-6
+        np.testing.assert_allclose((e64 * e64).sum(dim=1).cpu().numpy(), g[f"enc_{k}_chan_sq"], rtol=2e-4, atol=0.05)
+        del e, e64
+    nm = synth.synth_normmat_256m(chrlen, seed=0)
+    for bg in (nm, P.Background256.to_device(nm, cuda)):
+        out = P.genomepredict_256Mb(codes, "chrS", [bg], chrlen, mpos, wpos, models=[model], padding_chr="chrP", use_cuda=True)
+        assert out["start_coords"] == list(g["start"])
+        assert [int(v) for v in out["end_coords"]] == list(g["end"])
+        for j, p in enumerate(out["predictions"][0]):
+            assert maxabs(p, g[f"pred_{j}"]) < TOL, (j, type(bg))
+            assert pearson(p, g[f"pred_{j}"]) > 0.99999
+
+
 def test_encoder_256mb_full_size_properties(cuda):
     """Config-4 size (256 Mb, 64 000 bins): size-independent properties instead of an oracle run -
     (i) a bin sub-range (one GPU's shard) equals the slice of the full encoding, (ii) internal

@@ -37,6 +37,27 @@ def test_encoder_blocks_and_edges():
     assert maxabs(O.encoder_forward(sd, x3)[0].numpy(), g["y_float"]) < TOL
 
 
+def test_encoder_full_256mb_fixture_window():
+    """G20 (the reference's Encoder on the full 256 Mb seed-2 sequence): the oracle on the 304 kb window around the 32 Mb seam
+    reproduces the stored columns there (bins 7992..8007: the window's halo is the reference's own 112 kb), both strands."""
+    g = golden("G20_full256m.npz")
+    L, seq_seed = int(g["args"][3]), int(g["args"][4])
+    codes = synth.synth_base_codes(L, seed=seq_seed)
+    bins = list(g["bins"])
+    sd = synth_sd("Encoder", int(g["args"][5]))
+    lo_bin, hi_bin = 7992, 8008
+    cols = [bins.index(b) for b in range(lo_bin, hi_bin)]
+    for k in range(2):
+        if k == 0:
+            w = codes[lo_bin * 4000 - 112000: hi_bin * 4000 + 112000]
+        else:      # reverse complement: strand position p is base L-1-p, complemented
+            w = 3 - codes[L - (hi_bin * 4000 + 112000): L - (lo_bin * 4000 - 112000)][::-1]
+        x = torch.zeros(1, 4, w.shape[0])
+        x[0, torch.from_numpy(w.astype(np.int64)), torch.arange(w.shape[0])] = 1.0
+        y = O.encoder_forward(sd, x)[0].numpy()[:, 28:28 + (hi_bin - lo_bin)]
+        assert maxabs(y, g[f"enc_{k}_cols"][:, cols]) < TOL, k
+
+
 def test_encoder2_encoder3():
     g = golden("G3_encoder23.npz")
     sd2 = synth_sd("Encoder2", 0)
