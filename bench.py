@@ -294,7 +294,8 @@ def main():
         g["launches"] += 1
         # a 17-tap launch is a composed linear pair Conv(cin->cout) - BN - Conv(cout->cout) - BN (orca_modules.py:811-816):
         # its ALGORITHMIC work is the pair's (SURVEY 8d counts the reference's convolutions)
-        g["flop"] += 2.0 * 9 * (cin * cout + (cout * cout if ksize == 17 else 0)) * n * batch
+        # (25 taps from the bases = conv1.a composed with lconv1: the launch carries conv1.a's 64 -> 64 work, lconv1's is on the 17-tap launch)
+        g["flop"] += 2.0 * 9 * (cout * cout if ksize == 25 else cin * cout + (cout * cout if ksize == 17 else 0)) * n * batch
     # kernel instantiation = (cout, arithmetic); records of the 16-bit split kernels carry tile = -precision
     PREC = {0: ("f32", "conv1d_k9_kernel", PEAK_F32_MFMA_TFLOPS, 1), 1: ("bf16", "conv1d_k9_bf16s_kernel", PEAK_16BIT_MFMA_TFLOPS, 1),
             2: ("bf16x2", "conv1d_k9_bf16s_kernel", PEAK_16BIT_MFMA_TFLOPS, 3), 3: ("bf16x3", "conv1d_k9_bf16s_kernel", PEAK_16BIT_MFMA_TFLOPS, 6),
@@ -307,6 +308,8 @@ def main():
         pname, kname, peak, nprod = PREC[prec]
         if ksize == 17:
             kname = "conv1d_first_mfma_p16_kernel[17 taps: composed lconv1]" if cin == 4 else kname + "[17 taps: composed pair]"
+        elif ksize == 25:
+            kname = "conv1d_first_mfma_p16_kernel[25 taps: conv1.a o lconv1]"
         key = f"{kname}<cout={cout},{pname}>" if prec else f"{kname}<cout={cout},kc={4 if cin == 4 else 8},tile={tile}>"
         d = inst.setdefault(key, {"ms": 0.0, "launches": 0, "flop": 0.0, "peak": peak, "nprod": nprod, "arith": pname})
         for k in ("ms", "launches", "flop"):

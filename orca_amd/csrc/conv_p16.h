@@ -771,6 +771,7 @@ struct FirstMfmaArgs {
   f32x4* y;           // P16, 64 channels
   long y_plen;
   unsigned* flag;
+  int relu;           // ReLU on the result (the 25-tap composition ends in conv1.a's BN + ReLU)
 };
 
 // ABL (tools/microbench_first.hip only): 1 = no MFMA, 16 = no stores, 32 = input not re-fetched per tile
@@ -780,6 +781,9 @@ struct FirstMfmaArgs {
 //   64 -> 64 launch at full resolution that used to follow the first layer is gone.  The 4 positions next to each end of
 //   the chunk are redone by lconv_edge_fix_kernel (the intermediate is zero-padded there, which a single conv cannot express).
 //   With packed input the X operand is exactly representable in fp16 (0, 0.25, 1): its lo plane is zero and the lo*hi product is skipped.
+// NTAP = 25: conv1.a's pre-activation is linear in the bases too - Conv(64,64,k9)-BN applied to lconv1's output (orca_modules.py:819-821
+//   on :811-816) = ONE 25-tap conv from the bases, K = 100 -> 112, followed by the ReLU (a.relu): the second 64 -> 64 launch at full
+//   resolution is gone as well.  Its 8 positions next to each end are redone by the edge-fix chain.
 template <int ABL = 0, int FMT = 0, int NTAP = 9>
 __global__ __launch_bounds__(256, 2) void conv1d_first_mfma_p16_kernel(FirstMfmaArgs a) {
   constexpr int H = (NTAP - 1) / 2;               // conv half width
@@ -871,6 +875,14 @@ __global__ __launch_bounds__(256, 2) void conv1d_first_mfma_p16_kernel(FirstMfma
     // (g = 0: the hi unit, g = 1: the lo unit); positions >= n get zeros (they are tail guard units of the plane)
     const long ypl = a.y_plen * 16;
     const unsigned lane_unit = (unsigned)(l31 * 16) + (g ? (unsigned)ypl : 0u);
+    if (a.relu) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = p16_vmax(acc[i][j][r], 0.f);
+    }
     if constexpr (FMT == 1) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
@@ -1000,79 +1012,108 @@ __global__ void p16_to_nlc_kernel(const f32x4* __restrict__ x, float* __restrict
       p16_load4(reinterpret_cast<const char*>(x) + (long)(c4 >> 1) * 2 * plen * 16 + (P16_GUARD + pos) * 16 + (c4 & 1) * 8, plen * 16);
 }
 
-// ---- composed linear pairs: exact ends -------------------------------------------------------------------------------
+// ---- composed linear groups: exact ends -------------------------------------------------------------------------------
 // lconv_i = [MaxPool] Conv k9 - BN - Conv k9 - BN has no nonlinearity (orca_modules.py:811-816, 829-835, 846-852), so the
-// library runs it as ONE 17-tap conv with weights composed on the host in fp64 (orca_hip.hip: compose_pair).  The single
-// conv differs from the pair in the 4 outputs next to each end of the chunk: PyTorch zero-pads the INTERMEDIATE there,
-// while the composed conv sees the intermediate's virtual values b1 + (partial window).  This kernel recomputes those
-// 8 positions with the two-step formula in fp32 and overwrites them; one workgroup per position.  (Ends that are halo
-// seams of a longer sequence are discarded by the caller anyway; ends of the true sequence are what this is for.)
-struct EdgeFixArgs {
-  int in_mode;                 // 0: float rows (x, sc, sl; 4 channels)  1: base codes (4 channels)  2: P16 planes  3: B16 planes
+// library runs it as ONE 17-tap conv with weights composed on the host in fp64 (orca_hip.hip: compose_pair); in stage 1 the
+// first conv of conv1 (linear up to its ReLU) joins the group: 25 taps from the bases.  A single conv differs from the chain
+// in the 4 (8) outputs next to each end of the chunk: PyTorch zero-pads every INTERMEDIATE there, while the composed conv sees
+// the intermediates' virtual values b + (partial window).  Those positions are recomputed with the reference's own step-by-step
+// formula in fp32 and overwritten.  (Ends that are halo seams of a longer sequence are discarded by the caller anyway; ends of the
+// true sequence are what this is for.)
+struct EdgeFixArgs {           // where a chunk's input comes from
+  int in_mode;                 // 0: float rows (x, sc, sl; 4 channels)  1: base codes (4 channels)  2: P16 planes  3: B16 planes  (-1: scratch)
   const float* x; long sc, sl;
   const unsigned char* codes; long codes_L, codes_off; int reverse;
   const f32x4* xp; long x_plen;
   long n;
-  int cin, cmid, cout;
-  const float* w1; const float* b1; int kc1;   // fp32 pack [cin/kc1][9][kc1][cmid]  (make_layer)
-  const float* w2; const float* b2; int kc2;   // fp32 pack [cmid/kc2][9][kc2][cout]
-  f32x4* y; long y_plen; int out_fmt;          // 0: P16, 1: B16
 };
 
-__global__ __launch_bounds__(256) void lconv_edge_fix_kernel(EdgeFixArgs a) {
-  __shared__ float xs[17][128];
-  __shared__ float mid[9][128];
-  const int b = blockIdx.x, tid = threadIdx.x;
-  const long p = b < 4 ? b : a.n - 8 + b;
-  if (p < 0 || p >= a.n || (b >= 4 && p < 4)) return;     // short chunks: every position once
-  for (int idx = tid; idx < 17 * a.cin; idx += 256) {
+// A chain of tiny launches, one per conv of the composed group: layer l turns the values at the first / last `half + 4` positions
+// (from the chunk's input, or from the previous layer's scratch) into the values at the first / last `half` positions - exactly the
+// reference's arithmetic, zero padding of every intermediate included - keeps them in a scratch for the next layer and stores the
+// outermost `store_half` of them into the planar tensor the composed conv wrote.  One workgroup per position, threads = (tap half,
+// output channel): weight reads coalesced over the channel, no divisions in the loops; ~10 us per layer (the first version - one
+// workgroup per OUTPUT recomputing its 9 intermediates with a division per MAC - took 150-760 us per stage).
+__device__ __forceinline__ float edge_fix_load(const EdgeFixArgs& a, long pos, int ci) {
+  if (pos < 0 || pos >= a.n) return 0.f;
+  if (a.in_mode == 0) return a.x[pos * a.sl + ci * a.sc];
+  if (a.in_mode == 1) {
+    const long P = a.codes_off + pos;
+    int c = a.reverse ? a.codes[a.codes_L - 1 - P] : a.codes[P];
+    if (a.reverse && c < 4) c = 3 - c;
+    return c == 4 ? 0.25f : (c == ci ? 1.f : 0.f);
+  }
+  if (a.in_mode == 2) {
+    const _Float16* u = reinterpret_cast<const _Float16*>(a.xp + (long)(ci >> 3) * 2 * a.x_plen + P16_GUARD + pos);
+    const _Float16* l = reinterpret_cast<const _Float16*>(a.xp + ((long)(ci >> 3) * 2 + 1) * a.x_plen + P16_GUARD + pos);
+    return (float)u[ci & 7] + (float)l[ci & 7];
+  }
+  const unsigned short* u = reinterpret_cast<const unsigned short*>(a.xp + (long)(ci >> 3) * a.x_plen + P16_GUARD + pos);
+  return __builtin_bit_cast(float, (unsigned)u[ci & 7] << 16);
+}
+
+// position handled by slot b of an end list of `half` positions per end: the first `half`, then the last `half` (each position once)
+__device__ __forceinline__ long edge_fix_pos(int b, int half, long n) {
+  const long p = b < half ? b : n - 2 * half + b;
+  return (p < 0 || p >= n || (b >= half && p < half)) ? -1 : p;
+}
+
+struct EdgeLayerArgs {
+  EdgeFixArgs in;              // layer 1: where the chunk's input comes from (in.in_mode 0..3, in.n); deeper layers: in.in_mode = -1
+  const float* sin;            // deeper layers: previous scratch [2 * half_in][128]
+  int half_in;                 // = half + 4
+  int half, store_half, relu;
+  int cin, cout, kc;
+  const float* w; const float* b;   // fp32 pack [cin/kc][9][kc][cout], bias
+  float* sout;                 // scratch [2 * half][128] (may be NULL for the last layer)
+  f32x4* y; long y_plen; int out_fmt;   // planar tensor receiving the outermost store_half positions per end (NULL: none)
+};
+
+__global__ __launch_bounds__(256) void lconv_edge_layer_kernel(EdgeLayerArgs a) {
+  __shared__ float xs[9][128];
+  __shared__ float part[128];
+  const int tid = threadIdx.x, co = tid & 127, th = tid >> 7;
+  const long n = a.in.n;
+  const long p = edge_fix_pos(blockIdx.x, a.half, n);
+  if (p < 0) return;
+  for (int idx = tid; idx < 9 * a.cin; idx += 256) {
     const int j = idx / a.cin, ci = idx - j * a.cin;
-    const long pos = p - 8 + j;
+    const long q = p - 4 + j;
     float v = 0.f;
-    if (pos >= 0 && pos < a.n) {
-      if (a.in_mode == 0) v = a.x[pos * a.sl + ci * a.sc];
-      else if (a.in_mode == 1) {
-        const long P = a.codes_off + pos;
-        int c = a.reverse ? a.codes[a.codes_L - 1 - P] : a.codes[P];
-        if (a.reverse && c < 4) c = 3 - c;
-        v = c == 4 ? 0.25f : (c == ci ? 1.f : 0.f);
-      } else if (a.in_mode == 2) {
-        const _Float16* u = reinterpret_cast<const _Float16*>(a.xp + (long)(ci >> 3) * 2 * a.x_plen + P16_GUARD + pos);
-        const _Float16* l = reinterpret_cast<const _Float16*>(a.xp + ((long)(ci >> 3) * 2 + 1) * a.x_plen + P16_GUARD + pos);
-        v = (float)u[ci & 7] + (float)l[ci & 7];
-      } else {
-        const unsigned short* u = reinterpret_cast<const unsigned short*>(a.xp + (long)(ci >> 3) * a.x_plen + P16_GUARD + pos);
-        v = __builtin_bit_cast(float, (unsigned)u[ci & 7] << 16);
-      }
+    if (a.in.in_mode >= 0) v = edge_fix_load(a.in, q, ci);
+    else if (q >= 0 && q < n) {      // slot of q in the previous scratch: left list [0, half_in), right list [n - half_in, n)
+      const int slot = q < a.half_in ? (int)q : (int)(a.half_in + q - (n - a.half_in));
+      v = a.sin[slot * 128 + ci];
     }
     xs[j][ci] = v;
   }
   __syncthreads();
-  for (int idx = tid; idx < 9 * a.cmid; idx += 256) {
-    const int jq = idx / a.cmid, m = idx - jq * a.cmid;
-    const long q = p - 4 + jq;
-    float acc = 0.f;
-    if (q >= 0 && q < a.n) {
-      acc = a.b1[m];
-      for (int t = 0; t < 9; ++t)
-        for (int ci = 0; ci < a.cin; ++ci)
-          acc = fmaf(a.w1[(((long)(ci / a.kc1) * 9 + t) * a.kc1 + ci % a.kc1) * a.cmid + m], xs[jq + t][ci], acc);
-    }
-    mid[jq][m] = acc;
+  float acc = 0.f;
+  if (co < a.cout) {
+    const int t0 = th ? 5 : 0, t1 = th ? 9 : 5;
+    const int nch = a.cin / a.kc;
+    for (int c = 0; c < nch; ++c)
+      for (int t = t0; t < t1; ++t) {
+        const float* w = a.w + (((long)c * 9 + t) * a.kc) * a.cout + co;
+        const float* xv = &xs[t][c * a.kc];
+        for (int k = 0; k < a.kc; ++k) acc = fmaf(w[(long)k * a.cout], xv[k], acc);
+      }
   }
+  if (th) part[co] = acc;
   __syncthreads();
-  for (int co = tid; co < a.cout; co += 256) {
-    float acc = a.b2[co];
-    for (int t = 0; t < 9; ++t)
-      for (int m = 0; m < a.cmid; ++m)
-        acc = fmaf(a.w2[(((long)(m / a.kc2) * 9 + t) * a.kc2 + m % a.kc2) * a.cout + co], mid[t][m], acc);
-    if (a.out_fmt == 0) {
-      const _Float16 h = (_Float16)acc;
-      const _Float16 l = (_Float16)(acc - (float)h);
-      reinterpret_cast<_Float16*>(a.y + (long)(co >> 3) * 2 * a.y_plen + P16_GUARD + p)[co & 7] = h;
-      reinterpret_cast<_Float16*>(a.y + ((long)(co >> 3) * 2 + 1) * a.y_plen + P16_GUARD + p)[co & 7] = l;
-    } else {
-      reinterpret_cast<unsigned short*>(a.y + (long)(co >> 3) * a.y_plen + P16_GUARD + p)[co & 7] = (unsigned short)(cvt_pk_bf16(acc, 0.f) & 0xffffu);
+  if (!th && co < a.cout) {
+    acc = a.b[co] + acc + part[co];
+    if (a.relu) acc = fmaxf(acc, 0.f);
+    if (a.sout) a.sout[blockIdx.x * 128 + co] = acc;
+    if (a.y && (p < a.store_half || p >= n - a.store_half)) {
+      if (a.out_fmt == 0) {
+        const _Float16 h = (_Float16)acc;
+        const _Float16 l = (_Float16)(acc - (float)h);
+        reinterpret_cast<_Float16*>(a.y + (long)(co >> 3) * 2 * a.y_plen + P16_GUARD + p)[co & 7] = h;
+        reinterpret_cast<_Float16*>(a.y + ((long)(co >> 3) * 2 + 1) * a.y_plen + P16_GUARD + p)[co & 7] = l;
+      } else {
+        reinterpret_cast<unsigned short*>(a.y + (long)(co >> 3) * a.y_plen + P16_GUARD + p)[co & 7] = (unsigned short)(cvt_pk_bf16(acc, 0.f) & 0xffffu);
+      }
     }
   }
 }

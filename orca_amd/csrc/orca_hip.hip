@@ -79,6 +79,7 @@ struct orca_ctx {
   bool timing = false;
   std::vector<TimedLaunch> timed;
   unsigned* d_flag = nullptr;   // fp16-range overflow flag written by the f16x2 kernels
+  float* d_edge = nullptr;      // 2 x 32 x 128 floats: ping-pong scratch of the edge-fix chain (lconv_edge_layer_kernel)
   // Decoders with an even batch run as two half-batches on two streams (see decoder_nhwc)
   hipStream_t aux = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -141,6 +142,8 @@ struct orca_net {
   // lconv2 / lconv3 as 17-tap planar convs (comp[1], comp[2]; ksize 17)
   void* d_l1_w16 = nullptr;
   float* d_l1_bias = nullptr;
+  void* d_c1a_w16 = nullptr;    // conv1.a o lconv1: 25 taps from the bases, K = 100 -> 112 fp16 split pack (ReLU follows)
+  float* d_c1a_bias = nullptr;
   ConvLayer comp[3];
   std::vector<ConvLayer> convs;
 };
@@ -313,29 +316,36 @@ static int make_layer(const orca_conv_desc& d, ConvLayer* out) {
 //   out[p] = b2 + sum_t2 W2[t2] (b1 + sum_t1 W1[t1] x[p + t1 + t2 - 8])  =>  W17[co][ci][t] = sum_m sum_{t1+t2=t} W2[co][m][t2] W1[m][ci][t1],
 //   b17[co] = b2[co] + sum_m sum_t2 W2[co][m][t2] b1[m]        (composed in fp64)
 // exact wherever the intermediate is not zero-padded, i.e. everywhere but the 4 outputs next to each end (lconv_edge_fix_kernel).
-static void compose_pair(const orca_conv_desc& c1, const orca_conv_desc& c2, std::vector<double>* w17, std::vector<double>* b17) {
-  const int cin = c1.cin, cm = c1.cout, cout = c2.cout;
-  w17->assign((size_t)cout * cin * 17, 0.0);
-  b17->assign(cout, 0.0);
-  std::vector<double> w1t((size_t)cm * cin * 9);
-  for (size_t i = 0; i < w1t.size(); ++i) w1t[i] = c1.weight_host[i];
+static void compose_taps(const std::vector<double>& w1, const std::vector<double>& b1, int cin, int cm, int k1, const orca_conv_desc& c2,
+                         std::vector<double>* wo_, std::vector<double>* bo_) {
+  // w1 [cm][cin][k1], b1 [cm] (already composed or a plain conv) followed by c2 = Conv(cm -> cout, k9): [cout][cin][k1 + 8]
+  const int cout = c2.cout, ko = k1 + 8;
+  std::vector<double> wout((size_t)cout * cin * ko, 0.0), bout(cout, 0.0);
   for (int co = 0; co < cout; ++co) {
     double bb = c2.bias_host[co];
-    double* wo = w17->data() + (size_t)co * cin * 17;
+    double* wo = wout.data() + (size_t)co * cin * ko;
     for (int m = 0; m < cm; ++m) {
       const float* w2 = c2.weight_host + ((size_t)co * cm + m) * 9;
       double s2 = 0.0;
       for (int t2 = 0; t2 < 9; ++t2) s2 += w2[t2];
-      bb += s2 * (double)c1.bias_host[m];
-      const double* w1 = w1t.data() + (size_t)m * cin * 9;
+      bb += s2 * b1[m];
+      const double* wm = w1.data() + (size_t)m * cin * k1;
       for (int ci = 0; ci < cin; ++ci)
         for (int t2 = 0; t2 < 9; ++t2) {
           const double v2 = w2[t2];
-          for (int t1 = 0; t1 < 9; ++t1) wo[ci * 17 + t1 + t2] += v2 * w1[ci * 9 + t1];
+          for (int t1 = 0; t1 < k1; ++t1) wo[ci * ko + t1 + t2] += v2 * wm[ci * k1 + t1];
         }
     }
-    (*b17)[co] = bb;
+    bout[co] = bb;
   }
+  wo_->swap(wout);
+  bo_->swap(bout);
+}
+static void compose_pair(const orca_conv_desc& c1, const orca_conv_desc& c2, std::vector<double>* w17, std::vector<double>* b17) {
+  std::vector<double> w1((size_t)c1.cout * c1.cin * 9), b1(c1.cout);
+  for (size_t i = 0; i < w1.size(); ++i) w1[i] = c1.weight_host[i];
+  for (int i = 0; i < c1.cout; ++i) b1[i] = c1.bias_host[i];
+  compose_taps(w1, b1, c1.cin, c1.cout, 9, c2, w17, b17);
 }
 
 // 17-tap planar conv layer: packs in the layout of the k9 kernels with TWICE the K-chunks - chunk 2c + h holds taps 9h .. 9h+8
@@ -728,14 +738,29 @@ static int launch_conv1d_p16(orca_ctx* ctx, const ConvLayer& L, const float* x, 
   return ORCA_OK;
 }
 
-// the 4 + 4 end positions of a composed linear pair, recomputed with the two-step formula (conv_p16.h: lconv_edge_fix_kernel)
-static int launch_edge_fix(orca_ctx* ctx, const ConvLayer& A, const ConvLayer& Bl, EdgeFixArgs a, long n, float* y, int fmt) {
-  if (!A.d_w || !Bl.d_w) return fail(ORCA_EINVAL, "edge fix: layer without an fp32 pack");
-  a.n = n; a.cin = A.cin; a.cmid = A.cout; a.cout = Bl.cout;
-  a.w1 = A.d_w; a.b1 = A.d_bias; a.kc1 = A.kc; a.w2 = Bl.d_w; a.b2 = Bl.d_bias; a.kc2 = Bl.kc;
-  a.y = reinterpret_cast<f32x4*>(y); a.y_plen = p16_plen(n); a.out_fmt = fmt;
-  hipLaunchKernelGGL(lconv_edge_fix_kernel, dim3(8), dim3(256), 0, ctx->stream, a);
-  LAUNCHCHECK("lconv_edge_fix_kernel");
+// the end positions of a composed linear group, recomputed conv by conv (conv_p16.h: lconv_edge_layer_kernel).  layers[l] with
+// relu[l]; the LAST layer's outermost `last_store` positions per end go to y_last, the layer before it (if y_prev) stores 4 per end
+// to y_prev (stage 1: lout1 next to conv1.a's activation).  Scratch: two 32 x 128 float slabs of the context, ping-pong.
+static int launch_edge_chain(orca_ctx* ctx, const ConvLayer* const* layers, const int* relu, int nl, EdgeFixArgs src, long n,
+                             float* y_prev, float* y_last, int fmt) {
+  src.n = n;
+  for (int l = 0; l < nl; ++l) {
+    const ConvLayer& L = *layers[l];
+    if (!L.d_w) return fail(ORCA_EINVAL, "edge fix: layer without an fp32 pack");
+    EdgeLayerArgs a{};
+    a.in = src;
+    if (l > 0) a.in.in_mode = -1;
+    a.half = 4 * (2 * nl - 2 - l); a.half_in = a.half + 4;   // an nl-conv group differs from its composition within 4 (nl - 1) of the ends
+    a.relu = relu[l]; a.cin = L.cin; a.cout = L.cout; a.kc = L.kc; a.w = L.d_w; a.b = L.d_bias;
+    a.sin = l > 0 ? ctx->d_edge + ((l - 1) & 1) * 32 * 128 : nullptr;
+    a.sout = l + 1 < nl ? ctx->d_edge + (l & 1) * 32 * 128 : nullptr;
+    float* y = l == nl - 1 ? y_last : (l == nl - 2 ? y_prev : nullptr);
+    a.y = reinterpret_cast<f32x4*>(y); a.y_plen = p16_plen(n); a.out_fmt = fmt;
+    a.store_half = l == nl - 1 ? a.half : 4;
+    if (2 * a.half > 32) return fail(ORCA_EINVAL, "edge fix: chain too deep");
+    hipLaunchKernelGGL(lconv_edge_layer_kernel, dim3((unsigned)(2 * a.half)), dim3(256), 0, ctx->stream, a);
+  }
+  LAUNCHCHECK("lconv_edge_layer_kernel");
   return ORCA_OK;
 }
 
@@ -787,7 +812,8 @@ extern "C" int orca_ctx_create(int device, void* hip_stream, orca_ctx** out) {
   orca_ctx* c = new orca_ctx();
   c->device = device;
   c->stream = static_cast<hipStream_t>(hip_stream);
-  if (hipMalloc(reinterpret_cast<void**>(&c->d_flag), 4 * sizeof(unsigned)) != hipSuccess || hipMemset(c->d_flag, 0, 4 * sizeof(unsigned)) != hipSuccess) {
+  if (hipMalloc(reinterpret_cast<void**>(&c->d_flag), 4 * sizeof(unsigned)) != hipSuccess || hipMemset(c->d_flag, 0, 4 * sizeof(unsigned)) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void**>(&c->d_edge), 2 * 32 * 128 * sizeof(float)) != hipSuccess) {
     delete c;
     return fail(ORCA_ENOMEM, "could not allocate the context flag word");
   }
@@ -804,6 +830,7 @@ extern "C" int orca_ctx_destroy(orca_ctx* ctx) {
     (void)hipFree(ctx->ws);
   }
   if (ctx->d_flag) (void)hipFree(ctx->d_flag);
+  if (ctx->d_edge) (void)hipFree(ctx->d_edge);
   if (ctx->aux) { (void)hipStreamSynchronize(ctx->aux); (void)hipStreamDestroy(ctx->aux); (void)hipEventDestroy(ctx->ev_fork); (void)hipEventDestroy(ctx->ev_join); }
   delete ctx;
   return ORCA_OK;
@@ -983,25 +1010,31 @@ extern "C" int orca_net_create(orca_ctx* ctx, int kind, const orca_conv_desc* co
     if (rc != ORCA_OK) { orca_net_free(net); return rc; }
     // composed linear pairs (compose_pair): lconv1 -> K = 68 (tap*4 + ci) fp16 split pack for conv1d_first_mfma_p16_kernel<.,.,17>
     {
-      std::vector<double> w17, b17;
+      std::vector<double> w17, b17, w25, b25;
       compose_pair(convs[0], convs[1], &w17, &b17);
-      std::vector<uint16_t> p17((size_t)2 * 5 * 2 * 64 * 8, 0);
-      for (int co = 0; co < 64; ++co)
-        for (int k = 0; k < 68; ++k) {
-          float v = (float)w17[((size_t)co * 4 + (k & 3)) * 17 + (k >> 2)];
-          const int kk = k / 16, gg = (k % 16) / 8, e = k % 8;
-          for (int sp = 0; sp < 2; ++sp) {
-            const _Float16 hh = (_Float16)v;
-            v -= (float)hh;
-            uint16_t bits;
-            memcpy(&bits, &hh, 2);
-            p17[((((size_t)sp * 5 + kk) * 2 + gg) * 64 + co) * 8 + e] = bits;
+      compose_taps(w17, b17, 4, 64, 17, convs[2], &w25, &b25);       // conv1.a (BN folded; its ReLU stays in the kernel)
+      // K = tap*4 + ci fp16 split pack [2 splits][KS][2 g][64][8] for conv1d_first_mfma_p16_kernel<., ., ntap>
+      auto pack_first = [&](const std::vector<double>& w, const std::vector<double>& b, int ntap, void** d_w, float** d_b) -> int {
+        const int KS = (4 * ntap + 15) / 16;
+        std::vector<uint16_t> pk((size_t)2 * KS * 2 * 64 * 8, 0);
+        for (int co = 0; co < 64; ++co)
+          for (int k = 0; k < 4 * ntap; ++k) {
+            float v = (float)w[((size_t)co * 4 + (k & 3)) * ntap + (k >> 2)];
+            const int kk = k / 16, gg = (k % 16) / 8, e = k % 8;
+            for (int sp = 0; sp < 2; ++sp) {
+              const _Float16 hh = (_Float16)v;
+              v -= (float)hh;
+              uint16_t bits;
+              memcpy(&bits, &hh, 2);
+              pk[((((size_t)sp * KS + kk) * 2 + gg) * 64 + co) * 8 + e] = bits;
+            }
           }
-        }
-      std::vector<float> bf(64);
-      for (int i = 0; i < 64; ++i) bf[i] = (float)b17[i];
-      if (hipMalloc(&net->d_l1_w16, p17.size() * 2) != hipSuccess ||
-          hipMemcpy(net->d_l1_w16, p17.data(), p17.size() * 2, hipMemcpyHostToDevice) != hipSuccess || upload(bf, &net->d_l1_bias) != ORCA_OK) {
+        std::vector<float> bf(64);
+        for (int i = 0; i < 64; ++i) bf[i] = (float)b[i];
+        if (hipMalloc(d_w, pk.size() * 2) != hipSuccess || hipMemcpy(*d_w, pk.data(), pk.size() * 2, hipMemcpyHostToDevice) != hipSuccess) return ORCA_EHIP;
+        return upload(bf, d_b);
+      };
+      if (pack_first(w17, b17, 17, &net->d_l1_w16, &net->d_l1_bias) != ORCA_OK || pack_first(w25, b25, 25, &net->d_c1a_w16, &net->d_c1a_bias) != ORCA_OK) {
         orca_net_free(net);
         return fail(ORCA_EHIP, "composed first-layer upload failed");
       }
@@ -1038,6 +1071,8 @@ extern "C" int orca_net_free(orca_net* net) {
   if (net->d_sep) (void)hipFree(net->d_sep);
   if (net->d_l1_w16) (void)hipFree(net->d_l1_w16);
   if (net->d_l1_bias) (void)hipFree(net->d_l1_bias);
+  if (net->d_c1a_w16) (void)hipFree(net->d_c1a_w16);
+  if (net->d_c1a_bias) (void)hipFree(net->d_c1a_bias);
   for (auto& L : net->comp) free_layer(L);
   delete net;
   return ORCA_OK;
@@ -1103,7 +1138,8 @@ static int encoder_chunk(orca_ctx* ctx, orca_net* net, const SeqSource& src, lon
       fa.w = net->d_first_w;
       // Composed linear pairs (default; ORCA_NO_COMPOSE=1 = the two-conv form, kept as the in-library A/B reference): lconv1 is ONE
       // 17-tap first layer straight into buf[LO] (K = 68 MFMA GEMM from the bases / float rows), lconv2 / lconv3 are 17-tap planar
-      // convs; the 4 + 4 end positions of each are redone exactly by lconv_edge_fix_kernel.
+      // convs; conv1.a, linear up to its ReLU, is composed with lconv1 as well (25 taps from the bases).  The end positions of each
+      // group are redone exactly by the edge-fix chain (lconv_edge_layer_kernel).
       const bool no_compose = getenv("ORCA_NO_COMPOSE") != nullptr;   // read per call: the tests flip it
       const bool compose = !no_compose && net->d_l1_w16 != nullptr;
       // packed input: the first layer is fused into the input-tile producer of the conv that follows it (conv_p16.h, F1)
@@ -1116,39 +1152,56 @@ static int encoder_chunk(orca_ctx* ctx, orca_net* net, const SeqSource& src, lon
       // (guards and tails of every planar tensor are zeroed by p16_zero_pads_kernel AFTER its producer: the conv kernels
       // write the units of a ragged last tile unmasked)
       const bool flat = src.codes || (sx_c == 1 && sx_l == 4 && al16(x));
+      // conv1.a joins the composed group (25 taps from the bases + ReLU, K = 112): ORCA_NO_COMPOSE25=1 keeps it a 64 -> 64 launch
+      const bool compose25 = compose && getenv("ORCA_NO_COMPOSE25") == nullptr && net->d_c1a_w16 != nullptr;
       float* first_out = compose ? buf[LO] : buf[T];
-      if (fuse1) {
-        // nothing to launch: buf[1] is never materialised
-      } else if (compose || flat || fmt == 1) {
-        FirstMfmaArgs fm;   // K=48 / K=80 GEMM on the flat [L][4] window (or straight from the packed bases)
+      const float* rows = x;     // flat [n][4] float rows for the MFMA first-layer kernels (unused with packed input)
+      // one first-layer GEMM launch: ntap 9 (lconv1.a alone), 17 (lconv1 composed), 25 (conv1.a o lconv1, + ReLU)
+      auto launch_first = [&](int ntap, const void* w16, const float* bias, int relu, float* out) -> int {
+        FirstMfmaArgs fm;
         fm.codes = src.codes; fm.codes_L = src.codes_L; fm.codes_off = src.codes_off; fm.reverse = src.reverse;
-        fm.x = src.codes ? nullptr : x; fm.n = n1;
-        if (!flat) {
-          // strided float rows: gather them into a flat [n][4] copy (buf[S] is free until the stage's last conv), then the MFMA kernel
-          hipLaunchKernelGGL(seq_to_rows_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, s, x, sx_c, sx_l, n1, buf[S]);
-          LAUNCHCHECK("seq_to_rows_kernel");
-          fm.x = buf[S];
-        }
-        fm.w = reinterpret_cast<const f32x4*>(compose ? net->d_l1_w16 : net->d_first_w16); fm.bias = compose ? net->d_l1_bias : L[0].d_bias;
-        fm.y = reinterpret_cast<f32x4*>(first_out); fm.y_plen = p16_plen(n1); fm.flag = ctx->d_flag;
+        fm.x = src.codes ? nullptr : rows; fm.n = n1;
+        fm.w = reinterpret_cast<const f32x4*>(w16); fm.bias = bias; fm.relu = relu;
+        fm.y = reinterpret_cast<f32x4*>(out); fm.y_plen = p16_plen(n1); fm.flag = ctx->d_flag;
         const long nt = (n1 + 255) / 256;
         const dim3 grid((unsigned)(nt < 2048 ? nt : 2048));
-        const bool timed = ctx->timing && n1 >= 65536 && compose;
+        const bool timed = ctx->timing && n1 >= 65536 && ntap > 9;
         TimedLaunch tl;
         if (timed) {
           HIPCHECK(hipEventCreate(&tl.e0));
           HIPCHECK(hipEventCreate(&tl.e1));
           HIPCHECK(hipEventRecord(tl.e0, s));
         }
-        if (compose && fmt == 1) hipLaunchKernelGGL((conv1d_first_mfma_p16_kernel<0, 1, 17>), grid, dim3(256), 0, s, fm);
-        else if (compose) hipLaunchKernelGGL((conv1d_first_mfma_p16_kernel<0, 0, 17>), grid, dim3(256), 0, s, fm);
-        else if (fmt == 1) hipLaunchKernelGGL((conv1d_first_mfma_p16_kernel<0, 1, 9>), grid, dim3(256), 0, s, fm);
-        else hipLaunchKernelGGL((conv1d_first_mfma_p16_kernel<0, 0, 9>), grid, dim3(256), 0, s, fm);
+        switch (ntap * 2 + fmt) {
+          case 18: hipLaunchKernelGGL((conv1d_first_mfma_p16_kernel<0, 0, 9>), grid, dim3(256), 0, s, fm); break;
+          case 19: hipLaunchKernelGGL((conv1d_first_mfma_p16_kernel<0, 1, 9>), grid, dim3(256), 0, s, fm); break;
+          case 34: hipLaunchKernelGGL((conv1d_first_mfma_p16_kernel<0, 0, 17>), grid, dim3(256), 0, s, fm); break;
+          case 35: hipLaunchKernelGGL((conv1d_first_mfma_p16_kernel<0, 1, 17>), grid, dim3(256), 0, s, fm); break;
+          case 50: hipLaunchKernelGGL((conv1d_first_mfma_p16_kernel<0, 0, 25>), grid, dim3(256), 0, s, fm); break;
+          default: hipLaunchKernelGGL((conv1d_first_mfma_p16_kernel<0, 1, 25>), grid, dim3(256), 0, s, fm); break;
+        }
         LAUNCHCHECK("conv1d_first_mfma_p16_kernel");
         if (timed) {
           HIPCHECK(hipEventRecord(tl.e1, s));
-          tl.rec.cout = 64; tl.rec.cin = 4; tl.rec.tile = fmt == 1 ? -6 : -5; tl.rec.batch = 1; tl.rec.n = n1; tl.rec.ms = 0.f; tl.rec.ksize = 17;
+          tl.rec.cout = 64; tl.rec.cin = 4; tl.rec.tile = fmt == 1 ? -6 : -5; tl.rec.batch = 1; tl.rec.n = n1; tl.rec.ms = 0.f; tl.rec.ksize = ntap;
           ctx->timed.push_back(tl);
+        }
+        return ORCA_OK;
+      };
+      if (fuse1) {
+        // nothing to launch: buf[1] is never materialised
+      } else if (compose || flat || fmt == 1) {
+        if (!flat) {
+          // strided float rows: gather them into a flat [n][4] copy (buf[S] is free until the stage's last conv), then the MFMA kernel
+          hipLaunchKernelGGL(seq_to_rows_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, s, x, sx_c, sx_l, n1, buf[S]);
+          LAUNCHCHECK("seq_to_rows_kernel");
+          rows = buf[S];
+        }
+        if (compose) ORCA_TRY(launch_first(17, net->d_l1_w16, net->d_l1_bias, 0, buf[LO]));
+        else ORCA_TRY(launch_first(9, net->d_first_w16, L[0].d_bias, 0, buf[T]));
+        if (compose25) {
+          ORCA_TRY(launch_first(25, net->d_c1a_w16, net->d_c1a_bias, 1, buf[T]));
+          ORCA_TRY(launch_p16_zero_pads(ctx, buf[T], 64, n1, fmt));
         }
       } else {
         hipLaunchKernelGGL(conv1d_first_p16_kernel, dim3((unsigned)((n1 + 255) / 256), 8), dim3(256), 0, s, fa);
@@ -1159,7 +1212,10 @@ static int encoder_chunk(orca_ctx* ctx, orca_net* net, const SeqSource& src, lon
         EdgeFixArgs ef{};
         if (src.codes) { ef.in_mode = 1; ef.codes = src.codes; ef.codes_L = src.codes_L; ef.codes_off = src.codes_off; ef.reverse = src.reverse; }
         else { ef.in_mode = 0; ef.x = x; ef.sc = sx_c; ef.sl = sx_l; }
-        ORCA_TRY(launch_edge_fix(ctx, L[0], L[1], ef, n1, buf[LO], fmt));
+        const ConvLayer* chain[3] = {&L[0], &L[1], &L[2]};
+        const int relus[3] = {0, 0, 1};
+        if (compose25) ORCA_TRY(launch_edge_chain(ctx, chain, relus, 3, ef, n1, buf[LO], buf[T], fmt));
+        else ORCA_TRY(launch_edge_chain(ctx, chain, relus, 2, ef, n1, nullptr, buf[LO], fmt));
       }
       n = n1;
       static const bool no_st4 = getenv("ORCA_NO_P16_STAGE4") != nullptr;   // A/B switch: stage 4 on the register-staged kernel again
@@ -1180,7 +1236,9 @@ static int encoder_chunk(orca_ctx* ctx, orca_net* net, const SeqSource& src, lon
           ORCA_TRY(launch_p16_zero_pads(ctx, buf[LO], C, n, fmt));
           EdgeFixArgs ef{};
           ef.in_mode = fmt == 1 ? 3 : 2; ef.xp = reinterpret_cast<const f32x4*>(buf[S]); ef.x_plen = p16_plen(n);
-          ORCA_TRY(launch_edge_fix(ctx, Ls[0], Ls[1], ef, n, buf[LO], fmt));
+          const ConvLayer* chain[2] = {&Ls[0], &Ls[1]};
+          const int relus[2] = {0, 0};
+          ORCA_TRY(launch_edge_chain(ctx, chain, relus, 2, ef, n, nullptr, buf[LO], fmt));
         } else if (!comp_st) {
           if (st0 > 0) {  // first conv of the stage: previous (pooled) output in buf[S] -> buf[T]
             ORCA_TRY(launch_conv1d_p16(ctx, Ls[0], buf[S], buf[T], nullptr, n, 0, 0, nullptr, fmt));
@@ -1189,8 +1247,10 @@ static int encoder_chunk(orca_ctx* ctx, orca_net* net, const SeqSource& src, lon
           ORCA_TRY(launch_conv1d_p16(ctx, Ls[1], buf[T], buf[LO], nullptr, n, 0, 0, (st0 == 0 && fuse1) ? &f1 : nullptr, fmt));   // lout
           ORCA_TRY(launch_p16_zero_pads(ctx, buf[LO], C, n, fmt));
         }
-        ORCA_TRY(launch_conv1d_p16(ctx, Ls[2], buf[LO], buf[T], nullptr, n, 1, 0, nullptr, fmt));
-        ORCA_TRY(launch_p16_zero_pads(ctx, buf[T], C, n, fmt));
+        if (!(st0 == 0 && compose25)) {     // (stage 1, composed: conv1.a's output is already in buf[T], straight from the bases)
+          ORCA_TRY(launch_conv1d_p16(ctx, Ls[2], buf[LO], buf[T], nullptr, n, 1, 0, nullptr, fmt));
+          ORCA_TRY(launch_p16_zero_pads(ctx, buf[T], C, n, fmt));
+        }
         if (st0 + 1 < nplanar && kEncPools[st0 + 1] == 4) {
           ORCA_TRY(launch_conv1d_p16(ctx, Ls[3], buf[T], buf[S], buf[LO], n, 1, 1, nullptr, fmt));          // relu(.)+lout, MaxPool1d(4)
           ORCA_TRY(launch_p16_zero_pads(ctx, buf[S], C, n / 4, fmt));

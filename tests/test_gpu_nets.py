@@ -49,7 +49,8 @@ def test_encoder_ragged_length_and_batch_vs_oracle(cuda):
 
 @pytest.mark.parametrize("precision", ["f16x2", "bf16"])
 def test_encoder_composed_linear_pairs_vs_two_conv_form_and_oracle(cuda, precision, monkeypatch):
-    """lconv1..3 run as single 17-tap convs (weights composed on the host, ends redone by lconv_edge_fix_kernel).  Against
+    """lconv1..3 run as single 17-tap convs and conv1.a o lconv1 as a 25-tap conv from the bases (weights composed on the host, ends
+    redone by the edge-fix chain).  Against
     (a) the CPU oracle = the reference's two-conv form, on sequences so short that the 4 + 4 end positions of every stage
     carry weight (1 and 2 bins: 250 / 500 positions at stage 3), one-hot with N runs, reverse strand from codes, and raw
     floats; (b) the library's own two-conv form (ORCA_NO_COMPOSE=1) on the same inputs."""
@@ -73,13 +74,14 @@ def test_encoder_composed_linear_pairs_vs_two_conv_form_and_oracle(cuda, precisi
         refr = O.encoder_forward(sd, xr).numpy()
         yr = enc.forward_codes(codes, reverse=True).cpu().numpy()
         assert maxabs(yr, refr) < tol, (L, "reverse codes")
-        monkeypatch.setenv("ORCA_NO_COMPOSE", "1")
-        y2 = enc(xc).cpu().numpy()
-        yc2 = enc.forward_codes(codes).cpu().numpy()
-        monkeypatch.delenv("ORCA_NO_COMPOSE")
-        assert maxabs(y2, ref) < tol and maxabs(yc2, ref) < tol
-        if precision == "f16x2":
-            assert maxabs(y, y2) < 2e-5 and maxabs(yc, yc2) < 2e-5
+        for switch in ("ORCA_NO_COMPOSE", "ORCA_NO_COMPOSE25"):      # two-conv form everywhere / only conv1.a kept as its own launch
+            monkeypatch.setenv(switch, "1")
+            y2 = enc(xc).cpu().numpy()
+            yc2 = enc.forward_codes(codes).cpu().numpy()
+            monkeypatch.delenv(switch)
+            assert maxabs(y2, ref) < tol and maxabs(yc2, ref) < tol, switch
+            if precision == "f16x2":
+                assert maxabs(y, y2) < 2e-5 and maxabs(yc, yc2) < 2e-5, switch
     xf = torch.from_numpy(np.random.RandomState(14).rand(1, 4, 4000 * 2).astype(np.float32))     # arbitrary float rows
     reff = O.encoder_forward(sd, xf).numpy()
     assert maxabs(enc(xf.to(cuda)).cpu().numpy(), reff) < tol
