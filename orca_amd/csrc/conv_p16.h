@@ -45,6 +45,8 @@ struct ConvP16Args {
   const unsigned char* f1_codes;   // 1 byte per base of the whole sequence (see FirstMfmaArgs)
   long f1_codes_L, f1_codes_off;   // chunk position p is strand position codes_off + p
   int f1_reverse;
+  const f32x4* rl_w;               // RL: fp16 split pack [2 splits][5 k-steps][2 g][64 couts][8] of the composed 17-tap lconv1 (K = tap*4 + ci);
+                                   //     its bias comes in f1_bias, the bases in f1_codes / f1_codes_L / f1_codes_off / f1_reverse
   const float* f1_table;           // [9 taps][4 K-chunks][6 codes][4 quads][4] fp32: folded first-layer weights per base code
                                    // (4 = N, 5 = padding); (code, quad) adjacent so the 16 lanes of a ds_read_b128 group -
                                    // 4 positions x 4 channel quads - hit 16 different 16-byte bank slots
@@ -216,8 +218,14 @@ __device__ __forceinline__ void p16_lds_wait(f16x8 (&a)[2][MW], f16x8 (&b)[2][NW
 //   fragment reads and the counted waits are shared; only the product list and the epilogue differ.
 //   B16 planes: unit(p = ch/8, pos) at base + (p * PLEN + 4 + pos) * 16 bytes, guards as in P16.
 //   B16 weight pack: [cin/32][2 k-pairs][9][2][cout][8] bf16.
-template <int CT, int MW, int NW, int WM, int OM, bool R1, int ABL = 0, bool F1 = false, int FMT = 0>
+// RL (conv1.b of stage 1, packed input): the residual `lout1` is not LOADED from a stored tensor but COMPUTED in the epilogue - lout1 is
+//   the 17-tap composed conv of the bases (see conv1d_first_mfma_p16_kernel, NTAP = 17), i.e. per 32 x 32 accumulator tile a K = 80 GEMM of
+//   the W17 pack (20 KB of LDS) with one-hot operand units built from the tile's base codes (544 bytes of LDS): 10 MFMAs per tile that
+//   accumulate straight into the ReLU'd accumulators, in the part of the step where the matrix pipe used to idle.  The 17-tap first-layer
+//   launch with its 8 GB store, and this kernel's 8 GB residual read, disappear.
+template <int CT, int MW, int NW, int WM, int OM, bool R1, int ABL = 0, bool F1 = false, int FMT = 0, bool RL = false>
 __global__ __launch_bounds__(WM * 64, WM / 4) void conv1d_k9_p16_kernel(ConvP16Args a) {
+  static_assert(!RL || (CT == 64 && WM == 8 && MW == 2 && NW == 2 && FMT == 0 && !R1 && !F1), "residual from the bases: the 64 -> 64 P16 conv of stage 1");
   static_assert(!F1 || (CT == 64 && WM == 8 && MW == 2), "fused first layer: 64-cout tiles of 512 positions");
   static_assert(!F1 || FMT == 0, "fused first layer: P16 only");
   static_assert(NW * 32 == CT, "one wave covers all couts of the tile");
@@ -253,6 +261,21 @@ __global__ __launch_bounds__(WM * 64, WM / 4) void conv1d_k9_p16_kernel(ConvP16A
   if (F1) {
     for (int i = tid; i < 9 * 6 * 64; i += NT) f1_tab[i] = a.f1_table[i];
     if (tid < 64) f1_b[tid] = a.f1_bias[tid];
+  }
+  constexpr int RL_WIN = 544;                          // bases a tile's residual looks at: positions m0-8 .. m0+MT+11 (532 used)
+  __shared__ f32x4 rl_ws[RL ? 2 * 5 * 2 * 64 : 1];
+  __shared__ float rl_b[RL ? 64 : 4];
+  __shared__ unsigned char rl_win[RL ? 2 * RL_WIN : 4];
+  __shared__ u32x2 rl_oh[RL ? 8 : 1];                  // fp16 one-hot row per base code (4 = N = 0.25 x 4, 5 = zero row)
+  if (RL) {
+    for (int i = tid; i < 2 * 5 * 2 * 64; i += NT) rl_ws[i] = a.rl_w[i];
+    if (tid < 64) rl_b[tid] = a.f1_bias[tid];
+    if (tid < 8) {
+      u32x2 v;
+      v.x = tid == 0 ? 0x3C00u : tid == 1 ? 0x3C000000u : tid == 4 ? 0x34003400u : 0u;
+      v.y = tid == 2 ? 0x3C00u : tid == 3 ? 0x3C000000u : tid == 4 ? 0x34003400u : 0u;
+      rl_oh[tid] = v;
+    }
   }
   // base code at chunk position p (5 = outside the chunk: the first layer's zero padding).  Split in two so that the
   // global load (f1_fetch) and the use of its result (f1_fix) can sit a whole step apart.
@@ -400,6 +423,7 @@ __global__ __launch_bounds__(WM * 64, WM / 4) void conv1d_k9_p16_kernel(ConvP16A
   long epi_tile = -1;  // finished tile whose accumulators still await their epilogue (-1: none)
   int epi_cb = 0;
   long epi_pos = 0;
+  int epi_slot = 0;    // RL: window slot of that tile
 
   // Runs at the START of the next step (after the barrier that drained this step's DMA): its stores drain
   // underneath that step's MFMA block and are retired by the step's closing barrier.
@@ -513,6 +537,26 @@ __global__ __launch_bounds__(WM * 64, WM / 4) void conv1d_k9_p16_kernel(ConvP16A
       }                                                                                                          \
     }                                                                                                            \
   }
+  // (conv_ws.h defines its own, empty, P16_EPI_HOOK)
+#define P16_EPI_HOOK()                                                                                           \
+    if constexpr (RL) {   /* + lout1 of the tile's positions, straight from the bases (see the RL note above) */  \
+      const unsigned char* win_ = rl_win + epi_slot * RL_WIN + wave * (MW * 32) + l31 + 2 * g;                   \
+      _Pragma("unroll") for (int i = 0; i < MW; ++i) {                                                           \
+        f16x8 xf_[5];                                                                                            \
+        _Pragma("unroll") for (int kk = 0; kk < 5; ++kk) {                                                       \
+          const u32x2 o0_ = rl_oh[win_[i * 32 + 4 * kk]], o1_ = rl_oh[win_[i * 32 + 4 * kk + 1]];                \
+          u32x4_t u_;                                                                                            \
+          u_.x = o0_.x; u_.y = o0_.y; u_.z = o1_.x; u_.w = o1_.y;                                                \
+          xf_[kk] = __builtin_bit_cast(f16x8, u_);                                                               \
+        }                                                                                                        \
+        _Pragma("unroll") for (int j = 0; j < NW; ++j) _Pragma("unroll") for (int q = 0; q < 4; ++q) {           \
+          const f32x4 b_ = *reinterpret_cast<const f32x4*>(rl_b + j * 32 + 8 * q + 4 * g);                       \
+          acc[i][j][4 * q + 0] += b_.x; acc[i][j][4 * q + 1] += b_.y; acc[i][j][4 * q + 2] += b_.z; acc[i][j][4 * q + 3] += b_.w; \
+        }                                                                                                        \
+        _Pragma("unroll") for (int kk = 0; kk < 5; ++kk) _Pragma("unroll") for (int sp = 1; sp >= 0; --sp) _Pragma("unroll") for (int j = 0; j < NW; ++j) \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, rl_ws[((sp * 5 + kk) * 2 + g) * 64 + j * 32 + l31]), xf_[kk], acc[i][j], 0, 0, 0); \
+      }                                                                                                          \
+    }
   // ReLU in place on the accumulators, skipped as a whole (scalar branch) by the linear layers.  The units of a ragged last
   // tile beyond n are written unmasked: the caller runs p16_zero_pads_kernel AFTER the conv (tail and guards must read zero).
 #define P16_EPILOGUE()                                                                                           \
@@ -521,6 +565,7 @@ __global__ __launch_bounds__(WM * 64, WM / 4) void conv1d_k9_p16_kernel(ConvP16A
       _Pragma("unroll") for (int i = 0; i < MW; ++i) _Pragma("unroll") for (int j = 0; j < NW; ++j) _Pragma("unroll") for (int r = 0; r < 16; ++r) \
         acc[i][j][r] = p16_vmax(acc[i][j][r], 0.f);                                                              \
     }                                                                                                            \
+    P16_EPI_HOOK()                                                                                               \
     if constexpr (FMT == 1) P16_EPILOGUE_B16() else P16_EPILOGUE_P16()                                           \
   }
 
@@ -529,6 +574,10 @@ __global__ __launch_bounds__(WM * 64, WM / 4) void conv1d_k9_p16_kernel(ConvP16A
   for (int it = 0; it < NIT; ++it) P16_DMA_ONE(it, 0);
   int f1_slot = 0;                      // window slot of the CURRENT tile
   unsigned char f1_next[2] = {5, 5};    // bases of the next tile's window, in flight between step 0 and step 1 of a tile
+  if (RL) {                             // the first tile's window; the table, bias and pack become visible with it
+    const long m0_ = tile_pos * MT;
+    for (int k = tid; k < RL_WIN; k += NT) rl_win[k] = f1_fix(f1_fetch(m0_ - 8 + k));
+  }
   if (F1) {
     const long m0_ = tile_pos * MT;
     for (int k = tid; k < F1_WIN; k += NT) f1_win[k] = f1_fix(f1_fetch(m0_ - 8 + k));
@@ -580,6 +629,18 @@ __global__ __launch_bounds__(WM * 64, WM / 4) void conv1d_k9_p16_kernel(ConvP16A
       if (c == 1 && nxt_ < ntiles) {
         f1_win[(f1_slot ^ 1) * F1_WIN + tid] = f1_fix(f1_next[0]);
         if (tid < F1_WIN - NT) f1_win[(f1_slot ^ 1) * F1_WIN + NT + tid] = f1_fix(f1_next[1]);
+      }
+    }
+    if (RL) {   // the next tile's bases, as above, for its epilogue
+      const long nxt_ = tile + gridDim.x;
+      const long m0n_ = nx_pos * MT - 8;
+      if (c == 0 && nxt_ < ntiles) {
+        f1_next[0] = f1_fetch(m0n_ + tid);
+        if (tid < RL_WIN - NT) f1_next[1] = f1_fetch(m0n_ + NT + tid);
+      }
+      if (c == 1 && nxt_ < ntiles) {
+        rl_win[(f1_slot ^ 1) * RL_WIN + tid] = f1_fix(f1_next[0]);
+        if (tid < RL_WIN - NT) rl_win[(f1_slot ^ 1) * RL_WIN + NT + tid] = f1_fix(f1_next[1]);
       }
     }
     const long f1_m0 = F1 ? ntile_pos * MT : 0;      // tile whose input the producer builds during this step
@@ -655,12 +716,12 @@ __global__ __launch_bounds__(WM * 64, WM / 4) void conv1d_k9_p16_kernel(ConvP16A
     if (ABL & 512) {   // micro-benchmark: TIMING of a de-phased variant - waves WM/2.. take their epilogue half a tile later
       if (wave < WM / 2 ? last_chunk : (c + 1 == a.nchunks / 2)) { epi_tile = tile; epi_cb = tile_cb; epi_pos = tile_pos; }   // (the late group's results are meaningless)
     } else
-    if (last_chunk) { epi_tile = tile; epi_cb = tile_cb; epi_pos = tile_pos; }
+    if (last_chunk) { epi_tile = tile; epi_cb = tile_cb; epi_pos = tile_pos; epi_slot = f1_slot; }
 
     if (!more) break;
     if (ABL & 128) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); P16_STAMP(4); ++nstamp; }
     __syncthreads();   // next buffer has landed (vmcnt drained), everyone is done reading the current one
-    if (F1 && last_chunk) f1_slot ^= 1;
+    if ((F1 || RL) && last_chunk) f1_slot ^= 1;
     tile = ntile;
     tile_cb = ntile_cb;
     tile_pos = ntile_pos;
@@ -674,6 +735,7 @@ __global__ __launch_bounds__(WM * 64, WM / 4) void conv1d_k9_p16_kernel(ConvP16A
   }
 #undef P16_EPI_CB
 #undef P16_EPI_M0
+#undef P16_EPI_HOOK
 #undef P16_STAMP
 #undef P16_DMA_ONE
 #undef P16_SRC
@@ -1032,7 +1094,7 @@ struct EdgeFixArgs {           // where a chunk's input comes from
 // (from the chunk's input, or from the previous layer's scratch) into the values at the first / last `half` positions - exactly the
 // reference's arithmetic, zero padding of every intermediate included - keeps them in a scratch for the next layer and stores the
 // outermost `store_half` of them into the planar tensor the composed conv wrote.  One workgroup per position, threads = (tap half,
-// output channel): weight reads coalesced over the channel, no divisions in the loops; ~10 us per layer (the first version - one
+// output channel): weight reads coalesced over the channel, 4 or 8 independent loads in flight per thread; ~10 us per layer (the first version - one
 // workgroup per OUTPUT recomputing its 9 intermediates with a division per MAC - took 150-760 us per stage).
 __device__ __forceinline__ float edge_fix_load(const EdgeFixArgs& a, long pos, int ci) {
   if (pos < 0 || pos >= a.n) return 0.f;
@@ -1069,14 +1131,32 @@ struct EdgeLayerArgs {
   f32x4* y; long y_plen; int out_fmt;   // planar tensor receiving the outermost store_half positions per end (NULL: none)
 };
 
-__global__ __launch_bounds__(256) void lconv_edge_layer_kernel(EdgeLayerArgs a) {
+template <int KC>
+__device__ __forceinline__ float edge_layer_dot(const EdgeLayerArgs& a, const float (*xs)[128], int co, int th) {
+  // items (chunk c, tap t) of KC MACs each, dealt round-robin to the 4 thread groups; the KC loads of an item are independent
+  float acc = 0.f;
+  const int nitems = (a.cin / KC) * 9;
+  for (int it = th; it < nitems; it += 4) {
+    const int c = it / 9, t = it - c * 9;
+    const float* w = a.w + ((long)it * KC) * a.cout + co;
+    const float* xv = &xs[t][c * KC];
+    float wv[KC];
+#pragma unroll
+    for (int k = 0; k < KC; ++k) wv[k] = w[(long)k * a.cout];
+#pragma unroll
+    for (int k = 0; k < KC; ++k) acc = fmaf(wv[k], xv[k], acc);
+  }
+  return acc;
+}
+
+__global__ __launch_bounds__(512) void lconv_edge_layer_kernel(EdgeLayerArgs a) {
   __shared__ float xs[9][128];
-  __shared__ float part[128];
+  __shared__ float part[3][128];
   const int tid = threadIdx.x, co = tid & 127, th = tid >> 7;
   const long n = a.in.n;
   const long p = edge_fix_pos(blockIdx.x, a.half, n);
   if (p < 0) return;
-  for (int idx = tid; idx < 9 * a.cin; idx += 256) {
+  for (int idx = tid; idx < 9 * a.cin; idx += 512) {
     const int j = idx / a.cin, ci = idx - j * a.cin;
     const long q = p - 4 + j;
     float v = 0.f;
@@ -1089,20 +1169,11 @@ __global__ __launch_bounds__(256) void lconv_edge_layer_kernel(EdgeLayerArgs a) 
   }
   __syncthreads();
   float acc = 0.f;
-  if (co < a.cout) {
-    const int t0 = th ? 5 : 0, t1 = th ? 9 : 5;
-    const int nch = a.cin / a.kc;
-    for (int c = 0; c < nch; ++c)
-      for (int t = t0; t < t1; ++t) {
-        const float* w = a.w + (((long)c * 9 + t) * a.kc) * a.cout + co;
-        const float* xv = &xs[t][c * a.kc];
-        for (int k = 0; k < a.kc; ++k) acc = fmaf(w[(long)k * a.cout], xv[k], acc);
-      }
-  }
-  if (th) part[co] = acc;
+  if (co < a.cout) acc = a.kc == 8 ? edge_layer_dot<8>(a, xs, co, th) : edge_layer_dot<4>(a, xs, co, th);
+  if (th) part[th - 1][co] = acc;
   __syncthreads();
   if (!th && co < a.cout) {
-    acc = a.b[co] + acc + part[co];
+    acc = a.b[co] + ((acc + part[0][co]) + (part[1][co] + part[2][co]));
     if (a.relu) acc = fmaxf(acc, 0.f);
     if (a.sout) a.sout[blockIdx.x * 128 + co] = acc;
     if (a.y && (p < a.store_half || p >= n - a.store_half)) {
@@ -1115,5 +1186,42 @@ __global__ __launch_bounds__(256) void lconv_edge_layer_kernel(EdgeLayerArgs a) 
         reinterpret_cast<unsigned short*>(a.y + (long)(co >> 3) * a.y_plen + P16_GUARD + p)[co & 7] = (unsigned short)(cvt_pk_bf16(acc, 0.f) & 0xffffu);
       }
     }
+  }
+}
+
+// RL form of stage 1 (the residual lout1 is computed in conv1.b's epilogue, never stored): the pooled output's windows that touch
+// the first / last 4 positions are redone from the chain's scratches - v[p] = relu(conv1.b)[p] + lout1[p] (true values), MaxPool1d(4).
+// Block 0: window 0; blocks 1, 2: the last two windows (the earlier one only if it reaches into the last 4 positions).
+struct EdgePoolArgs {
+  const float* sc; int half_c;     // relu(conv1.b) at the first / last half_c positions   [2 half_c][128]
+  const float* sl; int half_l;     // lout1 at the first / last half_l positions            [2 half_l][128]
+  long n; int cout;
+  f32x4* y; long y_plen; int out_fmt;
+};
+__global__ __launch_bounds__(128) void lconv_edge_pool_kernel(EdgePoolArgs a) {
+  const long nw = a.n / 4;
+  long w;
+  if (blockIdx.x == 0) w = 0;
+  else {
+    w = nw - (long)blockIdx.x;                 // nw-1, nw-2
+    if (w <= 0 || 4 * w + 3 < a.n - 4) return; // window 0 is block 0's; untouched windows stay
+  }
+  if (w >= nw) return;
+  const int co = threadIdx.x;
+  if (co >= a.cout) return;
+  float m = -3.4e38f;
+  for (int r = 0; r < 4; ++r) {
+    const long p = 4 * w + r;
+    const int s1 = p < a.half_c ? (int)p : (int)(a.half_c + p - (a.n - a.half_c));
+    const int s2 = p < a.half_l ? (int)p : (int)(a.half_l + p - (a.n - a.half_l));
+    m = fmaxf(m, a.sc[s1 * 128 + co] + a.sl[s2 * 128 + co]);
+  }
+  if (a.out_fmt == 0) {
+    const _Float16 h = (_Float16)m;
+    const _Float16 l = (_Float16)(m - (float)h);
+    reinterpret_cast<_Float16*>(a.y + (long)(co >> 3) * 2 * a.y_plen + P16_GUARD + w)[co & 7] = h;
+    reinterpret_cast<_Float16*>(a.y + ((long)(co >> 3) * 2 + 1) * a.y_plen + P16_GUARD + w)[co & 7] = l;
+  } else {
+    reinterpret_cast<unsigned short*>(a.y + (long)(co >> 3) * a.y_plen + P16_GUARD + w)[co & 7] = (unsigned short)(cvt_pk_bf16(m, 0.f) & 0xffffu);
   }
 }

@@ -93,6 +93,7 @@ __global__ __launch_bounds__(512, 2) void conv1d_k9_ws_kernel(ConvP16Args a) {
   float vmax = 0.f;
   long epi_tile = -1;
 #define P16_EPI_CB cb
+#define P16_EPI_HOOK()
 #define P16_EPI_M0 (epi_tile * MTW)
   // the macros of conv_p16.h index the bias and the cout block through `tcb * CT`: bias_s holds only this block's couts
 #define WS_ACC_INIT()                                                                                         \
@@ -200,6 +201,7 @@ __global__ __launch_bounds__(512, 2) void conv1d_k9_ws_kernel(ConvP16Args a) {
 #undef WS_DMA_ONE
 #undef WS_SRC
 #undef P16_EPI_CB
+#undef P16_EPI_HOOK
 #undef P16_EPI_M0
   if (FMT == 0 && OM != 2 && vmax > 65504.f && a.flag) *a.flag = 1u;
 }

@@ -79,7 +79,7 @@ struct orca_ctx {
   bool timing = false;
   std::vector<TimedLaunch> timed;
   unsigned* d_flag = nullptr;   // fp16-range overflow flag written by the f16x2 kernels
-  float* d_edge = nullptr;      // 2 x 32 x 128 floats: ping-pong scratch of the edge-fix chain (lconv_edge_layer_kernel)
+  float* d_edge = nullptr;      // 4 x 40 x 128 floats: one scratch slab per layer of the edge-fix chain (lconv_edge_layer_kernel)
   // Decoders with an even batch run as two half-batches on two streams (see decoder_nhwc)
   hipStream_t aux = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -637,6 +637,25 @@ static void launch_p16_fused_first(hipStream_t s, ConvP16Args a) {
   hipLaunchKernelGGL((conv1d_k9_p16_kernel<64, 2, 2, 8, 0, false, 0, true>), grid, dim3(512), 0, s, a);
 }
 
+// stage 1's pooled conv with the residual computed from the bases in its epilogue (conv_p16.h, RL)
+static void launch_p16_res_bases(hipStream_t s, ConvP16Args a) {
+  constexpr int MT = 512;
+  static int resident = [] {
+    int dev = 0, ncu = 256, per_cu = 1;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv1d_k9_p16_kernel<64, 2, 2, 8, 1, false, 0, false, 0, true>, 512, 0) != hipSuccess || per_cu < 1) {
+      (void)hipGetLastError();
+      per_cu = 1;
+    }
+    return ncu * per_cu;
+  }();
+  a.tiles_per_row = (a.n + MT - 1) / MT;
+  const long ntiles = a.tiles_per_row;
+  dim3 grid((unsigned)(ntiles < resident ? ntiles : resident));
+  hipLaunchKernelGGL((conv1d_k9_p16_kernel<64, 2, 2, 8, 1, false, 0, false, 0, true>), grid, dim3(512), 0, s, a);
+}
+
 // W-stationary barrier-free form (conv_ws.h): persistent, one workgroup per CU; the grid is a multiple of the number
 // of cout blocks (of 8 x that where possible: the blocks of one position range then share an XCD)
 template <int FMT, int CIN, int CT, int MW, int NW, int OM, bool R1>
@@ -684,6 +703,7 @@ struct FusedFirst {   // packed bases + first-layer table: the conv's input is p
   int reverse = 0;
   const float* table = nullptr;
   const float* bias = nullptr;
+  bool residual = false;   // RL form instead: x IS read; the bases + the 17-tap pack (in `table`) give the residual in the epilogue
 };
 
 // fmt 0: P16 activations (fp32-class f16x2 arithmetic); fmt 1: B16 activations (plain bf16, BASELINE config 3)
@@ -705,12 +725,17 @@ static int launch_conv1d_p16(orca_ctx* ctx, const ConvLayer& L, const float* x, 
     HIPCHECK(hipEventCreate(&tl.e1));
     HIPCHECK(hipEventRecord(tl.e0, ctx->stream));
   }
-  a.f1_codes = nullptr; a.f1_codes_L = a.f1_codes_off = 0; a.f1_reverse = 0; a.f1_table = a.f1_bias = nullptr; a.stamps = nullptr;
+  a.f1_codes = nullptr; a.f1_codes_L = a.f1_codes_off = 0; a.f1_reverse = 0; a.f1_table = a.f1_bias = nullptr; a.stamps = nullptr; a.rl_w = nullptr;
   static const bool no_ws = getenv("ORCA_NO_WS") != nullptr;   // A/B switch: W-stationary barrier-free kernel (conv_ws.h)
   static const bool ws_p16 = getenv("ORCA_WS_P16") != nullptr; // ... also for P16 (measured 3 % slower there: off)
   const bool ws_ok = !no_ws && (fmt == 1 || ws_p16) && !k17;
   int tile_tag = fmt == 1 ? -6 : -5;
-  if (f1) {
+  if (f1 && f1->residual) {
+    if (L.cout != 64 || L.cin != 64 || out_mode != 1 || r1 || fmt != 0 || k17) return fail(ORCA_EINVAL, "residual from the bases: only stage 1's pooled 64 -> 64 P16 conv");
+    a.f1_codes = f1->codes; a.f1_codes_L = f1->codes_L; a.f1_codes_off = f1->codes_off; a.f1_reverse = f1->reverse;
+    a.rl_w = reinterpret_cast<const f32x4*>(f1->table); a.f1_bias = f1->bias;
+    launch_p16_res_bases(ctx->stream, a);
+  } else if (f1) {
     if (L.cout != 64 || L.cin != 64 || out_mode != 0 || r1 || fmt != 0 || k17) return fail(ORCA_EINVAL, "fused first layer: only the 64 -> 64 P16 conv that follows it");
     a.f1_codes = f1->codes; a.f1_codes_L = f1->codes_L; a.f1_codes_off = f1->codes_off; a.f1_reverse = f1->reverse;
     a.f1_table = f1->table; a.f1_bias = f1->bias;
@@ -739,26 +764,26 @@ static int launch_conv1d_p16(orca_ctx* ctx, const ConvLayer& L, const float* x, 
 }
 
 // the end positions of a composed linear group, recomputed conv by conv (conv_p16.h: lconv_edge_layer_kernel).  layers[l] with
-// relu[l]; the LAST layer's outermost `last_store` positions per end go to y_last, the layer before it (if y_prev) stores 4 per end
-// to y_prev (stage 1: lout1 next to conv1.a's activation).  Scratch: two 32 x 128 float slabs of the context, ping-pong.
-static int launch_edge_chain(orca_ctx* ctx, const ConvLayer* const* layers, const int* relu, int nl, EdgeFixArgs src, long n,
-                             float* y_prev, float* y_last, int fmt) {
+// relu[l]; the last layer covers `half_last` positions per end, layer l four more per layer behind it; ys[l] (may be NULL) receives
+// the outermost stores[l] positions per end of layer l.  Scratch: one 40 x 128 float slab per layer in the context.
+#define ORCA_EDGE_SLAB (40 * 128)
+static int launch_edge_chain(orca_ctx* ctx, const ConvLayer* const* layers, const int* relu, int nl, int half_last, EdgeFixArgs src, long n,
+                             float* const* ys, const int* stores, int fmt) {
   src.n = n;
+  if (nl > 4 || 2 * (half_last + 4 * (nl - 1)) > 40) return fail(ORCA_EINVAL, "edge fix: chain too deep");
   for (int l = 0; l < nl; ++l) {
     const ConvLayer& L = *layers[l];
     if (!L.d_w) return fail(ORCA_EINVAL, "edge fix: layer without an fp32 pack");
     EdgeLayerArgs a{};
     a.in = src;
     if (l > 0) a.in.in_mode = -1;
-    a.half = 4 * (2 * nl - 2 - l); a.half_in = a.half + 4;   // an nl-conv group differs from its composition within 4 (nl - 1) of the ends
+    a.half = half_last + 4 * (nl - 1 - l); a.half_in = a.half + 4;
     a.relu = relu[l]; a.cin = L.cin; a.cout = L.cout; a.kc = L.kc; a.w = L.d_w; a.b = L.d_bias;
-    a.sin = l > 0 ? ctx->d_edge + ((l - 1) & 1) * 32 * 128 : nullptr;
-    a.sout = l + 1 < nl ? ctx->d_edge + (l & 1) * 32 * 128 : nullptr;
-    float* y = l == nl - 1 ? y_last : (l == nl - 2 ? y_prev : nullptr);
-    a.y = reinterpret_cast<f32x4*>(y); a.y_plen = p16_plen(n); a.out_fmt = fmt;
-    a.store_half = l == nl - 1 ? a.half : 4;
-    if (2 * a.half > 32) return fail(ORCA_EINVAL, "edge fix: chain too deep");
-    hipLaunchKernelGGL(lconv_edge_layer_kernel, dim3((unsigned)(2 * a.half)), dim3(256), 0, ctx->stream, a);
+    a.sin = l > 0 ? ctx->d_edge + (l - 1) * ORCA_EDGE_SLAB : nullptr;
+    a.sout = ctx->d_edge + l * ORCA_EDGE_SLAB;
+    a.y = reinterpret_cast<f32x4*>(ys[l]); a.y_plen = p16_plen(n); a.out_fmt = fmt;
+    a.store_half = stores[l];
+    hipLaunchKernelGGL(lconv_edge_layer_kernel, dim3((unsigned)(2 * a.half)), dim3(512), 0, ctx->stream, a);
   }
   LAUNCHCHECK("lconv_edge_layer_kernel");
   return ORCA_OK;
@@ -813,7 +838,7 @@ extern "C" int orca_ctx_create(int device, void* hip_stream, orca_ctx** out) {
   c->device = device;
   c->stream = static_cast<hipStream_t>(hip_stream);
   if (hipMalloc(reinterpret_cast<void**>(&c->d_flag), 4 * sizeof(unsigned)) != hipSuccess || hipMemset(c->d_flag, 0, 4 * sizeof(unsigned)) != hipSuccess ||
-      hipMalloc(reinterpret_cast<void**>(&c->d_edge), 2 * 32 * 128 * sizeof(float)) != hipSuccess) {
+      hipMalloc(reinterpret_cast<void**>(&c->d_edge), 4 * 40 * 128 * sizeof(float)) != hipSuccess) {
     delete c;
     return fail(ORCA_ENOMEM, "could not allocate the context flag word");
   }
@@ -1154,6 +1179,9 @@ static int encoder_chunk(orca_ctx* ctx, orca_net* net, const SeqSource& src, lon
       const bool flat = src.codes || (sx_c == 1 && sx_l == 4 && al16(x));
       // conv1.a joins the composed group (25 taps from the bases + ReLU, K = 112): ORCA_NO_COMPOSE25=1 keeps it a 64 -> 64 launch
       const bool compose25 = compose && getenv("ORCA_NO_COMPOSE25") == nullptr && net->d_c1a_w16 != nullptr;
+      // ... and with packed bases the residual lout1 is computed inside conv1.b's epilogue (conv_p16.h, RL) instead of being stored by a
+      // 17-tap first-layer launch and re-read: ORCA_NO_RL=1 keeps the stored form
+      const bool res_from_bases = compose25 && src.codes && fmt == 0 && getenv("ORCA_NO_RL") == nullptr;
       float* first_out = compose ? buf[LO] : buf[T];
       const float* rows = x;     // flat [n][4] float rows for the MFMA first-layer kernels (unused with packed input)
       // one first-layer GEMM launch: ntap 9 (lconv1.a alone), 17 (lconv1 composed), 25 (conv1.a o lconv1, + ReLU)
@@ -1197,7 +1225,8 @@ static int encoder_chunk(orca_ctx* ctx, orca_net* net, const SeqSource& src, lon
           LAUNCHCHECK("seq_to_rows_kernel");
           rows = buf[S];
         }
-        if (compose) ORCA_TRY(launch_first(17, net->d_l1_w16, net->d_l1_bias, 0, buf[LO]));
+        if (res_from_bases) { /* no lout1 tensor */ }
+        else if (compose) ORCA_TRY(launch_first(17, net->d_l1_w16, net->d_l1_bias, 0, buf[LO]));
         else ORCA_TRY(launch_first(9, net->d_first_w16, L[0].d_bias, 0, buf[T]));
         if (compose25) {
           ORCA_TRY(launch_first(25, net->d_c1a_w16, net->d_c1a_bias, 1, buf[T]));
@@ -1207,15 +1236,26 @@ static int encoder_chunk(orca_ctx* ctx, orca_net* net, const SeqSource& src, lon
         hipLaunchKernelGGL(conv1d_first_p16_kernel, dim3((unsigned)((n1 + 255) / 256), 8), dim3(256), 0, s, fa);
         LAUNCHCHECK("conv1d_first_p16_kernel");
       }
-      if (!fuse1) ORCA_TRY(launch_p16_zero_pads(ctx, first_out, 64, n1, fmt));
+      if (!fuse1 && !res_from_bases) ORCA_TRY(launch_p16_zero_pads(ctx, first_out, 64, n1, fmt));
       if (compose) {
         EdgeFixArgs ef{};
         if (src.codes) { ef.in_mode = 1; ef.codes = src.codes; ef.codes_L = src.codes_L; ef.codes_off = src.codes_off; ef.reverse = src.reverse; }
         else { ef.in_mode = 0; ef.x = x; ef.sc = sx_c; ef.sl = sx_l; }
-        const ConvLayer* chain[3] = {&L[0], &L[1], &L[2]};
-        const int relus[3] = {0, 0, 1};
-        if (compose25) ORCA_TRY(launch_edge_chain(ctx, chain, relus, 3, ef, n1, buf[LO], buf[T], fmt));
-        else ORCA_TRY(launch_edge_chain(ctx, chain, relus, 2, ef, n1, nullptr, buf[LO], fmt));
+        const ConvLayer* chain[4] = {&L[0], &L[1], &L[2], &L[3]};
+        const int relus[4] = {0, 0, 1, 1};
+        if (res_from_bases) {        // lout1 is never stored; conv1.b's own end positions are needed for the pooled windows (after the conv, below)
+          float* ys[4] = {nullptr, nullptr, buf[T], nullptr};
+          const int st_[4] = {0, 0, 8, 0};
+          ORCA_TRY(launch_edge_chain(ctx, chain, relus, 4, 8, ef, n1, ys, st_, fmt));
+        } else if (compose25) {
+          float* ys[3] = {nullptr, buf[LO], buf[T]};
+          const int st_[3] = {0, 4, 8};
+          ORCA_TRY(launch_edge_chain(ctx, chain, relus, 3, 8, ef, n1, ys, st_, fmt));
+        } else {
+          float* ys[2] = {nullptr, buf[LO]};
+          const int st_[2] = {0, 4};
+          ORCA_TRY(launch_edge_chain(ctx, chain, relus, 2, 4, ef, n1, ys, st_, fmt));
+        }
       }
       n = n1;
       static const bool no_st4 = getenv("ORCA_NO_P16_STAGE4") != nullptr;   // A/B switch: stage 4 on the register-staged kernel again
@@ -1238,7 +1278,9 @@ static int encoder_chunk(orca_ctx* ctx, orca_net* net, const SeqSource& src, lon
           ef.in_mode = fmt == 1 ? 3 : 2; ef.xp = reinterpret_cast<const f32x4*>(buf[S]); ef.x_plen = p16_plen(n);
           const ConvLayer* chain[2] = {&Ls[0], &Ls[1]};
           const int relus[2] = {0, 0};
-          ORCA_TRY(launch_edge_chain(ctx, chain, relus, 2, ef, n, nullptr, buf[LO], fmt));
+          float* ys[2] = {nullptr, buf[LO]};
+          const int st_[2] = {0, 4};
+          ORCA_TRY(launch_edge_chain(ctx, chain, relus, 2, 4, ef, n, ys, st_, fmt));
         } else if (!comp_st) {
           if (st0 > 0) {  // first conv of the stage: previous (pooled) output in buf[S] -> buf[T]
             ORCA_TRY(launch_conv1d_p16(ctx, Ls[0], buf[S], buf[T], nullptr, n, 0, 0, nullptr, fmt));
@@ -1251,7 +1293,19 @@ static int encoder_chunk(orca_ctx* ctx, orca_net* net, const SeqSource& src, lon
           ORCA_TRY(launch_conv1d_p16(ctx, Ls[2], buf[LO], buf[T], nullptr, n, 1, 0, nullptr, fmt));
           ORCA_TRY(launch_p16_zero_pads(ctx, buf[T], C, n, fmt));
         }
-        if (st0 + 1 < nplanar && kEncPools[st0 + 1] == 4) {
+        if (st0 == 0 && res_from_bases) {
+          FusedFirst rl;     // relu(.) + lout1 computed from the bases in the epilogue, MaxPool1d(4)
+          rl.codes = src.codes; rl.codes_L = src.codes_L; rl.codes_off = src.codes_off; rl.reverse = src.reverse;
+          rl.table = reinterpret_cast<const float*>(net->d_l1_w16); rl.bias = net->d_l1_bias; rl.residual = true;
+          ORCA_TRY(launch_conv1d_p16(ctx, Ls[3], buf[T], buf[S], nullptr, n, 1, 1, &rl, fmt));
+          ORCA_TRY(launch_p16_zero_pads(ctx, buf[S], C, n / 4, fmt));
+          EdgePoolArgs ep{};
+          ep.sc = ctx->d_edge + 3 * ORCA_EDGE_SLAB; ep.half_c = 8; ep.sl = ctx->d_edge + 1 * ORCA_EDGE_SLAB; ep.half_l = 16; ep.n = n; ep.cout = C;
+          ep.y = reinterpret_cast<f32x4*>(buf[S]); ep.y_plen = p16_plen(n / 4); ep.out_fmt = fmt;
+          if (n / 4 > 0) hipLaunchKernelGGL(lconv_edge_pool_kernel, dim3(3), dim3(128), 0, s, ep);
+          LAUNCHCHECK("lconv_edge_pool_kernel");
+          n /= 4;
+        } else if (st0 + 1 < nplanar && kEncPools[st0 + 1] == 4) {
           ORCA_TRY(launch_conv1d_p16(ctx, Ls[3], buf[T], buf[S], buf[LO], n, 1, 1, nullptr, fmt));          // relu(.)+lout, MaxPool1d(4)
           ORCA_TRY(launch_p16_zero_pads(ctx, buf[S], C, n / 4, fmt));
           n /= 4;

@@ -74,7 +74,7 @@ def test_encoder_composed_linear_pairs_vs_two_conv_form_and_oracle(cuda, precisi
         refr = O.encoder_forward(sd, xr).numpy()
         yr = enc.forward_codes(codes, reverse=True).cpu().numpy()
         assert maxabs(yr, refr) < tol, (L, "reverse codes")
-        for switch in ("ORCA_NO_COMPOSE", "ORCA_NO_COMPOSE25"):      # two-conv form everywhere / only conv1.a kept as its own launch
+        for switch in ("ORCA_NO_COMPOSE", "ORCA_NO_COMPOSE25", "ORCA_NO_RL"):   # two-conv form everywhere / conv1.a as its own launch / lout1 stored
             monkeypatch.setenv(switch, "1")
             y2 = enc(xc).cpu().numpy()
             yc2 = enc.forward_codes(codes).cpu().numpy()
