@@ -210,6 +210,125 @@ def sharded_256mb(args, rank, world, dev, dist):
             "bins_this_rank": [int(lo), int(hi)]}
 
 
+def inst_rooflines(recs):
+    """Per-kernel-instantiation HIP-event timings of the planar conv1d launches -> {name: {...}} (see main)."""
+    groups = {}
+    for cout, cin, tile, batch, n, ms, ksize in recs:
+        g = groups.setdefault((cout, cin, tile, ksize), {"ms": 0.0, "launches": 0, "flop": 0.0, "bytes": 0.0})
+        g["ms"] += ms
+        g["launches"] += 1
+        # a 17-tap launch is a composed linear pair Conv(cin->cout) - BN - Conv(cout->cout) - BN (orca_modules.py:811-816):
+        # its ALGORITHMIC work is the pair's (SURVEY 8d counts the reference's convolutions)
+        # (25 taps from the bases = conv1.a composed with lconv1: the launch carries conv1.a's 64 -> 64 work, lconv1's is on the 17-tap launch)
+        g["flop"] += 2.0 * 9 * (cout * cout if ksize == 25 else cin * cout + (cout * cout if ksize == 17 else 0)) * n * batch
+        g["bytes"] += float(cin + cout) * n * batch      # x elements in + out; bytes per element applied per arithmetic below
+    PREC = {0: ("f32", "conv1d_k9_kernel", PEAK_F32_MFMA_TFLOPS, 1, 4), 1: ("bf16", "conv1d_k9_bf16s_kernel", PEAK_16BIT_MFMA_TFLOPS, 1, 4),
+            2: ("bf16x2", "conv1d_k9_bf16s_kernel", PEAK_16BIT_MFMA_TFLOPS, 3, 4), 3: ("bf16x3", "conv1d_k9_bf16s_kernel", PEAK_16BIT_MFMA_TFLOPS, 6, 4),
+            4: ("f16x2", "conv1d_k9_bf16s_kernel", PEAK_16BIT_MFMA_TFLOPS, 3, 4),
+            5: ("f16x2", "conv1d_k9_p16_kernel", PEAK_16BIT_MFMA_TFLOPS, 3, 4), 6: ("bf16", "conv1d_k9_p16_kernel", PEAK_16BIT_MFMA_TFLOPS, 1, 2),
+            7: ("f16x2", "conv1d_k9_ws_kernel", PEAK_16BIT_MFMA_TFLOPS, 3, 4), 8: ("bf16", "conv1d_k9_ws_kernel", PEAK_16BIT_MFMA_TFLOPS, 1, 2)}
+    inst = {}
+    for (cout, cin, tile, ksize), g in groups.items():
+        prec = -tile if tile < 0 else 0
+        pname, kname, peak, nprod, bpe = PREC[prec]
+        if ksize == 17:
+            kname = "conv1d_first_mfma_p16_kernel[17 taps: composed lconv1]" if cin == 4 else kname + "[17 taps: composed pair]"
+        elif ksize == 25:
+            kname = "conv1d_first_mfma_p16_kernel[25 taps: conv1.a o lconv1]"
+        key = f"{kname}<cout={cout},{pname}>" if prec else f"{kname}<cout={cout},kc={4 if cin == 4 else 8},tile={tile}>"
+        d = inst.setdefault(key, {"ms": 0.0, "launches": 0, "flop": 0.0, "bytes": 0.0, "peak": peak, "nprod": nprod, "arith": pname})
+        for k in ("ms", "launches", "flop"):
+            d[k] += g[k]
+        d["bytes"] += g["bytes"] * bpe
+    return inst
+
+
+def config3_section(dev):
+    """BASELINE.json configs[2]: HFF-shaped 32 Mb model, batch of 8 random 32 Mb sequences, throughput mode - Encoder on single bf16
+    planes (plain bf16 operands, one MFMA product), Decoders on single fp16 planes (2 B/element end to end; the residual stream keeps 11
+    significant bits), module-level forward of the forward strand (`genomepredict` keeps only batch row 0, orca_predict.py:514-523)."""
+    from orca_amd import engine, orca_models, orca_predict as P, synth
+    seed, mpos, wpos = 7, 17_234_567, 16_000_000                      # = tools/make_golden.py CONFIG3 / tests/test_gpu_config3.py
+    hff = orca_models.Hff(synthetic_seed=seed)
+    codes = torch.from_numpy(np.stack([synth.synth_base_codes(L_BP, seed=10 + b) for b in range(8)])).to(dev)
+    de = {lv: torch.log(torch.from_numpy(hff.normmats[lv][None, None].astype(np.float32))).to(dev) for lv in hff.levels}
+    hff.net0.precision = "bf16"
+    for lv in hff.levels:
+        hff.denets[lv].precision = "f16"
+    hff.denet_1_pt.precision = "f16"
+
+    def fwd():
+        enc0 = hff.net0.forward_codes(codes)
+        encs = dict(zip([1, 2, 4, 8, 16, 32], hff.net(enc0)))
+        return P.run_cascade(hff, encs, [32, 16, 8, 4, 2, 1], lambda lv: lv, 8, [False], lambda lv, k, st: de[lv],
+                             lambda lv, st, rev: P.zoom_index_32m(lv, st, mpos, wpos, rev), add_1m_level=1)[0]
+
+    ctx = engine.get_context(dev)
+    fwd()
+    torch.cuda.synchronize(dev)
+    ctx.set_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(2):
+        preds = fwd()
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / 2
+    ctx.set_timing(False)
+    inst = inst_rooflines(ctx.get_timing())
+    flop = 8 * step_flops() / 2          # one strand per row
+    out = {"workload": "HFF-shaped 32 Mb model, batch of 8 random 32 Mb sequences (seeds 10-17), forward strand, module-level forward: Encoder "
+                       "precision 'bf16' (B16 planes, one product), Decoders 'f16' (single fp16 planes), 2 bytes per activation end to end",
+           "batches_timed": 2, "s_per_batch": round(dt, 4), "Mb_per_s": round(8 * 32 / dt, 1), "maps_per_s": round(48 / dt, 1),
+           "whole_batch_tflops": round(flop / dt, 1), "frac_of_2500TF_16bit_peak": round(flop / dt / PEAK_16BIT_MFMA_TFLOPS, 4)}
+    if inst:
+        name, d = max(inst.items(), key=lambda kv: kv[1]["ms"])
+        ach = d["flop"] / (d["ms"] * 1e-3) / 1e12
+        out["roofline"] = {"kernel": name, "bound": "hbm+mfma", "achieved": round(ach, 1), "peak": d["peak"], "unit": "TFLOP/s", "frac": round(ach / d["peak"], 4),
+                           "algorithmic_hbm_GBps": round(d["bytes"] / (d["ms"] * 1e-3) / 1e9, 1), "hbm_frac_of_8TBps": round(d["bytes"] / (d["ms"] * 1e-3) / 8e12, 4),
+                           "avg_launch_ms": round(d["ms"] / d["launches"], 4), "launches": d["launches"]}
+    g17 = os.path.join(ROOT, "tests", "golden", "G17_config3.npz")
+    if os.path.exists(g17):
+        g = np.load(g17)
+        errs, rs = [], []
+        for b in (0, 5):
+            for j, p in enumerate(preds):
+                a, r = p[b, 0].cpu().numpy().astype(np.float64), g[f"maps_row{b}"][j].astype(np.float64)
+                errs.append(float(np.abs(a - r).max()))
+                rs.append(float(np.corrcoef(a.ravel(), r.ravel())[0, 1]))
+        out["parity"] = {"against": "tests/golden/G17_config3.npz = rows 0 and 5 through the reference's own modules (PyTorch CPU fp32)",
+                         "max_abs": round(max(errs), 5), "pearson_min": round(min(rs), 7), "stated_tolerance": {"max_abs": 0.1, "pearson": 0.99999},
+                         "ok": bool(max(errs) < 0.1 and min(rs) > 0.99999)}
+    del codes, preds, hff
+    ctx.release_workspace()
+    torch.cuda.empty_cache()
+    return out
+
+
+def config5_section(dev, n_svs=16):
+    """BASELINE.json configs[4] on this rank: `n_svs` of the 1024 synthetic structural variants (orca_amd.sv.synth_svs: del / dup / inv,
+    10 kb - 5 Mb) x reference + alternative allele, each a full 32 Mb `genomepredict` (both strands, 6 maps) assembled on the device
+    from a packed 40 Mb chromosome.  Variants are independent: N GPUs take every N-th (replicas, no collective)."""
+    from orca_amd import engine, orca_models, sv
+    h1 = orca_models.H1esc(synthetic_seed=0)
+    g = torch.Generator(device=dev).manual_seed(5)
+    genome = torch.randint(0, 4, (40_000_000,), device=dev, generator=g, dtype=torch.uint8)
+    svs = sv.synth_svs(n_svs + 2, 40_000_000)
+    sv.sv_screen([h1], genome, svs[:2], 40_000_000)      # warm-up: workspace growth, both window shapes
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    res = sv.sv_screen([h1], genome, svs[2:], 40_000_000)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    chk = float(sum(float(np.sum(r[a]["predictions"][0][0], dtype=np.float64)) for r in res.values() for a in ("ref", "alt")))
+    out = {"workload": f"{n_svs} of the 1024 synthetic SVs x (reference + alternative allele) x 32 Mb genomepredict (both strands, 6 maps), windows "
+                       "gathered on the device from a packed 40 Mb chromosome", "svs": n_svs, "s_per_sv": round(dt / n_svs, 4),
+           "svs_per_s": round(n_svs / dt, 2), "Mb_per_s": round(n_svs * 2 * 2 * 32 / dt, 1), "projected_1024_svs_s_one_gpu": round(1024 * dt / n_svs, 1),
+           "kinds": "".join(v.kind[0] for v in svs[2:]), "level32_maps_checksum": round(chk, 3)}
+    del genome, res, h1
+    engine.get_context(dev).release_workspace()
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -219,6 +338,7 @@ def main():
     ap.add_argument("--seq-mb", type=int, default=32, help="debug only: shorter sequence (invalidates the metric)")
     ap.add_argument("--float-input", action="store_true", help="keep the strands as float32 [1,4,L] views (the reference's input form)")
     ap.add_argument("--no-sharded", action="store_true", help="skip the 256 Mb sharded-encoder section")
+    ap.add_argument("--no-configs", action="store_true", help="skip the config 3 (B = 8 bf16) and config 5 (SV screen) sections")
     ap.add_argument("--sharded-timeout", type=float, default=420.0, help="N > 1: seconds the 256 Mb sharded section (and the final barrier) may take before the line is printed without it")
     ap.add_argument("--sharded-steps", type=int, default=3)
     ap.add_argument("--torch-collective", action="store_true", help="256 Mb section: torch.distributed all-gather instead of the C ABI's RCCL communicator")
@@ -287,33 +407,7 @@ def main():
         elapsed = float(t.item())
 
     # ---- dominant kernel: per-instantiation HIP-event timings collected in the timed region
-    groups = {}
-    for cout, cin, tile, batch, n, ms, ksize in recs:
-        g = groups.setdefault((cout, cin, tile, ksize), {"ms": 0.0, "launches": 0, "flop": 0.0})
-        g["ms"] += ms
-        g["launches"] += 1
-        # a 17-tap launch is a composed linear pair Conv(cin->cout) - BN - Conv(cout->cout) - BN (orca_modules.py:811-816):
-        # its ALGORITHMIC work is the pair's (SURVEY 8d counts the reference's convolutions)
-        # (25 taps from the bases = conv1.a composed with lconv1: the launch carries conv1.a's 64 -> 64 work, lconv1's is on the 17-tap launch)
-        g["flop"] += 2.0 * 9 * (cout * cout if ksize == 25 else cin * cout + (cout * cout if ksize == 17 else 0)) * n * batch
-    # kernel instantiation = (cout, arithmetic); records of the 16-bit split kernels carry tile = -precision
-    PREC = {0: ("f32", "conv1d_k9_kernel", PEAK_F32_MFMA_TFLOPS, 1), 1: ("bf16", "conv1d_k9_bf16s_kernel", PEAK_16BIT_MFMA_TFLOPS, 1),
-            2: ("bf16x2", "conv1d_k9_bf16s_kernel", PEAK_16BIT_MFMA_TFLOPS, 3), 3: ("bf16x3", "conv1d_k9_bf16s_kernel", PEAK_16BIT_MFMA_TFLOPS, 6),
-            4: ("f16x2", "conv1d_k9_bf16s_kernel", PEAK_16BIT_MFMA_TFLOPS, 3),
-            5: ("f16x2", "conv1d_k9_p16_kernel", PEAK_16BIT_MFMA_TFLOPS, 3), 6: ("bf16", "conv1d_k9_p16_kernel", PEAK_16BIT_MFMA_TFLOPS, 1),
-            7: ("f16x2", "conv1d_k9_ws_kernel", PEAK_16BIT_MFMA_TFLOPS, 3), 8: ("bf16", "conv1d_k9_ws_kernel", PEAK_16BIT_MFMA_TFLOPS, 1)}
-    inst = {}
-    for (cout, cin, tile, ksize), g in groups.items():
-        prec = -tile if tile < 0 else 0
-        pname, kname, peak, nprod = PREC[prec]
-        if ksize == 17:
-            kname = "conv1d_first_mfma_p16_kernel[17 taps: composed lconv1]" if cin == 4 else kname + "[17 taps: composed pair]"
-        elif ksize == 25:
-            kname = "conv1d_first_mfma_p16_kernel[25 taps: conv1.a o lconv1]"
-        key = f"{kname}<cout={cout},{pname}>" if prec else f"{kname}<cout={cout},kc={4 if cin == 4 else 8},tile={tile}>"
-        d = inst.setdefault(key, {"ms": 0.0, "launches": 0, "flop": 0.0, "peak": peak, "nprod": nprod, "arith": pname})
-        for k in ("ms", "launches", "flop"):
-            d[k] += g[k]
+    inst = inst_rooflines(recs)
     roofline = None
     if inst:
         name, d = max(inst.items(), key=lambda kv: kv[1]["ms"])
@@ -329,6 +423,7 @@ def main():
         tot_ms = sum(v["ms"] for v in inst.values())
         roofline = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": d["peak"],
                     "unit": "TFLOP/s", "frac": round(achieved / d["peak"], 4), "traffic": traffic, "traffic_source": traffic_src,
+                    "traffic_measured_in_run": False,     # replayed from the committed rocprofv3 --pmc passes of the same kernel (tools/profile_run.sh)
                     "arithmetic": d["arith"], "mfma_products_per_algorithmic_mac": d["nprod"],
                     "mfma_pipe_frac": round(achieved * d["nprod"] / d["peak"], 4),
                     "frac_of_f32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
@@ -347,7 +442,8 @@ def main():
         "value": round(mb_per_s, 3), "unit": "Mb/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": f"Encoder Conv1d stages 1-7: {enc_prec} = {ARITH[enc_prec]}; Decoder / Decoder_1m Conv2d: {dec_prec} = {ARITH[dec_prec]}; "
-                 f"Encoder2 Conv1d: {getattr(model.net, 'precision', 'f32')}; 1x1 heads, pools, upsampling, merges: fp32",
+                 f"Encoder2 Conv1d: exact fp32 MFMA kernels (requested {getattr(model.net, 'precision', 'f32')}; 2 strands x 8000 bins is below the 32 000 positions "
+                 "from which the split-operand kernels run); 1x1 heads, pools, upsampling, merges: fp32",
         "data": "synthetic",
         "config": {"workload": f"H1-ESC 32Mb model forward, single random {args.seq_mb}Mb sequence, fp32-class ({enc_prec} split operands on the 16-bit matrix "
                                "cores, see dtype; parity vs the reference's fp32 in `parity`), both strands (genomepredict-equivalent, 1 model): "
@@ -390,9 +486,39 @@ def main():
             m.precision = p_
         res["exact_f32"] = {"ms_per_step": round(t32 * 1e3, 2), "Mb_per_s": round(2 * Lbp / 1e6 / t32, 2), "whole_step_tflops": round(step_flops() / t32, 2),
                             "frac_of_157TF_fp32_mfma_peak": round(step_flops() / t32 / PEAK_F32_MFMA_TFLOPS, 4)}
+    # ---- the Decoders' share: one Decoder forward (118 Conv2d, both strands batched as in the step) under HIP events
+    if world == 1 and Lbp == L_BP:
+        dec = model.denets[16]
+        xd = torch.from_numpy((np.random.RandomState(31).rand(2, 128, 250) * 0.5).astype(np.float32)).to(dev)
+        yd = torch.from_numpy(np.random.RandomState(32).randn(2, 1, 125, 125).astype(np.float32)).to(dev)
+        ded = distencs[16].expand(2, -1, -1, -1)
+        dec(xd, ded, yd)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(dev)
+        e0.record()
+        for _ in range(10):
+            dec(xd, ded, yd)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        dms = e0.elapsed_time(e1) / 10
+        dtf = 2 * DEC_TFLOP["withy"] / (dms * 1e-3)
+        res["roofline_decoder"] = {"kernel": "conv2d_3x3_m16_kernel<32|64,2,1> (dilation 1-8, 72 launches) + conv2d_dblock_kernel<2,1> (dilation 16-64, 12 launches of 4 convs) "
+                                             "= one Decoder forward with y at B = 2 (the two strands)", "bound": "mfma", "ms_per_forward": round(dms, 3),
+                                   "achieved": round(dtf, 1), "peak": PEAK_16BIT_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(dtf / PEAK_16BIT_MFMA_TFLOPS, 4),
+                                   "mfma_products_per_algorithmic_mac": 3, "mfma_pipe_frac": round(3 * dtf / PEAK_16BIT_MFMA_TFLOPS, 4),
+                                   "decoders_share_of_step": round(7 * dms / ms_per_step, 3),
+                                   "mfma_busy_source": "profiles/r03_pmc_dec_sq.txt (SQ_VALU_MFMA_BUSY_CYCLES / SIMD cycles per kernel)"}
+        del xd, yd, ded
     strands = outs = None
     engine.get_context(dev).release_workspace()
     torch.cuda.empty_cache()
+    # ---- BASELINE configs 3 and 5 on this GPU (N = 1), outside the timed region
+    if world == 1 and Lbp == L_BP and not args.no_configs:
+        for name, fn in (("config3", config3_section), ("config5", config5_section)):
+            try:
+                res[name] = fn(dev)
+            except Exception as e:
+                res[name] = {"error": f"{type(e).__name__}: {e}"}
 
     # ---- north star / config 4: 256 Mb model, Encoder bins sharded over the ranks + one RCCL all-gather per strand
     #      (N > 1: under a watchdog - a collective that never completes must not take the replica-mode line above down with it)

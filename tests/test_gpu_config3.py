@@ -8,8 +8,9 @@ nn.Modules on CPU (tests/golden/G17_config3.npz, tools/make_golden.py --config3)
     feature maps - residual stream included - as single bf16 planes, bf16 operands, one MFMA product, fp32 accumulate): bf16
     keeps 8 significant bits and the Decoders round their residual stream 56 times, so the maps agree to 1-2 decimal digits -
     stated tolerance: max-abs 0.6 on maps of range ~+-3 (measured 0.40), Pearson r >= 0.999 per level (measured 0.9998);
-  * the same with the Decoders on single fp16 planes ("f16": same traffic and rate, 11 significant bits, fp16 range guard) -
-    stated tolerance max-abs 0.2, Pearson r >= 0.9995 (the Encoder's bf16 rounding dominates)."""
+  * the same with the Decoders on single fp16 planes ("f16": same traffic and rate, the residual stream keeps 11 significant bits, fp16
+    range guard) - THE config-3 mode of bench.py / tools/run_configs.py: stated tolerance max-abs 0.1 (2 x the measured 0.045),
+    Pearson r >= 0.99999 (measured 0.999994; the Encoder's bf16 rounding dominates)."""
 import numpy as np
 import pytest
 import torch
@@ -60,7 +61,7 @@ def test_config3_default_arithmetic_vs_reference(setup):
     assert max(maxabs(m[0], m[5]) for m in maps) > 1e-3
 
 
-@pytest.mark.parametrize("dec_precision,tol,rmin", [("bf16", 0.6, 0.999), ("f16", 0.2, 0.9995)])
+@pytest.mark.parametrize("dec_precision,tol,rmin", [("bf16", 0.6, 0.999), ("f16", 0.1, 0.99999)])
 def test_config3_bf16_throughput_mode_vs_reference(setup, dec_precision, tol, rmin):
     model, codes, de = setup
     g = golden("G17_config3.npz")
