@@ -108,7 +108,18 @@ def sharded_256mb(args, rank, world, dev, dist):
     from orca_amd import dist as odist, engine, orca_models, orca_predict, synth
     L256 = 256_000_000
     model = orca_models.H1esc_256M(synthetic_seed=0)
-    codes = torch.from_numpy(synth.synth_base_codes(L256, seed=2)[None]).to(dev)      # the SAME sequence on every rank
+    host_codes = synth.synth_base_codes(L256, seed=2)[None]                           # the SAME sequence on every rank ...
+    total_bins = engine.encoder_num_bins(L256)
+    lo, hi = odist.bin_range(total_bins, rank, world)
+    if world > 1:      # ... of which a rank keeps only what its bins read: bin range +- 112 kb, once per strand (2 x 32 Mb at N = 8)
+        wins = []
+        for rev in (False, True):
+            b0, b1 = engine.code_window_range(L256, lo, hi, reverse=rev)
+            wins.append(engine.CodeWindow(torch.from_numpy(np.ascontiguousarray(host_codes[:, b0:b1])).to(dev), b0, L256))
+    else:
+        full = torch.from_numpy(host_codes).to(dev)
+        wins = [full, full]
+    del host_codes
     comm, collective = None, "none (single rank)"
     if world > 1:
         collective = f"torch.distributed all_gather_into_tensor ({'RCCL' if dist.get_backend() == 'nccl' else dist.get_backend()})"
@@ -139,8 +150,8 @@ def sharded_256mb(args, rank, world, dev, dist):
 
     def one(timed):
         ev[0].record()
-        ef = enc._local(lambda: model.net0.forward_codes(codes, reverse=False, **rng))      # rank-local bins, both strands
-        er = enc._local(lambda: model.net0.forward_codes(codes, reverse=True, **rng))
+        ef = enc._local(lambda: model.net0.forward_codes(wins[0], reverse=False, **rng))      # rank-local bins, both strands
+        er = enc._local(lambda: model.net0.forward_codes(wins[1], reverse=True, **rng))
         ev[1].record()
         enc0 = torch.cat([gather(ef), gather(er)], dim=0)
         last["enc0"] = enc0
@@ -153,8 +164,6 @@ def sharded_256mb(args, rank, world, dev, dist):
             acc[:] += [ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2]), ev[2].elapsed_time(ev[3])]
         return outs_
 
-    total_bins = engine.encoder_num_bins(L256)
-    lo, hi = odist.bin_range(total_bins, rank, world)
     rng = {"bin_lo": lo, "bin_hi": hi} if world > 1 else {}
     gather = (lambda part: odist.sharded_encode(lambda x, a, b: part, None, total_bins, None, comm)) if world > 1 else (lambda part: part)
 
@@ -207,7 +216,7 @@ def sharded_256mb(args, rank, world, dev, dist):
             "ms_per_step": round(ms, 2), "Mb_per_s": round(2 * 256 / (ms * 1e-3), 1),
             "encoder_ms_per_rank_max": round(float(parts[0]), 2), "allgather_ms_max": round(float(parts[1]), 3), "tail_ms_max": round(float(parts[2]), 2),
             "encoder_Mb_per_s": round(2 * 256 / (float(parts[0]) * 1e-3), 1), "maps_checksum": round(chk, 4), "parity": parity,
-            "bins_this_rank": [int(lo), int(hi)]}
+            "bins_this_rank": [int(lo), int(hi)], "sequence_bytes_on_this_rank": int(sum(w.codes.numel() if isinstance(w, engine.CodeWindow) else w.numel() for w in (wins if world > 1 else wins[:1])))}
 
 
 def inst_rooflines(recs):
@@ -329,6 +338,71 @@ def config5_section(dev, n_svs=16):
     return out
 
 
+def sharded_32mb(args, rank, world, dev, dist, comm):
+    """Strong scaling of the HEADLINE workload (one 32 Mb window, both strands, H1-ESC-shaped model): strand split x Encoder bin shards
+    (dist.strand_bin_sharded_32m: rank parity = strand, world/2 bin shards per strand, ONE all-gather of the encodings, the two strands'
+    tails on ranks 0 / 1, ONE all-gather of the maps).  N = 1: both strands here.  Needs an even N."""
+    from orca_amd import dist as odist, engine, orca_models, synth
+    if world > 1 and world % 2:
+        return {"skipped": f"needs an even number of ranks, got {world}"}
+    model = orca_models.H1esc(synthetic_seed=0)
+    host_codes = synth.synth_base_codes(L_BP, seed=1)[None]                               # = the replica-mode sequence of rank 0 (G8's)
+    total = engine.encoder_num_bins(L_BP)
+    if world > 1:
+        st, lo, hi = odist.strand_bin_plan(total, rank, world)[0]
+        b0, b1 = engine.code_window_range(L_BP, lo, hi, reverse=bool(st))
+        codes = engine.CodeWindow(torch.from_numpy(np.ascontiguousarray(host_codes[:, b0:b1])).to(dev), b0, L_BP)
+    else:
+        codes = torch.from_numpy(host_codes).to(dev)
+    del host_codes
+    distencs = {lv: torch.log(torch.from_numpy(model.normmats[lv][None, None].astype(np.float32))).to(dev) for lv in model.levels}
+    mpos, wpos = L_BP // 2 + 1234567, L_BP // 2
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(2):
+        outs = odist.strand_bin_sharded_32m(model, codes, mpos, wpos, distencs, comm=comm)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.sharded_steps * 2):
+        outs = odist.strand_bin_sharded_32m(model, codes, mpos, wpos, distencs, comm=comm)
+    sync()
+    el = (time.perf_counter() - t0) / (args.sharded_steps * 2)
+    if dist is not None:
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t[0])
+    out = {"workload": "the headline workload as ONE job: H1-ESC 32Mb model, one random 32 Mb sequence, both strands - strand split (rank parity) x "
+                       f"{max(1, world // 2)} Encoder bin shard(s) per strand, one all-gather of the [1,128,{-(-total // max(1, world // 2))}] encodings, the strands' tails on "
+                       "ranks 0 / 1, one all-gather of the [6,1,250,250] maps, strand merge on every rank",
+           "n_gpus": world, "scaling": "strong", "steps": args.sharded_steps * 2, "ms_per_step": round(el * 1e3, 3), "Mb_per_s": round(2 * 32 / el, 1)}
+    g8 = os.path.join(ROOT, "tests", "golden", "G8_full32m.npz")
+    if rank == 0 and os.path.exists(g8):
+        g = np.load(g8)
+        errs = [float(np.abs(o[0].cpu().numpy().astype(np.float64) - g[f"pred_{j}"]).max()) for j, o in enumerate(outs)]
+        out["parity"] = {"against": "tests/golden/G8_full32m.npz (the reference's genomepredict on this sequence)", "max_abs_per_level": [round(e, 8) for e in errs],
+                         "tolerance": 1e-4, "ok": bool(max(errs) < 1e-4)}
+    engine.get_context(dev).release_workspace()
+    torch.cuda.empty_cache()
+    return out
+
+
+def rccl_log_tail(nbytes=1500):
+    """What RCCL printed at NCCL_DEBUG=WARN (N > 1 runs set NCCL_DEBUG_FILE): the tail of this process's log, for the error fields."""
+    import glob
+    txt = ""
+    for f in sorted(glob.glob("/tmp/orca_bench_rccl_*.log")):
+        try:
+            txt += open(f).read()[-nbytes:]
+        except OSError:
+            pass
+    return txt[-nbytes:]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -355,6 +429,8 @@ def main():
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
+        os.environ.setdefault("NCCL_DEBUG", "WARN")       # RCCL's own diagnostics go to a per-process file; their tail is quoted in `error` fields
+        os.environ.setdefault("NCCL_DEBUG_FILE", "/tmp/orca_bench_rccl_%h_%p.log")
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("ORCA_BENCH_BACKEND", "nccl")
@@ -530,7 +606,8 @@ def main():
             print(json.dumps(res), flush=True)
 
     def bail():
-        res.setdefault("sharded_256mb", {"error": f"no completion within {args.sharded_timeout} s (rank {rank}); the replica-mode figures of this line are unaffected"})
+        res.setdefault("sharded_256mb", {"error": f"no completion within {args.sharded_timeout} s (rank {rank}); the replica-mode figures of this line are unaffected",
+                                         "rccl_log_tail": rccl_log_tail()})
         emit()
         os._exit(0)
 
@@ -543,7 +620,11 @@ def main():
         try:
             res["sharded_256mb"] = sharded_256mb(args, rank, world, dev, dist)
         except Exception as e:      # reported, not fatal: the ranks may be out of step now, the watchdog covers the final barrier
-            res["sharded_256mb"] = {"error": f"{type(e).__name__}: {e}"}
+            res["sharded_256mb"] = {"error": f"{type(e).__name__}: {e}", "rccl_log_tail": rccl_log_tail() if world > 1 else ""}
+        try:
+            res["sharded_32mb"] = sharded_32mb(args, rank, world, dev, dist, None)
+        except Exception as e:
+            res["sharded_32mb"] = {"error": f"{type(e).__name__}: {e}", "rccl_log_tail": rccl_log_tail() if world > 1 else ""}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(0)
         res["speedup_vs_cpu"] = round(res["value"] / world / res["cpu_baseline"]["value"], 1)

@@ -171,6 +171,15 @@ int orca_encoder_forward(orca_ctx* ctx, orca_net* net, const float* x, int64_t s
 int orca_pack_sequence(orca_ctx* ctx, const float* x, int64_t sx_c, int64_t sx_l, int64_t L, uint8_t* codes_out, int* packable);
 int orca_encoder_forward_codes(orca_ctx* ctx, orca_net* net, const uint8_t* codes, int64_t sc_b, int reverse, int B, int64_t L,
                                int64_t bin_lo, int64_t bin_hi, float* out, int64_t so_b, int64_t so_c, int64_t chunk_bp);
+/* The same from a WINDOW of the sequence: `codes` holds only bases [win_origin, win_origin + win_len) of the L-base
+ * sequence (batch stride sc_b) - what a rank of a sharded run keeps of it: its bin range +- the 112 kb halo, i.e.
+ * bases [bin_lo*4000 - 112000, bin_hi*4000 + 112000) for the forward strand and the mirror image
+ * [L - bin_hi*4000 - 112000, L - bin_lo*4000 + 112000) for the reverse complement (clipped to [0, L)).  A window that
+ * does not cover what the requested bins read is an error (ORCA_EINVAL), never a silent zero fill.
+ * Replaces: the replicated `.cuda()` of the whole sequence per DataParallel replica (orca_predict.py:334, :675-683). */
+int orca_encoder_forward_codes_window(orca_ctx* ctx, orca_net* net, const uint8_t* codes, int64_t sc_b, int64_t win_origin,
+                                      int64_t win_len, int reverse, int B, int64_t L, int64_t bin_lo, int64_t bin_hi,
+                                      float* out, int64_t so_b, int64_t so_c, int64_t chunk_bp);
 
 /* Number of 4 kb bins Encoder emits for an L-bp input (floor through the
  * 4,4,5,5,5,2 pooling chain). */
@@ -194,7 +203,10 @@ int orca_unet_forward(orca_ctx* ctx, orca_net* net, const float* x, int64_t sx_b
  * for the `.expand` of orca_predict.py:353); y: NULL or the [B,1,n/2,n/2]
  * crop of the coarser prediction (orca_predict.py:374-379).
  * out: contiguous [B,1,n,n].  accumulate!=0 adds into out instead of
- * overwriting (used for `+ denet_1_pt(...)`, orca_predict.py:362-366). */
+ * overwriting (used for `+ denet_1_pt(...)`, orca_predict.py:362-366).
+ * Streams: an even batch >= 2 runs as two half-batches, the second on an INTERNAL non-blocking stream of the context
+ * (forked from / joined back into the caller's stream by events inside the call: on return all work is ordered behind
+ * the caller's stream again; callers that capture the stream into a graph set ORCA_DECODER_ONE_STREAM=1). */
 int orca_decoder_forward(orca_ctx* ctx, orca_net* net, const float* x, int64_t sx_b, int64_t sx_c,
                          int64_t sx_l, const float* distenc, int64_t sd_b, int64_t sd_h, int64_t sd_w,
                          const float* y, int64_t sy_b, int64_t sy_h, int64_t sy_w, int B, int n,

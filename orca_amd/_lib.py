@@ -51,6 +51,8 @@ SIGNATURES = {
     "orca_pack_sequence": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, POINTER(c_int)]),
     "orca_encoder_forward_codes": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int64, c_int64, c_int64,
                                            c_void_p, c_int64, c_int64, c_int64]),
+    "orca_encoder_forward_codes_window": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_int64, c_int64, c_int64,
+                                                  c_void_p, c_int64, c_int64, c_int64]),
     "orca_encoder_num_bins": (c_int64, [c_int64]),
     "orca_unet_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_int,
                                   POINTER(c_void_p), c_int]),

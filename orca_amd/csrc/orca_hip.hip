@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -1362,7 +1363,7 @@ static int encoder_chunk(orca_ctx* ctx, orca_net* net, const SeqSource& src, lon
 static int encoder_forward_impl(orca_ctx* ctx, orca_net* net, const float* x, int64_t sx_b, int64_t sx_c, int64_t sx_l,
                                 const unsigned char* codes, int64_t sc_b, int reverse,
                                 int B, int64_t L, int64_t bin_lo, int64_t bin_hi, float* out, int64_t so_b,
-                                int64_t so_c, int64_t chunk_bp) {
+                                int64_t so_c, int64_t chunk_bp, int64_t win_origin = 0, int64_t win_len = -1) {
   if (!ctx || !net || (!x && !codes) || !out) return fail(ORCA_EINVAL, "orca_encoder_forward: NULL argument");
   if (net->kind != ORCA_NET_ENCODER) return fail(ORCA_EINVAL, "orca_encoder_forward: net is not an Encoder");
   HIPCHECK(hipSetDevice(ctx->device));
@@ -1395,7 +1396,15 @@ static int encoder_forward_impl(orca_ctx* ctx, orca_net* net, const float* x, in
       const long hi = (cb1 == total) ? L : (cb1 * kBinBp + kHaloBp < L ? cb1 * kBinBp + kHaloBp : L);
       float* res; long rld, rn;
       SeqSource src;
-      if (codes) { src.codes = codes + (long)b * sc_b; src.codes_L = L; src.codes_off = lo; src.reverse = reverse; }
+      if (codes && win_len >= 0) {
+        // the caller holds only bases [win_origin, win_origin + win_len) of the L-base sequence: this chunk reads strand positions
+        // [lo, hi) = bases [lo, hi) (forward) or [L - hi, L - lo) (reverse complement)
+        const long b0 = reverse ? L - hi : lo, b1 = reverse ? L - lo : hi;
+        if (b0 < win_origin || b1 > win_origin + win_len)
+          return fail(ORCA_EINVAL, "code window [%ld,%ld) does not cover bases [%ld,%ld) needed for bins [%ld,%ld) (112 kb halo included)",
+                      (long)win_origin, (long)(win_origin + win_len), b0, b1, (long)cb0, (long)cb1);
+      }
+      if (codes) { src.codes = codes + (long)b * sc_b - win_origin; src.codes_L = L; src.codes_off = lo; src.reverse = reverse; }
       else { src.x = x + (long)b * sx_b + lo * sx_l; src.sx_c = sx_c; src.sx_l = sx_l; }
       ORCA_TRY(encoder_chunk(ctx, net, src, hi - lo, buf, ru4(hi - lo), &res, &rld, &rn));
       const long keep = cb0 - lo / kBinBp;
@@ -1419,6 +1428,13 @@ extern "C" int orca_encoder_forward_codes(orca_ctx* ctx, orca_net* net, const ui
                                           int64_t L, int64_t bin_lo, int64_t bin_hi, float* out, int64_t so_b, int64_t so_c,
                                           int64_t chunk_bp) {
   return encoder_forward_impl(ctx, net, nullptr, 0, 0, 0, codes, sc_b, reverse, B, L, bin_lo, bin_hi, out, so_b, so_c, chunk_bp);
+}
+
+extern "C" int orca_encoder_forward_codes_window(orca_ctx* ctx, orca_net* net, const uint8_t* codes, int64_t sc_b, int64_t win_origin, int64_t win_len,
+                                                 int reverse, int B, int64_t L, int64_t bin_lo, int64_t bin_hi, float* out, int64_t so_b,
+                                                 int64_t so_c, int64_t chunk_bp) {
+  if (win_origin < 0 || win_len < 0 || win_origin + win_len > L) return fail(ORCA_EINVAL, "code window [%ld,+%ld) outside the %ld-base sequence", (long)win_origin, (long)win_len, (long)L);
+  return encoder_forward_impl(ctx, net, nullptr, 0, 0, 0, codes, sc_b, reverse, B, L, bin_lo, bin_hi, out, so_b, so_c, chunk_bp, win_origin, win_len);
 }
 
 extern "C" int orca_pack_sequence(orca_ctx* ctx, const float* x, int64_t sx_c, int64_t sx_l, int64_t L, uint8_t* codes, int* packable) {
@@ -1707,15 +1723,24 @@ static int decoder_m16(orca_ctx* ctx, orca_net* net, const RowSrc& x, long sx_c,
     HIPCHECK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
     HIPCHECK(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
   }
+  // (the aux stream is internal: whatever happens below, the caller's stream is made to wait for it before this returns, so that
+  // work queued on aux can never outlive the call unordered - the fp16-range flag read-back and the caller's allocator see it)
   hipStream_t main_s = ctx->stream;
-  HIPCHECK(hipEventRecord(ctx->ev_fork, main_s));
-  HIPCHECK(hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
-  int rc = run(0, B / 2);
+  int rc = ORCA_OK;
+  if (hipEventRecord(ctx->ev_fork, main_s) != hipSuccess || hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    return run(0, B);                    // could not fork: everything on the caller's stream
+  }
+  rc = run(0, B / 2);
   ctx->stream = ctx->aux;
   const int rc2 = rc == ORCA_OK ? run(B / 2, B / 2) : rc;
   ctx->stream = main_s;
-  HIPCHECK(hipEventRecord(ctx->ev_join, ctx->aux));
-  HIPCHECK(hipStreamWaitEvent(main_s, ctx->ev_join, 0));
+  const hipError_t e1 = hipEventRecord(ctx->ev_join, ctx->aux);
+  const hipError_t e2 = e1 == hipSuccess ? hipStreamWaitEvent(main_s, ctx->ev_join, 0) : e1;
+  if (e2 != hipSuccess) {                // the join itself failed: fall back to a host-side wait, then report
+    (void)hipStreamSynchronize(ctx->aux);
+    if (rc2 == ORCA_OK) return fail(ORCA_EHIP, "decoder: joining the internal stream failed: %s", hipGetErrorString(e2));
+  }
   return rc2;
 }
 
@@ -1936,27 +1961,35 @@ static int find_loaded_rccl(struct dl_phdr_info* info, size_t, void* out) {
   return 0;
 }
 
+static std::string g_rccl_err;      // why RCCL could not be loaded (written once, under the call_once below)
 static RcclApi* rccl_api() {
   static RcclApi api;
-  static bool tried = false;
-  if (tried) return api.lib ? &api : nullptr;
-  tried = true;
-  std::string loaded;
-  dl_iterate_phdr(find_loaded_rccl, &loaded);      // PyTorch-ROCm brings its own RCCL: share it
-  void* h = nullptr;
-  if (!loaded.empty()) h = dlopen(loaded.c_str(), RTLD_NOW | RTLD_GLOBAL);
-  if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-  if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-  if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-  if (!h) return nullptr;
-  api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
-  api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
-  api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
-  api.AllGather = reinterpret_cast<decltype(api.AllGather)>(dlsym(h, "ncclAllGather"));
-  api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
-  if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllGather) return nullptr;
-  api.lib = h;
-  return &api;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    std::string loaded;
+    dl_iterate_phdr(find_loaded_rccl, &loaded);      // PyTorch-ROCm brings its own RCCL: share it
+    void* h = nullptr;
+    if (!loaded.empty()) h = dlopen(loaded.c_str(), RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) {
+      const char* e = dlerror();       // once: the call clears the state
+      g_rccl_err = e ? e : "librccl.so not found";
+      return;
+    }
+    api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+    api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
+    api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+    api.AllGather = reinterpret_cast<decltype(api.AllGather)>(dlsym(h, "ncclAllGather"));
+    api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+    if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllGather) {
+      g_rccl_err = "librccl.so lacks ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllGather";
+      return;
+    }
+    api.lib = h;
+  });
+  return api.lib ? &api : nullptr;
 }
 
 struct orca_comm {
@@ -1971,7 +2004,7 @@ static int rccl_fail(RcclApi* r, const char* what, int rc) {
 extern "C" int orca_comm_unique_id(void* id128_host) {
   if (!id128_host) return fail(ORCA_EINVAL, "orca_comm_unique_id: NULL argument");
   RcclApi* r = rccl_api();
-  if (!r) return fail(ORCA_ENODEV, "RCCL (librccl.so) could not be loaded: %s", dlerror() ? dlerror() : "not found");
+  if (!r) return fail(ORCA_ENODEV, "RCCL (librccl.so) could not be loaded: %s", g_rccl_err.c_str());
   Id128 id;
   const int rc = r->GetUniqueId(&id);
   if (rc != 0) return rccl_fail(r, "ncclGetUniqueId", rc);
@@ -1983,7 +2016,7 @@ extern "C" int orca_comm_init_rank(orca_ctx* ctx, int nranks, int rank, const vo
   if (!ctx || !id128_host || !out) return fail(ORCA_EINVAL, "orca_comm_init_rank: NULL argument");
   if (nranks < 1 || rank < 0 || rank >= nranks) return fail(ORCA_EINVAL, "orca_comm_init_rank: rank %d of %d", rank, nranks);
   RcclApi* r = rccl_api();
-  if (!r) return fail(ORCA_ENODEV, "RCCL (librccl.so) could not be loaded");
+  if (!r) return fail(ORCA_ENODEV, "RCCL (librccl.so) could not be loaded: %s", g_rccl_err.c_str());
   HIPCHECK(hipSetDevice(ctx->device));
   Id128 id;
   memcpy(&id, id128_host, sizeof id);

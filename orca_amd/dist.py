@@ -69,14 +69,33 @@ class AbiComm:
             world, rank = dist.get_world_size(group), dist.get_rank(group)
         self.world, self.rank = int(world), int(rank)
         idbuf = ctypes.create_string_buffer(128)
+        err = None
         if self.rank == 0:
-            _lib.check(self.lib.orca_comm_unique_id(idbuf), "orca_comm_unique_id")
+            try:
+                _lib.check(self.lib.orca_comm_unique_id(idbuf), "orca_comm_unique_id")
+            except Exception as e:          # every rank must still pass through the broadcast below, then fail TOGETHER
+                err = f"{type(e).__name__}: {e}"
         if self.world > 1:
-            box = [idbuf.raw if self.rank == 0 else None]
+            box = [(err, idbuf.raw) if self.rank == 0 else None]
             dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-            idbuf = ctypes.create_string_buffer(box[0], 128)
+            err, raw = box[0]
+            idbuf = ctypes.create_string_buffer(raw, 128)
+        if err is not None:
+            raise RuntimeError(f"AbiComm: rank 0 could not create the RCCL unique id ({err})")
         self.handle = ctypes.c_void_p()
         _lib.check(self.lib.orca_comm_init_rank(self.ctx.handle, self.world, self.rank, idbuf, ctypes.byref(self.handle)), "orca_comm_init_rank")
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def all_gather(self, slab):
         """slab: contiguous fp32 ROCm tensor -> [world, *slab.shape] (rank-major)."""
@@ -91,7 +110,7 @@ class AbiComm:
         return out
 
     def close(self):
-        if self.handle:
+        if getattr(self, "handle", None):
             self.lib.orca_comm_destroy(self.handle)
             self.handle = None
 
@@ -173,9 +192,9 @@ def strand_tail_256m(model, enc0, strand, mpos, wpos, chrlen, normmat):
 
 def strand_parallel_cascade_256m(model, enc0, mpos, wpos, chrlen, normmat, group=None, comm=None):
     """The part of genomepredict_256Mb after the Encoder (orca_predict.py:675-838 + the strand merge :866-877), with the
-    two strands' tails on different ranks: the strands are independent until the merge, so even ranks run the forward
-    strand, odd ranks the reverse strand, and ONE all-gather of the [4,C,250,250] maps (1 MB per rank) replaces the
-    second half of the replicated work.  Returns the four merged [C,250,250] maps, identical on every rank.
+    two strands' tails on different ranks: the strands are independent until the merge, so rank 0 runs the forward
+    strand, rank 1 the reverse strand (the four levels of a strand are one dependent chain: further ranks only receive),
+    and ONE all-gather of the [4,C,250,250] maps (1 MB per rank) replaces the second half of the replicated work.  Returns the four merged [C,250,250] maps, identical on every rank.
     With one rank (or no process group) both strands run here, batched, exactly as cascade_256m does."""
     from . import engine, orca_predict
     if comm is not None:
@@ -189,13 +208,90 @@ def strand_parallel_cascade_256m(model, enc0, mpos, wpos, chrlen, normmat, group
         preds, _ = orca_predict.cascade_256m(model, enc0, mpos, wpos, chrlen, normmat)
         fwd, rev = torch.stack([p[0] for p in preds]), torch.stack([p[B] for p in preds])
     else:
-        slab = strand_tail_256m(model, enc0, rank & 1, mpos, wpos, chrlen, normmat)
+        if rank < 2:
+            slab = strand_tail_256m(model, enc0, rank, mpos, wpos, chrlen, normmat)
+        else:       # the tail is one dependent chain per strand: ranks 2.. have nothing to add and only receive the maps
+            C = getattr(model.denets[256], "num_2d", 1) if hasattr(model, "denets") else 1
+            slab = torch.zeros((4, C, 250, 250), dtype=torch.float32, device=enc0.device)
         if comm is not None:
             allm = comm.all_gather(slab)
         else:
             allm = torch.empty((world,) + tuple(slab.shape), dtype=slab.dtype, device=slab.device)
             dist.all_gather_into_tensor(allm.view(-1), slab.view(-1), group=group)
-        fwd, rev = allm[0], allm[1]      # ranks 0 and 1 hold one strand each; the other ranks' slabs are copies of these
+        fwd, rev = allm[0], allm[1]      # ranks 0 and 1 hold one strand each; the other ranks' slabs are placeholders
+    return [torch.stack([engine.strand_merge(fwd[j, c], rev[j, c]) for c in range(fwd.shape[1])]) for j in range(fwd.shape[0])]
+
+
+def strand_bin_plan(total_bins, rank, world):
+    """Work split of ONE 32 Mb window over `world` ranks (strong scaling): the two strands first (rank parity), then
+    contiguous bin ranges of the strand's Encoder (world/2 shards per strand; world = 1: both strands, all bins).
+    Returns [(strand, bin_lo, bin_hi)] this rank encodes.  world must be 1 or even."""
+    if world == 1:
+        return [(0, 0, total_bins), (1, 0, total_bins)]
+    if world % 2:
+        raise ValueError("strand x bin sharding needs an even number of ranks")
+    lo, hi = bin_range(total_bins, rank // 2, world // 2)
+    return [(rank % 2, lo, hi)]
+
+
+def strand_bin_sharded_32m(model, codes, mpos, wpos, distencs=None, group=None, comm=None):
+    """`genomepredict`'s device work for ONE 32 Mb window ([B,L] packed bases replicated on every rank) shared by all ranks: rank r
+    encodes bins `strand_bin_plan` of strand r % 2, ONE all-gather assembles both strands' [B,128,8000] encodings on every rank, ranks
+    0 and 1 run one strand's tail each (Encoder2 -> six Decoders + Decoder_1m: a dependent chain, not shardable further) and ONE
+    all-gather of the [6,C,250,250] maps precedes the strand merge.  Returns the six merged [C,250,250] maps (on every rank).
+    Replaces nn.DataParallel around the sub-networks (orca_models.py:44-50), which only splits batches."""
+    from . import engine, orca_predict
+    if comm is not None:
+        world, rank = comm.world, comm.rank
+    elif dist.is_initialized():
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+    else:
+        world, rank = 1, 0
+    B, L = codes.shape
+    total = engine.encoder_num_bins(L)
+    plan = strand_bin_plan(total, rank, world)
+
+    def local(strand, lo, hi):
+        with engine.immediate_overflow_guard():      # a rank's fp16-range retry happens before the collective, never after it on one rank only
+            return model.net0.forward_codes(codes, reverse=bool(strand), bin_lo=lo, bin_hi=hi)
+
+    if world == 1:
+        enc0 = torch.cat([local(*plan[0]), local(*plan[1])], dim=0)
+    else:
+        strand, lo, hi = plan[0]
+        part = local(strand, lo, hi)
+        width = -(-total // (world // 2))
+        slab = torch.zeros((B, 128, width), dtype=part.dtype, device=part.device)
+        slab[:, :, : hi - lo] = part
+        if comm is not None:
+            gathered = comm.all_gather(slab)
+        else:
+            gathered = torch.empty((world, B, 128, width), dtype=part.dtype, device=part.device)
+            dist.all_gather_into_tensor(gathered.view(world * B, 128, width), slab, group=group)
+        strands = []
+        for st in range(2):
+            pieces = []
+            for sh in range(world // 2):
+                rlo, rhi = bin_range(total, sh, world // 2)
+                pieces.append(gathered[2 * sh + st, :, :, : rhi - rlo])
+            strands.append(torch.cat(pieces, dim=2))
+        enc0 = torch.cat(strands, dim=0)
+    if world == 1:
+        preds, _ = orca_predict.cascade_32m_from_enc(model, enc0, mpos, wpos, [False, True], distencs)
+        fwd, rev = torch.stack([p[0] for p in preds]), torch.stack([p[B] for p in preds])
+    else:
+        if rank < 2:
+            preds, _ = orca_predict.cascade_32m_from_enc(model, enc0[rank * B: (rank + 1) * B], mpos, wpos, [bool(rank)], distencs)
+            slab = torch.stack([p[0] for p in preds]).contiguous()
+        else:
+            C = getattr(model.denets[32], "num_2d", 1)
+            slab = torch.zeros((6, C, 250, 250), dtype=torch.float32, device=enc0.device)
+        if comm is not None:
+            allm = comm.all_gather(slab)
+        else:
+            allm = torch.empty((world,) + tuple(slab.shape), dtype=slab.dtype, device=slab.device)
+            dist.all_gather_into_tensor(allm.view(-1), slab.view(-1), group=group)
+        fwd, rev = allm[0], allm[1]
     return [torch.stack([engine.strand_merge(fwd[j, c], rev[j, c]) for c in range(fwd.shape[1])]) for j in range(fwd.shape[0])]
 
 

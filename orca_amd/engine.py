@@ -251,12 +251,41 @@ def pack_sequence(x):
     return codes, ok
 
 
+class CodeWindow:
+    """A rank's share of a packed sequence: ``codes`` [B, n] = bases [origin, origin + n) of an L-base sequence (see
+    `code_window_range` for what a bin range needs).  Accepted wherever the Encoder takes packed bases."""
+
+    def __init__(self, codes, origin, L):
+        self.codes, self.origin, self.L = codes, int(origin), int(L)
+
+    @property
+    def shape(self):
+        return (self.codes.shape[0], self.L)
+
+    device = property(lambda self: self.codes.device)
+    dtype = property(lambda self: self.codes.dtype)
+
+
+def code_window_range(L, bin_lo, bin_hi, reverse=False, halo=112000, binsize=4000):
+    """[b0, b1): bases of the FORWARD sequence the Encoder reads for bins [bin_lo, bin_hi) of the forward strand / of the reverse
+    complement (input halo of orca_modules.py:929-980 included; the last bin range runs to the end of the sequence)."""
+    total = encoder_num_bins(L)
+    lo = max(0, bin_lo * binsize - halo)
+    hi = L if bin_hi >= total else min(L, bin_hi * binsize + halo)
+    return (L - hi, L - lo) if reverse else (lo, hi)
+
+
 def encoder_forward_codes(net, codes, reverse=False, bin_lo=0, bin_hi=0, chunk_bp=0, out=None):
+    win = codes if isinstance(codes, CodeWindow) else None
+    if win is not None:
+        codes = win.codes
     if not (isinstance(codes, torch.Tensor) and codes.is_cuda and codes.dtype == torch.uint8 and codes.dim() == 2):
         raise ValueError("codes must be a [B,L] uint8 ROCm tensor")
     if codes.stride(1) != 1:
         codes = codes.contiguous()
     B, L = codes.shape
+    if win is not None:
+        L = win.L
     total = encoder_num_bins(L)
     hi = total if bin_hi <= 0 else bin_hi
     if out is None:
@@ -264,6 +293,11 @@ def encoder_forward_codes(net, codes, reverse=False, bin_lo=0, bin_hi=0, chunk_b
     elif tuple(out.shape) != (B, 128, hi - bin_lo) or out.stride(2) != 1:
         raise ValueError(f"out must be a [{B},128,{hi - bin_lo}] view with unit stride along the bins")
     net.ctx.sync_stream()
+    if win is not None:
+        check(_lib.load().orca_encoder_forward_codes_window(net.ctx.handle, net.handle, _p(codes), codes.stride(0), win.origin, codes.shape[1],
+                                                            1 if reverse else 0, B, L, bin_lo, hi, _p(out), out.stride(0), out.stride(1), chunk_bp),
+              "orca_encoder_forward_codes_window")
+        return out
     check(_lib.load().orca_encoder_forward_codes(net.ctx.handle, net.handle, _p(codes), codes.stride(0), 1 if reverse else 0, B, L,
                                                  bin_lo, hi, _p(out), out.stride(0), out.stride(1), chunk_bp), "orca_encoder_forward_codes")
     return out

@@ -403,6 +403,29 @@ def cascade_32m(model, xs, mpos, wpos, reverse_flags, distencs=None, merge=False
     return engine.run_with_overflow_retry(forward, xs[0].device)
 
 
+def cascade_32m_from_enc(model, enc0, mpos, wpos, reverse_flags, distencs=None):
+    """The part of `cascade_32m` AFTER the Encoder: ``enc0`` [S*B,128,8000] (strand k = rows k*B..) -> Encoder2 -> six decoder
+    levels (+ denet_1_pt at 4 kb).  Returns (preds[6], starts[k][6]).  (Multi-GPU: every rank holds the gathered encodings and
+    runs the strands it owns, dist.strand_bin_sharded_32m.)"""
+    S = len(reverse_flags)
+    B = enc0.shape[0] // S
+    cache = {}
+
+    def background(level, k, start):
+        if distencs is not None:
+            return distencs[level]
+        if level not in cache:
+            cache[level] = _cached_log_background(model, level, enc0.is_cuda)
+        return cache[level]
+
+    def forward():
+        encodings = dict(zip([1, 2, 4, 8, 16, 32], model.net(enc0)))
+        return run_cascade(model, encodings, [32, 16, 8, 4, 2, 1], lambda lv: lv, B, [bool(r) for r in reverse_flags], background,
+                           lambda lv, st, rev: zoom_index_32m(lv, st, mpos, wpos, rev), add_1m_level=1)
+
+    return engine.run_with_overflow_retry(forward, enc0.device)
+
+
 def cascade_256m(model, enc0, mpos, wpos, chrlen, normmat, reverse_flags=(False, True)):
     """Device part of genomepredict_256Mb AFTER the Encoder (orca_predict.py:675-838): ``enc0`` [S*B,128,64000] (strand k =
     rows k*B..) -> net1 -> [-1] -> net -> the four decoder levels, numerically the same as the full call: every strand's

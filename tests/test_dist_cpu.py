@@ -49,6 +49,30 @@ def _worker(rank, world, port, L, q):
         assert seen == [rank & 1] and len(maps) == 4 and maps[0].shape == (1, 6, 6)
         want = 0.5 * (10 + torch.arange(36.).view(6, 6)) + 0.5 * torch.flip(11 + torch.arange(36.).view(6, 6), [0, 1])
         assert all(torch.equal(m[0], want) for m in maps)
+        # strand x bin sharding of ONE 32 Mb window (strong scaling): rank parity = strand, then bin shards; one all-gather of the encodings,
+        # the strands' tails on ranks 0 / 1, one all-gather of the maps.  Stand-ins for the device work: the encoder returns
+        # f(strand, bin, channel), the tail returns maps that depend on every entry of its strand's assembled encoding.
+        from orca_amd import orca_predict
+
+        class _Net0:
+            def forward_codes(self, codes, reverse=False, bin_lo=0, bin_hi=0):
+                b = torch.arange(bin_lo, bin_hi, dtype=torch.float32)
+                return (b[None, None, :] + 1000.0 * float(reverse) + 0.001 * torch.arange(128.)[None, :, None]).expand(codes.shape[0], -1, -1).contiguous()
+
+        class _Model:
+            net0 = _Net0()
+            denets = {32: type("D", (), {"num_2d": 1})()}
+
+        def _tail(model, enc0, mpos, wpos, flags, de=None):
+            v = (enc0 * torch.arange(1, enc0.shape[2] + 1.)).sum()       # position-weighted: any misplaced bin changes it
+            return [torch.full((enc0.shape[0], 1, 250, 250), float(v) * (j + 1)) + (1.0 if flags[0] else 0.0) for j in range(6)], None
+        orca_predict.cascade_32m_from_enc = _tail
+        codes = torch.zeros((1, 4000 * 75), dtype=torch.uint8)
+        assert D.strand_bin_plan(75, rank, 2) == [(rank, 0, 75)] and D.strand_bin_plan(75, 3, 4) == [(1, 38, 75)]
+        maps32 = D.strand_bin_sharded_32m(_Model(), codes, 0, 0)
+        ref = [_Net0().forward_codes(codes, bool(st), 0, 75) for st in range(2)]
+        wf, wr = _tail(None, ref[0], 0, 0, [False])[0], _tail(None, ref[1], 0, 0, [True])[0]
+        assert len(maps32) == 6 and all(torch.equal(m[0], 0.5 * wf[j][0, 0] + 0.5 * torch.flip(wr[j][0, 0], [0, 1])) for j, m in enumerate(maps32))
         q.put((rank, out.numpy(), t))
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

@@ -81,6 +81,48 @@ def test_strand_parallel_tail_equals_genomepredict_256mb_fixture(cuda):
             assert torch.equal(engine.strand_merge(f[j, 0], r[j, 0]), maps[j][0]), (ci, j)
 
 
+def test_strand_bin_sharded_32m_single_process_equals_cascade(cuda):
+    """dist.strand_bin_sharded_32m with one rank (both strands, all bins here) IS cascade_32m + merge; and the per-rank pieces of a
+    4-rank world - strand x bin-shard encodings reassembled by hand, one strand's tail at a time - merge to the same maps."""
+    from orca_amd import dist as D
+    from orca_amd import engine, orca_models, orca_predict, synth
+    model = orca_models.H1esc(synthetic_seed=0)
+    L = 32_000_000      # the cascade needs the full 8000 bins
+    codes = torch.from_numpy(synth.synth_base_codes(L, seed=33)[None]).to(cuda)
+    mpos, wpos = L // 2 + 123456, L // 2
+    ref = orca_predict.cascade_32m(model, [codes, codes], mpos, wpos, [False, True], merge=True)[2]
+    one = D.strand_bin_sharded_32m(model, codes, mpos, wpos)
+    assert all(torch.equal(a, b) for a, b in zip(one, ref))
+    encs = []
+    for st in range(2):
+        parts = [model.net0.forward_codes(codes, reverse=bool(st), bin_lo=lo, bin_hi=hi) for (_, lo, hi) in (D.strand_bin_plan(8000, 2 * sh + st, 4)[0] for sh in range(2))]
+        encs.append(torch.cat(parts, dim=2))
+    tails = [torch.stack([p[0] for p in orca_predict.cascade_32m_from_enc(model, encs[st], mpos, wpos, [bool(st)])[0]]) for st in range(2)]
+    for j in range(6):
+        assert float((engine.strand_merge(tails[0][j, 0], tails[1][j, 0]) - ref[j][0]).abs().max()) < 2e-5, j
+
+
+def test_encoder_from_a_code_window(cuda):
+    """A rank's share of the packed sequence (engine.CodeWindow = its bins' bases +- the 112 kb halo, mirrored for the reverse complement)
+    gives exactly the bins of the full-sequence call; a window that is too short is refused, not zero-filled."""
+    from orca_amd import engine, synth
+    from tests.util import product_module
+    enc = product_module("Encoder", 0)
+    L = 4000 * 900
+    codes = torch.from_numpy(synth.synth_base_codes(L, seed=44)[None]).to(cuda)
+    for rev in (False, True):
+        full = enc.forward_codes(codes, reverse=rev)
+        for lo, hi in ((0, 300), (300, 640), (640, 900)):
+            b0, b1 = engine.code_window_range(L, lo, hi, reverse=rev)
+            assert b1 - b0 <= (hi - lo) * 4000 + 224000
+            win = engine.CodeWindow(codes[:, b0:b1].contiguous(), b0, L)
+            part = enc.forward_codes(win, reverse=rev, bin_lo=lo, bin_hi=hi)
+            assert torch.equal(part, full[:, :, lo:hi]), (rev, lo, hi)
+    b0, b1 = engine.code_window_range(L, 300, 640)
+    with pytest.raises(Exception, match="code window"):
+        enc.forward_codes(engine.CodeWindow(codes[:, b0 + 4000:b1].contiguous(), b0 + 4000, L), bin_lo=300, bin_hi=640)
+
+
 def test_block_mean_bit_identical_to_numpy(cuda):
     """engine.block_mean (orca_block_mean_f64) against numpy's nanmean-of-nanmean on the same float64 background: identical BITS for
     every level of the 256 Mb cascade, windows off the origin, NaN entries; the log-background and its reverse-strand flip."""
@@ -147,3 +189,10 @@ def test_bench_two_ranks_on_one_gpu_over_gloo(cuda):
     assert "error" not in s2, s2
     assert s2["n_gpus"] == 2 and s2["bins_this_rank"] == [0, 32000] and s1["bins_this_rank"] == [0, 64000]
     assert abs(s2["maps_checksum"] - s1["maps_checksum"]) <= 1e-6 * abs(s1["maps_checksum"]), (s1["maps_checksum"], s2["maps_checksum"])
+    # both sharded sections check themselves against the reference's fixtures (G20 at 256 Mb, G8 at 32 Mb) - also at N = 2
+    assert s2["parity"]["ok"] and s1["parity"]["ok"], (s1["parity"], s2["parity"])
+    # a rank keeps its bins' bases +- halo, once per strand: at N = 2 that is two different halves (+ halos) - from N = 4 on it shrinks
+    assert s2["sequence_bytes_on_this_rank"] == 2 * (128_000_000 + 112_000)
+    t1, t2 = one["sharded_32mb"], two["sharded_32mb"]
+    assert "error" not in t2, t2
+    assert t2["n_gpus"] == 2 and t2["scaling"] == "strong" and t1["parity"]["ok"] and t2["parity"]["ok"], (t1, t2)
