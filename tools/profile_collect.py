@@ -7,7 +7,7 @@
 usage: python tools/profile_collect.py r02"""
 import collections, csv, json, os, shutil, subprocess, sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(ROOT, "gpurun_out", tag), os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
@@ -24,23 +24,24 @@ rows = list(csv.DictReader(open(os.path.join(src, "bench", "bench_kernel_trace.c
 by = collections.defaultdict(list)
 for r in rows:
     n = r["Kernel_Name"]
-    if n.startswith("void conv1d_k9_p16_kernel<64,") or n.startswith("void conv1d_k9_ws_kernel"):
+    if n.startswith("void conv1d_k9_p16_kernel<") or n.startswith("void conv1d_k9_ws_kernel") or n.startswith("void conv1d_first_mfma_p16_kernel"):
         by[n.replace("void ", "").split("(")[0]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 with open(os.path.join(dst, f"{tag}_bench_dominant_launches.txt"), "w") as f:
-    f.write("# rocprofv3 --kernel-trace of `python bench.py --no-cpu-baseline`: launches of conv1d_k9_p16_kernel<64,...> (the kernel bench.py names in\n"
-            "# `roofline`), split by problem size; template arguments <CT, MW, NW, WM, out_mode, residual, ABL, fused-first-layer, format>.\n"
-            "# n = 32 M launches (>= 4 ms: stage 1 of a 32 Mb strand or of a 32 Mb chunk of the 256 Mb section) and n = 2 M launches (stage 3).\n")
+    f.write("# rocprofv3 --kernel-trace of `python bench.py --no-cpu-baseline`: launches of the planar conv kernels (bench.py's `roofline` names the\n"
+            "# instantiation with the largest time share), split by problem size; template arguments <CT, MW, NW, WM, out_mode, residual, ABL,\n"
+            "# fused-first-layer, format, residual-from-bases>.  'big' = launches >= 2.5 ms (stage 1 at n = 32 M, stage 2 at n = 8 M of a 32 Mb strand\n"
+            "# or chunk), the rest are stages 3-4.\n")
     allbig, allsmall = [], []
     for k, v in sorted(by.items()):
-        big, small = [d for d in v if d >= 4000], [d for d in v if d < 4000]
+        big, small = [d for d in v if d >= 2500], [d for d in v if d < 2500]
         allbig += big; allsmall += small
         if big:
-            f.write(f"{k}  n=32M: {len(big)} launches, avg {sum(big) / len(big):.1f} us, min {min(big):.1f}, max {max(big):.1f}\n")
+            f.write(f"{k}  big: {len(big)} launches, avg {sum(big) / len(big):.1f} us, min {min(big):.1f}, max {max(big):.1f}\n")
             f.write("   " + " ".join(f"{d:.0f}" for d in big) + "\n")
         if small:
-            f.write(f"{k}  n=2M: {len(small)} launches, avg {sum(small) / len(small):.1f} us\n")
+            f.write(f"{k}  small: {len(small)} launches, avg {sum(small) / len(small):.1f} us\n")
     if allbig:
-        f.write(f"ALL n=32M launches: {len(allbig)}, avg {sum(allbig) / len(allbig):.1f} us;  = the population of bench.py's roofline.avg_launch_ms (cin = cout = 64: 3 per strand)\n")
+        f.write(f"ALL big launches: {len(allbig)}, avg {sum(allbig) / len(allbig):.1f} us\n")
 
 # ---- counter passes
 for run in sorted(os.listdir(src)):
@@ -59,6 +60,8 @@ def pmc_sum(run, counter, prefix, min_us=1500.0):
 
 traffic = {"_source": f"profiles/{tag}_pmc_enc_f16x2_fetch.txt + profiles/{tag}_pmc_enc_f16x2_write.txt (and the bf16 pair)"}
 for mode, key, prefix, min_us in (("f16x2", "conv1d_k9_p16_kernel<cout=64,f16x2>", "void conv1d_k9_p16_kernel<64,", 4000.0),
+                                  ("f16x2", "conv1d_k9_p16_kernel<cout=96,f16x2>", "void conv1d_k9_p16_kernel<96, 1, 3, 8, 0, false", 2500.0),   # 96 -> 96 (and the 17-tap 64 -> 96)
+                                  ("bf16", "conv1d_k9_p16_kernel<cout=96,bf16>", "void conv1d_k9_p16_kernel<96, 1, 3, 8, 0, false, 0, false, 1", 800.0),
                                   ("bf16", "conv1d_k9_ws_kernel<cout=64,bf16>", "void conv1d_k9_ws_kernel<1, 64, 64,", 1200.0)):
     try:
         fe, n1 = pmc_sum(f"pmc_enc_{mode}_fetch", "FETCH_SIZE", prefix, min_us)

@@ -3,7 +3,7 @@
 # bench command, then separate rocprofv3 --pmc passes (SQ / FETCH_SIZE / WRITE_SIZE: one pass each, MI355X_MICROARCH.md
 # "rocprofv3 PMC slots") over one 32 Mb Encoder forward in both arithmetic modes and over one Decoder forward.
 # Everything lands in gpurun_out/<tag>/; tools/profile_collect.py turns it into the summaries committed under profiles/.
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
@@ -20,6 +20,7 @@ rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $OUT/pmc_dec_sq -o p -
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_dec_fetch -o p -- python $ROOT/tools/prof_decoder.py > $OUT/pmc_dec_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_dec_write -o p -- python $ROOT/tools/prof_decoder.py > $OUT/pmc_dec_write.log 2>&1
 python $ROOT/tools/run_configs.py config3 > $OUT/configs.json 2> $OUT/configs.err
+python $ROOT/tools/run_configs.py config5_1024 > $OUT/config5_1024.json 2> $OUT/config5_1024.err
 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_enc_bf16_lds -o p -- python $ROOT/tools/prof_encoder.py 32 bf16 1 codes > $OUT/pmc_enc_bf16_lds.log 2>&1
 ( rocm-smi --showpower --showclocks --showtemp > $OUT/rocm_smi_idle.txt 2>&1 ) || true
 find $OUT -name "*.csv" | head -40 > $OUT/files.txt
