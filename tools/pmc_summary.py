@@ -15,3 +15,6 @@ with open(path) as f:
 for k, d in sorted(agg.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", kv[1].get("GRBM_GUI_ACTIVE", 0))):
     print(f"{k}  calls={cnt[k]}")
     print("   ", {a: (round(b) if abs(b) > 10 else b) for a, b in sorted(d.items())})
+    if d.get("SQ_VALU_MFMA_BUSY_CYCLES") and d.get("GRBM_GUI_ACTIVE"):
+        # counters are sums over the 8 XCDs: SIMD cycles of the launches = GRBM_GUI_ACTIVE / 8 x 1024 SIMDs (256 CUs x 4)
+        print(f"    matrix pipe busy: {100.0 * d['SQ_VALU_MFMA_BUSY_CYCLES'] / (d['GRBM_GUI_ACTIVE'] / 8.0 * 1024.0):.1f} % of the SIMD cycles")
