@@ -1060,12 +1060,22 @@ extern "C" int orca_net_create(orca_ctx* ctx, int kind, const orca_conv_desc* co
         if (hipMalloc(d_w, pk.size() * 2) != hipSuccess || hipMemcpy(*d_w, pk.data(), pk.size() * 2, hipMemcpyHostToDevice) != hipSuccess) return ORCA_EHIP;
         return upload(bf, d_b);
       };
-      if (pack_first(w17, b17, 17, &net->d_l1_w16, &net->d_l1_bias) != ORCA_OK || pack_first(w25, b25, 25, &net->d_c1a_w16, &net->d_c1a_bias) != ORCA_OK) {
-        orca_net_free(net);
-        return fail(ORCA_EHIP, "composed first-layer upload failed");
+      // A composed weight is a sum of products of folded weights: with extreme checkpoints it may leave the fp16 range even though
+      // every single layer fits.  Such a group simply keeps the reference's two-conv form (its packs stay NULL).
+      auto in_f16 = [](const std::vector<double>& w) {
+        for (double v : w) if (!(v > -65504.0 && v < 65504.0)) return false;
+        return true;
+      };
+      if (in_f16(w17) && in_f16(b17)) {
+        if (pack_first(w17, b17, 17, &net->d_l1_w16, &net->d_l1_bias) != ORCA_OK) { orca_net_free(net); return fail(ORCA_EHIP, "composed first-layer upload failed"); }
+        if (in_f16(w25) && in_f16(b25) && pack_first(w25, b25, 25, &net->d_c1a_w16, &net->d_c1a_bias) != ORCA_OK) {
+          orca_net_free(net);
+          return fail(ORCA_EHIP, "composed first-layer upload failed");
+        }
       }
       for (int st = 1; st <= 2; ++st) {
         compose_pair(convs[4 * st], convs[4 * st + 1], &w17, &b17);
+        if (!in_f16(w17)) continue;
         rc = make_layer17(convs[4 * st].cin, convs[4 * st + 1].cout, w17, b17, &net->comp[st]);
         if (rc != ORCA_OK) { orca_net_free(net); return rc; }
       }

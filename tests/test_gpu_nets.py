@@ -89,6 +89,32 @@ def test_encoder_composed_linear_pairs_vs_two_conv_form_and_oracle(cuda, precisi
     assert maxabs(enc(big.to(cuda)[:, ::2, :]).cpu().numpy(), O.encoder_forward(sd, big[:, ::2, :]).numpy()) < tol
 
 
+def test_encoder_composed_weights_outside_fp16_keep_the_two_conv_form(cuda, monkeypatch):
+    """A composed weight is a sum of products of folded weights and may leave the fp16 range although every single layer fits (extreme
+    checkpoints): such a group must keep the reference's two-conv form instead of packing infinities.  lconv1's two convs are scaled by
+    3000 each (singles ~5e2, composed ~1e6), the input by 1e-6 so that the activations stay in range; the result must be finite and
+    equal the ORCA_NO_COMPOSE form and the CPU oracle."""
+    from orca_amd import orca_modules as pm
+    sd = {k: np.array(v, copy=True) for k, v in synth_sd("Encoder", 9).items()}
+    for k in ("lconv1.0.weight", "lconv1.2.weight"):
+        sd[k] = sd[k] * 3000.0
+    for k in ("lconv1.0.bias", "lconv1.1.bias", "lconv1.1.running_mean"):
+        sd[k] = sd[k] * 0.0
+    enc = pm.Encoder()
+    enc.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    enc.eval()
+    x = torch.from_numpy((np.random.RandomState(3).rand(1, 4, 4000 * 3) * 1e-6).astype(np.float32))
+    ref = O.encoder_forward(sd, x).numpy()
+    y = enc(x.to(cuda)).cpu().numpy()
+    assert np.isfinite(y).all()
+    scale = float(np.abs(ref).max())
+    assert maxabs(y, ref) < 1e-4 * max(1.0, scale)
+    monkeypatch.setenv("ORCA_NO_COMPOSE", "1")
+    y2 = enc(x.to(cuda)).cpu().numpy()
+    monkeypatch.delenv("ORCA_NO_COMPOSE")
+    assert maxabs(y, y2) <= 1e-5 * max(1.0, scale)      # lconv1 ran uncomposed in both (lconv2 / lconv3 still differ in form)
+
+
 @pytest.mark.parametrize("precision", ["f16x2", "f32", "bf16x3"])
 def test_encoder2_encoder3_vs_golden(cuda, precision, monkeypatch):
     monkeypatch.setenv("ORCA_UNET_NLC_MIN", "0")     # the split-operand path also below its pay-off size (default: >= 32 000 positions)
