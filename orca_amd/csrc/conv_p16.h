@@ -225,7 +225,7 @@ __device__ __forceinline__ void p16_lds_wait(f16x8 (&a)[2][MW], f16x8 (&b)[2][NW
 //   launch with its 8 GB store, and this kernel's 8 GB residual read, disappear.
 template <int CT, int MW, int NW, int WM, int OM, bool R1, int ABL = 0, bool F1 = false, int FMT = 0, bool RL = false>
 __global__ __launch_bounds__(WM * 64, WM / 4) void conv1d_k9_p16_kernel(ConvP16Args a) {
-  static_assert(!RL || (CT == 64 && WM == 8 && MW == 2 && NW == 2 && FMT == 0 && !R1 && !F1), "residual from the bases: the 64 -> 64 P16 conv of stage 1");
+  static_assert(!RL || (CT == 64 && WM == 8 && MW == 2 && NW == 2 && !R1 && !F1), "residual from the bases: the 64 -> 64 planar conv of stage 1");
   static_assert(!F1 || (CT == 64 && WM == 8 && MW == 2), "fused first layer: 64-cout tiles of 512 positions");
   static_assert(!F1 || FMT == 0, "fused first layer: P16 only");
   static_assert(NW * 32 == CT, "one wave covers all couts of the tile");

@@ -638,14 +638,15 @@ static void launch_p16_fused_first(hipStream_t s, ConvP16Args a) {
   hipLaunchKernelGGL((conv1d_k9_p16_kernel<64, 2, 2, 8, 0, false, 0, true>), grid, dim3(512), 0, s, a);
 }
 
-// stage 1's pooled conv with the residual computed from the bases in its epilogue (conv_p16.h, RL)
+// stage 1's pooled conv with the residual computed from the bases in its epilogue (conv_p16.h, RL); FMT 0 = P16, 1 = B16
+template <int FMT>
 static void launch_p16_res_bases(hipStream_t s, ConvP16Args a) {
   constexpr int MT = 512;
   static int resident = [] {
     int dev = 0, ncu = 256, per_cu = 1;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv1d_k9_p16_kernel<64, 2, 2, 8, 1, false, 0, false, 0, true>, 512, 0) != hipSuccess || per_cu < 1) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv1d_k9_p16_kernel<64, 2, 2, 8, 1, false, 0, false, FMT, true>, 512, 0) != hipSuccess || per_cu < 1) {
       (void)hipGetLastError();
       per_cu = 1;
     }
@@ -654,7 +655,7 @@ static void launch_p16_res_bases(hipStream_t s, ConvP16Args a) {
   a.tiles_per_row = (a.n + MT - 1) / MT;
   const long ntiles = a.tiles_per_row;
   dim3 grid((unsigned)(ntiles < resident ? ntiles : resident));
-  hipLaunchKernelGGL((conv1d_k9_p16_kernel<64, 2, 2, 8, 1, false, 0, false, 0, true>), grid, dim3(512), 0, s, a);
+  hipLaunchKernelGGL((conv1d_k9_p16_kernel<64, 2, 2, 8, 1, false, 0, false, FMT, true>), grid, dim3(512), 0, s, a);
 }
 
 // W-stationary barrier-free form (conv_ws.h): persistent, one workgroup per CU; the grid is a multiple of the number
@@ -732,10 +733,11 @@ static int launch_conv1d_p16(orca_ctx* ctx, const ConvLayer& L, const float* x, 
   const bool ws_ok = !no_ws && (fmt == 1 || ws_p16) && !k17;
   int tile_tag = fmt == 1 ? -6 : -5;
   if (f1 && f1->residual) {
-    if (L.cout != 64 || L.cin != 64 || out_mode != 1 || r1 || fmt != 0 || k17) return fail(ORCA_EINVAL, "residual from the bases: only stage 1's pooled 64 -> 64 P16 conv");
+    if (L.cout != 64 || L.cin != 64 || out_mode != 1 || r1 || k17) return fail(ORCA_EINVAL, "residual from the bases: only stage 1's pooled 64 -> 64 planar conv");
     a.f1_codes = f1->codes; a.f1_codes_L = f1->codes_L; a.f1_codes_off = f1->codes_off; a.f1_reverse = f1->reverse;
     a.rl_w = reinterpret_cast<const f32x4*>(f1->table); a.f1_bias = f1->bias;
-    launch_p16_res_bases(ctx->stream, a);
+    if (fmt == 1) launch_p16_res_bases<1>(ctx->stream, a);
+    else launch_p16_res_bases<0>(ctx->stream, a);
   } else if (f1) {
     if (L.cout != 64 || L.cin != 64 || out_mode != 0 || r1 || fmt != 0 || k17) return fail(ORCA_EINVAL, "fused first layer: only the 64 -> 64 P16 conv that follows it");
     a.f1_codes = f1->codes; a.f1_codes_L = f1->codes_L; a.f1_codes_off = f1->codes_off; a.f1_reverse = f1->reverse;
@@ -1192,7 +1194,7 @@ static int encoder_chunk(orca_ctx* ctx, orca_net* net, const SeqSource& src, lon
       const bool compose25 = compose && getenv("ORCA_NO_COMPOSE25") == nullptr && net->d_c1a_w16 != nullptr;
       // ... and with packed bases the residual lout1 is computed inside conv1.b's epilogue (conv_p16.h, RL) instead of being stored by a
       // 17-tap first-layer launch and re-read: ORCA_NO_RL=1 keeps the stored form
-      const bool res_from_bases = compose25 && src.codes && fmt == 0 && getenv("ORCA_NO_RL") == nullptr;
+      const bool res_from_bases = compose25 && src.codes && getenv("ORCA_NO_RL") == nullptr;
       float* first_out = compose ? buf[LO] : buf[T];
       const float* rows = x;     // flat [n][4] float rows for the MFMA first-layer kernels (unused with packed input)
       // one first-layer GEMM launch: ntap 9 (lconv1.a alone), 17 (lconv1 composed), 25 (conv1.a o lconv1, + ReLU)
