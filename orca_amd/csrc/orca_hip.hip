@@ -535,7 +535,14 @@ static int launch_conv1d_b16_ns(orca_ctx* ctx, const ConvLayer& L, const ConvB16
   hipStream_t s = ctx->stream;
   if (L.cout == 64) launch_b16_t<64, 2, 2, 4, 1, NS, DT>(s, a, B);
   else if (L.cout == 96) launch_b16_t<96, 1, 3, 8, 1, NS, DT>(s, a, B);
-  else if (L.cout == 128) launch_b16_t<128, 2, 2, 4, 2, NS, DT>(s, a, B);
+  else if (L.cout == 128) {
+    // stages 6-7 of the Encoder (16 000 / 8 000 positions) make 63 / 32 tiles of 256 positions for 256 CUs: 64-position tiles there
+    static const bool no_small = getenv("ORCA_NO_SMALL_TILES") != nullptr;   // A/B switch
+    if constexpr (NS <= 2) {
+      if (!no_small && ((a.n + 255) / 256) * B < 200) { launch_b16_t<128, 1, 2, 2, 2, NS, DT>(s, a, B); return ORCA_OK; }
+    }
+    launch_b16_t<128, 2, 2, 4, 2, NS, DT>(s, a, B);
+  }
   else return fail(ORCA_EINVAL, "bf16s conv1d cout %d unsupported", L.cout);
   return ORCA_OK;
 }
