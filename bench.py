@@ -16,13 +16,21 @@ structural-variant-screen pattern, BASELINE config 5): weak scaling, no data-pat
 
 Also measured in the same run, OUTSIDE the timed region, and reported in the same JSON line:
   * `sharded_256mb` (every N, BASELINE config 4 / north star): H1esc_256M-shaped model on one random 256 Mb sequence,
-    both strands - the Encoder's 64 000 bins sharded over the N ranks (orca_amd.dist.ShardedEncoder), ONE RCCL
-    all-gather per strand (through the C ABI's orca_allgather; torch.distributed if that cannot be set up), then
-    Encoder2(64 000 bins) -> Encoder3 -> 4 Decoders replicated on every rank.  Strong scaling: per-rank encoder ms,
-    all-gather ms, tail ms, Mb/s.
+    both strands - the Encoder's 64 000 bins sharded over the N ranks (each rank holds only its bins' bases +- the 112 kb halo),
+    ONE RCCL all-gather per strand (through the C ABI's orca_allgather; torch.distributed if that cannot be set up), then
+    Encoder2(64 000 bins) -> Encoder3 -> 4 Decoders, one strand each on ranks 0 / 1, one all-gather of the maps.  Strong scaling:
+    per-rank encoder ms, all-gather ms, tail ms, Mb/s - and `parity` of the result against the reference's own
+    genomepredict_256Mb on this sequence (tests/golden/G20_full256m.npz).
+  * `sharded_32mb` (every even N and N = 1): the HEADLINE workload as one strong-scaling job - strand split x Encoder bin
+    shards (orca_amd.dist.strand_bin_sharded_32m), with `parity` against G8.
   * `parity` (N = 1): the timed steps' own six maps against the shipped fixture tests/golden/G8_full32m.npz - the
     REFERENCE's genomepredict on CPU for exactly this sequence, weights and zoom position.
   * `exact_f32` (N = 1): a short second loop with every module on the exact fp32 MFMA kernels.
+  * `roofline_decoder` (N = 1): one Decoder forward (118 Conv2d) at B = 2 under HIP events.
+  * `config3` (N = 1): BASELINE configs[2] - HFF-shaped model, batch of 8, bf16 Encoder + fp16-plane Decoders, 2 timed batches,
+    roofline of its dominant kernel, parity against the reference rows of G17.
+  * `config5` (N = 1): BASELINE configs[4] - 16 of the 1024 synthetic SVs through orca_amd.sv.sv_screen (the full screen:
+    tools/run_configs.py config5_1024, profiles/r03_config5_1024.json).
   * `cpu_baseline` (N = 1): the oracle (= the torch CPU ops the reference dispatches) on a bounded sample.
 
 Prints ONE JSON line (rank 0).  value = strand-Mb of sequence encoded AND decoded per second over the whole job
