@@ -110,6 +110,71 @@ def test_sharded_encoder_allgather_gloo_world2():
     assert np.array_equal(res[0], res[1])
 
 
+def _worker4(rank, world, port, q):
+    """world = 4 over gloo: what changes beyond two ranks - two bin shards per strand reassembled after the all-gather, ranks 2 / 3
+    contributing placeholders to the map gathers (32 Mb and 256 Mb tails) and receiving the result.  Device work replaced by stand-ins."""
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from orca_amd import dist as D
+    from orca_amd import engine, orca_predict
+    try:
+        D.init_from_env("gloo")
+        engine.strand_merge = lambda f, r: 0.5 * f + 0.5 * torch.flip(r, [0, 1])
+        calls = []
+
+        class _Net0:
+            def forward_codes(self, codes, reverse=False, bin_lo=0, bin_hi=0):
+                calls.append((bool(reverse), bin_lo, bin_hi))
+                b = torch.arange(bin_lo, bin_hi, dtype=torch.float32)
+                return (b[None, None, :] + 1000.0 * float(reverse) + 0.001 * torch.arange(128.)[None, :, None]).expand(codes.shape[0], -1, -1).contiguous()
+
+        class _Model:
+            net0 = _Net0()
+            denets = {32: type("D", (), {"num_2d": 1})(), 256: type("D", (), {"num_2d": 1})()}
+
+        tails = []
+
+        def _tail(model, enc0, mpos, wpos, flags, de=None):
+            tails.append(bool(flags[0]))
+            v = (enc0 * torch.arange(1, enc0.shape[2] + 1.)).sum()
+            return [torch.full((enc0.shape[0], 1, 250, 250), float(v) * (j + 1)) + (1.0 if flags[0] else 0.0) for j in range(6)], None
+        orca_predict.cascade_32m_from_enc = _tail
+        codes = torch.zeros((1, 4000 * 75), dtype=torch.uint8)
+        maps32 = D.strand_bin_sharded_32m(_Model(), codes, 0, 0)
+        lo, hi = D.bin_range(75, rank // 2, 2)
+        assert calls == [(bool(rank % 2), lo, hi)]                      # one strand, one bin shard per rank
+        assert tails == ([bool(rank)] if rank < 2 else [])              # only ranks 0 / 1 run a tail
+        ref = [_Net0().forward_codes(codes, bool(st), 0, 75) for st in range(2)]
+        wf, wr = _tail(None, ref[0], 0, 0, [False])[0], _tail(None, ref[1], 0, 0, [True])[0]
+        ok32 = all(torch.equal(m[0], 0.5 * wf[j][0, 0] + 0.5 * torch.flip(wr[j][0, 0], [0, 1])) for j, m in enumerate(maps32))
+        seen = []
+        D.strand_tail_256m = lambda model, enc0, strand, *a: (seen.append(strand), torch.full((4, 1, 250, 250), float(10 + strand)))[1]
+        maps256 = D.strand_parallel_cascade_256m(_Model(), torch.zeros(2, 128, 8), 0, 0, 0, None)
+        ok256 = seen == ([rank] if rank < 2 else []) and all(torch.equal(m, torch.full((1, 250, 250), 10.5)) for m in maps256)
+        q.put((rank, ok32, ok256))
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+    except Exception as e:
+        q.put((rank, repr(e), False))
+
+
+def test_strand_bin_sharding_gloo_world4():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker4, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    for _ in range(4):
+        rank, ok32, ok256 = q.get(timeout=300)
+        assert ok32 is True and ok256 is True, (rank, ok32, ok256)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+
+
 def test_overflow_guard_policy_is_per_thread_and_immediate_around_a_sharded_encoder():
     """(a) the deferred-guard scope of one thread must not leak into another thread; (b) a ShardedEncoder runs
     its rank-local encoder with the IMMEDIATE guard even inside a deferred scope, so that an fp16-range retry happens
