@@ -89,6 +89,30 @@ def test_encoder_composed_linear_pairs_vs_two_conv_form_and_oracle(cuda, precisi
     assert maxabs(enc(big.to(cuda)[:, ::2, :]).cpu().numpy(), O.encoder_forward(sd, big[:, ::2, :]).numpy()) < tol
 
 
+@pytest.mark.parametrize("seed,gain", [(1, 1.0), (2, 1.0), (3, 1.6), (4, 0.6)])
+def test_encoder_weight_seed_and_gain_sweep_vs_oracle(cuda, seed, gain):
+    """The goldens pin ONE set of synthetic weights; the composed forms multiply weights together, so their error depends on the weight
+    statistics: other seeds and other conv gains (activations 0.2x .. 4x as large) against the CPU oracle on the same input, both
+    strands from packed bases, tolerance 1e-4 relative to the output's range."""
+    from orca_amd import engine
+    from orca_amd import orca_modules as pm
+    from tests.util import shapes_of
+    sd = synth.synth_state_dict(shapes_of("Encoder"), seed=seed, relu_gain=gain)
+    enc = pm.Encoder()
+    enc.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    enc.eval()
+    xs = synth.synth_sequence(4000 * 114, seed=20 + seed, n_frac=0.01)
+    x = torch.from_numpy(xs).transpose(1, 2)
+    codes, ok = engine.pack_sequence(x.to(cuda))
+    assert ok
+    for rev in (False, True):
+        xin = torch.from_numpy(np.ascontiguousarray(xs[:, ::-1, ::-1])).transpose(1, 2) if rev else x
+        ref = O.encoder_forward(sd, xin).numpy()
+        y = enc.forward_codes(codes, reverse=rev).cpu().numpy()
+        scale = max(1.0, float(np.abs(ref).max()))
+        assert maxabs(y, ref) < 1e-4 * scale and pearson(y, ref) > 0.999999, (seed, gain, rev, maxabs(y, ref), scale)
+
+
 def test_encoder_composed_weights_outside_fp16_keep_the_two_conv_form(cuda, monkeypatch):
     """A composed weight is a sum of products of folded weights and may leave the fp16 range although every single layer fits (extreme
     checkpoints): such a group must keep the reference's two-conv form instead of packing infinities.  lconv1's two convs are scaled by
