@@ -1130,7 +1130,8 @@ struct EdgeLayerArgs {
   int cin, cout, kc;
   const float* w; const float* b;   // fp32 pack [cin/kc][9][kc][cout], bias
   float* sout;                 // scratch [2 * half][128] (may be NULL for the last layer)
-  f32x4* y; long y_plen; int out_fmt;   // planar tensor receiving the outermost store_half positions per end (NULL: none)
+  f32x4* y; long y_plen; int out_fmt;   // planar tensor receiving the outermost store_half positions per end (NULL: none);
+                                        // out_fmt 0: P16, 1: B16, 2: fp32 channel-major [cout][y_plen] (the exact-fp32 mode; y_plen = row stride in floats)
 };
 
 template <int KC>
@@ -1179,13 +1180,79 @@ __global__ __launch_bounds__(512) void lconv_edge_layer_kernel(EdgeLayerArgs a) 
     if (a.relu) acc = fmaxf(acc, 0.f);
     if (a.sout) a.sout[blockIdx.x * 128 + co] = acc;
     if (a.y && (p < a.store_half || p >= n - a.store_half)) {
-      if (a.out_fmt == 0) {
+      if (a.out_fmt == 2) {
+        reinterpret_cast<float*>(a.y)[(long)co * a.y_plen + p] = acc;
+      } else if (a.out_fmt == 0) {
         const _Float16 h = (_Float16)acc;
         const _Float16 l = (_Float16)(acc - (float)h);
         reinterpret_cast<_Float16*>(a.y + (long)(co >> 3) * 2 * a.y_plen + P16_GUARD + p)[co & 7] = h;
         reinterpret_cast<_Float16*>(a.y + ((long)(co >> 3) * 2 + 1) * a.y_plen + P16_GUARD + p)[co & 7] = l;
       } else {
         reinterpret_cast<unsigned short*>(a.y + (long)(co >> 3) * a.y_plen + P16_GUARD + p)[co & 7] = (unsigned short)(cvt_pk_bf16(acc, 0.f) & 0xffffu);
+      }
+    }
+  }
+}
+
+// ---- the composed first-layer groups in EXACT fp32 (precision "f32") ------------------------------------------------------------
+// out[co][p] = [relu](b[co] + sum_{t < NTAP} sum_{ci < 4} W[t][ci][co] * x[p + t - (NTAP-1)/2][ci]) with fp32 FMAs in a fixed order:
+// NTAP = 17 -> lconv1, NTAP = 25 -> conv1.a o lconv1 + ReLU (weights composed on the host in fp64, see orca_hip.hip).  One thread per
+// position and 32-channel half; the workgroup's input window sits in LDS, the weights are read as wave-uniform (broadcast) float4.
+// 6 400 FMA per position for the 25-tap group against the 73 728 of the 64 -> 64 conv it replaces in this mode.
+struct FirstF32Args {
+  EdgeFixArgs in;        // in_mode 0 (float rows: x, sc, sl) or 1 (base codes); in.n = positions
+  const float* w;        // [NTAP][4][64]
+  const float* bias;     // [64]
+  float* y;              // [64][ldy] channel-major
+  long ldy;
+  int relu;
+};
+template <int NTAP>
+__global__ __launch_bounds__(256) void first_taps_f32_kernel(FirstF32Args a) {
+  constexpr int H = (NTAP - 1) / 2, PT = 128, WINP = PT + NTAP - 1;
+  __shared__ f32x4 xw[WINP];             // window rows: the 4 channels of positions m0 - H ..
+  __shared__ f32x4 ws[NTAP * 4 * 16];    // [t][ci][16 float4 = 64 couts]
+  __shared__ f32x4 bs[16];
+  const int tid = threadIdx.x, pl = tid & (PT - 1), half = tid >> 7;      // half: couts 32 half .. +31
+  for (int i = tid; i < NTAP * 4 * 16; i += 256) ws[i] = reinterpret_cast<const f32x4*>(a.w)[i];
+  if (tid < 16) bs[tid] = reinterpret_cast<const f32x4*>(a.bias)[tid];
+  const long ntiles = (a.in.n + PT - 1) / PT;
+  for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const long m0 = tile * PT;
+    __syncthreads();                     // previous tile's window reads are done (and, first time, the weights are in)
+    for (int i = tid; i < WINP; i += 256) {
+      f32x4 v;
+      v.x = edge_fix_load(a.in, m0 - H + i, 0); v.y = edge_fix_load(a.in, m0 - H + i, 1);
+      v.z = edge_fix_load(a.in, m0 - H + i, 2); v.w = edge_fix_load(a.in, m0 - H + i, 3);
+      xw[i] = v;
+    }
+    __syncthreads();
+    f32x4 acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc[q] = bs[half * 8 + q];
+#pragma unroll 1
+    for (int t = 0; t < NTAP; ++t) {
+      const f32x4 xv = xw[pl + t];
+#pragma unroll
+      for (int ci = 0; ci < 4; ++ci) {
+        const float xs_ = ci == 0 ? xv.x : ci == 1 ? xv.y : ci == 2 ? xv.z : xv.w;
+        const f32x4* wr = ws + (t * 4 + ci) * 16 + half * 8;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const f32x4 w4 = wr[q];
+          acc[q].x = fmaf(w4.x, xs_, acc[q].x); acc[q].y = fmaf(w4.y, xs_, acc[q].y);
+          acc[q].z = fmaf(w4.z, xs_, acc[q].z); acc[q].w = fmaf(w4.w, xs_, acc[q].w);
+        }
+      }
+    }
+    const long p = m0 + pl;
+    if (p < a.in.n) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        f32x4 v = acc[q];
+        if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        float* yo = a.y + (long)(half * 32 + 4 * q) * a.ldy + p;
+        yo[0] = v.x; yo[a.ldy] = v.y; yo[2 * a.ldy] = v.z; yo[3 * a.ldy] = v.w;
       }
     }
   }

@@ -147,6 +147,10 @@ struct orca_net {
   float* d_l1_bias = nullptr;
   void* d_c1a_w16 = nullptr;    // conv1.a o lconv1: 25 taps from the bases, K = 100 -> 112 fp16 split pack (ReLU follows)
   float* d_c1a_bias = nullptr;
+  float* d_l1_f32 = nullptr;    // the same two groups as fp32 [ntap][4][64] tables + biases for the exact-fp32 mode (first_taps_f32_kernel)
+  float* d_c1a_f32 = nullptr;
+  float* d_l1_bias32 = nullptr;
+  float* d_c1a_bias32 = nullptr;
   ConvLayer comp[3];
   std::vector<ConvLayer> convs;
 };
@@ -807,7 +811,7 @@ static int launch_conv1d_p16(orca_ctx* ctx, const ConvLayer& L, const float* x, 
 // the outermost stores[l] positions per end of layer l.  Scratch: one 40 x 128 float slab per layer in the context.
 #define ORCA_EDGE_SLAB (40 * 128)
 static int launch_edge_chain(orca_ctx* ctx, const ConvLayer* const* layers, const int* relu, int nl, int half_last, EdgeFixArgs src, long n,
-                             float* const* ys, const int* stores, int fmt) {
+                             float* const* ys, const int* stores, int fmt, long ld_f32 = 0) {
   src.n = n;
   if (nl > 4 || 2 * (half_last + 4 * (nl - 1)) > 40) return fail(ORCA_EINVAL, "edge fix: chain too deep");
   for (int l = 0; l < nl; ++l) {
@@ -820,7 +824,7 @@ static int launch_edge_chain(orca_ctx* ctx, const ConvLayer* const* layers, cons
     a.relu = relu[l]; a.cin = L.cin; a.cout = L.cout; a.kc = L.kc; a.w = L.d_w; a.b = L.d_bias;
     a.sin = l > 0 ? ctx->d_edge + (l - 1) * ORCA_EDGE_SLAB : nullptr;
     a.sout = ctx->d_edge + l * ORCA_EDGE_SLAB;
-    a.y = reinterpret_cast<f32x4*>(ys[l]); a.y_plen = p16_plen(n); a.out_fmt = fmt;
+    a.y = reinterpret_cast<f32x4*>(ys[l]); a.y_plen = fmt == 2 ? ld_f32 : p16_plen(n); a.out_fmt = fmt;      // fmt 2: fp32 channel-major, row stride ld_f32
     a.store_half = stores[l];
     hipLaunchKernelGGL(lconv_edge_layer_kernel, dim3((unsigned)(2 * a.half)), dim3(512), 0, ctx->stream, a);
   }
@@ -1106,6 +1110,21 @@ extern "C" int orca_net_create(orca_ctx* ctx, int kind, const orca_conv_desc* co
         for (double v : w) if (!(v > -65504.0 && v < 65504.0)) return false;
         return true;
       };
+      {   // fp32 tables [t][ci][co] for the exact-fp32 mode (no range limit there)
+        auto tab32 = [&](const std::vector<double>& w, const std::vector<double>& b, int ntap, float** d_w, float** d_b) -> int {
+          std::vector<float> t((size_t)ntap * 4 * 64), bf(64);
+          for (int co = 0; co < 64; ++co) {
+            bf[co] = (float)b[co];
+            for (int ci = 0; ci < 4; ++ci)
+              for (int tt = 0; tt < ntap; ++tt) t[((size_t)tt * 4 + ci) * 64 + co] = (float)w[((size_t)co * 4 + ci) * ntap + tt];
+          }
+          return upload(t, d_w) != ORCA_OK ? ORCA_EHIP : upload(bf, d_b);
+        };
+        if (tab32(w17, b17, 17, &net->d_l1_f32, &net->d_l1_bias32) != ORCA_OK || tab32(w25, b25, 25, &net->d_c1a_f32, &net->d_c1a_bias32) != ORCA_OK) {
+          orca_net_free(net);
+          return fail(ORCA_EHIP, "composed first-layer upload failed");
+        }
+      }
       if (in_f16(w17) && in_f16(b17)) {
         if (pack_first(w17, b17, 17, &net->d_l1_w16, &net->d_l1_bias) != ORCA_OK) { orca_net_free(net); return fail(ORCA_EHIP, "composed first-layer upload failed"); }
         if (in_f16(w25) && in_f16(b25) && pack_first(w25, b25, 25, &net->d_c1a_w16, &net->d_c1a_bias) != ORCA_OK) {
@@ -1149,6 +1168,10 @@ extern "C" int orca_net_free(orca_net* net) {
   if (net->d_l1_bias) (void)hipFree(net->d_l1_bias);
   if (net->d_c1a_w16) (void)hipFree(net->d_c1a_w16);
   if (net->d_c1a_bias) (void)hipFree(net->d_c1a_bias);
+  if (net->d_l1_f32) (void)hipFree(net->d_l1_f32);
+  if (net->d_c1a_f32) (void)hipFree(net->d_c1a_f32);
+  if (net->d_l1_bias32) (void)hipFree(net->d_l1_bias32);
+  if (net->d_c1a_bias32) (void)hipFree(net->d_c1a_bias32);
   for (auto& L : net->comp) free_layer(L);
   delete net;
   return ORCA_OK;
@@ -1189,14 +1212,16 @@ static int encoder_chunk(orca_ctx* ctx, orca_net* net, const SeqSource& src, lon
   const bool use_b16 = net->precision == ORCA_PRECISION_BF16 && !no_b16;
   const bool use_p16 = (net->precision == ORCA_PRECISION_F16X2 && !no_p16) || use_b16;
   const int fmt = use_b16 ? 1 : 0;
-  if (src.codes && !use_p16) {
+  if (src.codes && !use_p16 && !(net->precision == ORCA_PRECISION_F32 && net->d_l1_f32 && getenv("ORCA_NO_COMPOSE") == nullptr && getenv("ORCA_NO_COMPOSE25") == nullptr)) {
     // the other arithmetic modes start from float rows: expand the packed bases into buf[2] as [n][4]
     hipLaunchKernelGGL(expand_codes_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, s, src.codes, src.codes_L, src.codes_off,
                        src.reverse, n1, buf[2]);
     LAUNCHCHECK("expand_codes_kernel");
     x = buf[2]; sx_c = 1; sx_l = 4;
   }
-  if (!use_p16) {
+  // exact-fp32 mode: stage 1's linear groups composed as in the 16-bit modes (conv_p16.h: first_taps_f32_kernel reads the source directly)
+  const bool compose32 = net->precision == ORCA_PRECISION_F32 && net->d_l1_f32 && getenv("ORCA_NO_COMPOSE") == nullptr && getenv("ORCA_NO_COMPOSE25") == nullptr;
+  if (!use_p16 && !compose32) {
     hipLaunchKernelGGL(seq_to_channel_major_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, s, x, sx_c, sx_l, n1, buf[P], ld1);
     LAUNCHCHECK("seq_to_channel_major_kernel");
   }
@@ -1400,9 +1425,29 @@ static int encoder_chunk(orca_ctx* ctx, orca_net* net, const SeqSource& src, lon
       P = Q; n = n2; ld = ld2;
     }
     const int T = (P + 1) % 3, LO = (P + 2) % 3;
+    if (st == 0 && compose32) {
+      // lconv1 (17 taps) and conv1.a o lconv1 (25 taps + ReLU) straight from the source, fp32 FMAs; exact ends by the edge chain
+      FirstF32Args fa{};
+      if (src.codes) { fa.in.in_mode = 1; fa.in.codes = src.codes; fa.in.codes_L = src.codes_L; fa.in.codes_off = src.codes_off; fa.in.reverse = src.reverse; }
+      else { fa.in.in_mode = 0; fa.in.x = src.x; fa.in.sc = src.sx_c; fa.in.sl = src.sx_l; }
+      fa.in.n = n; fa.ldy = ld;
+      const long nt = (n + 127) / 128;
+      const dim3 grid((unsigned)(nt < 4096 ? nt : 4096));
+      fa.w = net->d_l1_f32; fa.bias = net->d_l1_bias32; fa.relu = 0; fa.y = buf[LO];
+      hipLaunchKernelGGL((first_taps_f32_kernel<17>), grid, dim3(256), 0, s, fa);
+      fa.w = net->d_c1a_f32; fa.bias = net->d_c1a_bias32; fa.relu = 1; fa.y = buf[T];
+      hipLaunchKernelGGL((first_taps_f32_kernel<25>), grid, dim3(256), 0, s, fa);
+      LAUNCHCHECK("first_taps_f32_kernel");
+      const ConvLayer* chain[3] = {&L[0], &L[1], &L[2]};
+      const int relus[3] = {0, 0, 1};
+      float* ys[3] = {nullptr, buf[LO], buf[T]};
+      const int st_[3] = {0, 4, 8};
+      ORCA_TRY(launch_edge_chain(ctx, chain, relus, 3, 8, fa.in, n, ys, st_, 2, ld));
+    } else {
     ORCA_TRY(launch_conv1d(ctx, L[0], buf[P], 0, ld, buf[T], 0, ld, nullptr, nullptr, 1, n, 0, 0));
     ORCA_TRY(launch_conv1d(ctx, L[1], buf[T], 0, ld, buf[LO], 0, ld, nullptr, nullptr, 1, n, 0, 0));
     ORCA_TRY(launch_conv1d(ctx, L[2], buf[LO], 0, ld, buf[T], 0, ld, nullptr, nullptr, 1, n, 1, 0));
+    }
     ORCA_TRY(launch_conv1d(ctx, L[3], buf[T], 0, ld, buf[P], 0, ld, st < 6 ? buf[LO] : nullptr, nullptr, 1, n, 1, 0));
     cprev = L[3].cout;
   }
