@@ -839,7 +839,7 @@ struct FirstMfmaArgs {
 };
 
 // ABL (tools/microbench_first.hip only): 1 = no MFMA, 16 = no stores, 32 = input not re-fetched per tile
-// FMT = 1: the output is B16 (one bf16 plane per 8 channels) instead of P16; the arithmetic is unchanged.
+// FMT = 1: the output is B16 (one bf16 plane per 8 channels) instead of P16, FMT = 2: fp32 channel-last [n][64]; the arithmetic is unchanged.
 // NTAP = 9: the first layer alone (lconv1.a).  NTAP = 17: the COMPOSED linear pair lconv1 = Conv(4,64,k9)-BN-Conv(64,64,k9)-BN
 //   (orca_modules.py:811-816 has no nonlinearity between the two) as ONE 17-tap conv from the bases, K = 68 -> 80: the
 //   64 -> 64 launch at full resolution that used to follow the first layer is gone.  The 4 positions next to each end of
@@ -946,6 +946,24 @@ __global__ __launch_bounds__(256, 2) void conv1d_first_mfma_p16_kernel(FirstMfma
         for (int j = 0; j < 2; ++j)
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[i][j][r] = p16_vmax(acc[i][j][r], 0.f);
+    }
+    if constexpr (FMT == 2) {   // fp32 channel-last [n][64]: the hand-over to the register-staged kernels (conv_bf16s.h) of the bf16x3 / bf16x2 modes
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const long p = tile * MT + wave * 64 + i * 32 + l31;
+        if (p < a.n) {
+          float* o_ = reinterpret_cast<float*>(a.y) + p * 64 + 4 * g;
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              f32x4 v;
+              v.x = acc[i][j][4 * q + 0]; v.y = acc[i][j][4 * q + 1]; v.z = acc[i][j][4 * q + 2]; v.w = acc[i][j][4 * q + 3];
+              *reinterpret_cast<f32x4*>(o_ + j * 32 + 8 * q) = v;
+            }
+        }
+      }
+      continue;
     }
     if constexpr (FMT == 1) {
 #pragma unroll
@@ -1131,7 +1149,7 @@ struct EdgeLayerArgs {
   const float* w; const float* b;   // fp32 pack [cin/kc][9][kc][cout], bias
   float* sout;                 // scratch [2 * half][128] (may be NULL for the last layer)
   f32x4* y; long y_plen; int out_fmt;   // planar tensor receiving the outermost store_half positions per end (NULL: none);
-                                        // out_fmt 0: P16, 1: B16, 2: fp32 channel-major [cout][y_plen] (the exact-fp32 mode; y_plen = row stride in floats)
+                                        // out_fmt 0: P16, 1: B16, 2: fp32 channel-major [cout][y_plen] (the exact-fp32 mode; y_plen = row stride in floats), 3: fp32 channel-last [n][cout]
 };
 
 template <int KC>
@@ -1182,6 +1200,8 @@ __global__ __launch_bounds__(512) void lconv_edge_layer_kernel(EdgeLayerArgs a) 
     if (a.y && (p < a.store_half || p >= n - a.store_half)) {
       if (a.out_fmt == 2) {
         reinterpret_cast<float*>(a.y)[(long)co * a.y_plen + p] = acc;
+      } else if (a.out_fmt == 3) {            // fp32 channel-last [n][cout]
+        reinterpret_cast<float*>(a.y)[p * a.cout + co] = acc;
       } else if (a.out_fmt == 0) {
         const _Float16 h = (_Float16)acc;
         const _Float16 l = (_Float16)(acc - (float)h);

@@ -1212,16 +1212,19 @@ static int encoder_chunk(orca_ctx* ctx, orca_net* net, const SeqSource& src, lon
   const bool use_b16 = net->precision == ORCA_PRECISION_BF16 && !no_b16;
   const bool use_p16 = (net->precision == ORCA_PRECISION_F16X2 && !no_p16) || use_b16;
   const int fmt = use_b16 ? 1 : 0;
-  if (src.codes && !use_p16 && !(net->precision == ORCA_PRECISION_F32 && net->d_l1_f32 && getenv("ORCA_NO_COMPOSE") == nullptr && getenv("ORCA_NO_COMPOSE25") == nullptr)) {
+  // the channel-last split-operand pipeline (bf16x3 / bf16x2, or f16x2 with ORCA_NO_P16): stage 1 composed from a flat source
+  const bool compose_nlc = !use_p16 && net->precision != ORCA_PRECISION_F32 && net->d_c1a_w16 && getenv("ORCA_NO_COMPOSE") == nullptr &&
+                           getenv("ORCA_NO_COMPOSE25") == nullptr && (src.codes || (src.sx_c == 1 && src.sx_l == 4 && al16(src.x)));
+  // exact-fp32 mode: stage 1's linear groups composed as in the 16-bit modes (conv_p16.h: first_taps_f32_kernel reads the source directly)
+  const bool compose32 = net->precision == ORCA_PRECISION_F32 && net->d_l1_f32 && getenv("ORCA_NO_COMPOSE") == nullptr && getenv("ORCA_NO_COMPOSE25") == nullptr;
+  if (src.codes && !use_p16 && !compose32 && !compose_nlc) {
     // the other arithmetic modes start from float rows: expand the packed bases into buf[2] as [n][4]
     hipLaunchKernelGGL(expand_codes_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, s, src.codes, src.codes_L, src.codes_off,
                        src.reverse, n1, buf[2]);
     LAUNCHCHECK("expand_codes_kernel");
     x = buf[2]; sx_c = 1; sx_l = 4;
   }
-  // exact-fp32 mode: stage 1's linear groups composed as in the 16-bit modes (conv_p16.h: first_taps_f32_kernel reads the source directly)
-  const bool compose32 = net->precision == ORCA_PRECISION_F32 && net->d_l1_f32 && getenv("ORCA_NO_COMPOSE") == nullptr && getenv("ORCA_NO_COMPOSE25") == nullptr;
-  if (!use_p16 && !compose32) {
+  if (!use_p16 && !compose32 && !compose_nlc) {
     hipLaunchKernelGGL(seq_to_channel_major_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, s, x, sx_c, sx_l, n1, buf[P], ld1);
     LAUNCHCHECK("seq_to_channel_major_kernel");
   }
@@ -1405,10 +1408,33 @@ static int encoder_chunk(orca_ctx* ctx, orca_net* net, const SeqSource& src, lon
         P = Q; n = n2;
       }
       const int T = (P + 1) % 3, LO = (P + 2) % 3;
+      if (st == 0 && compose_nlc) {
+        // stage 1's linear groups composed here too (the fallback of the fp16-range guard runs this branch in bf16x3): lconv1 and
+        // conv1.a o lconv1 as 17- / 25-tap first-layer GEMMs writing fp32 channel-last, exact ends by the edge chain
+        FirstMfmaArgs fm;
+        fm.codes = src.codes; fm.codes_L = src.codes_L; fm.codes_off = src.codes_off; fm.reverse = src.reverse;
+        fm.x = src.codes ? nullptr : src.x; fm.n = n; fm.y_plen = 0; fm.flag = nullptr;
+        const long nt = (n + 255) / 256;
+        const dim3 grid((unsigned)(nt < 2048 ? nt : 2048));
+        fm.w = reinterpret_cast<const f32x4*>(net->d_l1_w16); fm.bias = net->d_l1_bias; fm.relu = 0; fm.y = reinterpret_cast<f32x4*>(buf[LO]);
+        hipLaunchKernelGGL((conv1d_first_mfma_p16_kernel<0, 2, 17>), grid, dim3(256), 0, s, fm);
+        fm.w = reinterpret_cast<const f32x4*>(net->d_c1a_w16); fm.bias = net->d_c1a_bias; fm.relu = 1; fm.y = reinterpret_cast<f32x4*>(buf[T]);
+        hipLaunchKernelGGL((conv1d_first_mfma_p16_kernel<0, 2, 25>), grid, dim3(256), 0, s, fm);
+        LAUNCHCHECK("conv1d_first_mfma_p16_kernel");
+        EdgeFixArgs ef{};
+        if (src.codes) { ef.in_mode = 1; ef.codes = src.codes; ef.codes_L = src.codes_L; ef.codes_off = src.codes_off; ef.reverse = src.reverse; }
+        else { ef.in_mode = 0; ef.x = src.x; ef.sc = src.sx_c; ef.sl = src.sx_l; }
+        const ConvLayer* chain[3] = {&L[0], &L[1], &L[2]};
+        const int relus[3] = {0, 0, 1};
+        float* ys[3] = {nullptr, buf[LO], buf[T]};
+        const int st_[3] = {0, 4, 8};
+        ORCA_TRY(launch_edge_chain(ctx, chain, relus, 3, 8, ef, n, ys, st_, 3));
+      } else {
       if (st == 0) ORCA_TRY(launch_conv1d(ctx, L[0], buf[P], 0, ld1, buf[T], 0, 0, nullptr, nullptr, 1, n, 0, 0, 1));
       else ORCA_TRY(launch_conv1d_b16(ctx, L[0], prec, buf[P], 0, buf[T], 0, nullptr, 1, n, 0));
       ORCA_TRY(launch_conv1d_b16(ctx, L[1], prec, buf[T], 0, buf[LO], 0, nullptr, 1, n, 0));
       ORCA_TRY(launch_conv1d_b16(ctx, L[2], prec, buf[LO], 0, buf[T], 0, nullptr, 1, n, 1));
+      }
       ORCA_TRY(launch_conv1d_b16(ctx, L[3], prec, buf[T], 0, buf[P], 0, st < 6 ? buf[LO] : nullptr, 1, n, 1,
                                  (st < 6 && kEncPools[st + 1] == 4) ? 1 : 0));
     }

@@ -47,7 +47,7 @@ def test_encoder_ragged_length_and_batch_vs_oracle(cuda):
     assert maxabs(y, ref) < TOL
 
 
-@pytest.mark.parametrize("precision", ["f16x2", "bf16", "f32"])
+@pytest.mark.parametrize("precision", ["f16x2", "bf16", "f32", "bf16x3"])
 def test_encoder_composed_linear_pairs_vs_two_conv_form_and_oracle(cuda, precision, monkeypatch):
     """lconv1..3 run as single 17-tap convs and conv1.a o lconv1 as a 25-tap conv from the bases (weights composed on the host, ends
     redone by the edge-fix chain).  Against
