@@ -1212,9 +1212,10 @@ static int encoder_chunk(orca_ctx* ctx, orca_net* net, const SeqSource& src, lon
   const bool use_b16 = net->precision == ORCA_PRECISION_BF16 && !no_b16;
   const bool use_p16 = (net->precision == ORCA_PRECISION_F16X2 && !no_p16) || use_b16;
   const int fmt = use_b16 ? 1 : 0;
-  // the channel-last split-operand pipeline (bf16x3 / bf16x2, or f16x2 with ORCA_NO_P16): stage 1 composed from a flat source
+  // the channel-last split-operand pipeline (bf16x3 / bf16x2, or f16x2 with ORCA_NO_P16): stage 1 composed - from PACKED bases only: the
+  // first-layer GEMM splits its X operand into fp16 parts, exact for 0 / 0.25 / 1, while these modes promise fp32 range for arbitrary float rows
   const bool compose_nlc = !use_p16 && net->precision != ORCA_PRECISION_F32 && net->d_c1a_w16 && getenv("ORCA_NO_COMPOSE") == nullptr &&
-                           getenv("ORCA_NO_COMPOSE25") == nullptr && (src.codes || (src.sx_c == 1 && src.sx_l == 4 && al16(src.x)));
+                           getenv("ORCA_NO_COMPOSE25") == nullptr && src.codes;
   // exact-fp32 mode: stage 1's linear groups composed as in the 16-bit modes (conv_p16.h: first_taps_f32_kernel reads the source directly)
   const bool compose32 = net->precision == ORCA_PRECISION_F32 && net->d_l1_f32 && getenv("ORCA_NO_COMPOSE") == nullptr && getenv("ORCA_NO_COMPOSE25") == nullptr;
   if (src.codes && !use_p16 && !compose32 && !compose_nlc) {
