@@ -516,6 +516,21 @@ def main():
                     "conv1d_time_share_of_step": round(tot_ms / (elapsed * 1e3), 4),
                     "all_conv1d_tflops": round(sum(v["flop"] for v in inst.values()) / (tot_ms * 1e-3) / 1e12, 2)}
 
+    # the one HBM-bound kernel of the step: the 25-tap first-layer GEMM (conv1.a o lconv1 from the bases) writes 4 B per element of a
+    # 64-channel tensor and reads 1 byte per base - algorithmic bytes / HIP-event time against the 8 TB/s HBM3E peak
+    roofline_hbm = None
+    f25 = [(n, ms) for cout, cin, tile, batch, n, ms, ksize in recs if ksize == 25 and ms > 0]
+    if f25:
+        byts = sum(n * (64 * 4 + 1) for n, _ in f25)
+        tms = sum(ms for _, ms in f25)
+        roofline_hbm = {"bound": "hbm", "kernel": "conv1d_first_mfma_p16_kernel<0,0,25> (conv1.a o lconv1: 25 taps from the bases + ReLU, P16 out)",
+                        "achieved": round(byts / (tms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(byts / (tms * 1e-3) / 8e12, 4),
+                        "bytes_per_launch_algorithmic": byts / len(f25), "avg_launch_ms": round(tms / len(f25), 4), "launches": len(f25),
+                        "traffic": None, "traffic_measured_in_run": False}
+        try:
+            roofline_hbm["traffic"] = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get("conv1d_first_mfma_p16_kernel<0,0,25>")
+        except Exception:
+            pass
     ms_per_step = elapsed / args.steps * 1e3
     mb_per_s = world * 2 * (Lbp / 1e6) * args.steps / elapsed
     enc_prec, dec_prec = model.net0.precision, model.denets[32].precision
@@ -539,6 +554,7 @@ def main():
         "step_tflop_algorithmic": round(step_flops() * Lbp / L_BP, 3) if Lbp == L_BP else None,
         "whole_step_tflops": round(world * step_flops() * args.steps / elapsed, 2) if Lbp == L_BP else None,
         "roofline": roofline,
+        "roofline_hbm_bound_kernel": roofline_hbm,
     }
 
     # ---- parity of THIS run's maps against the reference's own output for the same sequence / weights / position (G8)
