@@ -196,3 +196,22 @@ def test_bench_two_ranks_on_one_gpu_over_gloo(cuda):
     t1, t2 = one["sharded_32mb"], two["sharded_32mb"]
     assert "error" not in t2, t2
     assert t2["n_gpus"] == 2 and t2["scaling"] == "strong" and t1["parity"]["ok"] and t2["parity"]["ok"], (t1, t2)
+
+
+def test_bench_four_ranks_on_one_gpu_over_gloo(cuda):
+    """The same with FOUR ranks (the first world size at which a strand's Encoder bins are split over several ranks, a rank holds less
+    than half of the packed sequence, and ranks 2 / 3 only contribute placeholders to the map gathers): both sharded sections must
+    reproduce the reference's fixtures (G20 at 256 Mb, G8 at 32 Mb) exactly as at N = 1."""
+    env = dict(os.environ, ORCA_BENCH_ONE_DEVICE="1", ORCA_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=4", "--master-addr", "127.0.0.1",
+           "--master-port", str(29700 + os.getpid() % 200), os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "1",
+           "--sharded-steps", "1", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-1500:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    s, t = d["sharded_256mb"], d["sharded_32mb"]
+    assert d["n_gpus"] == 4 and "error" not in s and "error" not in t, (s, t)
+    assert s["bins_this_rank"] == [0, 16000] and s["sequence_bytes_on_this_rank"] == 2 * (64_000_000 + 112_000)
+    assert s["parity"]["ok"] and t["parity"]["ok"], (s["parity"], t["parity"])
