@@ -2207,6 +2207,12 @@ static int conv1d_planar_test(orca_ctx* ctx, const orca_conv_desc* conv, const f
   if (!ctx || !conv || !x || !y) return fail(ORCA_EINVAL, "orca_conv1d_p16/b16_forward: NULL argument");
   HIPCHECK(hipSetDevice(ctx->device));
   ConvLayer L;
+  if (conv->ksize == 17) {     // a 17-tap layer as the Encoder's composed pairs run it: weight_host [cout][cin][17]
+    std::vector<double> w17((size_t)conv->cout * conv->cin * 17), b17(conv->cout);
+    for (size_t i = 0; i < w17.size(); ++i) w17[i] = conv->weight_host[i];
+    for (int i = 0; i < conv->cout; ++i) b17[i] = conv->bias_host[i];
+    ORCA_TRY(make_layer17(conv->cin, conv->cout, w17, b17, &L));
+  } else
   ORCA_TRY(make_layer(*conv, &L));
   const long nout = out_mode == 1 ? n / 4 : n;
   const size_t sx = (size_t)conv->cin * p16_plen(n), sy = (size_t)conv->cout * p16_plen(nout), sr = (size_t)conv->cout * p16_plen(n);

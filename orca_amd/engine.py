@@ -491,7 +491,7 @@ def conv1d_p16(x, w, b, relu=False, r1=None, out_mode=0, fmt="p16"):
     w = np.ascontiguousarray(w, dtype=np.float32)
     b = np.ascontiguousarray(b, dtype=np.float32)
     cout = w.shape[0]
-    d = make_descs([{"w": w, "b": b, "cout": cout, "cin": cin, "k": 9, "dil": 1}])
+    d = make_descs([{"w": w, "b": b, "cout": cout, "cin": cin, "k": int(w.shape[2]), "dil": 1}])     # 9 taps, or 17 (the composed-pair form)
     y = torch.empty((n // 4 if out_mode == 1 else n, cout), dtype=torch.float32, device=x.device)
     ctx = get_context(x.device)
     r1 = r1.contiguous() if r1 is not None else None

@@ -132,6 +132,31 @@ def test_conv1d_p16_dma(cuda, cin, cout, n, out_mode):
         assert err < 2e-5, (cin, cout, n, out_mode, relu, err)
 
 
+@pytest.mark.parametrize("cin,cout,n", [(64, 96, 1500), (96, 128, 1031), (64, 64, 4097), (64, 96, 300000)])
+@pytest.mark.parametrize("fmt", ["p16", "b16"])
+def test_conv1d_17_taps_planar(cuda, cin, cout, n, fmt):
+    """The 17-tap form of the planar conv (a composed linear pair: ConvP16Args.k17 = twice the K-chunks, the second tap half on the input
+    shifted by 9, its ninth tap skipped) against torch's own 17-tap conv1d in fp32 - kernel level, zero padding of 8 at both ends,
+    ragged last tile, with and without residual."""
+    rs = np.random.RandomState(cin + cout + n)
+    x = torch.from_numpy(rs.randn(1, cin, n).astype(np.float32))
+    w = (rs.randn(cout, cin, 17) / np.sqrt(cin * 17)).astype(np.float32)
+    b = rs.randn(cout).astype(np.float32) * 0.1
+    r1 = torch.from_numpy(rs.randn(1, cout, n).astype(np.float32))
+    if fmt == "b16":
+        x, r1 = _bf16(x), _bf16(r1)
+        w = _bf16(torch.from_numpy(w)).numpy()
+    for relu, ra in [(False, None), (True, r1)]:
+        y = engine.conv1d_p16(x[0].t().contiguous().to(cuda), w, b, relu, None if ra is None else ra[0].t().contiguous().to(cuda), 0, fmt=fmt)
+        ref = F.conv1d(x.double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(), padding=8)
+        if relu:
+            ref = F.relu(ref)
+        if ra is not None:
+            ref = ref + ra.double()
+        err = float((y.cpu().t()[None].double() - ref).abs().max())
+        assert err < (2e-5 if fmt == "p16" else 3e-2), (cin, cout, n, fmt, relu, err)
+
+
 def _bf16(t):
     return t.to(torch.bfloat16).to(torch.float32)
 
