@@ -309,7 +309,9 @@ int orca_conv1d_nlc_forward(orca_ctx* ctx, const orca_conv_desc* conv, int preci
                             const float* r1, int B, int64_t n, int relu);
 /* The P16 / LDS-DMA conv1d of the Encoder's stages 1-3 (conv_p16.h), wrapped for tests: channel-last fp32
  * in/out (x [n][cin], r1 [n][cout], y [n][cout] or, with out_mode 1 = fused MaxPool1d(4), [n/4][cout]);
- * out_mode 0/1 round-trip through the planar split-fp16 storage, out_mode 2 writes fp32 directly. */
+ * out_mode 0/1 round-trip through the planar split-fp16 storage, out_mode 2 writes fp32 directly.
+ * conv->ksize may be 9, or 17 with weight_host [cout][cin][17] - the form the Encoder's composed linear pairs
+ * (Conv-BN-Conv-BN without a nonlinearity, orca_modules.py:829-835, 846-852) run as; cin % 32 == 0 then. */
 int orca_conv1d_p16_forward(orca_ctx* ctx, const orca_conv_desc* conv, const float* x, float* y, const float* r1,
                             int64_t n, int relu, int out_mode);
 /* The same kernel on "B16" activations - ONE bf16 plane per 8 channels, plain bf16 operands, one MFMA product,
