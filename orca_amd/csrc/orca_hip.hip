@@ -22,6 +22,7 @@
 #include "conv2d_dblock.h"
 #include "conv_p16.h"
 #include "conv_ws.h"
+#include "conv_p16w1.h"
 #include "misc_kernels.h"
 #include "coarsegrain.h"
 #include "orca_hip.h"
@@ -698,6 +699,23 @@ static void launch_p16_res_bases(hipStream_t s, ConvP16Args a) {
   hipLaunchKernelGGL((conv1d_k9_p16_kernel<64, 2, 2, 8, 1, false, 0, false, FMT, true>), grid, dim3(512), 0, s, a);
 }
 
+// the 96-cout layers on 512-position tiles with ONE half-by-half refilled weight buffer (conv_p16w1.h)
+template <int OM, bool R1, int FMT>
+static void launch_p16w1_k(hipStream_t s, ConvP16Args a) {
+  static int ncu = [] { int dev = 0, v = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev); return v; }();
+  a.tiles_per_row = (a.n + 511) / 512;
+  dim3 grid((unsigned)(a.tiles_per_row < ncu ? a.tiles_per_row : ncu));
+  hipLaunchKernelGGL((conv1d_k9_p16w1_kernel<OM, R1, FMT>), grid, dim3(512), 0, s, a);
+}
+template <int FMT>
+static bool launch_p16w1(hipStream_t s, const ConvP16Args& a) {     // false: this (out_mode, residual) pair stays on the 256-position kernel
+  const bool r1 = a.r1 != nullptr;
+  if (a.out_mode == 0 && !r1) launch_p16w1_k<0, false, FMT>(s, a);
+  else if (a.out_mode == 1 && r1) launch_p16w1_k<1, true, FMT>(s, a);
+  else return false;
+  return true;
+}
+
 // W-stationary barrier-free form (conv_ws.h): persistent, one workgroup per CU; the grid is a multiple of the number
 // of cout blocks (of 8 x that where possible: the blocks of one position range then share an XCD)
 template <int FMT, int CIN, int CT, int MW, int NW, int OM, bool R1>
@@ -789,6 +807,8 @@ static int launch_conv1d_p16(orca_ctx* ctx, const ConvLayer& L, const float* x, 
   } else if (ws_ok && fmt == 0 && L.cin == 64 && (L.cout == 64 || L.cout == 96)) {
     launch_ws_t<0, 64, 32, 2, 1>(ctx->stream, a);
     tile_tag = -7;
+  } else if (L.cout == 96 && n >= 65536 && getenv("ORCA_NO_P16W1") == nullptr && (fmt == 1 ? launch_p16w1<1>(ctx->stream, a) : launch_p16w1<0>(ctx->stream, a))) {
+    tile_tag = fmt == 1 ? -10 : -9;      // stage 2 of the Encoder: 512-position tiles (conv_p16w1.h)
   } else if (fmt == 1) {
     if (L.cout == 96) launch_p16_t<96, 1, 3, 8, 1>(ctx->stream, a);
     else if (L.cout % 64 == 0) launch_p16_t<64, 2, 2, 8, 1>(ctx->stream, a);

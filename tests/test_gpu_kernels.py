@@ -113,7 +113,7 @@ def test_conv1d_split_bf16_wide_dynamic_range(cuda):
 
 
 @pytest.mark.parametrize("cin,cout,n", [(64, 64, 2000), (64, 64, 513), (64, 96, 1500), (96, 96, 777), (96, 128, 1030), (128, 128, 3000),
-                                        (64, 64, 2051), (64, 64, 4097), (64, 64, 300000)])
+                                        (64, 64, 2051), (64, 64, 4097), (64, 64, 300000), (96, 96, 300001), (64, 96, 70000)])   # the last two: 512-position tiles (conv_p16w1.h)
 @pytest.mark.parametrize("out_mode", [0, 1, 2])
 def test_conv1d_p16_dma(cuda, cin, cout, n, out_mode):
     """conv_p16.h: planar split-fp16 activations + LDS-DMA staging; optional fused MaxPool1d(4); vs torch fp32."""
@@ -162,7 +162,7 @@ def _bf16(t):
 
 
 @pytest.mark.parametrize("cin,cout,n", [(64, 64, 2000), (64, 64, 513), (64, 96, 1500), (96, 96, 777), (96, 128, 1030), (128, 128, 3000),
-                                        (64, 64, 4097), (64, 64, 300000)])
+                                        (64, 64, 4097), (64, 64, 300000), (96, 96, 300001), (64, 96, 70000)])
 @pytest.mark.parametrize("out_mode", [0, 1, 2])
 def test_conv1d_b16_dma(cuda, cin, cout, n, out_mode):
     """conv_p16.h, FMT = 1 (B16): single-plane bf16 activations, bf16 weights, ONE MFMA product, fp32 accumulate.

@@ -5,7 +5,7 @@
    <tag>_pmc_<run>.txt                 per-kernel sums of the counter passes (tools/pmc_summary.py format)
    pmc_traffic.json                    HBM bytes per launch of the dominant kernel (FETCH_SIZE x 2 + WRITE_SIZE, KiB)
 usage: python tools/profile_collect.py r02"""
-import collections, csv, json, os, shutil, subprocess, sys
+import collections, csv, json, os, re, shutil, subprocess, sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -24,12 +24,12 @@ rows = list(csv.DictReader(open(os.path.join(src, "bench", "bench_kernel_trace.c
 by = collections.defaultdict(list)
 for r in rows:
     n = r["Kernel_Name"]
-    if n.startswith("void conv1d_k9_p16_kernel<") or n.startswith("void conv1d_k9_ws_kernel") or n.startswith("void conv1d_first_mfma_p16_kernel"):
+    if n.startswith("void conv1d_k9_p16_kernel<") or n.startswith("void conv1d_k9_p16w1_kernel<") or n.startswith("void conv1d_k9_ws_kernel") or n.startswith("void conv1d_first_mfma_p16_kernel"):
         by[n.replace("void ", "").split("(")[0]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 with open(os.path.join(dst, f"{tag}_bench_dominant_launches.txt"), "w") as f:
     f.write("# rocprofv3 --kernel-trace of `python bench.py --no-cpu-baseline`: launches of the planar conv kernels (bench.py's `roofline` names the\n"
             "# instantiation with the largest time share), split by problem size; template arguments <CT, MW, NW, WM, out_mode, residual, ABL,\n"
-            "# fused-first-layer, format, residual-from-bases>.  'big' = launches >= 2.5 ms (stage 1 at n = 32 M, stage 2 at n = 8 M of a 32 Mb strand\n"
+            "# fused-first-layer, format, residual-from-bases> (conv_p16w1.h: <out_mode, residual, format>).  'big' = launches >= 2.5 ms (stage 1 at n = 32 M, stage 2 at n = 8 M of a 32 Mb strand\n"
             "# or chunk), the rest are stages 3-4.\n")
     allbig, allsmall = [], []
     for k, v in sorted(by.items()):
@@ -54,15 +54,15 @@ def pmc_sum(run, counter, prefix, min_us=1500.0):
     """sum of `counter` over the launches of kernels named prefix* that ran >= min_us (the n = 32 M launches)"""
     tot, disp = 0.0, set()
     for r in csv.DictReader(open(os.path.join(src, run, "p_counter_collection.csv"))):
-        if r["Kernel_Name"].startswith(prefix) and r["Counter_Name"] == counter and (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 >= min_us:
+        if (prefix.search(r["Kernel_Name"]) if hasattr(prefix, "search") else r["Kernel_Name"].startswith(prefix)) and r["Counter_Name"] == counter and (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 >= min_us:
             tot += float(r["Counter_Value"]); disp.add(r["Dispatch_Id"])
     return tot, len(disp)
 
 traffic = {"_source": f"profiles/{tag}_pmc_enc_f16x2_fetch.txt + profiles/{tag}_pmc_enc_f16x2_write.txt (and the bf16 pair)"}
 for mode, key, prefix, min_us in (("f16x2", "conv1d_k9_p16_kernel<cout=64,f16x2>", "void conv1d_k9_p16_kernel<64,", 4000.0),
-                                  ("f16x2", "conv1d_k9_p16_kernel<cout=96,f16x2>", "void conv1d_k9_p16_kernel<96, 1, 3, 8, 0, false", 2500.0),   # 96 -> 96 (and the 17-tap 64 -> 96)
+                                  ("f16x2", "conv1d_k9_p16w1_kernel<cout=96,f16x2>", re.compile(r"^void conv1d_k9_p16w1_kernel<\d, (true|false), 0>"), 2500.0),   # 96 -> 96, plain and pooled + residual (and the 17-tap 64 -> 96)
                                   ("f16x2", "conv1d_first_mfma_p16_kernel<0,0,25>", "void conv1d_first_mfma_p16_kernel<0, 0, 25>", 800.0),
-                                  ("bf16", "conv1d_k9_p16_kernel<cout=96,bf16>", "void conv1d_k9_p16_kernel<96, 1, 3, 8, 0, false, 0, false, 1", 800.0),
+                                  ("bf16", "conv1d_k9_p16w1_kernel<cout=96,bf16>", re.compile(r"^void conv1d_k9_p16w1_kernel<\d, (true|false), 1>"), 800.0),
                                   ("bf16", "conv1d_k9_ws_kernel<cout=64,bf16>", "void conv1d_k9_ws_kernel<1, 64, 64,", 1200.0)):
     try:
         fe, n1 = pmc_sum(f"pmc_enc_{mode}_fetch", "FETCH_SIZE", prefix, min_us)
