@@ -113,7 +113,7 @@ def test_conv1d_split_bf16_wide_dynamic_range(cuda):
 
 
 @pytest.mark.parametrize("cin,cout,n", [(64, 64, 2000), (64, 64, 513), (64, 96, 1500), (96, 96, 777), (96, 128, 1030), (128, 128, 3000),
-                                        (64, 64, 2051), (64, 64, 4097), (64, 64, 300000), (96, 96, 300001), (64, 96, 70000)])   # the last two: 512-position tiles (conv_p16w1.h)
+                                        (64, 64, 2051), (64, 64, 4097), (64, 64, 300000), (96, 96, 300001), (64, 96, 70000), (96, 128, 66001)])   # the last three: 512-position tiles (conv_p16w1.h / conv_p16f.h)
 @pytest.mark.parametrize("out_mode", [0, 1, 2])
 def test_conv1d_p16_dma(cuda, cin, cout, n, out_mode):
     """conv_p16.h: planar split-fp16 activations + LDS-DMA staging; optional fused MaxPool1d(4); vs torch fp32."""
@@ -129,6 +129,28 @@ def test_conv1d_p16_dma(cuda, cin, cout, n, out_mode):
             ref = F.max_pool1d(ref, 4, 4)
         err = float((y.cpu().t()[None] - ref).abs().max())
         assert y.shape[0] == ref.shape[2]
+        assert err < 2e-5, (cin, cout, n, out_mode, relu, err)
+
+
+@pytest.mark.parametrize("cin,cout,n", [(96, 96, 300001), (64, 96, 70000), (96, 128, 66001), (64, 64, 131072)])
+@pytest.mark.parametrize("out_mode", [0, 1, 2])
+def test_conv1d_p16_fast_fir(cuda, monkeypatch, cin, cout, n, out_mode):
+    """conv_p16f.h (opt-in, ORCA_FFA=1): the k9 conv as a 2-parallel fast FIR - three half-rate filters on X1, X0 - X1 and X0' - X1 with
+    the tap sums H0 + H1, H0, H1 (14 instead of 18 tap products per output pair) - against torch fp32: same bound as the plain planar
+    kernel (the differences and tap sums are exact in fp32 / fp64 before they are split into 2 x fp16 again)."""
+    monkeypatch.setenv("ORCA_FFA", "1")
+    rs = np.random.RandomState(cin + cout + n + out_mode)
+    x = torch.from_numpy(rs.randn(1, cin, n).astype(np.float32))
+    w = (rs.randn(cout, cin, 9) / np.sqrt(cin * 9)).astype(np.float32)
+    b = rs.randn(cout).astype(np.float32) * 0.1
+    r1 = torch.from_numpy(rs.randn(1, cout, n).astype(np.float32))
+    for relu, ra in [(False, None), (True, r1)]:
+        y = engine.conv1d_p16(x[0].t().contiguous().to(cuda), w, b, relu, None if ra is None else ra[0].t().contiguous().to(cuda), out_mode)
+        ref = _ref_conv1d(x, w, b, relu, ra, None)
+        if out_mode == 1:
+            ref = F.max_pool1d(ref, 4, 4)
+        assert y.shape[0] == ref.shape[2]
+        err = float((y.cpu().t()[None] - ref).abs().max())
         assert err < 2e-5, (cin, cout, n, out_mode, relu, err)
 
 

@@ -1,0 +1,74 @@
+// Cost split of the fast-FIR planar conv (conv_p16f.h) by timing-only ablations, beside the 512-position kernel it competes with:
+// hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -I orca_amd/csrc tools/microbench_p16f.hip -o tools/microbench_p16f
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#include <cstring>
+#include "conv_p16w1.h"
+#include "conv_p16f.h"
+template <typename K>
+static float time_it(K launch) {
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  float best = 1e9;
+  for (int r = 0; r < 4; ++r) {
+    hipEventRecord(e0, 0); launch(); hipEventRecord(e1, 0); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); if (r > 0 && ms < best) best = ms;
+  }
+  return best;
+}
+template <int CT, int ABL>
+static void run_f(ConvP16Args a, const char* what) {
+  a.tiles_per_row = (a.n + 511) / 512; a.out_mode = 0;
+  long ntiles = a.tiles_per_row * (a.cout / CT), grid = 256; if (grid > ntiles) grid = ntiles;
+  const float ms = time_it([&] { hipLaunchKernelGGL((conv1d_k9_p16f_kernel<CT, 0, false, ABL>), dim3((unsigned)grid), dim3(512), 0, 0, a); });
+  double fl = 2.0 * 9 * a.nchunks * 16 * a.cout * (double)a.n;
+  printf("p16f  CT=%d cin=%d cout=%d n=%ld ABL=%2d (%s): %.3f ms  %.1f TFLOP/s-eq  [%s]\n", CT, a.nchunks * 16, a.cout, a.n, ABL, what, ms, fl / ms / 1e9, hipGetErrorString(hipGetLastError()));
+}
+int main(int argc, char** argv) {
+  setvbuf(stdout, nullptr, _IONBF, 0);
+  long n = argc > 1 ? atol(argv[1]) : 8000000;
+  const long plen = ((n + 512) / 512) * 512 + 32;
+  f32x4 *x, *y, *w; float* bias;
+  hipMalloc(&x, (size_t)32 * plen * 16); hipMalloc(&y, (size_t)32 * plen * 16); hipMalloc(&w, (size_t)16 * 14 * 4 * 128 * 16); hipMalloc(&bias, 512);
+  // activations shaped like the Encoder's: ReLU of a unit normal (half of them zero), stored as hi = fp16(v), lo = fp16(v - hi)
+  std::vector<unsigned short> hx((size_t)32 * plen * 8);
+  unsigned s = 1234567u;
+  const bool dense = argc > 2;     // any second argument: random bit patterns instead (the worst case for the power cap)
+  if (dense) {
+    for (auto& v : hx) { s = s * 1664525u + 1013904223u; v = (unsigned short)(((s >> 9) & 0x8fff) | 0x3000); }
+  } else {
+    for (int p = 0; p < 16; ++p)
+      for (long pos = 0; pos < plen; ++pos)
+        for (int e = 0; e < 8; ++e) {
+          float u = -2.f;
+          for (int k = 0; k < 4; ++k) { s = s * 1664525u + 1013904223u; u += (float)(s >> 8) * (1.f / 16777216.f); }
+          const float v = u > 0.f ? u * 1.7f : 0.f;
+          const _Float16 h = (_Float16)v, l = (_Float16)(v - (float)h);
+          memcpy(&hx[((size_t)(2 * p) * plen + pos) * 8 + e], &h, 2);
+          memcpy(&hx[((size_t)(2 * p + 1) * plen + pos) * 8 + e], &l, 2);
+        }
+  }
+  hipMemcpy(x, hx.data(), hx.size() * 2, hipMemcpyHostToDevice);
+  std::vector<unsigned short> hw((size_t)16 * 14 * 4 * 128 * 8);
+  for (auto& v : hw) { s = s * 1664525u + 1013904223u; v = (unsigned short)(((s >> 9) & 0x8fff) | 0x2800); }
+  hipMemcpy(w, hw.data(), hw.size() * 2, hipMemcpyHostToDevice); hipMemset(bias, 0, 512);
+  ConvP16Args a{}; a.x = x; a.w = w; a.bias = bias; a.y = y; a.x_plen = plen; a.y_plen = plen; a.n = n; a.nchunks = 6; a.cout = 96; a.relu = 1;
+  {
+    ConvP16Args b = a; b.tiles_per_row = (n + 511) / 512;
+    const float ms = time_it([&] { hipLaunchKernelGGL((conv1d_k9_p16w1_kernel<0, false, 0>), dim3(256), dim3(512), 0, 0, b); });
+    printf("p16w1 96 -> 96 n=%ld: %.3f ms  %.1f TFLOP/s-eq\n", n, ms, 2.0 * 9 * 96 * 96 * (double)n / ms / 1e9);
+  }
+  run_f<96, 0>(a, "warm");
+  run_f<96, 0>(a, "96 -> 96 plain");
+  run_f<96, 1>(a, "no DMA after the prologue");
+  run_f<96, 2>(a, "no U producer");
+  run_f<96, 4>(a, "no stores");
+  run_f<96, 8>(a, "one barrier per step");
+  run_f<96, 16>(a, "raw X fetched contiguously (wrong results)");
+  run_f<96, 1 + 2>(a, "no DMA, no U");
+  run_f<96, 1 + 2 + 4>(a, "no DMA, no U, no stores");
+  run_f<96, 1 + 2 + 4 + 8>(a, "no DMA, no U, no stores, one barrier");
+  { ConvP16Args b = a; b.cout = 64; run_f<64, 0>(b, "96 -> 64"); run_f<64, 1>(b, "96 -> 64 no DMA"); }
+  { ConvP16Args b = a; b.cout = 128; b.nchunks = 8; b.n = n / 4; run_f<64, 0>(b, "128 -> 128 at n/4"); }
+  return 0;
+}

@@ -78,7 +78,9 @@ traffic["_note"] = ("HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024
                     "the 64 -> 64 convs, the population of bench.py's roofline.achieved): f16x2 = 3 per strand, the first with its input produced in LDS from "
                     "1 byte/base (reads 72 MB instead of 8.2 GB), the last pooled (writes 2 GB) with a residual (reads 8.2 GB more): algorithmic "
                     "(0 + 8.2) + (8.2 + 8.2) + (8.2 + 8.2 + 2.05) = 43.1 GB = 14.4 GB/launch... of which the P16 planes are 4 B/element; bf16 (B16 planes, "
-                    "2 B/element) = 2 ws launches per strand + the pooled one: (4.1 + 4.1) + (4.1 + 4.1) + (4.1 + 4.1 + 1.0) = 25.6 GB = 8.5 GB/launch.")
+                    "2 B/element) = 2 ws launches per strand + the pooled one: (4.1 + 4.1) + (4.1 + 4.1) + (4.1 + 4.1 + 1.0) = 25.6 GB = 8.5 GB/launch.  conv1d_k9_p16w1_kernel<cout=96,...>: the average over stage 2's three "
+                    "launches per strand at n = 8 M (17-tap 64 -> 96, 96 -> 96, 96 -> 96 pooled + residual: algorithmic 5.12 + 6.14 + 6.91 GB = 6.06 GB/launch in f16x2, "
+                    "half of that on B16 planes); bench.py's roofline.achieved for that kernel is over the two 96 -> 96 launches.")
 json.dump(traffic, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
 print(json.dumps({k: v for k, v in traffic.items() if not k.startswith("_")}, indent=1))
 print(open(os.path.join(dst, f"{tag}_bench_dominant_launches.txt")).read()[-700:])
