@@ -90,7 +90,7 @@ def test_encoder_composed_linear_pairs_vs_two_conv_form_and_oracle(cuda, precisi
 
 
 @pytest.mark.parametrize("seed,gain", [(1, 1.0), (2, 1.0), (3, 1.6), (4, 0.6)])
-def test_encoder_weight_seed_and_gain_sweep_vs_oracle(cuda, seed, gain):
+def test_encoder_weight_seed_and_gain_sweep_vs_oracle(cuda, monkeypatch, seed, gain):
     """The goldens pin ONE set of synthetic weights; the composed forms multiply weights together, so their error depends on the weight
     statistics: other seeds and other conv gains (activations 0.2x .. 4x as large) against the CPU oracle on the same input, both
     strands from packed bases, tolerance 1e-4 relative to the output's range."""
@@ -111,6 +111,12 @@ def test_encoder_weight_seed_and_gain_sweep_vs_oracle(cuda, seed, gain):
         y = enc.forward_codes(codes, reverse=rev).cpu().numpy()
         scale = max(1.0, float(np.abs(ref).max()))
         assert maxabs(y, ref) < 1e-4 * scale and pearson(y, ref) > 0.999999, (seed, gain, rev, maxabs(y, ref), scale)
+        if seed == 1:   # stage 2 runs at 114 000 positions here: its kernel variants (256-position tiles / the fast-FIR form) on the same input
+            for switch in ("ORCA_NO_P16W1", "ORCA_FFA"):
+                monkeypatch.setenv(switch, "1")
+                y2 = enc.forward_codes(codes, reverse=rev).cpu().numpy()
+                monkeypatch.delenv(switch)
+                assert maxabs(y2, ref) < 1e-4 * scale and maxabs(y2, y) < 2e-5 * scale, (switch, rev, maxabs(y2, ref), maxabs(y2, y))
 
 
 def test_encoder_composed_weights_outside_fp16_keep_the_two_conv_form(cuda, monkeypatch):
