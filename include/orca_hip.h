@@ -101,7 +101,7 @@ int orca_ctx_release_workspace(orca_ctx* ctx);
  * clears the log. */
 typedef struct orca_kernel_time {
   int32_t cout, cin, tile, batch; /* tile > 0: position tile of the exact-fp32 kernel; < 0: kernel family = -1..-4 conv_bf16s.h (bf16, bf16x2, bf16x3, f16x2),
-                                   * -5 / -6 conv_p16.h (P16 / B16), -7 / -8 conv_ws.h, -9 / -10 conv_p16w1.h (P16 / B16) */
+                                   * -5 / -6 conv_p16.h (P16 / B16), -7 / -8 conv_ws.h, -9 / -10 conv_p16w1.h (P16 / B16), -11 conv_p16f.h, -12 / -13 conv_p16p5.h (P16 / B16) */
   int64_t n;      /* positions per batch row            */
   float ms;       /* elapsed between the two HIP events */
   int32_t ksize;  /* taps of the launch: 9, or 17 = a composed linear pair (its algorithmic FLOPs are the pair's) */
@@ -309,7 +309,8 @@ int orca_conv1d_forward(orca_ctx* ctx, const orca_conv_desc* conv, const float* 
 int orca_conv1d_nlc_forward(orca_ctx* ctx, const orca_conv_desc* conv, int precision, const float* x, float* y,
                             const float* r1, int B, int64_t n, int relu);
 /* The P16 / LDS-DMA conv1d of the Encoder's stages 1-3 (conv_p16.h), wrapped for tests: channel-last fp32
- * in/out (x [n][cin], r1 [n][cout], y [n][cout] or, with out_mode 1 = fused MaxPool1d(4), [n/4][cout]);
+ * in/out (x [n][cin], r1 [n][cout], y [n][cout] or, with out_mode 1 = fused MaxPool1d(4), [n/4][cout], with out_mode 3 = fused
+ * MaxPool1d(5) (128 couts: conv_p16p5.h), [n/5][cout]);
  * out_mode 0/1 round-trip through the planar split-fp16 storage, out_mode 2 writes fp32 directly.
  * conv->ksize may be 9, or 17 with weight_host [cout][cin][17] - the form the Encoder's composed linear pairs
  * (Conv-BN-Conv-BN without a nonlinearity, orca_modules.py:829-835, 846-852) run as; cin % 32 == 0 then. */

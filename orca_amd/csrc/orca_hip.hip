@@ -24,6 +24,7 @@
 #include "conv_ws.h"
 #include "conv_p16w1.h"
 #include "conv_p16f.h"
+#include "conv_p16p5.h"
 #include "misc_kernels.h"
 #include "coarsegrain.h"
 #include "orca_hip.h"
@@ -753,6 +754,16 @@ static bool launch_p16w1(hipStream_t s, const ConvP16Args& a) {     // false: th
   return true;
 }
 
+// a 128-cout layer with ReLU, residual and MaxPool1d(5) fused (conv_p16p5.h): out_mode 3
+template <int FMT>
+static void launch_p16p5(hipStream_t s, ConvP16Args a) {
+  static int ncu = [] { int dev = 0, v = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev); return v; }();
+  a.tiles_per_row = (a.n + 319) / 320;
+  dim3 grid((unsigned)(a.tiles_per_row < ncu ? a.tiles_per_row : ncu));
+  if (a.r1) hipLaunchKernelGGL((conv1d_k9_p16p5_kernel<true, FMT>), grid, dim3(512), 0, s, a);
+  else hipLaunchKernelGGL((conv1d_k9_p16p5_kernel<false, FMT>), grid, dim3(512), 0, s, a);
+}
+
 // the fast-FIR form (conv_p16f.h): 14 instead of 18 tap products per output pair
 template <int CT, int OM, bool R1>
 static void launch_p16f_k(hipStream_t s, ConvP16Args a) {
@@ -829,7 +840,7 @@ static int launch_conv1d_p16(orca_ctx* ctx, const ConvLayer& L, const float* x, 
   if (n <= 0) return ORCA_OK;
   ConvP16Args a;
   a.x = reinterpret_cast<const f32x4*>(x); a.w = reinterpret_cast<const f32x4*>(fmt == 0 ? L.d_wf16 : L.d_wb16p); a.bias = L.d_bias; a.y = y;
-  a.r1 = reinterpret_cast<const f32x4*>(r1); a.x_plen = p16_plen(n); a.y_plen = p16_plen(out_mode == 1 ? n / 4 : n); a.n = n;
+  a.r1 = reinterpret_cast<const f32x4*>(r1); a.x_plen = p16_plen(n); a.y_plen = p16_plen(out_mode == 1 ? n / 4 : out_mode == 3 ? n / 5 : n); a.n = n;
   a.nchunks = (fmt == 0 ? L.cin / 16 : L.cin / 32) * (k17 ? 2 : 1); a.cout = L.cout; a.relu = relu; a.out_mode = out_mode; a.flag = ctx->d_flag;
   a.k17 = k17 ? 1 : 0;
   const bool timed = ctx->timing && n >= 65536;
@@ -861,6 +872,10 @@ static int launch_conv1d_p16(orca_ctx* ctx, const ConvLayer& L, const float* x, 
   } else if (ws_ok && fmt == 0 && L.cin == 64 && (L.cout == 64 || L.cout == 96)) {
     launch_ws_t<0, 64, 32, 2, 1>(ctx->stream, a);
     tile_tag = -7;
+  } else if (out_mode == 3) {
+    if (k17 || L.cout != 128) return fail(ORCA_EINVAL, "fused MaxPool1d(5): only the 128-cout k9 conv (conv_p16p5.h)");
+    if (fmt == 1) launch_p16p5<1>(ctx->stream, a); else launch_p16p5<0>(ctx->stream, a);
+    tile_tag = fmt == 1 ? -13 : -12;
   } else if (fmt == 0 && !k17 && L.d_wf14 && n >= 65536 && getenv("ORCA_FFA") != nullptr) {
     a.w = reinterpret_cast<const f32x4*>(L.d_wf14);
     if (L.cout == 96) launch_p16f<96>(ctx->stream, a);
@@ -1419,10 +1434,14 @@ static int encoder_chunk(orca_ctx* ctx, orca_net* net, const SeqSource& src, lon
       n = n1;
       static const bool no_st4 = getenv("ORCA_NO_P16_STAGE4") != nullptr;   // A/B switch: stage 4 on the register-staged kernel again
       const int nplanar = no_st4 ? 3 : 4;                                   // stages on the planar kernels (pools 4, 4 fused; 5 as a planar pass)
+      bool pooled_ahead = false;
       for (st0 = 0; st0 < nplanar; ++st0) {
         const ConvLayer* Ls = L + 4 * st0;
         const int C = Ls[3].cout;
-        if (kEncPools[st0] == 5) {   // MaxPool1d(5) in front of this stage: previous output buf[S] (n positions) -> buf[LO] -> becomes S
+        if (kEncPools[st0] == 5 && pooled_ahead) {   // the previous stage's last conv already pooled (conv_p16p5.h): buf[S] holds n / 5 positions
+          n /= 5;
+          pooled_ahead = false;
+        } else if (kEncPools[st0] == 5) {   // MaxPool1d(5) in front of this stage: previous output buf[S] (n positions) -> buf[LO] -> becomes S
           ORCA_TRY(launch_p16_pool5(ctx, buf[S], buf[LO], Ls[0].cin, n, fmt));
           n /= 5;
           ORCA_TRY(launch_p16_zero_pads(ctx, buf[LO], Ls[0].cin, n, fmt));
@@ -1468,6 +1487,10 @@ static int encoder_chunk(orca_ctx* ctx, orca_net* net, const SeqSource& src, lon
           ORCA_TRY(launch_conv1d_p16(ctx, Ls[3], buf[T], buf[S], buf[LO], n, 1, 1, nullptr, fmt));          // relu(.)+lout, MaxPool1d(4)
           ORCA_TRY(launch_p16_zero_pads(ctx, buf[S], C, n / 4, fmt));
           n /= 4;
+        } else if (st0 + 1 < nplanar && kEncPools[st0 + 1] == 5 && C == 128 && getenv("ORCA_NO_POOL5_FUSE") == nullptr) {
+          ORCA_TRY(launch_conv1d_p16(ctx, Ls[3], buf[T], buf[S], buf[LO], n, 1, 3, nullptr, fmt));          // relu(.)+lout, MaxPool1d(5) (conv_p16p5.h)
+          ORCA_TRY(launch_p16_zero_pads(ctx, buf[S], C, n / 5, fmt));
+          pooled_ahead = true;
         } else if (st0 + 1 < nplanar) {
           ORCA_TRY(launch_conv1d_p16(ctx, Ls[3], buf[T], buf[S], buf[LO], n, 1, 0, nullptr, fmt));          // relu(.)+lout, planar; pooled by the next stage
           ORCA_TRY(launch_p16_zero_pads(ctx, buf[S], C, n, fmt));
@@ -2293,7 +2316,7 @@ static int conv1d_planar_test(orca_ctx* ctx, const orca_conv_desc* conv, const f
     ORCA_TRY(make_layer17(conv->cin, conv->cout, w17, b17, &L));
   } else
   ORCA_TRY(make_layer(*conv, &L));
-  const long nout = out_mode == 1 ? n / 4 : n;
+  const long nout = out_mode == 1 ? n / 4 : out_mode == 3 ? n / 5 : n;
   const size_t sx = (size_t)conv->cin * p16_plen(n), sy = (size_t)conv->cout * p16_plen(nout), sr = (size_t)conv->cout * p16_plen(n);
   int rc = ws_ensure(ctx, ru256(sx * 4) + ru256(sy * 4) + ru256(sr * 4));
   if (rc == ORCA_OK) {
@@ -2313,8 +2336,8 @@ static int conv1d_planar_test(orca_ctx* ctx, const orca_conv_desc* conv, const f
       to_planar(r1, rp, conv->cout);
     }
     rc = launch_conv1d_p16(ctx, L, xp, out_mode == 2 ? (void*)y : (void*)yp, r1 ? rp : nullptr, n, relu, out_mode, nullptr, fmt);
-    if (rc == ORCA_OK && out_mode != 2) (void)launch_p16_zero_pads(ctx, yp, conv->cout, nout, fmt);   // as in the Encoder: pads after the producer
-    if (rc == ORCA_OK && out_mode != 2) {
+    if (rc == ORCA_OK && out_mode != 2 && nout > 0) (void)launch_p16_zero_pads(ctx, yp, conv->cout, nout, fmt);   // as in the Encoder: pads after the producer
+    if (rc == ORCA_OK && out_mode != 2 && nout > 0) {
       if (fmt == 1) hipLaunchKernelGGL(b16_to_nlc_kernel, blocks(nout, conv->cout), dim3(256), 0, s, reinterpret_cast<const f32x4*>(yp), y, nout, conv->cout, p16_plen(nout));
       else hipLaunchKernelGGL(p16_to_nlc_kernel, blocks(nout, conv->cout), dim3(256), 0, s, reinterpret_cast<const f32x4*>(yp), y, nout, conv->cout, p16_plen(nout));
     }

@@ -484,7 +484,7 @@ def conv1d_nlc(x, w, b, precision="bf16x3", relu=False, r1=None):
 
 
 def conv1d_p16(x, w, b, relu=False, r1=None, out_mode=0, fmt="p16"):
-    """P16 / LDS-DMA conv (test wrapper): x [n,cin] channel-last fp32 -> [n or n/4, cout].
+    """P16 / LDS-DMA conv (test wrapper): x [n,cin] channel-last fp32 -> [n, n/4 (out_mode 1) or n/5 (out_mode 3: 128 couts), cout].
     fmt="b16": the same kernel on single-plane bf16 activations (cin % 32 == 0)."""
     x = _f32_cuda(x, "x").contiguous()
     n, cin = x.shape
@@ -492,7 +492,9 @@ def conv1d_p16(x, w, b, relu=False, r1=None, out_mode=0, fmt="p16"):
     b = np.ascontiguousarray(b, dtype=np.float32)
     cout = w.shape[0]
     d = make_descs([{"w": w, "b": b, "cout": cout, "cin": cin, "k": int(w.shape[2]), "dil": 1}])     # 9 taps, or 17 (the composed-pair form)
-    y = torch.empty((n // 4 if out_mode == 1 else n, cout), dtype=torch.float32, device=x.device)
+    y = torch.empty((n // 4 if out_mode == 1 else n // 5 if out_mode == 3 else n, cout), dtype=torch.float32, device=x.device)
+    if y.numel() == 0:
+        return y
     ctx = get_context(x.device)
     r1 = r1.contiguous() if r1 is not None else None
     fn = _lib.load().orca_conv1d_b16_forward if fmt == "b16" else _lib.load().orca_conv1d_p16_forward

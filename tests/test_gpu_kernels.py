@@ -132,6 +132,34 @@ def test_conv1d_p16_dma(cuda, cin, cout, n, out_mode):
         assert err < 2e-5, (cin, cout, n, out_mode, relu, err)
 
 
+@pytest.mark.parametrize("cin,n", [(128, 2000), (128, 323), (96, 1603), (128, 200004), (128, 4)])
+@pytest.mark.parametrize("fmt", ["p16", "b16"])
+def test_conv1d_p16_pool5_fused(cuda, cin, n, fmt):
+    """conv_p16p5.h (out_mode 3): a 128-cout k9 conv with ReLU, residual and MaxPool1d(5) in one launch - positions dealt to the lanes with
+    stride 5, the pool a register-local max over five accumulator tiles - against torch fp32 (conv, relu, + residual, max_pool1d(5, 5):
+    the ragged last window is dropped), ragged tiles and sizes below one window included; P16 and B16 (bf16-rounded operands, one final
+    rounding of the pooled output to bf16) formats."""
+    if fmt == "b16" and cin % 32:
+        pytest.skip("B16: 32 input channels per step")
+    rs = np.random.RandomState(cin + n)
+    x = torch.from_numpy(rs.randn(1, cin, n).astype(np.float32))
+    w = (rs.randn(128, cin, 9) / np.sqrt(cin * 9)).astype(np.float32)
+    b = rs.randn(128).astype(np.float32) * 0.1
+    r1 = torch.from_numpy(rs.randn(1, 128, n).astype(np.float32))
+    if fmt == "b16":
+        x, r1 = _bf16(x), _bf16(r1)
+        w = _bf16(torch.from_numpy(w)).numpy()
+    for relu, ra in [(True, r1), (False, None)]:
+        y = engine.conv1d_p16(x[0].t().contiguous().to(cuda), w, b, relu, None if ra is None else ra[0].t().contiguous().to(cuda), 3, fmt=fmt)
+        ref = _ref_conv1d(x, w, b, relu, ra, None)
+        ref = F.max_pool1d(ref, 5, 5) if n >= 5 else ref[:, :, :0]
+        assert y.shape[0] == ref.shape[2] == n // 5
+        if n >= 5:
+            d = (y.cpu().t()[None] - ref).abs()
+            bound = 2e-5 + (ref.abs() * 2.0 ** -8 if fmt == "b16" else 0.0)
+            assert bool((d <= bound).all()), (cin, n, fmt, relu, float(d.max()))
+
+
 @pytest.mark.parametrize("cin,cout,n", [(96, 96, 300001), (64, 96, 70000), (96, 128, 66001), (64, 64, 131072)])
 @pytest.mark.parametrize("out_mode", [0, 1, 2])
 def test_conv1d_p16_fast_fir(cuda, monkeypatch, cin, cout, n, out_mode):

@@ -74,7 +74,7 @@ def test_encoder_composed_linear_pairs_vs_two_conv_form_and_oracle(cuda, precisi
         refr = O.encoder_forward(sd, xr).numpy()
         yr = enc.forward_codes(codes, reverse=True).cpu().numpy()
         assert maxabs(yr, refr) < tol, (L, "reverse codes")
-        for switch in ("ORCA_NO_COMPOSE", "ORCA_NO_COMPOSE25", "ORCA_NO_RL"):   # two-conv form everywhere / conv1.a as its own launch / lout1 stored
+        for switch in ("ORCA_NO_COMPOSE", "ORCA_NO_COMPOSE25", "ORCA_NO_RL", "ORCA_NO_POOL5_FUSE"):   # two-conv form everywhere / conv1.a as its own launch / lout1 stored / MaxPool1d(5) as its own pass
             monkeypatch.setenv(switch, "1")
             y2 = enc(xc).cpu().numpy()
             yc2 = enc.forward_codes(codes).cpu().numpy()
@@ -112,7 +112,7 @@ def test_encoder_weight_seed_and_gain_sweep_vs_oracle(cuda, monkeypatch, seed, g
         scale = max(1.0, float(np.abs(ref).max()))
         assert maxabs(y, ref) < 1e-4 * scale and pearson(y, ref) > 0.999999, (seed, gain, rev, maxabs(y, ref), scale)
         if seed == 1:   # stage 2 runs at 114 000 positions here: its kernel variants (256-position tiles / the fast-FIR form) on the same input
-            for switch in ("ORCA_NO_P16W1", "ORCA_FFA"):
+            for switch in ("ORCA_NO_P16W1", "ORCA_FFA", "ORCA_NO_POOL5_FUSE"):
                 monkeypatch.setenv(switch, "1")
                 y2 = enc.forward_codes(codes, reverse=rev).cpu().numpy()
                 monkeypatch.delenv(switch)

@@ -24,7 +24,7 @@ rows = list(csv.DictReader(open(os.path.join(src, "bench", "bench_kernel_trace.c
 by = collections.defaultdict(list)
 for r in rows:
     n = r["Kernel_Name"]
-    if n.startswith("void conv1d_k9_p16_kernel<") or n.startswith("void conv1d_k9_p16w1_kernel<") or n.startswith("void conv1d_k9_ws_kernel") or n.startswith("void conv1d_first_mfma_p16_kernel"):
+    if n.startswith("void conv1d_k9_p16_kernel<") or n.startswith("void conv1d_k9_p16w1_kernel<") or n.startswith("void conv1d_k9_p16p5_kernel<") or n.startswith("void conv1d_k9_ws_kernel") or n.startswith("void conv1d_first_mfma_p16_kernel"):
         by[n.replace("void ", "").split("(")[0]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 with open(os.path.join(dst, f"{tag}_bench_dominant_launches.txt"), "w") as f:
     f.write("# rocprofv3 --kernel-trace of `python bench.py --no-cpu-baseline`: launches of the planar conv kernels (bench.py's `roofline` names the\n"
