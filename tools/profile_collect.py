@@ -16,8 +16,9 @@ for f in ("bench.json", "bench_under_rocprof.json"):
     lines = [l for l in open(os.path.join(src, f)).read().splitlines() if l.startswith("{")]
     open(os.path.join(dst, f"{tag}_{f}"), "w").write(lines[-1] + "\n")
 
-if os.path.exists(os.path.join(src, "configs.json")):
-    shutil.copy(os.path.join(src, "configs.json"), os.path.join(dst, f"{tag}_configs.json"))
+for f in ("configs.json", "config5_1024.json"):
+    if os.path.exists(os.path.join(src, f)) and os.path.getsize(os.path.join(src, f)) > 2:
+        shutil.copy(os.path.join(src, f), os.path.join(dst, f"{tag}_{f}"))
 
 # ---- dominant kernel: per-launch durations from the trace
 rows = list(csv.DictReader(open(os.path.join(src, "bench", "bench_kernel_trace.csv"))))
