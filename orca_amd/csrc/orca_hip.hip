@@ -755,13 +755,13 @@ static bool launch_p16w1(hipStream_t s, const ConvP16Args& a) {     // false: th
 }
 
 // a 128-cout layer with ReLU, residual and MaxPool1d(5) fused (conv_p16p5.h): out_mode 3
-template <int FMT>
+template <int FMT, int OM>
 static void launch_p16p5(hipStream_t s, ConvP16Args a) {
   static int ncu = [] { int dev = 0, v = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev); return v; }();
   a.tiles_per_row = (a.n + 319) / 320;
   dim3 grid((unsigned)(a.tiles_per_row < ncu ? a.tiles_per_row : ncu));
-  if (a.r1) hipLaunchKernelGGL((conv1d_k9_p16p5_kernel<true, FMT>), grid, dim3(512), 0, s, a);
-  else hipLaunchKernelGGL((conv1d_k9_p16p5_kernel<false, FMT>), grid, dim3(512), 0, s, a);
+  if (a.r1) hipLaunchKernelGGL((conv1d_k9_p16p5_kernel<true, FMT, OM>), grid, dim3(512), 0, s, a);
+  else hipLaunchKernelGGL((conv1d_k9_p16p5_kernel<false, FMT, OM>), grid, dim3(512), 0, s, a);
 }
 
 // the fast-FIR form (conv_p16f.h): 14 instead of 18 tap products per output pair
@@ -874,8 +874,13 @@ static int launch_conv1d_p16(orca_ctx* ctx, const ConvLayer& L, const float* x, 
     tile_tag = -7;
   } else if (out_mode == 3) {
     if (k17 || L.cout != 128) return fail(ORCA_EINVAL, "fused MaxPool1d(5): only the 128-cout k9 conv (conv_p16p5.h)");
-    if (fmt == 1) launch_p16p5<1>(ctx->stream, a); else launch_p16p5<0>(ctx->stream, a);
+    if (fmt == 1) launch_p16p5<1, 3>(ctx->stream, a); else launch_p16p5<0, 3>(ctx->stream, a);
     tile_tag = fmt == 1 ? -13 : -12;
+  } else if (fmt == 0 && L.cout == 128 && (out_mode == 0 || out_mode == 2) && n >= 65536 && getenv("ORCA_P16C128") != nullptr) {
+    // opt-in (measured equal: 24.66 vs 24.69 ms per strand): the unpooled 128-cout layers of stages 3-4 on the same 320-position x 128-cout
+    // geometry, k17 included
+    if (out_mode == 0) launch_p16p5<0, 0>(ctx->stream, a); else launch_p16p5<0, 2>(ctx->stream, a);
+    tile_tag = -12;
   } else if (fmt == 0 && !k17 && L.d_wf14 && n >= 65536 && getenv("ORCA_FFA") != nullptr) {
     a.w = reinterpret_cast<const f32x4*>(L.d_wf14);
     if (L.cout == 96) launch_p16f<96>(ctx->stream, a);

@@ -132,6 +132,28 @@ def test_conv1d_p16_dma(cuda, cin, cout, n, out_mode):
         assert err < 2e-5, (cin, cout, n, out_mode, relu, err)
 
 
+@pytest.mark.parametrize("cin,k,n", [(128, 9, 70001), (96, 17, 66003)])
+@pytest.mark.parametrize("out_mode", [0, 2])
+def test_conv1d_p16_128_couts_one_workgroup(cuda, monkeypatch, cin, k, n, out_mode):
+    """conv_p16p5.h without the pool (opt-in ORCA_P16C128=1: the geometry pays only where it removes the MaxPool1d(5) pass): P16 and fp32
+    channel-last outputs, 9 and 17 taps, with and without residual, against torch fp32."""
+    monkeypatch.setenv("ORCA_P16C128", "1")
+    rs = np.random.RandomState(cin + k + n + out_mode)
+    x = torch.from_numpy(rs.randn(1, cin, n).astype(np.float32))
+    w = (rs.randn(128, cin, k) / np.sqrt(cin * k)).astype(np.float32)
+    b = rs.randn(128).astype(np.float32) * 0.1
+    r1 = torch.from_numpy(rs.randn(1, 128, n).astype(np.float32))
+    for relu, ra in [(False, None), (True, r1)]:
+        y = engine.conv1d_p16(x[0].t().contiguous().to(cuda), w, b, relu, None if ra is None else ra[0].t().contiguous().to(cuda), out_mode)
+        ref = F.conv1d(x.double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(), padding=k // 2)
+        if relu:
+            ref = F.relu(ref)
+        if ra is not None:
+            ref = ref + ra.double()
+        err = float((y.cpu().t()[None].double() - ref).abs().max())
+        assert err < 2e-5, (cin, k, n, out_mode, relu, err)
+
+
 @pytest.mark.parametrize("cin,n", [(128, 2000), (128, 323), (96, 1603), (128, 200004), (128, 4)])
 @pytest.mark.parametrize("fmt", ["p16", "b16"])
 def test_conv1d_p16_pool5_fused(cuda, cin, n, fmt):
@@ -182,7 +204,7 @@ def test_conv1d_p16_fast_fir(cuda, monkeypatch, cin, cout, n, out_mode):
         assert err < 2e-5, (cin, cout, n, out_mode, relu, err)
 
 
-@pytest.mark.parametrize("cin,cout,n", [(64, 96, 1500), (96, 128, 1031), (64, 64, 4097), (64, 96, 300000)])
+@pytest.mark.parametrize("cin,cout,n", [(64, 96, 1500), (96, 128, 1031), (64, 64, 4097), (64, 96, 300000), (96, 128, 70003)])
 @pytest.mark.parametrize("fmt", ["p16", "b16"])
 def test_conv1d_17_taps_planar(cuda, cin, cout, n, fmt):
     """The 17-tap form of the planar conv (a composed linear pair: ConvP16Args.k17 = twice the K-chunks, the second tap half on the input
