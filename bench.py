@@ -245,7 +245,7 @@ def inst_rooflines(recs):
             5: ("f16x2", "conv1d_k9_p16_kernel", PEAK_16BIT_MFMA_TFLOPS, 3, 4), 6: ("bf16", "conv1d_k9_p16_kernel", PEAK_16BIT_MFMA_TFLOPS, 1, 2),
             7: ("f16x2", "conv1d_k9_ws_kernel", PEAK_16BIT_MFMA_TFLOPS, 3, 4), 8: ("bf16", "conv1d_k9_ws_kernel", PEAK_16BIT_MFMA_TFLOPS, 1, 2),
             9: ("f16x2", "conv1d_k9_p16w1_kernel", PEAK_16BIT_MFMA_TFLOPS, 3, 4), 10: ("bf16", "conv1d_k9_p16w1_kernel", PEAK_16BIT_MFMA_TFLOPS, 1, 2),
-            11: ("f16x2", "conv1d_k9_p16f_kernel", PEAK_16BIT_MFMA_TFLOPS, 3, 4), 12: ("f16x2", "conv1d_k9_p16p5_kernel", PEAK_16BIT_MFMA_TFLOPS, 3, 4), 13: ("bf16", "conv1d_k9_p16p5_kernel", PEAK_16BIT_MFMA_TFLOPS, 1, 2)}
+            11: ("f16x2", "conv1d_k9_p16f_kernel", PEAK_16BIT_MFMA_TFLOPS, 3, 4), 12: ("f16x2", "conv1d_k9_p16p5_kernel", PEAK_16BIT_MFMA_TFLOPS, 3, 4), 13: ("bf16", "conv1d_k9_p16p5_kernel", PEAK_16BIT_MFMA_TFLOPS, 1, 2), 14: ("f16x2", "conv1d_k9_p16x_kernel", PEAK_16BIT_MFMA_TFLOPS, 3, 4)}
     inst = {}
     for (cout, cin, tile, ksize), g in groups.items():
         prec = -tile if tile < 0 else 0

@@ -25,6 +25,7 @@
 #include "conv_p16w1.h"
 #include "conv_p16f.h"
 #include "conv_p16p5.h"
+#include "conv_p16x.h"
 #include "misc_kernels.h"
 #include "coarsegrain.h"
 #include "orca_hip.h"
@@ -745,6 +746,21 @@ static void launch_p16w1_k(hipStream_t s, ConvP16Args a) {
   dim3 grid((unsigned)(a.tiles_per_row < ncu ? a.tiles_per_row : ncu));
   hipLaunchKernelGGL((conv1d_k9_p16w1_kernel<OM, R1, FMT>), grid, dim3(512), 0, s, a);
 }
+// the same layers on the 16 x 16 x 32 matrix instruction (conv_p16x.h; P16 only)
+template <int OM, bool R1>
+static void launch_p16x_k(hipStream_t s, ConvP16Args a) {
+  static int ncu = [] { int dev = 0, v = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev); return v; }();
+  a.tiles_per_row = (a.n + 511) / 512;
+  dim3 grid((unsigned)(a.tiles_per_row < ncu ? a.tiles_per_row : ncu));
+  hipLaunchKernelGGL((conv1d_k9_p16x_kernel<OM, R1, 3>), grid, dim3(1024), 0, s, a);
+}
+static bool launch_p16x(hipStream_t s, const ConvP16Args& a) {
+  const bool r1 = a.r1 != nullptr;
+  if (a.out_mode == 0 && !r1) launch_p16x_k<0, false>(s, a);
+  else if (a.out_mode == 1 && r1) launch_p16x_k<1, true>(s, a);
+  else return false;
+  return true;
+}
 template <int FMT>
 static bool launch_p16w1(hipStream_t s, const ConvP16Args& a) {     // false: this (out_mode, residual) pair stays on the 256-position kernel
   const bool r1 = a.r1 != nullptr;
@@ -886,6 +902,8 @@ static int launch_conv1d_p16(orca_ctx* ctx, const ConvLayer& L, const float* x, 
     if (L.cout == 96) launch_p16f<96>(ctx->stream, a);
     else launch_p16f<64>(ctx->stream, a);
     tile_tag = -11;                      // fast-FIR form (conv_p16f.h)
+  } else if (L.cout == 96 && n >= 65536 && fmt == 0 && getenv("ORCA_NO_P16X") == nullptr && launch_p16x(ctx->stream, a)) {
+    tile_tag = -14;                      // 16 x 16 x 32 matrix instruction (conv_p16x.h)
   } else if (L.cout == 96 && n >= 65536 && getenv("ORCA_NO_P16W1") == nullptr && (fmt == 1 ? launch_p16w1<1>(ctx->stream, a) : launch_p16w1<0>(ctx->stream, a))) {
     tile_tag = fmt == 1 ? -10 : -9;      // stage 2 of the Encoder: 512-position tiles (conv_p16w1.h)
   } else if (fmt == 1) {

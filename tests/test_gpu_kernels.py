@@ -113,7 +113,7 @@ def test_conv1d_split_bf16_wide_dynamic_range(cuda):
 
 
 @pytest.mark.parametrize("cin,cout,n", [(64, 64, 2000), (64, 64, 513), (64, 96, 1500), (96, 96, 777), (96, 128, 1030), (128, 128, 3000),
-                                        (64, 64, 2051), (64, 64, 4097), (64, 64, 300000), (96, 96, 300001), (64, 96, 70000), (96, 128, 66001)])   # the last three: 512-position tiles (conv_p16w1.h / conv_p16f.h)
+                                        (64, 64, 2051), (64, 64, 4097), (64, 64, 300000), (96, 96, 300001), (64, 96, 70000), (96, 128, 66001)])   # the last three: 512-position tiles (conv_p16x.h / conv_p16w1.h / conv_p16f.h)
 @pytest.mark.parametrize("out_mode", [0, 1, 2])
 def test_conv1d_p16_dma(cuda, cin, cout, n, out_mode):
     """conv_p16.h: planar split-fp16 activations + LDS-DMA staging; optional fused MaxPool1d(4); vs torch fp32."""
@@ -130,6 +130,29 @@ def test_conv1d_p16_dma(cuda, cin, cout, n, out_mode):
         err = float((y.cpu().t()[None] - ref).abs().max())
         assert y.shape[0] == ref.shape[2]
         assert err < 2e-5, (cin, cout, n, out_mode, relu, err)
+
+
+@pytest.mark.parametrize("cin,k,n", [(96, 9, 300001), (64, 17, 70000)])
+@pytest.mark.parametrize("out_mode,res", [(0, False), (1, True)])
+def test_conv1d_p16_96_couts_on_32x32x16(cuda, monkeypatch, cin, k, n, out_mode, res):
+    """The 96-cout layers run on conv_p16x.h (16 x 16 x 32 MFMAs) by default; ORCA_NO_P16X=1 puts them back on conv_p16w1.h (32 x 32 x 16,
+    512-position tiles), ORCA_NO_P16W1=1 as well on the 256-position tile of conv_p16.h: all three against torch fp32."""
+    rs = np.random.RandomState(cin + k + n + out_mode)
+    x = torch.from_numpy(rs.randn(1, cin, n).astype(np.float32))
+    w = (rs.randn(96, cin, k) / np.sqrt(cin * k)).astype(np.float32)
+    b = rs.randn(96).astype(np.float32) * 0.1
+    r1 = torch.from_numpy(rs.randn(1, 96, n).astype(np.float32)) if res else None
+    ref = F.conv1d(x.double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(), padding=k // 2)
+    ref = F.relu(ref) + r1.double() if res else ref
+    ref = F.max_pool1d(ref, 4, 4) if out_mode == 1 else ref
+    for envs in ((), ("ORCA_NO_P16X",), ("ORCA_NO_P16X", "ORCA_NO_P16W1")):
+        for e in envs:
+            monkeypatch.setenv(e, "1")
+        y = engine.conv1d_p16(x[0].t().contiguous().to(cuda), w, b, res, None if r1 is None else r1[0].t().contiguous().to(cuda), out_mode)
+        for e in envs:
+            monkeypatch.delenv(e)
+        err = float((y.cpu().t()[None].double() - ref).abs().max())
+        assert err < 2e-5, (cin, k, n, out_mode, envs, err)
 
 
 @pytest.mark.parametrize("cin,k,n", [(128, 9, 70001), (96, 17, 66003)])

@@ -112,7 +112,7 @@ def test_encoder_weight_seed_and_gain_sweep_vs_oracle(cuda, monkeypatch, seed, g
         scale = max(1.0, float(np.abs(ref).max()))
         assert maxabs(y, ref) < 1e-4 * scale and pearson(y, ref) > 0.999999, (seed, gain, rev, maxabs(y, ref), scale)
         if seed == 1:   # stage 2 runs at 114 000 positions here: its kernel variants (256-position tiles / the fast-FIR form) on the same input
-            for switch in ("ORCA_NO_P16W1", "ORCA_FFA", "ORCA_NO_POOL5_FUSE", "ORCA_P16C128"):
+            for switch in ("ORCA_NO_P16X", "ORCA_NO_P16W1", "ORCA_FFA", "ORCA_NO_POOL5_FUSE", "ORCA_P16C128"):
                 monkeypatch.setenv(switch, "1")
                 y2 = enc.forward_codes(codes, reverse=rev).cpu().numpy()
                 monkeypatch.delenv(switch)

@@ -25,7 +25,7 @@ rows = list(csv.DictReader(open(os.path.join(src, "bench", "bench_kernel_trace.c
 by = collections.defaultdict(list)
 for r in rows:
     n = r["Kernel_Name"]
-    if n.startswith("void conv1d_k9_p16_kernel<") or n.startswith("void conv1d_k9_p16w1_kernel<") or n.startswith("void conv1d_k9_p16p5_kernel<") or n.startswith("void conv1d_k9_ws_kernel") or n.startswith("void conv1d_first_mfma_p16_kernel"):
+    if n.startswith("void conv1d_k9_p16_kernel<") or n.startswith("void conv1d_k9_p16w1_kernel<") or n.startswith("void conv1d_k9_p16x_kernel<") or n.startswith("void conv1d_k9_p16p5_kernel<") or n.startswith("void conv1d_k9_ws_kernel") or n.startswith("void conv1d_first_mfma_p16_kernel"):
         by[n.replace("void ", "").split("(")[0]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 with open(os.path.join(dst, f"{tag}_bench_dominant_launches.txt"), "w") as f:
     f.write("# rocprofv3 --kernel-trace of `python bench.py --no-cpu-baseline`: launches of the planar conv kernels (bench.py's `roofline` names the\n"
@@ -61,7 +61,7 @@ def pmc_sum(run, counter, prefix, min_us=1500.0):
 
 traffic = {"_source": f"profiles/{tag}_pmc_enc_f16x2_fetch.txt + profiles/{tag}_pmc_enc_f16x2_write.txt (and the bf16 pair)"}
 for mode, key, prefix, min_us in (("f16x2", "conv1d_k9_p16_kernel<cout=64,f16x2>", "void conv1d_k9_p16_kernel<64,", 4000.0),
-                                  ("f16x2", "conv1d_k9_p16w1_kernel<cout=96,f16x2>", re.compile(r"^void conv1d_k9_p16w1_kernel<\d, (true|false), 0>"), 2500.0),   # 96 -> 96, plain and pooled + residual (and the 17-tap 64 -> 96)
+                                  ("f16x2", "conv1d_k9_p16x_kernel<cout=96,f16x2>", re.compile(r"^void conv1d_k9_p16x_kernel<\d, (true|false), 3>"), 2500.0),   # 96 -> 96, plain and pooled + residual (and the 17-tap 64 -> 96)
                                   ("f16x2", "conv1d_first_mfma_p16_kernel<0,0,25>", "void conv1d_first_mfma_p16_kernel<0, 0, 25>", 800.0),
                                   ("bf16", "conv1d_k9_p16w1_kernel<cout=96,bf16>", re.compile(r"^void conv1d_k9_p16w1_kernel<\d, (true|false), 1>"), 800.0),
                                   ("bf16", "conv1d_k9_ws_kernel<cout=64,bf16>", "void conv1d_k9_ws_kernel<1, 64, 64,", 1200.0)):
@@ -79,7 +79,7 @@ traffic["_note"] = ("HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024
                     "the 64 -> 64 convs, the population of bench.py's roofline.achieved): f16x2 = 3 per strand, the first with its input produced in LDS from "
                     "1 byte/base (reads 72 MB instead of 8.2 GB), the last pooled (writes 2 GB) with a residual (reads 8.2 GB more): algorithmic "
                     "(0 + 8.2) + (8.2 + 8.2) + (8.2 + 8.2 + 2.05) = 43.1 GB = 14.4 GB/launch... of which the P16 planes are 4 B/element; bf16 (B16 planes, "
-                    "2 B/element) = 2 ws launches per strand + the pooled one: (4.1 + 4.1) + (4.1 + 4.1) + (4.1 + 4.1 + 1.0) = 25.6 GB = 8.5 GB/launch.  conv1d_k9_p16w1_kernel<cout=96,...>: the average over stage 2's three "
+                    "2 B/element) = 2 ws launches per strand + the pooled one: (4.1 + 4.1) + (4.1 + 4.1) + (4.1 + 4.1 + 1.0) = 25.6 GB = 8.5 GB/launch.  conv1d_k9_p16x_kernel / conv1d_k9_p16w1_kernel<cout=96,...>: the average over stage 2's three "
                     "launches per strand at n = 8 M (17-tap 64 -> 96, 96 -> 96, 96 -> 96 pooled + residual: algorithmic 5.12 + 6.14 + 6.91 GB = 6.06 GB/launch in f16x2, "
                     "half of that on B16 planes); bench.py's roofline.achieved for that kernel is over the two 96 -> 96 launches.")
 json.dump(traffic, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
