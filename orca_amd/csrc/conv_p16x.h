@@ -35,8 +35,10 @@ __device__ __forceinline__ void p16_swap16(unsigned& a, unsigned& b) {   // v_pe
 }
 template <int NC>
 __device__ __forceinline__ void p16x_wait11(f16x8 (&x0)[4], f16x8 (&x1)[4], f16x8 (&w)[NC]) {
-  static_assert(NC == 3 || NC == 6, "operand lists below");
-  if constexpr (NC == 3)
+  static_assert(NC == 2 || NC == 3 || NC == 6, "operand lists below");
+  if constexpr (NC == 2)
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x0[0]), "+v"(x0[1]), "+v"(x0[2]), "+v"(x0[3]), "+v"(x1[0]), "+v"(x1[1]), "+v"(x1[2]), "+v"(x1[3]), "+v"(w[0]), "+v"(w[1]));
+  else if constexpr (NC == 3)
     asm volatile("s_waitcnt lgkmcnt(0)"
                  : "+v"(x0[0]), "+v"(x0[1]), "+v"(x0[2]), "+v"(x0[3]), "+v"(x1[0]), "+v"(x1[1]), "+v"(x1[2]), "+v"(x1[3]), "+v"(w[0]), "+v"(w[1]), "+v"(w[2]));
   else
@@ -46,28 +48,20 @@ __device__ __forceinline__ void p16x_wait11(f16x8 (&x0)[4], f16x8 (&x1)[4], f16x
 }
 template <int NC>
 __device__ __forceinline__ void p16x_wait3(f16x8 (&w)[NC]) {
-  if constexpr (NC == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]));
+  if constexpr (NC == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w[0]), "+v"(w[1]));
+  else if constexpr (NC == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]));
   else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]));
 }
 
 // NC = cout tiles (of 16) per wave: 3 -> 16 waves (2 cout groups), 6 -> 8 waves
 // NC = cout tiles (of 16) per wave: 3 -> 16 waves (2 cout groups), 6 -> 8 waves
-template <int N>
-__device__ __forceinline__ void p16x_wait_wx(f16x8 (&w)[6], f16x8 (&x)[4]) {
-  asm volatile("s_waitcnt lgkmcnt(%10)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]) : "n"(N));
-}
-template <int N>
-__device__ __forceinline__ void p16x_wait_x(f16x8 (&x)[4]) {
-  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]) : "n"(N));
-}
-template <int N>
-__device__ __forceinline__ void p16x_wait_w(f16x8 (&w)[6]) {
-  asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]) : "n"(N));
-}
-
-template <int OM, bool R1, int NC = 3>
-__global__ __launch_bounds__(8 * (6 / NC) * 64) void conv1d_k9_p16x_kernel(ConvP16Args a) {
-  constexpr int CT = 96, CGS = 6 / NC, NT = 8 * CGS * 64, MT = 512;
+// CT = couts per workgroup tile (96: stage 2; 64: the cout blocks of the 64- / 128-cout layers - opt-in ORCA_P16X_64=1, measured equal to the
+// 32 x 32 x 16 tiles of conv_p16.h there: 24.65 vs 24.56 ms per strand), NC = cout tiles (of 16) per wave:
+// CT / 16 / NC cout groups x 8 position groups of waves (96 / 3 and 64 / 2: 16 waves)
+template <int OM, bool R1, int NC = 3, int CT = 96>
+__global__ __launch_bounds__(8 * (CT / 16 / NC) * 64) void conv1d_k9_p16x_kernel(ConvP16Args a) {
+  constexpr int CGS = CT / 16 / NC, NT = 8 * CGS * 64, MT = 512;
+  static_assert(CGS * NC * 16 == CT && (CT == 96 || CT == 64), "cout groups; weight rows of 64 or all 96 couts");
   constexpr int XROW = MT + 8;
   constexpr int XU = 2 * 2 * XROW;          // X image units [s][octet][XROW]
   constexpr int WU = 2 * 9 * 2 * CT;        // W image units [s][tap][octet][CT]
@@ -82,7 +76,7 @@ __global__ __launch_bounds__(8 * (6 / NC) * 64) void conv1d_k9_p16x_kernel(ConvP
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int pgrp = wave / CGS, cgrp = wave % CGS;     // 8 position groups of 64, CGS cout groups of NC * 16
   const int l15 = lane & 15, g = lane >> 4;
-  const long ntiles = a.tiles_per_row;
+  const long ntiles = CT == 96 ? a.tiles_per_row : a.tiles_per_row * (a.cout / CT);   // cout block cb = tile / tiles_per_row
   long tile = blockIdx.x;
   if (tile >= ntiles) return;
   float* bias_s = reinterpret_cast<float*>(smem + 2 * XU + WU);
@@ -103,11 +97,20 @@ __global__ __launch_bounds__(8 * (6 / NC) * 64) void conv1d_k9_p16x_kernel(ConvP
   auto w0_unit = [](int k) { return k < WSPLIT * 2 * CT ? k : k + (9 - WSPLIT) * 2 * CT; };                      // s = 0: taps 0..3 | s = 1
   auto w1_unit = [](int k) { return k < (9 - WSPLIT) * 2 * CT ? k + WSPLIT * 2 * CT : k + 2 * WSPLIT * 2 * CT; };
   const f32x4 *xsrc = nullptr, *wsrc = nullptr;
-  auto set_src = [&](long pos, int c) {
+  long wrow = 0;             // source stride of a weight row [s][tap][octet]: all couts of the layer
+  auto set_src = [&](long t, int c) {
+    long pos = t;
+    int cb = 0;
+    if constexpr (CT != 96) while (pos >= a.tiles_per_row) { pos -= a.tiles_per_row; ++cb; }
     const int cx = a.k17 ? (c >> 1) : c;
     const int xo = a.k17 ? ((c & 1) ? 9 : 0) : (P16_GUARD - P16_HALO);
     xsrc = a.x + (long)cx * 4 * a.x_plen + pos * MT + xo;
-    wsrc = a.w + (long)c * WU;
+    if constexpr (CT == 96) {
+      wsrc = a.w + (long)c * WU;
+    } else {
+      wrow = a.cout;
+      wsrc = a.w + (long)c * (2 * 9 * 2) * wrow + cb * CT;
+    }
   };
   auto issue_x = [&](int buf) {
 #pragma unroll
@@ -118,22 +121,32 @@ __global__ __launch_bounds__(8 * (6 / NC) * 64) void conv1d_k9_p16x_kernel(ConvP
 #pragma unroll
     for (int it = 0; it < W0IT; ++it) {
       const int k0 = it * NT + wave * 64;        // wave-uniform
-      if (k0 < WH0) p16_glds16(wsrc + w0_unit(k0) + lane, Wl + w0_unit(k0));
+      if constexpr (CT == 96) {           // the layer has 96 couts: image rows = source rows
+        if (k0 < WH0) p16_glds16(wsrc + w0_unit(k0) + lane, Wl + w0_unit(k0));
+      } else {                            // CT = 64: a wave's 64 lanes are one image row [s][tap][octet] = 64 of the source row's couts
+        if (k0 < WH0) p16_glds16(wsrc + (long)(w0_unit(k0) / CT) * wrow + lane, Wl + w0_unit(k0));
+      }
     }
   };
   auto issue_w1 = [&]() {
 #pragma unroll
     for (int it = 0; it < W1IT; ++it) {
       const int k0 = it * NT + wave * 64;
-      if (k0 < WH1) p16_glds16(wsrc + w1_unit(k0) + lane, Wl + w1_unit(k0));
+      if constexpr (CT == 96) {
+        if (k0 < WH1) p16_glds16(wsrc + w1_unit(k0) + lane, Wl + w1_unit(k0));
+      } else {
+        if (k0 < WH1) p16_glds16(wsrc + (long)(w1_unit(k0) / CT) * wrow + lane, Wl + w1_unit(k0));
+      }
     }
   };
 
   f32x4 acc[4][NC];      // [position tile][cout tile]: couts cgrp*48 + n*16 + 4 g + r of position pgrp*64 + i*16 + l15
-  auto acc_init = [&]() __attribute__((always_inline)) {
+  auto acc_init = [&](long t) __attribute__((always_inline)) {
+    int cb = 0;
+    if constexpr (CT != 96) while (t >= a.tiles_per_row) { t -= a.tiles_per_row; ++cb; }
 #pragma unroll
     for (int n = 0; n < NC; ++n) {
-      const f32x4 b = *reinterpret_cast<const f32x4*>(bias_s + cgrp * (NC * 16) + n * 16 + 4 * g);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(bias_s + cb * CT + cgrp * (NC * 16) + n * 16 + 4 * g);
 #pragma unroll
       for (int i = 0; i < 4; ++i) acc[i][n] = b;
     }
@@ -143,6 +156,8 @@ __global__ __launch_bounds__(8 * (6 / NC) * 64) void conv1d_k9_p16x_kernel(ConvP
   long epi_pos = -1;
 
   auto epilogue = [&](long pos) __attribute__((always_inline)) {
+    int cb = 0;
+    if constexpr (CT != 96) while (pos >= a.tiles_per_row) { pos -= a.tiles_per_row; ++cb; }
     // the lane's coordinates from an opaque copy: every per-lane address below is loop-invariant, and hoisted out of the tile loop they
     // would sit in ~20 registers through the MFMA blocks (the pooled + residual form then spills its DMA offsets)
     unsigned lane_ = (unsigned)lane;
@@ -158,11 +173,11 @@ __global__ __launch_bounds__(8 * (6 / NC) * 64) void conv1d_k9_p16x_kernel(ConvP
       if (R1) {
 #pragma unroll
         for (int n = 0; n < NC; ++n)
-          rr[n] = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const char*>(a.r1) + ((long)(cgrp * (NC * 2) + n * 2 + (g >> 1)) * 2 + (g & 1)) * xpl16 + (P16_GUARD + p) * 16);
+          rr[n] = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const char*>(a.r1) + ((long)(cb * (CT / 8) + cgrp * (NC * 2) + n * 2 + (g >> 1)) * 2 + (g & 1)) * xpl16 + (P16_GUARD + p) * 16);
       }
 #pragma unroll
       for (int n = 0; n < NC; ++n) {
-        const int oct = cgrp * (NC * 2) + n * 2 + (g >> 1);      // channel octet of the lane's row pair; plane 2 oct + (g & 1) after the swap
+        const int oct = cb * (CT / 8) + cgrp * (NC * 2) + n * 2 + (g >> 1);      // channel octet of the lane's row pair; plane 2 oct + (g & 1) after the swap
         f32x4 v = acc[i][n];
         if (a.relu) { v.x = p16_vmax(v.x, 0.f); v.y = p16_vmax(v.y, 0.f); v.z = p16_vmax(v.z, 0.f); v.w = p16_vmax(v.w, 0.f); }
         if (R1) {
@@ -176,7 +191,7 @@ __global__ __launch_bounds__(8 * (6 / NC) * 64) void conv1d_k9_p16x_kernel(ConvP
           v.z += (float)h1.x + (float)l1.x; v.w += (float)h1.y + (float)l1.y;
         }
         if (OM == 2) {
-          if (p < a.n) *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(a.y) + (p * a.cout + cgrp * (NC * 16) + n * 16 + 4 * g) * 4) = v;
+          if (p < a.n) *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(a.y) + (p * a.cout + cb * CT + cgrp * (NC * 16) + n * 16 + 4 * g) * 4) = v;
         } else {
           if (OM == 1) { v.x = p16_dpp_quad_max(v.x); v.y = p16_dpp_quad_max(v.y); v.z = p16_dpp_quad_max(v.z); v.w = p16_dpp_quad_max(v.w); }
           vmax = p16_vmax3_abs(p16_vmax3_abs(vmax, v.x, v.y), v.z, v.w);
@@ -202,7 +217,7 @@ __global__ __launch_bounds__(8 * (6 / NC) * 64) void conv1d_k9_p16x_kernel(ConvP
   issue_x(0);
   issue_w0();
   __syncthreads();            // X(0), weight taps 0-3 of the first step, the bias
-  acc_init();
+  acc_init(tile);
 
   // thread-constant fragment addresses (bytes in LDS)
   const unsigned x_lane = (unsigned)(((g & 1) * XROW + (g >> 1) + pgrp * 64 + l15) * 16);   // tap pair: + (s*2*XROW + i*16 + 2 j) * 16
@@ -235,7 +250,7 @@ __global__ __launch_bounds__(8 * (6 / NC) * 64) void conv1d_k9_p16x_kernel(ConvP
     // ---- phase A: everyone is done with weight taps 4-8 of the previous step.  The finished tile's epilogue first (nothing is in flight)
     if (epi_pos >= 0) {
       epilogue(epi_pos);
-      acc_init();
+      acc_init(tile);
       epi_pos = -1;
     }
     issue_w1();

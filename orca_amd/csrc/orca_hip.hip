@@ -747,18 +747,26 @@ static void launch_p16w1_k(hipStream_t s, ConvP16Args a) {
   hipLaunchKernelGGL((conv1d_k9_p16w1_kernel<OM, R1, FMT>), grid, dim3(512), 0, s, a);
 }
 // the same layers on the 16 x 16 x 32 matrix instruction (conv_p16x.h; P16 only)
-template <int OM, bool R1>
+template <int OM, bool R1, int CT>
 static void launch_p16x_k(hipStream_t s, ConvP16Args a) {
   static int ncu = [] { int dev = 0, v = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev); return v; }();
   a.tiles_per_row = (a.n + 511) / 512;
-  dim3 grid((unsigned)(a.tiles_per_row < ncu ? a.tiles_per_row : ncu));
-  hipLaunchKernelGGL((conv1d_k9_p16x_kernel<OM, R1, 3>), grid, dim3(1024), 0, s, a);
+  const long ntiles = a.tiles_per_row * (a.cout / CT);
+  dim3 grid((unsigned)(ntiles < ncu ? ntiles : ncu));
+  hipLaunchKernelGGL((conv1d_k9_p16x_kernel<OM, R1, CT / 32, CT>), grid, dim3(1024), 0, s, a);
 }
-static bool launch_p16x(hipStream_t s, const ConvP16Args& a) {
+static bool launch_p16x(hipStream_t s, const ConvP16Args& a) {      // false: this (cout, out_mode, residual) combination stays on the 32 x 32 x 16 kernels
   const bool r1 = a.r1 != nullptr;
-  if (a.out_mode == 0 && !r1) launch_p16x_k<0, false>(s, a);
-  else if (a.out_mode == 1 && r1) launch_p16x_k<1, true>(s, a);
-  else return false;
+  if (a.cout == 96) {
+    if (a.out_mode == 0 && !r1) launch_p16x_k<0, false, 96>(s, a);
+    else if (a.out_mode == 1 && r1) launch_p16x_k<1, true, 96>(s, a);
+    else return false;
+  } else if (a.cout % 64 == 0) {
+    if (a.out_mode == 0 && !r1) launch_p16x_k<0, false, 64>(s, a);
+    else if (a.out_mode == 0 && r1) launch_p16x_k<0, true, 64>(s, a);
+    else if (a.out_mode == 2 && r1) launch_p16x_k<2, true, 64>(s, a);
+    else return false;
+  } else return false;
   return true;
 }
 template <int FMT>
@@ -902,7 +910,8 @@ static int launch_conv1d_p16(orca_ctx* ctx, const ConvLayer& L, const float* x, 
     if (L.cout == 96) launch_p16f<96>(ctx->stream, a);
     else launch_p16f<64>(ctx->stream, a);
     tile_tag = -11;                      // fast-FIR form (conv_p16f.h)
-  } else if (L.cout == 96 && n >= 65536 && fmt == 0 && getenv("ORCA_NO_P16X") == nullptr && launch_p16x(ctx->stream, a)) {
+  } else if ((L.cout == 96 || (L.cout % 64 == 0 && getenv("ORCA_P16X_64") != nullptr)) && n >= 65536 && fmt == 0 && getenv("ORCA_NO_P16X") == nullptr &&
+             launch_p16x(ctx->stream, a)) {
     tile_tag = -14;                      // 16 x 16 x 32 matrix instruction (conv_p16x.h)
   } else if (L.cout == 96 && n >= 65536 && getenv("ORCA_NO_P16W1") == nullptr && (fmt == 1 ? launch_p16w1<1>(ctx->stream, a) : launch_p16w1<0>(ctx->stream, a))) {
     tile_tag = fmt == 1 ? -10 : -9;      // stage 2 of the Encoder: 512-position tiles (conv_p16w1.h)

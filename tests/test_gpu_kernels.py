@@ -155,6 +155,28 @@ def test_conv1d_p16_96_couts_on_32x32x16(cuda, monkeypatch, cin, k, n, out_mode,
         assert err < 2e-5, (cin, k, n, out_mode, envs, err)
 
 
+@pytest.mark.parametrize("cin,cout,k,n", [(64, 64, 9, 131072), (96, 128, 9, 66001), (96, 128, 17, 70003)])
+@pytest.mark.parametrize("out_mode", [0, 2])
+def test_conv1d_p16_64_cout_blocks_on_16x16x32(cuda, monkeypatch, cin, cout, k, n, out_mode):
+    """conv_p16x.h with 64-cout workgroup tiles (opt-in ORCA_P16X_64=1: measured equal to the 32 x 32 x 16 tiles of conv_p16.h on stages 3-4:
+    24.65 vs 24.56 ms per strand): cout blocks, strided weight rows, P16 and fp32 outputs, 9 and 17 taps, against torch fp32."""
+    monkeypatch.setenv("ORCA_P16X_64", "1")
+    rs = np.random.RandomState(cin + cout + k + n + out_mode)
+    x = torch.from_numpy(rs.randn(1, cin, n).astype(np.float32))
+    w = (rs.randn(cout, cin, k) / np.sqrt(cin * k)).astype(np.float32)
+    b = rs.randn(cout).astype(np.float32) * 0.1
+    r1 = torch.from_numpy(rs.randn(1, cout, n).astype(np.float32))
+    for relu, ra in [(False, None), (True, r1)]:
+        y = engine.conv1d_p16(x[0].t().contiguous().to(cuda), w, b, relu, None if ra is None else ra[0].t().contiguous().to(cuda), out_mode)
+        ref = F.conv1d(x.double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(), padding=k // 2)
+        if relu:
+            ref = F.relu(ref)
+        if ra is not None:
+            ref = ref + ra.double()
+        err = float((y.cpu().t()[None].double() - ref).abs().max())
+        assert err < 2e-5, (cin, cout, k, n, out_mode, relu, err)
+
+
 @pytest.mark.parametrize("cin,k,n", [(128, 9, 70001), (96, 17, 66003)])
 @pytest.mark.parametrize("out_mode", [0, 2])
 def test_conv1d_p16_128_couts_one_workgroup(cuda, monkeypatch, cin, k, n, out_mode):
