@@ -61,7 +61,7 @@ def pmc_sum(run, counter, prefix, min_us=1500.0):
 
 traffic = {"_source": f"profiles/{tag}_pmc_enc_f16x2_fetch.txt + profiles/{tag}_pmc_enc_f16x2_write.txt (and the bf16 pair)"}
 for mode, key, prefix, min_us in (("f16x2", "conv1d_k9_p16_kernel<cout=64,f16x2>", "void conv1d_k9_p16_kernel<64,", 4000.0),
-                                  ("f16x2", "conv1d_k9_p16x_kernel<cout=96,f16x2>", re.compile(r"^void conv1d_k9_p16x_kernel<\d, (true|false), 3>"), 2500.0),   # 96 -> 96, plain and pooled + residual (and the 17-tap 64 -> 96)
+                                  ("f16x2", "conv1d_k9_p16x_kernel<cout=96,f16x2>", re.compile(r"^void conv1d_k9_p16x_kernel<\d, (true|false), 3, 96>"), 2500.0),   # 96 -> 96, plain and pooled + residual (and the 17-tap 64 -> 96)
                                   ("f16x2", "conv1d_first_mfma_p16_kernel<0,0,25>", "void conv1d_first_mfma_p16_kernel<0, 0, 25>", 800.0),
                                   ("bf16", "conv1d_k9_p16w1_kernel<cout=96,bf16>", re.compile(r"^void conv1d_k9_p16w1_kernel<\d, (true|false), 1>"), 800.0),
                                   ("bf16", "conv1d_k9_ws_kernel<cout=64,bf16>", "void conv1d_k9_ws_kernel<1, 64, 64,", 1200.0)):
