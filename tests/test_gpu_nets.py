@@ -119,6 +119,27 @@ def test_encoder_weight_seed_and_gain_sweep_vs_oracle(cuda, monkeypatch, seed, g
                 assert maxabs(y2, ref) < 1e-4 * scale and maxabs(y2, y) < 2e-5 * scale, (switch, rev, maxabs(y2, ref), maxabs(y2, y))
 
 
+def test_encoder_default_dispatch_reaches_the_current_kernels(cuda):
+    """The kernel-variant switches make silent fallbacks easy: with no switch set, one Encoder forward from packed bases must put stage 2 on
+    conv_p16x.h (timing tag -14), stage 3's pooled conv on conv_p16p5.h (-12) and stage 1's `conv1.b` / stage 3's other convs on the 64-cout
+    tiles of conv_p16.h (-5), as recorded by the per-launch HIP-event timing (launches over >= 65 536 positions)."""
+    import os
+    from orca_amd import engine
+    assert not [k for k in os.environ if k.startswith("ORCA_NO_") or k in ("ORCA_FFA", "ORCA_P16C128", "ORCA_P16X_64")], "a kernel-variant switch is set"
+    enc = product_module("Encoder", 0)
+    codes, ok = engine.pack_sequence(torch.from_numpy(synth.synth_sequence(4000 * 300, seed=5)).transpose(1, 2).to(cuda))
+    assert ok
+    ctx = engine.get_context(cuda)
+    enc.forward_codes(codes)
+    ctx.set_timing(True)
+    enc.forward_codes(codes)
+    recs = ctx.get_timing()
+    ctx.set_timing(False)
+    tags = {(cout, tile) for cout, cin, tile, batch, n, ms, ksize in recs}
+    assert (96, -14) in tags and (128, -12) in tags and (64, -5) in tags and (128, -5) in tags, sorted(tags)
+    assert not any(tile in (-9, -11) for _, tile in tags), sorted(tags)     # (conv_p16w1.h / the fast-FIR form only behind their switches)
+
+
 def test_encoder_composed_weights_outside_fp16_keep_the_two_conv_form(cuda, monkeypatch):
     """A composed weight is a sum of products of folded weights and may leave the fp16 range although every single layer fits (extreme
     checkpoints): such a group must keep the reference's two-conv form instead of packing infinities.  lconv1's two convs are scaled by
