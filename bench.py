@@ -351,7 +351,8 @@ def config5_section(dev, n_svs=16):
 def sharded_32mb(args, rank, world, dev, dist, comm):
     """Strong scaling of the HEADLINE workload (one 32 Mb window, both strands, H1-ESC-shaped model): strand split x Encoder bin shards
     (dist.strand_bin_sharded_32m: rank parity = strand, world/2 bin shards per strand, ONE all-gather of the encodings, the two strands'
-    tails on ranks 0 / 1, ONE all-gather of the maps).  N = 1: both strands here.  Needs an even N."""
+    tails on ranks 0 / 1 - from 4 ranks on their independent `+ denet_1_pt` term on ranks 2 / 3 -, ONE all-gather of the maps).  N = 1: both
+    strands here.  Needs an even N."""
     from orca_amd import dist as odist, engine, orca_models, synth
     if world > 1 and world % 2:
         return {"skipped": f"needs an even number of ranks, got {world}"}

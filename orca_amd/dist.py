@@ -237,7 +237,8 @@ def strand_bin_plan(total_bins, rank, world):
 def strand_bin_sharded_32m(model, codes, mpos, wpos, distencs=None, group=None, comm=None):
     """`genomepredict`'s device work for ONE 32 Mb window ([B,L] packed bases replicated on every rank) shared by all ranks: rank r
     encodes bins `strand_bin_plan` of strand r % 2, ONE all-gather assembles both strands' [B,128,8000] encodings on every rank, ranks
-    0 and 1 run one strand's tail each (Encoder2 -> six Decoders + Decoder_1m: a dependent chain, not shardable further) and ONE
+    0 and 1 run one strand's tail each (Encoder2 -> six Decoders: a dependent chain, not shardable further; the independent `+ denet_1_pt`
+    term of the 4 kb level runs on ranks 2 / 3 from 4 ranks on, on ranks 0 / 1 otherwise) and ONE
     all-gather of the [6,C,250,250] maps precedes the strand merge.  Returns the six merged [C,250,250] maps (on every rank).
     Replaces nn.DataParallel around the sub-networks (orca_models.py:44-50), which only splits batches."""
     from . import engine, orca_predict
@@ -280,18 +281,26 @@ def strand_bin_sharded_32m(model, codes, mpos, wpos, distencs=None, group=None, 
         preds, _ = orca_predict.cascade_32m_from_enc(model, enc0, mpos, wpos, [False, True], distencs)
         fwd, rev = torch.stack([p[0] for p in preds]), torch.stack([p[B] for p in preds])
     else:
+        offload_1m = world >= 4      # ranks 2 / 3 are idle during the tails: they take the `+ denet_1_pt` term of strand 0 / 1 (independent of the cascade)
         if rank < 2:
-            preds, _ = orca_predict.cascade_32m_from_enc(model, enc0[rank * B: (rank + 1) * B], mpos, wpos, [bool(rank)], distencs)
+            preds, _ = orca_predict.cascade_32m_from_enc(model, enc0[rank * B: (rank + 1) * B], mpos, wpos, [bool(rank)], distencs, with_1m=not offload_1m)
             slab = torch.stack([p[0] for p in preds]).contiguous()
         else:
             C = getattr(model.denets[32], "num_2d", 1)
             slab = torch.zeros((6, C, 250, 250), dtype=torch.float32, device=enc0.device)
+            if offload_1m and rank < 4:
+                st = rank - 2
+                slab[5] = orca_predict.denet1m_32m_from_enc(model, enc0[st * B: (st + 1) * B], mpos, wpos, [bool(st)])[0]
         if comm is not None:
             allm = comm.all_gather(slab)
         else:
             allm = torch.empty((world,) + tuple(slab.shape), dtype=slab.dtype, device=slab.device)
             dist.all_gather_into_tensor(allm.view(-1), slab.view(-1), group=group)
         fwd, rev = allm[0], allm[1]
+        if offload_1m:
+            fwd, rev = fwd.clone(), rev.clone()
+            fwd[5] += allm[2][5]
+            rev[5] += allm[3][5]
     return [torch.stack([engine.strand_merge(fwd[j, c], rev[j, c]) for c in range(fwd.shape[1])]) for j in range(fwd.shape[0])]
 
 

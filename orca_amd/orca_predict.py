@@ -403,10 +403,38 @@ def cascade_32m(model, xs, mpos, wpos, reverse_flags, distencs=None, merge=False
     return engine.run_with_overflow_retry(forward, xs[0].device)
 
 
-def cascade_32m_from_enc(model, enc0, mpos, wpos, reverse_flags, distencs=None):
+def starts_32m(mpos, wpos, reverse):
+    """Window starts (4 kb bins) of the six levels for one strand: the zoom path depends on the coordinates only
+    (orca_predict.py:471-500), not on the predictions."""
+    st = [0]
+    for level in [32, 16, 8, 4, 2, 1]:
+        st.append(st[-1] + zoom_index_32m(level, st[-1], mpos, wpos, reverse) * level)
+    return st[:-1]
+
+
+def denet1m_32m_from_enc(model, enc0, mpos, wpos, reverse_flags):
+    """The `+ model.denet_1_pt.forward(...)` term of the 4 kb level ALONE (orca_predict.py:362), for the strands of ``enc0``
+    [S*B,128,8000]: it reads the level-1 encoding at the strand's last window and nothing of the decoder cascade, so another rank can
+    compute it (dist.strand_bin_sharded_32m from 4 ranks).  Returns [S*B,C,250,250]."""
+    S = len(reverse_flags)
+    B = enc0.shape[0] // S
+
+    def forward():
+        enc1 = model.net(enc0)[0]
+        xs = []
+        for k in range(S):
+            s = int(starts_32m(mpos, wpos, bool(reverse_flags[k]))[5])
+            xs.append(enc1[k * B: (k + 1) * B, :, s: s + 250])
+        return model.denet_1_pt(torch.cat(xs, dim=0).contiguous())
+
+    return engine.run_with_overflow_retry(forward, enc0.device)
+
+
+def cascade_32m_from_enc(model, enc0, mpos, wpos, reverse_flags, distencs=None, with_1m=True):
     """The part of `cascade_32m` AFTER the Encoder: ``enc0`` [S*B,128,8000] (strand k = rows k*B..) -> Encoder2 -> six decoder
-    levels (+ denet_1_pt at 4 kb).  Returns (preds[6], starts[k][6]).  (Multi-GPU: every rank holds the gathered encodings and
-    runs the strands it owns, dist.strand_bin_sharded_32m.)"""
+    levels (+ denet_1_pt at 4 kb unless ``with_1m`` is False: `denet1m_32m_from_enc` then supplies that term).  Returns
+    (preds[6], starts[k][6]).  (Multi-GPU: every rank holds the gathered encodings and runs the strands it owns,
+    dist.strand_bin_sharded_32m.)"""
     S = len(reverse_flags)
     B = enc0.shape[0] // S
     cache = {}
@@ -421,7 +449,7 @@ def cascade_32m_from_enc(model, enc0, mpos, wpos, reverse_flags, distencs=None):
     def forward():
         encodings = dict(zip([1, 2, 4, 8, 16, 32], model.net(enc0)))
         return run_cascade(model, encodings, [32, 16, 8, 4, 2, 1], lambda lv: lv, B, [bool(r) for r in reverse_flags], background,
-                           lambda lv, st, rev: zoom_index_32m(lv, st, mpos, wpos, rev), add_1m_level=1)
+                           lambda lv, st, rev: zoom_index_32m(lv, st, mpos, wpos, rev), add_1m_level=1 if with_1m else None)
 
     return engine.run_with_overflow_retry(forward, enc0.device)
 

@@ -63,7 +63,8 @@ def _worker(rank, world, port, L, q):
             net0 = _Net0()
             denets = {32: type("D", (), {"num_2d": 1})()}
 
-        def _tail(model, enc0, mpos, wpos, flags, de=None):
+        def _tail(model, enc0, mpos, wpos, flags, de=None, with_1m=True):
+            assert with_1m                                                # (2 ranks: the tails keep the `+ denet_1_pt` term)
             v = (enc0 * torch.arange(1, enc0.shape[2] + 1.)).sum()       # position-weighted: any misplaced bin changes it
             return [torch.full((enc0.shape[0], 1, 250, 250), float(v) * (j + 1)) + (1.0 if flags[0] else 0.0) for j in range(6)], None
         orca_predict.cascade_32m_from_enc = _tail
@@ -136,16 +137,28 @@ def _worker4(rank, world, port, q):
 
         tails = []
 
-        def _tail(model, enc0, mpos, wpos, flags, de=None):
+        ones = []
+
+        def _tail(model, enc0, mpos, wpos, flags, de=None, with_1m=True):
             tails.append(bool(flags[0]))
             v = (enc0 * torch.arange(1, enc0.shape[2] + 1.)).sum()
-            return [torch.full((enc0.shape[0], 1, 250, 250), float(v) * (j + 1)) + (1.0 if flags[0] else 0.0) for j in range(6)], None
+            maps = [torch.full((enc0.shape[0], 1, 250, 250), float(v) * (j + 1)) + (1.0 if flags[0] else 0.0) for j in range(6)]
+            if with_1m:
+                maps[5] = maps[5] + _one_m(model, enc0, mpos, wpos, flags, record=False)
+            return maps, None
+
+        def _one_m(model, enc0, mpos, wpos, flags, record=True):
+            if record:
+                ones.append(bool(flags[0]))
+            return torch.full((enc0.shape[0], 1, 250, 250), 0.25 * float(enc0.sum()) + (7.0 if flags[0] else 3.0))
         orca_predict.cascade_32m_from_enc = _tail
+        orca_predict.denet1m_32m_from_enc = _one_m
         codes = torch.zeros((1, 4000 * 75), dtype=torch.uint8)
         maps32 = D.strand_bin_sharded_32m(_Model(), codes, 0, 0)
         lo, hi = D.bin_range(75, rank // 2, 2)
         assert calls == [(bool(rank % 2), lo, hi)]                      # one strand, one bin shard per rank
         assert tails == ([bool(rank)] if rank < 2 else [])              # only ranks 0 / 1 run a tail
+        assert ones == ([] if rank < 2 else [bool(rank - 2)])          # ... and ranks 2 / 3 the `+ denet_1_pt` term of strand 0 / 1
         ref = [_Net0().forward_codes(codes, bool(st), 0, 75) for st in range(2)]
         wf, wr = _tail(None, ref[0], 0, 0, [False])[0], _tail(None, ref[1], 0, 0, [True])[0]
         ok32 = all(torch.equal(m[0], 0.5 * wf[j][0, 0] + 0.5 * torch.flip(wr[j][0, 0], [0, 1])) for j, m in enumerate(maps32))

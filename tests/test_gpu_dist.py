@@ -100,6 +100,14 @@ def test_strand_bin_sharded_32m_single_process_equals_cascade(cuda):
     tails = [torch.stack([p[0] for p in orca_predict.cascade_32m_from_enc(model, encs[st], mpos, wpos, [bool(st)])[0]]) for st in range(2)]
     for j in range(6):
         assert float((engine.strand_merge(tails[0][j, 0], tails[1][j, 0]) - ref[j][0]).abs().max()) < 2e-5, j
+    # from 4 ranks on, ranks 2 / 3 supply the `+ denet_1_pt` term of the 4 kb level (it does not depend on the cascade): tails without it
+    # plus `denet1m_32m_from_enc` must give the same maps, levels 32 .. 2 bit for bit
+    for st in range(2):
+        bare = torch.stack([p[0] for p in orca_predict.cascade_32m_from_enc(model, encs[st], mpos, wpos, [bool(st)], with_1m=False)[0]])
+        one_m = orca_predict.denet1m_32m_from_enc(model, encs[st], mpos, wpos, [bool(st)])[0]
+        assert torch.equal(bare[:5], tails[st][:5])
+        assert float((bare[5] + one_m - tails[st][5]).abs().max()) < 1e-6
+        assert float(one_m.abs().max()) > 1e-3
 
 
 def test_encoder_from_a_code_window(cuda):
