@@ -18,7 +18,7 @@
 #include "conv_kernels.h"
 #include "conv_bf16s.h"
 #include "conv2d_m16.h"
-#include "conv2d_m16w.h"
+#include "conv2d_m16q.h"
 #include "conv2d_dblock.h"
 #include "conv_p16.h"
 #include "conv_ws.h"
@@ -86,7 +86,7 @@ struct orca_ctx {
   std::vector<TimedLaunch> timed;
   unsigned* d_flag = nullptr;   // fp16-range overflow flag written by the f16x2 kernels
   float* d_edge = nullptr;      // 4 x 40 x 128 floats: one scratch slab per layer of the edge-fix chain (lconv_edge_layer_kernel)
-  float* d_zero = nullptr;      // 256 bytes of zeros (the source of out-of-map units in conv2d_3x3_m16w_kernel)
+  float* d_zero = nullptr;      // 256 bytes of zeros (the source of out-of-map units in conv2d_3x3_m16q_kernel)
   // Decoders with an even batch run as two half-batches on two streams (see decoder_nhwc)
   hipStream_t aux = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -524,31 +524,26 @@ static int launch_conv2d_m16(orca_ctx* ctx, const ConvLayer& L, const f32x4* x, 
   if (chunk0 > 0) a.w = static_cast<const char*>(a.w) + (size_t)chunk0 * (bf16 ? 1 : 2) * 9 * 2 * L.cout * 8 * 2;   // pack [chunk][splits][9][2][cout][8] halves
   if (a.nchunks * 2 > x_oct) return fail(ORCA_EINVAL, "conv2d_m16: input map has %d channel octets, layer needs %d", x_oct, a.nchunks * 2);
   if (L.cout / 8 > y_oct) return fail(ORCA_EINVAL, "conv2d_m16: output map narrower than the layer");
-  // second form (conv2d_m16w.h): persistent workgroups, resident weights, two-row half-width tiles - for the layers whose pieces fit.
-  // OPT-IN (ORCA_M16W=1, read per call): per conv it is 21-26 % faster (9.8 / 11.6 us per map against 12.4 / 15.7), but it wants the whole
-  // batch in one launch, and the one-row form on two streams overlaps its ramps and tails to the same end-to-end time (2.47 ms per Decoder
-  // forward at B = 2 either way; 4.1 against 3.9 ms at B = 8 on single fp16 planes) - DESIGN.md section 7.
-  const bool m16w = getenv("ORCA_M16W") != nullptr;
-  if (m16w && !tab && chunk0 == 0 && a.nchunks * (L.cout / 32) <= 4 && n > 128) {
-    static int ncu = [] { int dev = 0, v = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev); return v; }();
-    ConvM16WArgs aw;
-    aw.c = a; aw.c.banded = 0; aw.zero = reinterpret_cast<const f32x4*>(ctx->d_zero); aw.B = B;
-    aw.npairs = ((n + 2 * L.dil - 1) / (2 * L.dil)) * L.dil;
-    const long ntiles = (long)aw.npairs * 2 * B;
-    static const int grid_div = [] { const char* e = getenv("ORCA_M16W_GRID_DIV"); const int v = e ? atoi(e) : 1; return v > 0 ? v : 1; }();   // experiment hook
-    const int gmax = ncu / grid_div;
-    dim3 gridw((unsigned)(ntiles < gmax ? ntiles : gmax));
+  // batches (conv2d_m16q.h): tiles of four output rows (y .. y + 3d) x 128 pixels, one launch for the whole batch - both strands of a level
+  // are one round of 252-256 workgroups (Decoder forward at B = 2: 2.32 against 2.43 ms, same box).  A single map is 126-128 such workgroups,
+  // half the chip: it stays on the one-row kernel (1.40 against 1.62 ms).  ORCA_NO_M16Q=1 (read per call) selects the one-row kernel
+  // everywhere - the A/B and parity switch; ORCA_M16Q_ALWAYS=1 the four-row kernel for single maps too (tests).
+  if ((B >= 2 || getenv("ORCA_M16Q_ALWAYS") != nullptr) && getenv("ORCA_NO_M16Q") == nullptr) {
+    ConvM16QArgs aq;
+    aq.c = a; aq.c.banded = 0; aq.zero = reinterpret_cast<const f32x4*>(ctx->d_zero);
+    aq.ngroups = ((n + 4 * L.dil - 1) / (4 * L.dil)) * L.dil;
+    dim3 gridq((unsigned)((aq.ngroups * 2 + 7) / 8 * 8), (unsigned)B);
     if (bf16) {
-      if (L.cout == 64) hipLaunchKernelGGL((conv2d_3x3_m16w_kernel<64, 1, 0>), gridw, dim3(512), 0, ctx->stream, aw);
-      else hipLaunchKernelGGL((conv2d_3x3_m16w_kernel<32, 1, 0>), gridw, dim3(512), 0, ctx->stream, aw);
+      if (L.cout == 64) hipLaunchKernelGGL((conv2d_3x3_m16q_kernel<64, 1, 0>), gridq, dim3(512), 0, ctx->stream, aq);
+      else hipLaunchKernelGGL((conv2d_3x3_m16q_kernel<32, 1, 0>), gridq, dim3(512), 0, ctx->stream, aq);
     } else if (mode == 2) {
-      if (L.cout == 64) hipLaunchKernelGGL((conv2d_3x3_m16w_kernel<64, 1, 1>), gridw, dim3(512), 0, ctx->stream, aw);
-      else hipLaunchKernelGGL((conv2d_3x3_m16w_kernel<32, 1, 1>), gridw, dim3(512), 0, ctx->stream, aw);
+      if (L.cout == 64) hipLaunchKernelGGL((conv2d_3x3_m16q_kernel<64, 1, 1>), gridq, dim3(512), 0, ctx->stream, aq);
+      else hipLaunchKernelGGL((conv2d_3x3_m16q_kernel<32, 1, 1>), gridq, dim3(512), 0, ctx->stream, aq);
     } else {
-      if (L.cout == 64) hipLaunchKernelGGL((conv2d_3x3_m16w_kernel<64, 2, 1>), gridw, dim3(512), 0, ctx->stream, aw);
-      else hipLaunchKernelGGL((conv2d_3x3_m16w_kernel<32, 2, 1>), gridw, dim3(512), 0, ctx->stream, aw);
+      if (L.cout == 64) hipLaunchKernelGGL((conv2d_3x3_m16q_kernel<64, 2, 1>), gridq, dim3(512), 0, ctx->stream, aq);
+      else hipLaunchKernelGGL((conv2d_3x3_m16q_kernel<32, 2, 1>), gridq, dim3(512), 0, ctx->stream, aq);
     }
-    LAUNCHCHECK("conv2d_3x3_m16w_kernel");
+    LAUNCHCHECK("conv2d_3x3_m16q_kernel");
     return ORCA_OK;
   }
   static const bool no_banded = getenv("ORCA_NO_BANDED") != nullptr;   // A/B switch
@@ -1970,11 +1965,11 @@ static int decoder_m16(orca_ctx* ctx, orca_net* net, const RowSrc& x, long sx_c,
     LAUNCHCHECK("final_sym_m16_kernel");
     return ORCA_OK;
   };
-  // A Decoder is a chain of ~90 dependent launches per map.  The maps of a batch are independent, so an even batch runs as
-  // two half-batches on two streams: one half's ramps and tails are filled by the other half's workgroups.
-  // (With the persistent per-layer kernel of conv2d_m16w.h a launch should carry the WHOLE batch - a workgroup's second tile reuses the
-  // resident weights and hides its prologue - so one stream is the default there; ORCA_DECODER_TWO_STREAMS=1 / ORCA_DECODER_ONE_STREAM=1 force either.)
-  const bool one_stream = getenv("ORCA_DECODER_ONE_STREAM") != nullptr || (getenv("ORCA_M16W") != nullptr && getenv("ORCA_DECODER_TWO_STREAMS") == nullptr);
+  // A Decoder is a chain of ~90 dependent launches per map.  With the four-row kernel (conv2d_m16q.h) a launch carries the WHOLE batch: both
+  // strands of a level are 252-256 workgroups = one round on 256 CUs.  The one-row kernel of rounds 2-3 (ORCA_NO_M16Q=1) ran an even batch
+  // as two half-batches on two streams, one half's ramps and tails filled by the other half's workgroups; ORCA_DECODER_TWO_STREAMS=1 /
+  // ORCA_DECODER_ONE_STREAM=1 force either (read per call).
+  const bool one_stream = getenv("ORCA_DECODER_ONE_STREAM") != nullptr || (getenv("ORCA_NO_M16Q") == nullptr && getenv("ORCA_DECODER_TWO_STREAMS") == nullptr);
   if (B < 2 || (B & 1) || one_stream) return run(0, B);
   if (!ctx->aux) {
     HIPCHECK(hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking));

@@ -304,9 +304,12 @@ def test_conv1d_b16_dma(cuda, cin, cout, n, out_mode):
 
 @pytest.mark.parametrize("cin,cout,dil,n", [(64, 32, 1, 250), (32, 64, 2, 250), (64, 64, 1, 250), (64, 32, 8, 250), (32, 64, 4, 250), (129, 64, 1, 250),
                                             (65, 64, 1, 250), (128, 32, 1, 250), (64, 32, 8, 126), (32, 64, 8, 64), (64, 64, 2, 256), (64, 32, 4, 30)])
-def test_conv2d_m16_dilated(cuda, cin, cout, dil, n):
-    """conv2d_m16.h: the Decoders' conv on M16 maps (two fp16 planes, LDS-DMA'd operands, 3 products) vs torch fp32.  The
-    maps make a round trip through the 22-bit storage (inputs, residual and output each rounded once: 2^-22 relative)."""
+@pytest.mark.parametrize("kernel", ["four_row", "one_row"])
+def test_conv2d_m16_dilated(cuda, cin, cout, dil, n, kernel, monkeypatch):
+    """conv2d_m16q.h / conv2d_m16.h: the Decoders' conv on M16 maps (two fp16 planes, LDS-DMA'd operands, 3 products) vs torch fp32, on
+    the four-row kernel (the default for batches; forced for single maps here) and on the one-row kernel.  The maps make a round trip
+    through the 22-bit storage (inputs, residual and output each rounded once: 2^-22 relative)."""
+    monkeypatch.setenv("ORCA_M16Q_ALWAYS" if kernel == "four_row" else "ORCA_NO_M16Q", "1")
     rs = np.random.RandomState(cin * 100 + cout + dil + n)
     B = 2 if n < 250 else 1
     x = torch.from_numpy(rs.randn(B, cin, n, n).astype(np.float32))
@@ -326,9 +329,11 @@ def test_conv2d_m16_dilated(cuda, cin, cout, dil, n):
 
 @pytest.mark.parametrize("precision,ulp", [("bf16", 2.0 ** -8), ("f16", 2.0 ** -11)])
 @pytest.mark.parametrize("cin,cout,dil,n", [(64, 32, 1, 250), (32, 64, 8, 250), (144, 64, 1, 126), (64, 64, 4, 64)])
-def test_conv2d_m16_single_plane(cuda, cin, cout, dil, n, precision, ulp):
+@pytest.mark.parametrize("kernel", ["four_row", "one_row"])
+def test_conv2d_m16_single_plane(cuda, cin, cout, dil, n, precision, ulp, kernel, monkeypatch):
     """The single-plane modes: on operands that are exactly representable the only differences from torch fp32 are the
     summation order and ONE final rounding of the output to the plane's 16-bit type."""
+    monkeypatch.setenv("ORCA_M16Q_ALWAYS" if kernel == "four_row" else "ORCA_NO_M16Q", "1")
     rs = np.random.RandomState(cin + cout + dil + n)
     dt = torch.bfloat16 if precision == "bf16" else torch.float16
     q = lambda t: t.to(dt).to(torch.float32)
