@@ -408,7 +408,11 @@ __global__ __launch_bounds__(512, 2) void conv2d_3x3_m16_kernel(ConvM16Args a) {
   const bool allrows = rowok[0] && rowok[2];
   const unsigned ws_lds = p16_lds_addr(Ws + g * 32 + l31);
   const unsigned xs_lds = p16_lds_addr(Xs + g * 3 * ROWP + 8 + wave * 32 + l31);
+  const unsigned bias_lds = p16_lds_addr(bias_s + 4 * g);
 
+  // taps in kernel-column-major order (kx, then ky) and accumulators that start from the bias: the summation order of conv2d_m16q.h, so
+  // that a map comes out bit-identical whichever of the two kernels a batch size selects (tap t = ky * 3 + kx of the weight pack)
+#define M16_TAP(n_) (((n_) % 3) * 3 + (n_) / 3)
 #define M16_READ(buf_, t_)                                                                                          \
   if constexpr (!(M16_ABL & 2)) _Pragma("unroll") for (int s = 0; s < NS; ++s) {                                                                  \
     xv[buf_][s] = p16_lds_read16(xcol[(t_) % 3], (s * 6 + (t_) / 3) * ROWP * 16);                                   \
@@ -467,6 +471,16 @@ __global__ __launch_bounds__(512, 2) void conv2d_3x3_m16_kernel(ConvM16Args a) {
       // completion the counted waits establish, so the barrier itself is all that is needed.
       M16_BARRIER();
       M16_STAMP(3 + 2 * i);
+      if (i == 0) {                    // the bias has landed with the first piece: the accumulators start from it (register group q = couts 8q + 4g ..)
+#pragma unroll
+        for (int hh = 0; hh < NH; ++hh)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 b4 = p16_lds_read16f(bias_lds, (hh * 32 + 8 * q) * 4);
+            acc[hh][4 * q + 0] = b4.x; acc[hh][4 * q + 1] = b4.y; acc[hh][4 * q + 2] = b4.z; acc[hh][4 * q + 3] = b4.w;
+          }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
       if constexpr (NS == 2) {
         if (i + 1 == NP && rb && !(M16_ABL & 4)) {
 #pragma unroll
@@ -498,10 +512,10 @@ __global__ __launch_bounds__(512, 2) void conv2d_3x3_m16_kernel(ConvM16Args a) {
         if (h == 0) {
           M16_READ_XK(0); M16_READ_W(0, 0);
 #pragma unroll
-          for (int t = 0; t < 9; ++t) {
-            const int fb = t & 1;
-            if (M16_DMA_SPREAD) M16_DMA_SLOT(t);
-            if (t + 1 < 9) { M16_READ_XK(t + 1); M16_READ_W(fb ^ 1, t + 1); m16_wait<2 * NS, NS>(xk[t], wv[fb]); }
+          for (int n = 0; n < 9; ++n) {
+            const int fb = n & 1, t = M16_TAP(n), t1 = M16_TAP(n + 1);
+            if (M16_DMA_SPREAD) M16_DMA_SLOT(n);
+            if (n + 1 < 9) { M16_READ_XK(t1); M16_READ_W(fb ^ 1, t1); m16_wait<2 * NS, NS>(xk[t], wv[fb]); }
             else m16_wait<0, NS>(xk[t], wv[fb]);
             M16_MFMA_XK(t, fb, h);
             __builtin_amdgcn_sched_barrier(0);
@@ -509,10 +523,10 @@ __global__ __launch_bounds__(512, 2) void conv2d_3x3_m16_kernel(ConvM16Args a) {
         } else {
           M16_READ_W(0, 0);
 #pragma unroll
-          for (int t = 0; t < 9; ++t) {
-            const int fb = t & 1;
-            if (M16_DMA_SPREAD) M16_DMA_SLOT(t);
-            if (t + 1 < 9) { M16_READ_W(fb ^ 1, t + 1); m16_wait<NS, NS>(xk[t], wv[fb]); }
+          for (int n = 0; n < 9; ++n) {
+            const int fb = n & 1, t = M16_TAP(n), t1 = M16_TAP(n + 1);
+            if (M16_DMA_SPREAD) M16_DMA_SLOT(n);
+            if (n + 1 < 9) { M16_READ_W(fb ^ 1, t1); m16_wait<NS, NS>(xk[t], wv[fb]); }
             else m16_wait<0, NS>(xk[t], wv[fb]);
             M16_MFMA_XK(t, fb, h);
             __builtin_amdgcn_sched_barrier(0);
@@ -521,17 +535,18 @@ __global__ __launch_bounds__(512, 2) void conv2d_3x3_m16_kernel(ConvM16Args a) {
       } else if (allrows) {            // interior rows: all nine taps, fragments double-buffered across taps
         M16_READ(0, 0);
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-          const int fb = t & 1;
-          if (M16_DMA_SPREAD) M16_DMA_SLOT(t);
-          if (t + 1 < 9) { M16_READ(fb ^ 1, t + 1); m16_wait<2 * NS, NS>(xv[fb], wv[fb]); }
+        for (int n = 0; n < 9; ++n) {
+          const int fb = n & 1, t1 = M16_TAP(n + 1);
+          if (M16_DMA_SPREAD) M16_DMA_SLOT(n);
+          if (n + 1 < 9) { M16_READ(fb ^ 1, t1); m16_wait<2 * NS, NS>(xv[fb], wv[fb]); }
           else m16_wait<0, NS>(xv[fb], wv[fb]);
           M16_MFMA(fb, h);
           __builtin_amdgcn_sched_barrier(0);
         }
       } else {                         // rows near the top / bottom edge: taps of out-of-map source rows are skipped
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
+        for (int n = 0; n < 9; ++n) {
+          const int t = M16_TAP(n);
           if (!rowok[t / 3]) continue;
           M16_READ(0, t);
           m16_wait<0, NS>(xv[0], wv[0]);
@@ -542,6 +557,7 @@ __global__ __launch_bounds__(512, 2) void conv2d_3x3_m16_kernel(ConvM16Args a) {
     }
   }
 #undef M16_READ
+#undef M16_TAP
 #undef M16_MFMA
 #undef M16_DMA_SLOT
 #undef M16_READ_XK
@@ -569,9 +585,8 @@ __global__ __launch_bounds__(512, 2) void conv2d_3x3_m16_kernel(ConvM16Args a) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int o = h * 4 + q;
-        const f32x4 bs4 = *reinterpret_cast<const f32x4*>(bias_s + h * 32 + 8 * q + 4 * g);
         f32x4 v;
-        v.x = acc[h][4 * q + 0] + bs4.x; v.y = acc[h][4 * q + 1] + bs4.y; v.z = acc[h][4 * q + 2] + bs4.z; v.w = acc[h][4 * q + 3] + bs4.w;
+        v.x = acc[h][4 * q + 0]; v.y = acc[h][4 * q + 1]; v.z = acc[h][4 * q + 2]; v.w = acc[h][4 * q + 3];
         if (tabr) {
           const f32x4 tr = *reinterpret_cast<const f32x4*>(tabr + h * 32 + 8 * q + 4 * g), tc = *reinterpret_cast<const f32x4*>(tabc + h * 32 + 8 * q + 4 * g);
           v.x += tr.x + tc.x; v.y += tr.y + tc.y; v.z += tr.z + tc.z; v.w += tr.w + tc.w;
@@ -604,11 +619,9 @@ __global__ __launch_bounds__(512, 2) void conv2d_3x3_m16_kernel(ConvM16Args a) {
 #pragma unroll
       for (int qp = 0; qp < 2; ++qp) {
         const int o = h * 4 + 2 * qp;                 // octets o (q0 = 2 qp) and o + 1
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias_s + h * 32 + 16 * qp + 4 * g);
-        const f32x4 b1 = *reinterpret_cast<const f32x4*>(bias_s + h * 32 + 16 * qp + 8 + 4 * g);
         f32x4 v0, v1;
-        v0.x = acc[h][8 * qp + 0] + b0.x; v0.y = acc[h][8 * qp + 1] + b0.y; v0.z = acc[h][8 * qp + 2] + b0.z; v0.w = acc[h][8 * qp + 3] + b0.w;
-        v1.x = acc[h][8 * qp + 4] + b1.x; v1.y = acc[h][8 * qp + 5] + b1.y; v1.z = acc[h][8 * qp + 6] + b1.z; v1.w = acc[h][8 * qp + 7] + b1.w;
+        v0.x = acc[h][8 * qp + 0]; v0.y = acc[h][8 * qp + 1]; v0.z = acc[h][8 * qp + 2]; v0.w = acc[h][8 * qp + 3];
+        v1.x = acc[h][8 * qp + 4]; v1.y = acc[h][8 * qp + 5]; v1.z = acc[h][8 * qp + 6]; v1.w = acc[h][8 * qp + 7];
         if (tabr) {
           const int co_ = h * 32 + 16 * qp + 4 * g;
           const f32x4 r0 = *reinterpret_cast<const f32x4*>(tabr + co_), c0 = *reinterpret_cast<const f32x4*>(tabc + co_);
