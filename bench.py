@@ -29,8 +29,8 @@ Also measured in the same run, OUTSIDE the timed region, and reported in the sam
   * `roofline_decoder` (N = 1): one Decoder forward (118 Conv2d) at B = 2 under HIP events.
   * `config3` (N = 1): BASELINE configs[2] - HFF-shaped model, batch of 8, bf16 Encoder + fp16-plane Decoders, 2 timed batches,
     roofline of its dominant kernel, parity against the reference rows of G17.
-  * `config5` (N = 1): BASELINE configs[4] - 16 of the 1024 synthetic SVs through orca_amd.sv.sv_screen (the full screen:
-    tools/run_configs.py config5_1024, profiles/r03_config5_1024.json).
+  * `config5` (N = 1): BASELINE configs[4] - 64 of the 1024 synthetic SVs through orca_amd.sv.sv_screen (incremental encoding; 8 of them
+    also as two whole genomepredict calls; the full screen: tools/run_configs.py config5_1024, profiles/r04_config5_1024.json).
   * `cpu_baseline` (N = 1): the oracle (= the torch CPU ops the reference dispatches) on a bounded sample.
 
 Prints ONE JSON line (rank 0).  value = strand-Mb of sequence encoded AND decoded per second over the whole job
@@ -322,27 +322,43 @@ def config3_section(dev):
     return out
 
 
-def config5_section(dev, n_svs=16):
+def config5_section(dev, n_svs=64):
     """BASELINE.json configs[4] on this rank: `n_svs` of the 1024 synthetic structural variants (orca_amd.sv.synth_svs: del / dup / inv,
-    10 kb - 5 Mb) x reference + alternative allele, each a full 32 Mb `genomepredict` (both strands, 6 maps) assembled on the device
-    from a packed 40 Mb chromosome.  Variants are independent: N GPUs take every N-th (replicas, no collective)."""
+    10 kb - 5 Mb) x reference + alternative allele, 6 maps each, from a packed 40 Mb chromosome in HBM.  Incremental screen
+    (orca_amd/sv.py): the chromosome's strands are encoded once per 4 kb phase, a window re-encodes only its ends and junctions, the four
+    strands of a variant are one decoder batch; 8 of the variants are also run as the reference does it - two whole `genomepredict` calls
+    each - for the speed-up and the agreement of the maps.  Variants are independent: N GPUs take every N-th (replicas, no collective)."""
     from orca_amd import engine, orca_models, sv
     h1 = orca_models.H1esc(synthetic_seed=0)
     g = torch.Generator(device=dev).manual_seed(5)
     genome = torch.randint(0, 4, (40_000_000,), device=dev, generator=g, dtype=torch.uint8)
     svs = sv.synth_svs(n_svs + 2, 40_000_000)
-    sv.sv_screen([h1], genome, svs[:2], 40_000_000)      # warm-up: workspace growth, both window shapes
+    sv.sv_screen([h1], genome, svs[:2], 40_000_000, min_uses=1)      # warm-up: workspace growth, both window shapes
     torch.cuda.synchronize(dev)
+    stats = {}
     t0 = time.perf_counter()
-    res = sv.sv_screen([h1], genome, svs[2:], 40_000_000)
+    res = sv.sv_screen([h1], genome, svs[2:], 40_000_000, stats=stats)     # includes the chromosome encodings (4 here)
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
+    n_full = min(8, n_svs)
+    sv.sv_screen([h1], genome, svs[2:3], 40_000_000, incremental=False)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    full = sv.sv_screen([h1], genome, svs[2:2 + n_full], 40_000_000, incremental=False)
+    torch.cuda.synchronize(dev)
+    dt_full = time.perf_counter() - t0
+    diff = max(float(np.abs(res[i][a]["predictions"][0][j] - full[i][a]["predictions"][0][j]).max()) for i in range(n_full) for a in ("ref", "alt") for j in range(6))
     chk = float(sum(float(np.sum(r[a]["predictions"][0][0], dtype=np.float64)) for r in res.values() for a in ("ref", "alt")))
-    out = {"workload": f"{n_svs} of the 1024 synthetic SVs x (reference + alternative allele) x 32 Mb genomepredict (both strands, 6 maps), windows "
-                       "gathered on the device from a packed 40 Mb chromosome", "svs": n_svs, "s_per_sv": round(dt / n_svs, 4),
-           "svs_per_s": round(n_svs / dt, 2), "Mb_per_s": round(n_svs * 2 * 2 * 32 / dt, 1), "projected_1024_svs_s_one_gpu": round(1024 * dt / n_svs, 1),
+    out = {"workload": f"{n_svs} of the 1024 synthetic SVs x (reference + alternative allele) x 6 maps of a 32 Mb window (both strands), from a packed "
+                       "40 Mb chromosome in HBM; incremental screen: chromosome encoded once per strand and 4 kb phase, windows re-encode ends + junctions, "
+                       "ref + alt decoded as one batch of 4 maps per level", "svs": n_svs, "s_per_sv": round(dt / n_svs, 4),
+           "svs_per_s": round(n_svs / dt, 2), "window_Mb_per_s": round(n_svs * 2 * 2 * 32 / dt, 1), "projected_1024_svs_s_one_gpu": round(1024 * dt / n_svs, 1),
+           "encoder_bins_encoded_frac": round(stats["bins_encoded"] / stats["bins_total"], 4), "chromosome_encodings": stats["chromosome_encodings"],
+           "as_the_reference_does_it": {"svs": n_full, "s_per_sv": round(dt_full / n_full, 4), "svs_per_s": round(n_full / dt_full, 2),
+                                        "what": "two whole genomepredict calls per variant (every window through the whole Encoder)"},
+           "speedup": round((dt_full / n_full) / (dt / n_svs), 2), "max_abs_vs_whole_window_encoding": diff,
            "kinds": "".join(v.kind[0] for v in svs[2:]), "level32_maps_checksum": round(chk, 3)}
-    del genome, res, h1
+    del genome, res, full, h1
     engine.get_context(dev).release_workspace()
     torch.cuda.empty_cache()
     return out

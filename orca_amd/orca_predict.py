@@ -333,7 +333,7 @@ def run_cascade(model, encodings, levels, unit, B, reverse_flags, background, zo
 
     encodings: {level: [S*B,128,n]};  unit(level): encoding bins per map pixel at that level;
     background(level, k, start): [S... ] -> log-background tensor [B or 1,1,250,250] for strand k;
-    zoom(level, start, reverse) -> 0..125.  Returns (preds[level_idx] [S*B,1,250,250], starts[k][level_idx])."""
+    zoom(level, start, reverse) -> 0..125 (or one such callable per strand: strands of different windows).  Returns (preds[level_idx] [S*B,1,250,250], starts[k][level_idx])."""
     S = len(reverse_flags)
     starts = [[0] for _ in range(S)]
     zoom_idx = [0] * S
@@ -363,7 +363,7 @@ def run_cascade(model, encodings, levels, unit, B, reverse_flags, background, zo
         if on_level is not None:
             on_level(j, level, [starts[k][j] for k in range(S)])
         for k in range(S):
-            zoom_idx[k] = zoom(level, starts[k][j], reverse_flags[k])
+            zoom_idx[k] = (zoom[k] if isinstance(zoom, (list, tuple)) else zoom)(level, starts[k][j], reverse_flags[k])
             starts[k].append(starts[k][j] + zoom_idx[k] * u)
     return preds, [st[:-1] for st in starts]
 

@@ -14,6 +14,8 @@ from collections import namedtuple
 import numpy as np
 import torch
 
+from . import engine
+
 SV = namedtuple("SV", "kind start end")   # kind in {"del", "dup", "inv"}; half-open [start, end) on the chromosome
 WINDOW = 32_000_000
 
@@ -108,16 +110,242 @@ def assemble_codes(genome_codes, pieces):
     return torch.cat(parts)
 
 
-def sv_screen(models, genome_codes, svs, chrlen, mchr="chrS", rank=0, world=1):
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Incremental encoding (round 4).  The reference pushes every allele window through the whole Encoder (orca_predict.py:1510-1817 build
+# ref / alt windows, :231 encodes each): a screen of 1 024 variants on one chromosome encodes the same bases ~2 000 times - 74 % of
+# the screen's time.  The Encoder is a translation-covariant stack on a 4 kb grid: Encoder bin j of a sequence depends on the bases
+# within RF_BP of the bin only (orca_modules.py:811-927: receptive reach 104 016 bp; the 112 kb halo of :929-980 exists because of it).
+# So the chromosome's two strands are encoded ONCE per 4 kb phase (`ChromEncodings`), and a window of an allele - a list of pieces
+# of the chromosome - takes every bin whose receptive field lies inside ONE piece from there ('+' pieces from the forward strand's
+# encoding, '-' pieces from the reverse complement's); only the bins next to a window end (the reference zero-pads every layer there,
+# orca_modules.py:955-977) or next to a junction between pieces are run through the Encoder (its bin-range form, on the assembled window).
+# ---------------------------------------------------------------------------------------------------------------------------------
+RF_BP = 104_016          # receptive reach of the Encoder beyond a bin, in bases
+RF_BINS = 27             # ... in 4 kb bins (27 * 4000 = 108 000 >= RF_BP)
+BIN = 4000
+
+
+class ChromEncodings:
+    """Encoder outputs of a whole packed chromosome, per strand and 4 kb phase, computed on demand and kept in HBM
+    (128 x chrlen/4000 floats: 5 MB per entry for 40 Mb).  Strand '+', phase p: bins of chrom[p:], bin i = bases [p + 4000 i, ..);
+    strand '-', phase p: bins of revcomp(chrom)[p:] in reverse-complement coordinates (q = chrlen - 1 - forward position)."""
+
+    def __init__(self, net0, codes, max_entries=8):
+        if not (isinstance(codes, torch.Tensor) and codes.dtype == torch.uint8 and codes.dim() == 1):
+            raise ValueError("codes: a [chrlen] uint8 tensor (on the MI355X for an orca_amd Encoder)")
+        self.net0, self.codes, self.C, self.max_entries = net0, codes, int(codes.shape[0]), max_entries
+        self.entries = {}
+        self.builds = 0
+
+    def get(self, strand, phase, build=True):
+        key = (strand, int(phase))
+        e = self.entries.get(key)
+        if e is None and build and len(self.entries) < self.max_entries:
+            nb = (self.C - key[1]) // BIN
+            if nb <= 2 * RF_BINS:
+                return None
+            if strand == "+":
+                e = self.net0.forward_codes(self.codes[None, key[1]: key[1] + nb * BIN], reverse=False)[0]
+            else:
+                e = self.net0.forward_codes(self.codes[None, self.C - key[1] - nb * BIN: self.C - key[1]], reverse=True)[0]
+            self.entries[key] = e
+            self.builds += 1
+        return e
+
+    def lookup(self, strand, coord, nbins, build=True):
+        """[128, nbins] view of the bins starting at strand coordinate ``coord`` (forward position, or reverse-complement coordinate for
+        '-'), or None when no encoding of that phase is held / may be built, or the range touches the RF_BINS bins at an end of the
+        chromosome encoding (those saw the zero padding of the chromosome's ends)."""
+        phase = coord % BIN
+        e = self.get(strand, phase, build)
+        if e is None:
+            return None
+        i0 = (coord - phase) // BIN
+        if i0 < RF_BINS or i0 + nbins > e.shape[1] - RF_BINS:
+            return None
+        return e[:, i0: i0 + nbins]
+
+
+def strand_coord(piece, chrlen):
+    """Strand coordinate of the first base a piece contributes: forward position for '+', reverse-complement coordinate for '-'."""
+    src, ln, strand = piece
+    return src if strand == "+" else chrlen - src - ln
+
+
+def revcomp_pieces(pieces):
+    """The pieces of the reverse complement of a sequence given by ``pieces``."""
+    return [(src, ln, "-" if strand == "+" else "+") for src, ln, strand in reversed(pieces)]
+
+
+def reuse_plan(pieces, chrlen, nbins):
+    """For a sequence of ``nbins`` * 4000 bases given as pieces: [(bin_lo, bin_hi, strand, coord)] - runs of bins whose receptive field
+    lies inside one piece (and off the sequence's ends), with the strand coordinate of bin_lo's first base."""
+    out, o = [], 0
+    L = nbins * BIN
+    for piece in pieces:
+        ln = piece[1]
+        lo = max(-(-(o + RF_BINS * BIN) // BIN), RF_BINS)                          # ceil
+        hi = min((o + ln - RF_BINS * BIN) // BIN, nbins - RF_BINS)                 # exclusive
+        if hi > lo:
+            out.append((lo, hi, piece[2], strand_coord(piece, chrlen) + lo * BIN - o))
+        o += ln
+    if o != L:
+        raise ValueError("pieces do not add up to the window")
+    return out
+
+
+def encode_windows(cache, pieces_list, win_codes, out, merge_gap=2 * RF_BINS, build=True):
+    """Both strands of W allele windows into ``out`` [2W,128,nbins] (window w: row 2w forward, row 2w + 1 reverse complement): bins whose
+    receptive field lies inside one piece are copied from `cache` (ChromEncodings), the rest - window ends, junctions, pieces of a
+    phase that is not held - go through the Encoder's bin-range form on ``win_codes`` [W,L] (the assembled windows).  Bin ranges that
+    several windows have in common (the window ends, as a rule) are ONE batched call.  Returns the number of bins encoded (of 2W * nbins)."""
+    nbins = out.shape[2]
+    C = cache.C
+    W = len(pieces_list)
+    runs = {}                                                           # (reverse, lo, hi) -> [window]
+    for w, pieces in enumerate(pieces_list):
+        for rev, pcs in ((False, pieces), (True, revcomp_pieces(pieces))):
+            row = 2 * w + int(rev)
+            have = []
+            for lo, hi, strand, coord in reuse_plan(pcs, C, nbins):
+                src = cache.lookup(strand, coord, hi - lo, build)
+                if src is not None:
+                    out[row, :, lo:hi].copy_(src)
+                    have.append((lo, hi))
+            # the complement: runs of bins still to encode; runs closer than merge_gap are encoded as one (a call costs ~40 launches)
+            todo, pos = [], 0
+            for lo, hi in have:
+                if lo > pos:
+                    todo.append([pos, lo])
+                pos = hi
+            if pos < nbins:
+                todo.append([pos, nbins])
+            merged = []
+            for r in todo:
+                if merged and r[0] - merged[-1][1] < merge_gap:
+                    merged[-1][1] = r[1]
+                else:
+                    merged.append(r)
+            for lo, hi in merged:
+                runs.setdefault((rev, lo, hi), []).append(w)
+    encoded = 0
+    for (rev, lo, hi), ws in runs.items():
+        if len(ws) == W and W > 1:                                      # every window: the rows of one strand are a strided view of `out`
+            cache.net0.forward_codes(win_codes, reverse=rev, bin_lo=lo, bin_hi=hi, out=out[int(rev)::2, :, lo:hi])
+        else:
+            for w in ws:
+                cache.net0.forward_codes(win_codes[w:w + 1], reverse=rev, bin_lo=lo, bin_hi=hi, out=out[2 * w + int(rev):2 * w + int(rev) + 1, :, lo:hi])
+        encoded += (hi - lo) * len(ws)
+    return encoded
+
+
+def encode_window(cache, pieces, win_codes, out, merge_gap=2 * RF_BINS, build=True):
+    """`encode_windows` for one window: ``win_codes`` [L], ``out`` [2,128,nbins]."""
+    return encode_windows(cache, [pieces], win_codes[None], out, merge_gap, build)
+
+
+def needed_phases(svs, chrlen, length=WINDOW):
+    """{(strand, phase): number of runs that want it} over the windows of ``svs`` - what `sv_screen` builds before the loop."""
+    want = {}
+    nbins = length // BIN
+    for sv in svs:
+        rp, _, _, ap, _, _ = sv_windows(sv, chrlen, length)
+        for pcs in (rp, ap):
+            for p in (pcs, revcomp_pieces(pcs)):
+                for lo, hi, strand, coord in reuse_plan(p, chrlen, nbins):
+                    want[(strand, coord % BIN)] = want.get((strand, coord % BIN), 0) + 1
+    return want
+
+
+def _cascade_windows(model, enc0, params):
+    """Encoder2 + the six decoder levels for W windows whose Encoder outputs are given: ``enc0`` [2W,128,8000] (window w: forward strand
+    in row 2w, reverse complement in row 2w + 1), params[w] = (mpos, wpos).  ONE cascade: every decoder level is a batch of 2W maps.
+    Returns (strand-merged maps [W,6,250,250] on the device, starts[k][6])."""
+    from . import orca_predict as OP
+    W = len(params)
+    flags = [bool(k & 1) for k in range(2 * W)]
+    zooms = [(lambda lv, st, rev, m=params[k // 2][0], w=params[k // 2][1]: OP.zoom_index_32m(lv, st, m, w, rev)) for k in range(2 * W)]
+    bg_cache = {}
+
+    def background(level, k, start):
+        if level not in bg_cache:
+            bg_cache[level] = OP._cached_log_background(model, level, enc0.is_cuda)
+        return bg_cache[level]
+
+    encodings = dict(zip([1, 2, 4, 8, 16, 32], model.net(enc0)))
+    preds, starts = OP.run_cascade(model, encodings, [32, 16, 8, 4, 2, 1], lambda lv: lv, 1, flags, background, zooms, add_1m_level=1)
+    merged = [torch.stack([engine.strand_merge(p[2 * w, 0], p[2 * w + 1, 0]) for p in preds]) for w in range(W)]
+    return torch.stack(merged), starts
+
+
+def _window_outputs(model, merged, starts, params, mchr):
+    """`genomepredict`'s output dict (one model) per window."""
+    levels = [32, 16, 8, 4, 2, 1]
+    host = merged.cpu().numpy()
+    outs = []
+    for w, (mpos, wpos) in enumerate(params):
+        sc = [wpos - 16000000 + s * 4000 for s in starts[2 * w]]
+        outs.append({"predictions": [[host[w, j] for j in range(6)]], "experiments": None, "start_coords": sc,
+                     "end_coords": [int(sc[ii] + 32000000 / 2 ** ii) for ii in range(6)], "chr": mchr, "annos": None,
+                     "normmats": [[model.normmats[ii] for ii in levels]]})
+    return outs
+
+
+def sv_screen(models, genome_codes, svs, chrlen, mchr="chrS", rank=0, world=1, incremental=True, min_uses=3, stats=None):
     """Predict reference and alternative allele (6 maps each, per model) for this rank's share of ``svs``
     (independent windows: replicas, no collective).  genome_codes: [chrlen] uint8 tensor on the MI355X.
-    Returns {sv_index: {"sv": SV, "ref": output_dict, "alt": output_dict}} with genomepredict's output dicts."""
+    Returns {sv_index: {"sv": SV, "ref": output_dict, "alt": output_dict}} with genomepredict's output dicts.
+
+    ``incremental`` (default): the chromosome's strands are encoded once per 4 kb phase that at least ``min_uses`` window runs share
+    (a chromosome encoding costs chrlen / 32 Mb windows' worth of Encoder time), windows reuse those bins (`encode_window`), and the
+    four strands of a variant (ref / alt x forward / reverse) go through Encoder2 and every decoder level as ONE batch.  Variants whose
+    phases are not held fall back to encoding their windows whole - same maps either way (tests/test_gpu_sv_incremental.py).
+    ``incremental=False`` is the reference's cost structure: two independent `genomepredict` calls per variant."""
     from . import dist, orca_predict
     res = {}
-    for i in dist.shard_indices(len(svs), rank, world):
-        sv = svs[i]
-        rp, rw, rm, ap, aw, am = sv_windows(sv, chrlen)
-        ref = orca_predict.genomepredict(assemble_codes(genome_codes, rp)[None], mchr, rm, rw, models=models)
-        alt = orca_predict.genomepredict(assemble_codes(genome_codes, ap)[None], mchr, am, aw, models=models)
-        res[i] = {"sv": sv, "ref": ref, "alt": alt}
+    mine = list(dist.shard_indices(len(svs), rank, world))
+    if not incremental:
+        for i in mine:
+            sv = svs[i]
+            rp, rw, rm, ap, aw, am = sv_windows(sv, chrlen)
+            ref = orca_predict.genomepredict(assemble_codes(genome_codes, rp)[None], mchr, rm, rw, models=models)
+            alt = orca_predict.genomepredict(assemble_codes(genome_codes, ap)[None], mchr, am, aw, models=models)
+            res[i] = {"sv": sv, "ref": ref, "alt": alt}
+        return res
+    models = orca_predict._resolve_models(models, "32M", True)
+    nbins = WINDOW // BIN
+    want = needed_phases([svs[i] for i in mine], chrlen)
+    caches = []
+    with torch.no_grad():
+        for model in models:
+            cache = ChromEncodings(model.net0, genome_codes)
+            for key, n in sorted(want.items(), key=lambda kv: -kv[1]):
+                if n >= min_uses:
+                    cache.get(*key)
+            caches.append(cache)
+        enc0 = torch.empty((4, 128, nbins), dtype=torch.float32, device=genome_codes.device)
+        encoded = 0
+        for i in mine:
+            sv = svs[i]
+            rp, rw, rm, ap, aw, am = sv_windows(sv, chrlen)
+            codes = torch.stack([assemble_codes(genome_codes, rp), assemble_codes(genome_codes, ap)])
+            ref = alt = None
+            for model, cache in zip(models, caches):
+                def forward(model=model, cache=cache):
+                    n = encode_windows(cache, [rp, ap], codes, enc0, build=False)
+                    return _cascade_windows(model, enc0, [(rm, rw), (am, aw)]), n
+
+                (merged, starts), n = engine.run_with_overflow_retry(forward, genome_codes.device)     # ONE fp16-range check per variant
+                encoded += n
+                r, a = _window_outputs(model, merged, starts, [(rm, rw), (am, aw)], mchr)
+                if ref is None:
+                    ref, alt = r, a
+                else:
+                    for o, n in ((ref, r), (alt, a)):
+                        o["predictions"] += n["predictions"]
+                        o["normmats"] += n["normmats"]
+            res[i] = {"sv": sv, "ref": ref, "alt": alt}
+    if stats is not None:
+        stats.update({"bins_encoded": encoded, "bins_total": len(mine) * len(models) * 4 * nbins,
+                      "chromosome_encodings": sum(c.builds for c in caches)})
     return res

@@ -160,8 +160,10 @@ def test_sv_screen_packed_genome(cuda):
     genome = torch.randint(0, 4, (chrlen,), device=cuda, generator=gen, dtype=torch.uint8)
     genome[1_000_000:1_000_400] = 4                                 # an N run
     svs = [sv.SV("inv", 20_000_000, 20_400_000), sv.SV("del", 12_000_000, 12_100_000)]
-    res = sv.sv_screen([model], genome, svs, chrlen)
-    assert sorted(res) == [0, 1]
+    res = sv.sv_screen([model], genome, svs, chrlen, incremental=False)      # whole windows through the Encoder, as the reference does
+    inc = sv.sv_screen([model], genome, svs, chrlen, min_uses=1)              # the default: incremental (tests/test_gpu_sv_incremental.py)
+    assert sorted(res) == [0, 1] == sorted(inc)
+    assert max(maxabs(a, b) for i in res for al in ("ref", "alt") for a, b in zip(res[i][al]["predictions"][0], inc[i][al]["predictions"][0])) < 2e-5
     assert sorted(sv.sv_screen([model], genome, svs, chrlen, rank=1, world=2)) == [1]
     for i, r in res.items():
         for allele in ("ref", "alt"):

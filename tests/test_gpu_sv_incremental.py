@@ -1,0 +1,69 @@
+"""The incremental SV screen on the MI355X (orca_amd/sv.py, BASELINE configs[4]): allele windows assembled from chromosome-level Encoder
+outputs + locally encoded ends / junctions, ref and alt decoded as one batch - against the reference's cost structure (two whole
+`genomepredict` calls per variant, `incremental=False`) on the same variants."""
+import numpy as np
+import pytest
+import torch
+
+from orca_amd import orca_models, sv
+
+pytestmark = pytest.mark.gpu
+CHR = 40_000_000
+
+
+@pytest.fixture(scope="module")
+def setup(cuda):
+    g = torch.Generator(device=cuda).manual_seed(11)
+    genome = torch.randint(0, 4, (CHR,), device=cuda, generator=g, dtype=torch.uint8)
+    genome[7_000_000:7_003_000] = 4                                     # an N run inside the windows
+    return orca_models.H1esc(synthetic_seed=0), genome
+
+
+VARIANTS = [sv.SV("del", 18_000_000, 19_200_000), sv.SV("dup", 21_004_000, 21_500_000), sv.SV("inv", 15_000_000, 18_000_000),
+            sv.SV("inv", 20_000_000, 20_012_000), sv.SV("del", 17_001_234, 17_803_210)]
+
+
+def test_window_encodings_equal_whole_encodings(setup):
+    """encode_window == the Encoder on the assembled window.  Not bit for bit: the short bin-range calls run other kernel instantiations
+    than a 32 Mb / 40 Mb sequence (tile shapes chosen by length: another summation order) - measured max-abs 2.3e-6 on encodings of
+    range 0..8; the bound here is 1e-5, an order below what the 1e-4 parity bar of the maps needs."""
+    model, genome = setup
+    cache = sv.ChromEncodings(model.net0, genome, max_entries=16)
+    for v in VARIANTS:
+        rp, rw, rm, ap, aw, am = sv.sv_windows(v, CHR)
+        for pieces in (rp, ap):
+            w = sv.assemble_codes(genome, pieces)
+            whole = torch.cat([model.net0.forward_codes(w[None], reverse=False), model.net0.forward_codes(w[None], reverse=True)], dim=0)
+            out = torch.full((2, 128, 8000), float("nan"), device=genome.device)
+            n = sv.encode_window(cache, pieces, w, out)
+            assert n < 2 * 8000 // 10, (v, n)
+            assert float((out - whole).abs().max()) <= 1e-5, v
+
+
+def test_screen_incremental_equals_two_genomepredict_calls(setup):
+    model, genome = setup
+    stats = {}
+    inc = sv.sv_screen([model], genome, VARIANTS, CHR, min_uses=1, stats=stats)
+    full = sv.sv_screen([model], genome, VARIANTS, CHR, incremental=False)
+    assert stats["bins_encoded"] < 0.1 * stats["bins_total"] and stats["chromosome_encodings"] >= 4
+    for i in range(len(VARIANTS)):
+        for allele in ("ref", "alt"):
+            a, b = inc[i][allele], full[i][allele]
+            assert a["start_coords"] == b["start_coords"] and a["end_coords"] == b["end_coords"] and a["chr"] == b["chr"]
+            for j in range(6):
+                assert float(np.abs(a["predictions"][0][j] - b["predictions"][0][j]).max()) <= 2e-5, (VARIANTS[i], allele, j)
+
+
+def test_screen_falls_back_when_phases_are_not_held(setup):
+    """A lone variant off the 4 kb grid does not justify chromosome encodings of its phases (min_uses): its windows are encoded whole -
+    same maps."""
+    model, genome = setup
+    v = [VARIANTS[4]]
+    stats = {}
+    inc = sv.sv_screen([model], genome, v, CHR, min_uses=100, stats=stats)
+    full = sv.sv_screen([model], genome, v, CHR, incremental=False)
+    assert stats["chromosome_encodings"] == 0 and stats["bins_encoded"] == stats["bins_total"]
+    for allele in ("ref", "alt"):
+        for j in range(6):
+            # (not 0: the four strands of a variant are 32 000 Encoder2 positions - its split-operand kernels - where a window's two run the exact-fp32 ones)
+            assert float(np.abs(inc[0][allele]["predictions"][0][j] - full[0][allele]["predictions"][0][j]).max()) <= 2e-5
