@@ -111,7 +111,47 @@ def cpu_baseline(seed):
             "t_encoder_sample_s": round(t_enc, 2), "t_decoders_s": round(t_rest, 2)}
 
 
-def sharded_256mb(args, rank, world, dev, dist):
+XGMI_LINK_GB_S, XGMI_LINKS = 153.0, 7     # MI355X: 7 point-to-point xGMI links per GPU
+
+
+def make_comm(args, rank, world, dev, dist):
+    """The RCCL communicator of the C ABI (orca_comm_init_rank / orca_allgather) for BOTH sharded sections, or - together, on every rank -
+    the torch.distributed fall-back.  Returns (comm or None, description)."""
+    from orca_amd import dist as odist
+    if world == 1:
+        return None, "none (single rank)"
+    collective = f"torch.distributed all_gather_into_tensor ({'RCCL' if dist.get_backend() == 'nccl' else dist.get_backend()})"
+    if args.torch_collective:
+        return None, collective
+    ok, comm = 1, None
+    try:
+        comm = odist.AbiComm(dev)
+    except Exception as e:      # fall back together (see below)
+        ok = 0
+        if rank == 0:
+            print(f"bench: C-ABI RCCL communicator unavailable ({e}); using torch.distributed", file=sys.stderr)
+    t = torch.tensor([ok], dtype=torch.int32, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    if int(t.item()) == 1:
+        return comm, "RCCL all-gather through the C ABI (orca_comm_init_rank / orca_allgather)"
+    if comm is not None:
+        comm.close()
+    return None, collective
+
+
+def section_roofline(enc_strand_mb_per_rank, enc_ms, gather_bytes_received, gather_ms):
+    """Per-rank Encoder rate against the 16-bit MFMA peak and the all-gather's receive rate against xGMI, for a sharded section."""
+    tflop = ENC_FLOP_PER_BP * enc_strand_mb_per_rank * 1e6 / 1e12
+    out = {"encoder": {"bound": "mfma", "achieved": round(tflop / (enc_ms * 1e-3), 1), "peak": PEAK_16BIT_MFMA_TFLOPS, "unit": "TFLOP/s",
+                       "frac": round(tflop / (enc_ms * 1e-3) / PEAK_16BIT_MFMA_TFLOPS, 4), "algorithmic_tflop_per_rank": round(tflop, 2)}}
+    if gather_bytes_received > 0 and gather_ms > 0:
+        gbs = gather_bytes_received / (gather_ms * 1e-3) / 1e9
+        out["allgather"] = {"bound": "xgmi", "achieved": round(gbs, 1), "unit": "GB/s received per rank", "bytes_received_per_rank": int(gather_bytes_received),
+                            "peak_one_link": XGMI_LINK_GB_S, "peak_all_links": XGMI_LINK_GB_S * XGMI_LINKS, "frac_of_all_links": round(gbs / (XGMI_LINK_GB_S * XGMI_LINKS), 4)}
+    return out
+
+
+def sharded_256mb(args, rank, world, dev, dist, comm=None, collective="none (single rank)"):
     """BASELINE config 4 / north star: the 256 Mb model with the Encoder's bins sharded over the ranks."""
     from orca_amd import dist as odist, engine, orca_models, orca_predict, synth
     L256 = 256_000_000
@@ -128,23 +168,6 @@ def sharded_256mb(args, rank, world, dev, dist):
         full = torch.from_numpy(host_codes).to(dev)
         wins = [full, full]
     del host_codes
-    comm, collective = None, "none (single rank)"
-    if world > 1:
-        collective = f"torch.distributed all_gather_into_tensor ({'RCCL' if dist.get_backend() == 'nccl' else dist.get_backend()})"
-        if not args.torch_collective:
-            ok = 1
-            try:
-                comm = odist.AbiComm(dev)
-            except Exception as e:      # fall back together (see below)
-                ok, comm = 0, None
-                if rank == 0:
-                    print(f"bench: C-ABI RCCL communicator unavailable ({e}); using torch.distributed", file=sys.stderr)
-            t = torch.tensor([ok], dtype=torch.int32, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MIN)
-            if int(t.item()) == 1:
-                collective = "RCCL all-gather through the C ABI (orca_comm_init_rank / orca_allgather)"
-            else:
-                comm = None
     enc = odist.ShardedEncoder(model.net0, comm=comm)
     chrlen = 138_368_000
     # the 8000 x 8000 float64 background resident in HBM: per-level, per-strand block means + log + reverse-strand flip run on the
@@ -213,9 +236,25 @@ def sharded_256mb(args, rank, world, dev, dist):
                   "map_max_abs_per_level": [round(e, 8) for e in m_err], "map_pearson_min": round(min(m_r), 9), "tolerance": 1e-4,
                   "ok": bool(max(e_err + m_err) < 1e-4)}
     last.clear()
-    if comm is not None:
-        comm.close()
     ms = el / args.sharded_steps * 1e3
+    # the N = 1 job inside this N-rank run (every rank runs it alone, no collective): what `efficiency_vs_n1` divides by
+    n1_ms = ms
+    if world > 1:
+        full = torch.from_numpy(synth.synth_base_codes(L256, seed=2)[None]).to(dev)
+
+        def one_local():
+            e0 = torch.cat([enc._local(lambda: model.net0.forward_codes(full, reverse=False)), enc._local(lambda: model.net0.forward_codes(full, reverse=True))], dim=0)
+            return odist.strand_parallel_cascade_256m(model, e0, mpos, wpos, chrlen, de, local_only=True)
+        one_local()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        one_local()
+        torch.cuda.synchronize(dev)
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        n1_ms = float(t[0]) * 1e3
+        del full
+    recv = 2 * (world - 1) * 128 * (-(-total_bins // world)) * 4 if world > 1 else 0
     return {"workload": "H1esc_256M-shaped model, one random 256 Mb sequence (replicated on every rank as 1 byte/base), both strands: Encoder bins "
                         f"sharded {total_bins}/{world} per rank (112 kb input halo, orca_modules.py:955-977), one all-gather of [1,128,{-(-total_bins // world)}] fp32 "
                         "per rank and strand, then Encoder2(64000 bins) -> Encoder3 -> 4 Decoders: both strands on the one rank at N = 1, one strand per rank parity at N > 1 "
@@ -223,7 +262,8 @@ def sharded_256mb(args, rank, world, dev, dist):
             "n_gpus": world, "steps": args.sharded_steps, "scaling": "strong", "collective": collective,
             "ms_per_step": round(ms, 2), "Mb_per_s": round(2 * 256 / (ms * 1e-3), 1),
             "encoder_ms_per_rank_max": round(float(parts[0]), 2), "allgather_ms_max": round(float(parts[1]), 3), "tail_ms_max": round(float(parts[2]), 2),
-            "encoder_Mb_per_s": round(2 * 256 / (float(parts[0]) * 1e-3), 1), "maps_checksum": round(chk, 4), "parity": parity,
+            "encoder_Mb_per_s": round(2 * 256 / (float(parts[0]) * 1e-3), 1), "n1_ms_same_run": round(n1_ms, 2), "efficiency_vs_n1": round(n1_ms / (world * ms), 4),
+            "roofline": section_roofline(2 * 256 / world, float(parts[0]), recv, float(parts[1])), "maps_checksum": round(chk, 4), "parity": parity,
             "bins_this_rank": [int(lo), int(hi)], "sequence_bytes_on_this_rank": int(sum(w.codes.numel() if isinstance(w, engine.CodeWindow) else w.numel() for w in (wins if world > 1 else wins[:1])))}
 
 
@@ -364,25 +404,33 @@ def config5_section(dev, n_svs=64):
     return out
 
 
-def sharded_32mb(args, rank, world, dev, dist, comm):
-    """Strong scaling of the HEADLINE workload (one 32 Mb window, both strands, H1-ESC-shaped model): strand split x Encoder bin shards
-    (dist.strand_bin_sharded_32m: rank parity = strand, world/2 bin shards per strand, ONE all-gather of the encodings, the two strands'
-    tails on ranks 0 / 1 - from 4 ranks on their independent `+ denet_1_pt` term on ranks 2 / 3 -, ONE all-gather of the maps).  N = 1: both
-    strands here.  Needs an even N."""
+def sharded_32mb(args, rank, world, dev, dist, comm, collective, n_models=1):
+    """Strong scaling of the HEADLINE workload (one 32 Mb window, both strands, H1-ESC-shaped model) as ONE job (dist.units_sharded_32m):
+    units = (model, strand) - independent until the strand merge -, a unit's Encoder sharded further by bins, ONE all-gather of the
+    encodings, the units' tails one per rank (from 2 x units ranks on their independent `+ denet_1_pt` term on the next ranks), ONE
+    all-gather of the maps.  n_models = 2: the reference's default call (orca_predict.py:231, models=["h1esc","hff"]): four independent
+    tails, half the serial fraction per model from 4 ranks on.  N = 1: everything here."""
     from orca_amd import dist as odist, engine, orca_models, synth
-    if world > 1 and world % 2:
-        return {"skipped": f"needs an even number of ranks, got {world}"}
-    model = orca_models.H1esc(synthetic_seed=0)
+    U = 2 * n_models
+    if world > 1 and (world % U if world >= U else U % world):
+        return {"skipped": f"{U} (model, strand) units need a multiple or a divisor of {U} ranks, got {world}"}
+    models = [orca_models.H1esc(synthetic_seed=0)] + ([orca_models.Hff(synthetic_seed=1)] if n_models == 2 else [])
     host_codes = synth.synth_base_codes(L_BP, seed=1)[None]                               # = the replica-mode sequence of rank 0 (G8's)
     total = engine.encoder_num_bins(L_BP)
+    full = None
     if world > 1:
-        st, lo, hi = odist.strand_bin_plan(total, rank, world)[0]
-        b0, b1 = engine.code_window_range(L_BP, lo, hi, reverse=bool(st))
-        codes = engine.CodeWindow(torch.from_numpy(np.ascontiguousarray(host_codes[:, b0:b1])).to(dev), b0, L_BP)
+        plan = odist.unit_plan(U, total, rank, world)[0]
+        if len(plan) == 1:          # a rank keeps only the bases its bins read (+- 112 kb)
+            u, lo, hi = plan[0]
+            b0, b1 = engine.code_window_range(L_BP, lo, hi, reverse=bool(u & 1))
+            codes = engine.CodeWindow(torch.from_numpy(np.ascontiguousarray(host_codes[:, b0:b1])).to(dev), b0, L_BP)
+        else:
+            codes = torch.from_numpy(host_codes).to(dev)
+        full = codes if not isinstance(codes, engine.CodeWindow) else torch.from_numpy(host_codes).to(dev)
     else:
         codes = torch.from_numpy(host_codes).to(dev)
     del host_codes
-    distencs = {lv: torch.log(torch.from_numpy(model.normmats[lv][None, None].astype(np.float32))).to(dev) for lv in model.levels}
+    distencs = [{lv: torch.log(torch.from_numpy(m.normmats[lv][None, None].astype(np.float32))).to(dev) for lv in m.levels} for m in models]
     mpos, wpos = L_BP // 2 + 1234567, L_BP // 2
 
     def sync():
@@ -391,28 +439,50 @@ def sharded_32mb(args, rank, world, dev, dist, comm):
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    for _ in range(2):
-        outs = odist.strand_bin_sharded_32m(model, codes, mpos, wpos, distencs, comm=comm)
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.sharded_steps * 2):
-        outs = odist.strand_bin_sharded_32m(model, codes, mpos, wpos, distencs, comm=comm)
-    sync()
-    el = (time.perf_counter() - t0) / (args.sharded_steps * 2)
-    if dist is not None:
-        t = torch.tensor([el], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t[0])
-    out = {"workload": "the headline workload as ONE job: H1-ESC 32Mb model, one random 32 Mb sequence, both strands - strand split (rank parity) x "
-                       f"{max(1, world // 2)} Encoder bin shard(s) per strand, one all-gather of the [1,128,{-(-total // max(1, world // 2))}] encodings, the strands' tails on "
-                       "ranks 0 / 1, one all-gather of the [6,1,250,250] maps, strand merge on every rank",
-           "n_gpus": world, "scaling": "strong", "steps": args.sharded_steps * 2, "ms_per_step": round(el * 1e3, 3), "Mb_per_s": round(2 * 32 / el, 1)}
+    def timed(fn, steps):
+        fn(None)
+        fn(None)
+        sync()
+        phases = np.zeros(4)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            marks = []
+            outs = fn(marks)
+            torch.cuda.synchronize(dev)
+            ev = dict(marks)
+            phases += [ev["start"].elapsed_time(ev["encode"]), ev["encode"].elapsed_time(ev["gather"]), ev["gather"].elapsed_time(ev["tails"]),
+                       ev["tails"].elapsed_time(ev["maps"])]
+        sync()
+        el = (time.perf_counter() - t0) / steps
+        t = torch.tensor([el] + list(phases / steps), dtype=torch.float64, device=dev)
+        if dist is not None:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return outs, float(t[0]), t[1:].cpu().numpy()
+
+    steps = args.sharded_steps * 2
+    outs, el, ph = timed(lambda marks: odist.units_sharded_32m(models, codes, mpos, wpos, distencs, comm=comm, marks=marks), steps)
+    n1 = el
+    if world > 1:       # the N = 1 job inside this run (every rank alone, no collective)
+        _, n1, _ = timed(lambda marks: odist.units_sharded_32m(models, full, mpos, wpos, distencs, local_only=True, marks=marks), 2)
+    shards = max(1, world // U)
+    width = -(-total // shards)
+    units_here = max(1, U // world)
+    recv = (world - 1) * units_here * 128 * width * 4 if world > 1 else 0
+    out = {"workload": f"ONE job: {n_models} H1-ESC-shaped 32Mb model(s), one random 32 Mb sequence, both strands - {U} (model, strand) units x {shards} Encoder bin "
+                       f"shard(s) per unit, one all-gather of the [1,128,{width}] encodings, the units' tails one per rank, one all-gather of the [6,1,250,250] maps, "
+                       "strand merge on every rank", "n_gpus": world, "models": n_models, "scaling": "strong", "collective": collective, "steps": steps,
+           "ms_per_step": round(el * 1e3, 3), "Mb_per_s": round(n_models * 2 * 32 / el, 1),
+           "encoder_ms_per_rank_max": round(float(ph[0]), 3), "allgather_ms_max": round(float(ph[1]), 3), "tail_ms_max": round(float(ph[2]), 3),
+           "map_gather_ms_max": round(float(ph[3]), 3), "n1_ms_same_run": round(n1 * 1e3, 3), "efficiency_vs_n1": round(n1 / (world * el), 4),
+           "roofline": section_roofline(n_models * 2 * 32 / world, float(ph[0]), recv, float(ph[1])),
+           "maps_checksum": round(float(sum(float(o.double().sum()) for mo in outs for o in mo)), 4)}
     g8 = os.path.join(ROOT, "tests", "golden", "G8_full32m.npz")
     if rank == 0 and os.path.exists(g8):
         g = np.load(g8)
-        errs = [float(np.abs(o[0].cpu().numpy().astype(np.float64) - g[f"pred_{j}"]).max()) for j, o in enumerate(outs)]
-        out["parity"] = {"against": "tests/golden/G8_full32m.npz (the reference's genomepredict on this sequence)", "max_abs_per_level": [round(e, 8) for e in errs],
+        errs = [float(np.abs(o[0].cpu().numpy().astype(np.float64) - g[f"pred_{j}"]).max()) for j, o in enumerate(outs[0])]
+        out["parity"] = {"against": "tests/golden/G8_full32m.npz (the reference's genomepredict on this sequence; model 0)", "max_abs_per_level": [round(e, 8) for e in errs],
                          "tolerance": 1e-4, "ok": bool(max(errs) < 1e-4)}
+    del models, outs
     engine.get_context(dev).release_workspace()
     torch.cuda.empty_cache()
     return out
@@ -660,14 +730,24 @@ def main():
         dog.daemon = True
         dog.start()
     if not args.no_sharded and Lbp == L_BP:
+        comm, collective = None, "none (single rank)"
         try:
-            res["sharded_256mb"] = sharded_256mb(args, rank, world, dev, dist)
-        except Exception as e:      # reported, not fatal: the ranks may be out of step now, the watchdog covers the final barrier
-            res["sharded_256mb"] = {"error": f"{type(e).__name__}: {e}", "rccl_log_tail": rccl_log_tail() if world > 1 else ""}
-        try:
-            res["sharded_32mb"] = sharded_32mb(args, rank, world, dev, dist, None)
+            comm, collective = make_comm(args, rank, world, dev, dist)
         except Exception as e:
-            res["sharded_32mb"] = {"error": f"{type(e).__name__}: {e}", "rccl_log_tail": rccl_log_tail() if world > 1 else ""}
+            res["sharded_comm_error"] = f"{type(e).__name__}: {e}"
+        for name, fn in (("sharded_256mb", lambda: sharded_256mb(args, rank, world, dev, dist, comm, collective)),
+                         ("sharded_32mb", lambda: sharded_32mb(args, rank, world, dev, dist, comm, collective, 1)),
+                         ("sharded_32mb_two_models", lambda: sharded_32mb(args, rank, world, dev, dist, comm, collective, 2))):
+            try:
+                res[name] = fn()
+            except Exception as e:      # reported, not fatal: the ranks may be out of step now, the watchdog covers the rest
+                res[name] = {"error": f"{type(e).__name__}: {e}", "rccl_log_tail": rccl_log_tail() if world > 1 else ""}
+        if comm is not None:
+            comm.close()
+        res["strong_scaling"] = {k: {f: res[k].get(f) for f in ("n_gpus", "ms_per_step", "Mb_per_s", "n1_ms_same_run", "efficiency_vs_n1")}
+                                 for k in ("sharded_256mb", "sharded_32mb", "sharded_32mb_two_models") if isinstance(res.get(k), dict) and "ms_per_step" in res[k]}
+        res["strong_scaling"]["note"] = ("`value` above is replica mode (independent 32 Mb windows per rank, weak scaling, no collective); these are the north star's "
+                                         "one-job curves: efficiency_vs_n1 = the N = 1 time measured in THIS run / (N x this time)")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(0)
         res["speedup_vs_cpu"] = round(res["value"] / world / res["cpu_baseline"]["value"], 1)

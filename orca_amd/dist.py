@@ -92,6 +92,11 @@ class AbiComm:
         self.close()
 
     def __del__(self):
+        # Prefer close() / the context manager.  At interpreter shutdown the HIP context, the stream or the peer ranks may be gone already and
+        # ncclCommDestroy can hang or crash there: the handle is then left to the process exit.
+        import sys
+        if sys is None or sys.is_finalizing():
+            return
         try:
             self.close()
         except Exception:
@@ -190,118 +195,198 @@ def strand_tail_256m(model, enc0, strand, mpos, wpos, chrlen, normmat):
     return torch.stack([p[0] for p in preds]).contiguous()
 
 
-def strand_parallel_cascade_256m(model, enc0, mpos, wpos, chrlen, normmat, group=None, comm=None):
+def strand_parallel_cascade_256m(model, enc0, mpos, wpos, chrlen, normmat, group=None, comm=None, local_only=False):
     """The part of genomepredict_256Mb after the Encoder (orca_predict.py:675-838 + the strand merge :866-877), with the
     two strands' tails on different ranks: the strands are independent until the merge, so rank 0 runs the forward
     strand, rank 1 the reverse strand (the four levels of a strand are one dependent chain: further ranks only receive),
     and ONE all-gather of the [4,C,250,250] maps (1 MB per rank) replaces the second half of the replicated work.  Returns the four merged [C,250,250] maps, identical on every rank.
     With one rank (or no process group) both strands run here, batched, exactly as cascade_256m does."""
     from . import engine, orca_predict
-    if comm is not None:
-        world, rank = comm.world, comm.rank
-    elif dist.is_initialized():
-        world, rank = dist.get_world_size(group), dist.get_rank(group)
-    else:
-        world, rank = 1, 0
+    world, rank = (1, 0) if local_only else _world_rank(group, comm)
     B = enc0.shape[0] // 2
     if world == 1:
         preds, _ = orca_predict.cascade_256m(model, enc0, mpos, wpos, chrlen, normmat)
         fwd, rev = torch.stack([p[0] for p in preds]), torch.stack([p[B] for p in preds])
     else:
+        C = getattr(model.denets[256], "num_2d", 1) if hasattr(model, "denets") else 1
+        err = None
         if rank < 2:
-            slab = strand_tail_256m(model, enc0, rank, mpos, wpos, chrlen, normmat)
+            try:
+                slab = strand_tail_256m(model, enc0, rank, mpos, wpos, chrlen, normmat)
+            except Exception as e:      # stay in step with the other ranks (they would block in the all-gather); all raise after it
+                err, slab = e, torch.full((4, C, 250, 250), float("nan"), dtype=torch.float32, device=enc0.device)
         else:       # the tail is one dependent chain per strand: ranks 2.. have nothing to add and only receive the maps
-            C = getattr(model.denets[256], "num_2d", 1) if hasattr(model, "denets") else 1
             slab = torch.zeros((4, C, 250, 250), dtype=torch.float32, device=enc0.device)
-        if comm is not None:
-            allm = comm.all_gather(slab)
-        else:
-            allm = torch.empty((world,) + tuple(slab.shape), dtype=slab.dtype, device=slab.device)
-            dist.all_gather_into_tensor(allm.view(-1), slab.view(-1), group=group)
+        allm = _all_gather(slab, world, group, comm)
+        bad = bool(torch.isnan(allm[:2]).any())
+        if err is not None:
+            raise err
+        if bad:
+            raise RuntimeError("strand_parallel_cascade_256m: another rank failed in its strand's tail (its maps arrived as NaN)")
         fwd, rev = allm[0], allm[1]      # ranks 0 and 1 hold one strand each; the other ranks' slabs are placeholders
     return [torch.stack([engine.strand_merge(fwd[j, c], rev[j, c]) for c in range(fwd.shape[1])]) for j in range(fwd.shape[0])]
 
 
-def strand_bin_plan(total_bins, rank, world):
-    """Work split of ONE 32 Mb window over `world` ranks (strong scaling): the two strands first (rank parity), then
-    contiguous bin ranges of the strand's Encoder (world/2 shards per strand; world = 1: both strands, all bins).
-    Returns [(strand, bin_lo, bin_hi)] this rank encodes.  world must be 1 or even."""
+def _world_rank(group, comm):
+    if comm is not None:
+        return comm.world, comm.rank
+    if dist.is_initialized():
+        return dist.get_world_size(group), dist.get_rank(group)
+    return 1, 0
+
+
+def _all_gather(slab, world, group, comm):
+    """[world, *slab.shape] (rank-major) through the C ABI's RCCL communicator or torch.distributed."""
+    slab = slab.contiguous()
+    if comm is not None:
+        return comm.all_gather(slab)
+    out = torch.empty((world,) + tuple(slab.shape), dtype=slab.dtype, device=slab.device)
+    dist.all_gather_into_tensor(out.view(-1), slab.view(-1), group=group)
+    return out
+
+
+def unit_plan(n_units, total_bins, rank, world):
+    """Work split of ONE 32 Mb window over `world` ranks (strong scaling).  Units = (model, strand) pairs - independent
+    until the strand merge; a unit's Encoder shards further by bins.  world >= n_units: unit = rank % n_units, bin shard rank // n_units of
+    world // n_units; world < n_units: rank r takes units r, r + world, .. whole.  Returns ([(unit, bin_lo, bin_hi)] to encode,
+    [unit] whose tail - Encoder2 -> six Decoders, one dependent chain - runs here, [unit] whose `+ denet_1_pt` term runs here: from
+    2 x n_units ranks on the otherwise idle ranks n_units .. 2 n_units - 1 take it)."""
     if world == 1:
-        return [(0, 0, total_bins), (1, 0, total_bins)]
-    if world % 2:
+        return [(u, 0, total_bins) for u in range(n_units)], list(range(n_units)), []
+    if world >= n_units:
+        if world % n_units:
+            raise ValueError(f"{n_units} (model, strand) units need a multiple of {n_units} ranks (or a divisor), got {world}")
+        lo, hi = bin_range(total_bins, rank // n_units, world // n_units)
+        offload = world >= 2 * n_units
+        return [(rank % n_units, lo, hi)], ([rank] if rank < n_units else []), ([rank - n_units] if offload and n_units <= rank < 2 * n_units else [])
+    if n_units % world:
+        raise ValueError(f"{n_units} (model, strand) units need a divisor of {n_units} as rank count (or a multiple), got {world}")
+    mine = list(range(rank, n_units, world))
+    return [(u, 0, total_bins) for u in mine], mine, []
+
+
+def units_sharded_32m(models, codes, mpos, wpos, distencs=None, group=None, comm=None, local_only=False, marks=None):
+    """`genomepredict`'s device work for ONE 32 Mb window and SEVERAL models (the reference's default call has two,
+    orca_predict.py:231 models=["h1esc","hff"]) shared by all ranks: the units (model, strand) are independent until the strand merge
+    (`unit_plan`).  ONE all-gather assembles every unit's [B,128,8000] encoding on every rank, the tails run one unit per rank (four
+    independent tails for two models: half the serial fraction per model of the one-model job from 4 ranks on), ONE all-gather of the
+    [6,C,250,250] maps precedes the strand merges.  ``codes``: [B,L] packed bases (or an engine.CodeWindow holding this rank's share).
+    Returns per model the six merged [C,250,250] maps (on every rank).  Replaces nn.DataParallel around the sub-networks
+    (orca_models.py:44-50), which only splits batches.
+
+    A rank whose local work raises does NOT leave the others blocked in the collectives: it contributes NaN slabs, every rank finds them
+    after the map gather, and all raise together.
+    ``local_only``: run the whole job on this rank whatever the process group (the N = 1 time inside an N-rank bench run);
+    ``marks``: a list that receives (phase, torch.cuda.Event) after "encode", "gather", "tails", "maps" (bench.py's per-phase times)."""
+    from . import engine, orca_predict
+    world, rank = (1, 0) if local_only else _world_rank(group, comm)
+    M, U = len(models), 2 * len(models)
+
+    def mark(name):
+        if marks is not None and codes.device.type == "cuda":
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            marks.append((name, ev))
+
+    B, L = codes.shape
+    total = engine.encoder_num_bins(L)
+    enc_plan, tail_units, one_m_units = unit_plan(U, total, rank, world)
+    shards = max(1, world // U)
+    width = -(-total // shards)
+    dev = codes.device
+    err = None
+
+    def local(u, lo, hi):
+        with engine.immediate_overflow_guard():      # a rank's fp16-range retry happens before the collective, never after it on one rank only
+            return models[u // 2].net0.forward_codes(codes, reverse=bool(u & 1), bin_lo=lo, bin_hi=hi)
+
+    mark("start")
+    if world == 1:
+        enc = [local(u, 0, total) for u in range(U)]
+        mark("encode")
+        mark("gather")
+    else:
+        slab = torch.zeros((len(enc_plan), B, 128, width), dtype=torch.float32, device=dev)
+        try:
+            for i, (u, lo, hi) in enumerate(enc_plan):
+                slab[i, :, :, : hi - lo] = local(u, lo, hi)
+        except Exception as e:                       # stay in step with the other ranks; raise after the last collective
+            err = e
+            slab.fill_(float("nan"))
+        mark("encode")
+        gathered = _all_gather(slab, world, group, comm)          # [world, units per rank, B, 128, width]
+        mark("gather")
+        enc = []
+        for u in range(U):
+            if world >= U:
+                pieces = []
+                for sh in range(shards):
+                    rlo, rhi = bin_range(total, sh, shards)
+                    pieces.append(gathered[sh * U + u, 0, :, :, : rhi - rlo])
+                enc.append(torch.cat(pieces, dim=2))
+            else:
+                enc.append(gathered[u % world, u // world])
+    C = getattr(models[0].denets[32], "num_2d", 1)
+
+    def tail(u, with_1m):
+        preds, _ = orca_predict.cascade_32m_from_enc(models[u // 2], enc[u], mpos, wpos, [bool(u & 1)], distencs[u // 2] if isinstance(distencs, (list, tuple)) else distencs,
+                                                     with_1m=with_1m)
+        return torch.stack([p[0] for p in preds])
+
+    if world == 1:
+        maps = []
+        for m in range(M):           # both strands of a model as one batch, exactly as cascade_32m does
+            preds, _ = orca_predict.cascade_32m_from_enc(models[m], torch.cat([enc[2 * m], enc[2 * m + 1]], dim=0), mpos, wpos, [False, True],
+                                                         distencs[m] if isinstance(distencs, (list, tuple)) else distencs)
+            maps += [torch.stack([p[0] for p in preds]), torch.stack([p[B] for p in preds])]
+        mark("tails")
+        mark("maps")
+    else:
+        offload = world >= 2 * U
+        per = max(1, -(-U // world))
+        slab = torch.zeros((per, 6, C, 250, 250), dtype=torch.float32, device=dev)
+        try:
+            if err is None:
+                for i, u in enumerate(tail_units):
+                    slab[i] = tail(u, not offload)
+                for u in one_m_units:
+                    slab[0, 5] = orca_predict.denet1m_32m_from_enc(models[u // 2], enc[u], mpos, wpos, [bool(u & 1)])[0]
+        except Exception as e:
+            err = e
+        if err is not None:
+            slab.fill_(float("nan"))
+        mark("tails")
+        allm = _all_gather(slab, world, group, comm)              # [world, per, 6, C, 250, 250]
+        mark("maps")
+        bad = bool(torch.isnan(allm).any())                      # (the maps leave for the host next anyway)
+        if err is not None:
+            raise err
+        if bad:
+            raise RuntimeError("units_sharded_32m: another rank failed in its rank-local work (its slabs arrived as NaN)")
+        maps = []
+        for u in range(U):
+            mu = allm[u % world, u // world] if world < U else allm[u, 0]
+            if offload:
+                mu = mu.clone()
+                mu[5] += allm[U + u, 0, 5]
+            maps.append(mu)
+    return [[torch.stack([engine.strand_merge(maps[2 * m][j, c], maps[2 * m + 1][j, c]) for c in range(maps[2 * m].shape[1])]) for j in range(6)]
+            for m in range(M)]
+
+
+def strand_bin_plan(total_bins, rank, world):
+    """`unit_plan` for ONE model (two units = the strands): [(strand, bin_lo, bin_hi)] this rank encodes.  world must be 1 or even."""
+    if world > 1 and world % 2:
         raise ValueError("strand x bin sharding needs an even number of ranks")
-    lo, hi = bin_range(total_bins, rank // 2, world // 2)
-    return [(rank % 2, lo, hi)]
+    return unit_plan(2, total_bins, rank, world)[0]
 
 
 def strand_bin_sharded_32m(model, codes, mpos, wpos, distencs=None, group=None, comm=None):
-    """`genomepredict`'s device work for ONE 32 Mb window ([B,L] packed bases replicated on every rank) shared by all ranks: rank r
-    encodes bins `strand_bin_plan` of strand r % 2, ONE all-gather assembles both strands' [B,128,8000] encodings on every rank, ranks
-    0 and 1 run one strand's tail each (Encoder2 -> six Decoders: a dependent chain, not shardable further; the independent `+ denet_1_pt`
-    term of the 4 kb level runs on ranks 2 / 3 from 4 ranks on, on ranks 0 / 1 otherwise) and ONE
-    all-gather of the [6,C,250,250] maps precedes the strand merge.  Returns the six merged [C,250,250] maps (on every rank).
-    Replaces nn.DataParallel around the sub-networks (orca_models.py:44-50), which only splits batches."""
-    from . import engine, orca_predict
-    if comm is not None:
-        world, rank = comm.world, comm.rank
-    elif dist.is_initialized():
-        world, rank = dist.get_world_size(group), dist.get_rank(group)
-    else:
-        world, rank = 1, 0
-    B, L = codes.shape
-    total = engine.encoder_num_bins(L)
-    plan = strand_bin_plan(total, rank, world)
-
-    def local(strand, lo, hi):
-        with engine.immediate_overflow_guard():      # a rank's fp16-range retry happens before the collective, never after it on one rank only
-            return model.net0.forward_codes(codes, reverse=bool(strand), bin_lo=lo, bin_hi=hi)
-
-    if world == 1:
-        enc0 = torch.cat([local(*plan[0]), local(*plan[1])], dim=0)
-    else:
-        strand, lo, hi = plan[0]
-        part = local(strand, lo, hi)
-        width = -(-total // (world // 2))
-        slab = torch.zeros((B, 128, width), dtype=part.dtype, device=part.device)
-        slab[:, :, : hi - lo] = part
-        if comm is not None:
-            gathered = comm.all_gather(slab)
-        else:
-            gathered = torch.empty((world, B, 128, width), dtype=part.dtype, device=part.device)
-            dist.all_gather_into_tensor(gathered.view(world * B, 128, width), slab, group=group)
-        strands = []
-        for st in range(2):
-            pieces = []
-            for sh in range(world // 2):
-                rlo, rhi = bin_range(total, sh, world // 2)
-                pieces.append(gathered[2 * sh + st, :, :, : rhi - rlo])
-            strands.append(torch.cat(pieces, dim=2))
-        enc0 = torch.cat(strands, dim=0)
-    if world == 1:
-        preds, _ = orca_predict.cascade_32m_from_enc(model, enc0, mpos, wpos, [False, True], distencs)
-        fwd, rev = torch.stack([p[0] for p in preds]), torch.stack([p[B] for p in preds])
-    else:
-        offload_1m = world >= 4      # ranks 2 / 3 are idle during the tails: they take the `+ denet_1_pt` term of strand 0 / 1 (independent of the cascade)
-        if rank < 2:
-            preds, _ = orca_predict.cascade_32m_from_enc(model, enc0[rank * B: (rank + 1) * B], mpos, wpos, [bool(rank)], distencs, with_1m=not offload_1m)
-            slab = torch.stack([p[0] for p in preds]).contiguous()
-        else:
-            C = getattr(model.denets[32], "num_2d", 1)
-            slab = torch.zeros((6, C, 250, 250), dtype=torch.float32, device=enc0.device)
-            if offload_1m and rank < 4:
-                st = rank - 2
-                slab[5] = orca_predict.denet1m_32m_from_enc(model, enc0[st * B: (st + 1) * B], mpos, wpos, [bool(st)])[0]
-        if comm is not None:
-            allm = comm.all_gather(slab)
-        else:
-            allm = torch.empty((world,) + tuple(slab.shape), dtype=slab.dtype, device=slab.device)
-            dist.all_gather_into_tensor(allm.view(-1), slab.view(-1), group=group)
-        fwd, rev = allm[0], allm[1]
-        if offload_1m:
-            fwd, rev = fwd.clone(), rev.clone()
-            fwd[5] += allm[2][5]
-            rev[5] += allm[3][5]
-    return [torch.stack([engine.strand_merge(fwd[j, c], rev[j, c]) for c in range(fwd.shape[1])]) for j in range(fwd.shape[0])]
+    """`units_sharded_32m` for one model: rank r encodes bins `strand_bin_plan` of strand r % 2, ONE all-gather assembles both strands'
+    [B,128,8000] encodings on every rank, ranks 0 and 1 run one strand's tail each (the independent `+ denet_1_pt` term of the 4 kb level
+    on ranks 2 / 3 from 4 ranks on), ONE all-gather of the [6,C,250,250] maps precedes the strand merge.  Returns the six merged
+    [C,250,250] maps (on every rank)."""
+    return units_sharded_32m([model], codes, mpos, wpos, distencs, group, comm)[0]
 
 
 def max_over_ranks(value, device):

@@ -188,6 +188,89 @@ def test_strand_bin_sharding_gloo_world4():
         assert p.exitcode == 0
 
 
+def _worker4_models(rank, world, port, q):
+    """world = 4 over gloo: the TWO-model job (units = model x strand: four independent tails, one per rank) against two one-model runs,
+    and a rank that fails in its local work: nobody may stay blocked in a collective, every rank raises."""
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from orca_amd import dist as D
+    from orca_amd import engine, orca_predict
+    try:
+        D.init_from_env("gloo")
+        engine.strand_merge = lambda f, r: 0.5 * f + 0.5 * torch.flip(r, [0, 1])
+        calls, tails = [], []
+
+        class _Net0:
+            def __init__(self, tag):
+                self.tag = tag
+
+            def forward_codes(self, codes, reverse=False, bin_lo=0, bin_hi=0):
+                calls.append((self.tag, bool(reverse), bin_lo, bin_hi))
+                b = torch.arange(bin_lo, bin_hi, dtype=torch.float32)
+                return (b[None, None, :] * (1 + self.tag) + 1000.0 * float(reverse) + 0.001 * torch.arange(128.)[None, :, None]).expand(codes.shape[0], -1, -1).contiguous()
+
+        class _Model:
+            def __init__(self, tag):
+                self.tag, self.net0 = tag, _Net0(tag)
+                self.denets = {32: type("D", (), {"num_2d": 1})()}
+
+        def _tail(model, enc0, mpos, wpos, flags, de=None, with_1m=True):
+            tails.append((model.tag, [bool(f) for f in flags]))
+            if model.tag == 1 and getattr(_tail, "fail", False) and flags[0]:
+                raise ValueError("injected failure in one rank's tail")
+            v = (enc0 * torch.arange(1, enc0.shape[2] + 1.)).sum(dim=(1, 2))
+            maps = [v.view(-1, 1, 1, 1) * (j + 1) * (1 + model.tag) + torch.tensor([1.0 if f else 0.0 for f in flags]).repeat_interleave(enc0.shape[0] // len(flags)).view(-1, 1, 1, 1)
+                    + torch.zeros(enc0.shape[0], 1, 250, 250) for j in range(6)]
+            if with_1m:
+                maps[5] = maps[5] + _one_m(model, enc0, mpos, wpos, flags)
+            return maps, None
+
+        def _one_m(model, enc0, mpos, wpos, flags):
+            per = enc0.shape[0] // len(flags)
+            return torch.cat([torch.full((per, 1, 250, 250), 0.5 * float(enc0[k * per:(k + 1) * per].sum()) + (7.0 if f else 3.0) + model.tag) for k, f in enumerate(flags)])
+        orca_predict.cascade_32m_from_enc = _tail
+        orca_predict.denet1m_32m_from_enc = _one_m
+        codes = torch.zeros((1, 4000 * 75), dtype=torch.uint8)
+        models = [_Model(0), _Model(1)]
+        assert D.unit_plan(4, 75, rank, 4) == ([(rank, 0, 75)], [rank], []) and D.unit_plan(4, 75, 5, 8) == ([(1, 38, 75)], [], [1])
+        assert D.unit_plan(4, 75, 1, 2) == ([(1, 0, 75), (3, 0, 75)], [1, 3], [])
+        two = D.units_sharded_32m(models, codes, 0, 0)
+        ok_calls = calls == [(rank // 2, bool(rank & 1), 0, 75)] and tails == [(rank // 2, [bool(rank & 1)])]
+        calls.clear(); tails.clear()
+        ones = [D.strand_bin_sharded_32m(m, codes, 0, 0) for m in models]      # the one-model job, twice (bins sharded 2 x 2, tails on ranks 0 / 1)
+        ok_equal = all(torch.equal(two[m][j], ones[m][j]) for m in range(2) for j in range(6))
+        # failure on ONE rank (rank 3 = model 1, reverse strand): every rank raises, none hangs
+        _tail.fail = True
+        raised = ""
+        try:
+            D.units_sharded_32m(models, codes, 0, 0)
+        except Exception as e:
+            raised = type(e).__name__
+        q.put((rank, ok_calls, ok_equal, raised))
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+    except Exception as e:
+        q.put((rank, repr(e), False, ""))
+
+
+def test_two_model_job_and_failing_rank_gloo_world4():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker4_models, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    for _ in range(4):
+        rank, ok_calls, ok_equal, raised = q.get(timeout=300)
+        assert ok_calls is True and ok_equal is True, (rank, ok_calls, ok_equal)
+        assert raised == ("ValueError" if rank == 3 else "RuntimeError"), (rank, raised)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+
+
 def test_overflow_guard_policy_is_per_thread_and_immediate_around_a_sharded_encoder():
     """(a) the deferred-guard scope of one thread must not leak into another thread; (b) a ShardedEncoder runs
     its rank-local encoder with the IMMEDIATE guard even inside a deferred scope, so that an fp16-range retry happens

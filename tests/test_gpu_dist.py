@@ -204,6 +204,16 @@ def test_bench_two_ranks_on_one_gpu_over_gloo(cuda):
     t1, t2 = one["sharded_32mb"], two["sharded_32mb"]
     assert "error" not in t2, t2
     assert t2["n_gpus"] == 2 and t2["scaling"] == "strong" and t1["parity"]["ok"] and t2["parity"]["ok"], (t1, t2)
+    # the one-job sections: same maps at every N (a map does not depend on the batch size it was decoded in), per-phase times, the N = 1 time
+    # measured in the same run, rooflines, and the two-model job (four (model, strand) units: two per rank at N = 2)
+    m1, m2 = one["sharded_32mb_two_models"], two["sharded_32mb_two_models"]
+    assert "error" not in m2 and m2["models"] == 2 and m1["parity"]["ok"] and m2["parity"]["ok"], m2
+    for a, b in ((t1, t2), (m1, m2)):
+        assert abs(a["maps_checksum"] - b["maps_checksum"]) <= 1e-6 * abs(a["maps_checksum"]), (a["maps_checksum"], b["maps_checksum"])
+        for k in ("encoder_ms_per_rank_max", "allgather_ms_max", "tail_ms_max", "n1_ms_same_run", "efficiency_vs_n1"):
+            assert b[k] is not None and b[k] >= 0, (k, b)
+        assert 0 < b["roofline"]["encoder"]["frac"] < 1 and a["efficiency_vs_n1"] == 1.0
+    assert set(two["strong_scaling"]) >= {"sharded_256mb", "sharded_32mb", "sharded_32mb_two_models"} and s2["efficiency_vs_n1"] > 0
 
 
 def test_bench_four_ranks_on_one_gpu_over_gloo(cuda):
@@ -223,3 +233,9 @@ def test_bench_four_ranks_on_one_gpu_over_gloo(cuda):
     assert d["n_gpus"] == 4 and "error" not in s and "error" not in t, (s, t)
     assert s["bins_this_rank"] == [0, 16000] and s["sequence_bytes_on_this_rank"] == 2 * (64_000_000 + 112_000)
     assert s["parity"]["ok"] and t["parity"]["ok"], (s["parity"], t["parity"])
+    m = d["sharded_32mb_two_models"]                                    # four units on four ranks: one tail each
+    assert "error" not in m and m["parity"]["ok"] and m["models"] == 2, m
+    for sec in (s, t, m):
+        assert sec["efficiency_vs_n1"] > 0 and sec["n1_ms_same_run"] > 0 and 0 < sec["roofline"]["encoder"]["frac"] < 1, sec
+    assert t["roofline"]["allgather"]["bytes_received_per_rank"] == 3 * 128 * 4000 * 4
+    assert set(d["strong_scaling"]) >= {"sharded_256mb", "sharded_32mb", "sharded_32mb_two_models"}

@@ -1,0 +1,22 @@
+"""rocprofv3 driver: the local (ends + junctions) Encoder calls of ONE variant of the incremental SV screen."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from orca_amd import orca_models, sv
+dev = torch.device("cuda:0")
+h1 = orca_models.H1esc(synthetic_seed=0)
+g = torch.Generator(device=dev).manual_seed(5)
+genome = torch.randint(0, 4, (40_000_000,), device=dev, generator=g, dtype=torch.uint8)
+v = sv.synth_svs(4, 40_000_000)[2]
+cache = sv.ChromEncodings(h1.net0, genome)
+rp, rw, rm, ap, aw, am = sv.sv_windows(v, 40_000_000)
+codes = torch.stack([sv.assemble_codes(genome, rp), sv.assemble_codes(genome, ap)])
+enc0 = torch.empty((4, 128, 8000), device=dev)
+sv.encode_windows(cache, [rp, ap], codes, enc0)
+torch.cuda.synchronize()
+print("MARK")
+import time
+t = time.perf_counter()
+n = sv.encode_windows(cache, [rp, ap], codes, enc0, build=False)
+torch.cuda.synchronize()
+print(v, n, "bins", (time.perf_counter() - t) * 1e3, "ms")
