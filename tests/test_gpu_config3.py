@@ -61,7 +61,7 @@ def test_config3_default_arithmetic_vs_reference(setup):
     assert max(maxabs(m[0], m[5]) for m in maps) > 1e-3
 
 
-@pytest.mark.parametrize("dec_precision,tol,rmin", [("bf16", 0.6, 0.999), ("f16", 0.1, 0.99999)])
+@pytest.mark.parametrize("dec_precision,tol,rmin", [("bf16", 0.6, 0.999), ("f16", 0.1, 0.99999)])   # (the structure of these modes: the two tests below)
 def test_config3_bf16_throughput_mode_vs_reference(setup, dec_precision, tol, rmin):
     model, codes, de = setup
     g = golden("G17_config3.npz")
@@ -75,3 +75,176 @@ def test_config3_bf16_throughput_mode_vs_reference(setup, dec_precision, tol, rm
             assert err < tol and r > rmin, (b, j, err, r)
     print(f"config 3, Encoder bf16 / Decoders {dec_precision} vs reference: worst max-abs {worst[0]:.4g}, worst Pearson {worst[1]:.6f}")
     _forward(model, codes, de, "f16x2")   # leave the module-scoped model in its default arithmetic
+
+
+def _q(t, dt):
+    return t.to(dt).to(torch.float32)
+
+
+def _identity_blocks(sd, blocks):
+    """Make residual blocks `blocks` of a Decoder / Decoder_1m state dict the identity: zero convs under unit BatchNorms (lm(cur) = 0,
+    m(oth) = relu(0) = 0), exactly representable in every storage format."""
+    sd = dict(sd)
+    for i in blocks:
+        for pre in (f"lconvtwos.{i}.", f"convtwos.{i}."):
+            for k in [k for k in sd if k.startswith(pre)]:
+                v = np.asarray(sd[k])
+                if k.endswith("running_var") or (k.endswith("weight") and v.ndim == 1):
+                    sd[k] = np.ones_like(v)
+                elif k.endswith("num_batches_tracked"):
+                    continue
+                else:
+                    sd[k] = np.zeros_like(v)
+    return sd
+
+
+def _emulate(kind, convs, sd, x, de, y, dt, upsample="bilinear"):
+    """torch fp32 on the CPU with the HIP path's ROUNDING POINTS: BN-folded weights rounded to the plane's 16-bit type (except the separable
+    outer-sum part of lcombinerD.a, which the engine computes from the fp32 encoding with fp32 weights), every conv output - after bias,
+    ReLU and residual - rounded once, fp32 accumulation in between."""
+    import torch.nn.functional as F
+    from oracle import orca_oracle as O
+    from orca_amd.orca_modules import DECODER1M_DILATIONS, DECODER_DILATIONS
+    W = [torch.from_numpy(c["w"]) for c in convs]
+    Bv = [torch.from_numpy(c["b"]) for c in convs]
+
+    def conv(i, t, relu=False, res=None, d=1):
+        o = F.conv2d(t, _q(W[i], dt), Bv[i], padding=d, dilation=d)
+        if relu:
+            o = F.relu(o)
+        return o if res is None else o + res
+
+    with torch.no_grad():
+        mat = x[:, :, :, None] + x[:, :, None, :]
+        if kind == "Decoder":
+            a0 = F.conv2d(mat, W[0][:, :128], None, padding=1) + F.conv2d(_q(de, dt), _q(W[0][:, 128:], dt), Bv[0], padding=1)
+            t = _q(a0, dt)
+            c = _q(conv(1, t), dt)                                             # lcombinerD.b
+            t = _q(conv(2, c, relu=True), dt)                                  # combinerD.a
+            m = _q(conv(3, t, relu=True, res=c), dt)                           # combinerD.b + lcombinerD's output
+            up = _q(F.interpolate(y, scale_factor=(2, 2), mode=upsample), dt)
+            t = _q(conv(4, torch.cat([m, up], dim=1)), dt)                     # lcombiner.a
+            c = _q(conv(5, t), dt)
+            t = _q(conv(6, c, relu=True), dt)
+            cur = _q(conv(7, t, relu=True, res=c), dt)
+            first, dils, base = 1, DECODER_DILATIONS, 8
+        else:
+            cur, first, dils, base = _q(mat, dt), 0, DECODER1M_DILATIONS, 0
+        for i in range(first, len(dils)):
+            d, k = dils[i], base + 4 * i
+            t = _q(conv(k, cur, d=d), dt)
+            oth = _q(conv(k + 1, t, res=cur if (i > 0 or kind == "Decoder") else None, d=d), dt)
+            t = _q(conv(k + 2, oth, relu=True, d=d), dt)
+            cur = _q(conv(k + 3, t, relu=True, res=oth, d=d), dt)
+        return O._final_sym(O._SD(sd), cur)[0, 0].numpy()
+
+
+def _integer_blocks(sd, prefixes, rs, nnz=2):
+    """Give the conv pairs under `prefixes` of a state dict sparse +-1 weights (about `nnz` per output channel), biases in {-1, 0, 1} and
+    unit BatchNorms that fold to exactly 1: on integer inputs every activation is then a small integer - exactly representable in a
+    bf16 / fp16 plane, so no rounding happens anywhere and the single-plane kernels must reproduce the fp32 forward EXACTLY."""
+    sd = dict(sd)
+    for pre in prefixes:
+        for k in [k for k in sd if k.startswith(pre)]:
+            v = np.asarray(sd[k])
+            if k.endswith("num_batches_tracked"):
+                continue
+            if v.ndim == 4:
+                w = np.zeros(v.shape, dtype=np.float32)
+                for co in range(v.shape[0]):
+                    for _ in range(nnz):
+                        w[co, rs.randint(v.shape[1]), rs.randint(3), rs.randint(3)] = rs.choice([-1.0, 1.0])
+                sd[k] = w
+            elif k.endswith("running_var"):
+                sd[k] = np.full(v.shape, np.float32(1.0) - np.float32(1e-5), dtype=np.float32)
+            elif k.endswith("running_mean"):
+                sd[k] = np.zeros_like(v)
+            elif k.endswith("weight"):                      # BatchNorm gamma
+                sd[k] = np.ones_like(v)
+            else:                                           # conv bias / BatchNorm beta
+                sd[k] = rs.randint(-1, 2, v.shape).astype(np.float32) if ".0.bias" in k or ".2.bias" in k or ".3.bias" in k else np.zeros_like(v)
+    return sd
+
+
+@pytest.mark.parametrize("precision", ["bf16", "f16"])
+@pytest.mark.parametrize("kind,active,n", [("Decoder", (), 250), ("Decoder", (1, ), 126), ("Decoder", (3,), 126), ("Decoder", (4,), 126), ("Decoder_1m", (0, 2), 126),
+                                           ("Decoder_1m", (0, 4), 250), ("Decoder_1m", (0, 5), 250), ("Decoder_1m", (0, 6), 250)])
+def test_single_plane_decoder_exact_on_integer_networks(cuda, precision, kind, active, n):
+    """STRUCTURAL check of the single-plane Decoder modes (the all-bf16 mode sits 0.1-0.4 from the fp32 reference
+    on real-valued weights - its residual stream is rounded to 8 bits 116 times - and the tolerance that covers it could hide a
+    mis-packed weight chunk).  Emulating the rounding points does not help beyond ~2 layers: per layer the HIP kernels agree with such
+    an emulation in 99.8-99.99 % of the elements (next test), but a one-unit flip perturbs ~500 elements of the next layer by a tenth
+    of a unit each and flips ~50 of them - the quantised stack decorrelates within three layers, whoever computes it.  So rounding is
+    taken OUT: the sections under test get sparse +-1 weights, integer biases and unit BatchNorms (`_integer_blocks`), the input is
+    integer, every other block is the identity - all activations are small integers, exact in a bf16 / fp16 plane, and the whole path
+    (separable first conv + distance chunk, combiners, up-sampling, per-layer kernels at dilations 1-8, the fused block kernel at
+    16 / 32 / 64, residuals, `final`) must reproduce the fp32 reference forward to fp32 round-off.  A wrong chunk, tap, channel or
+    residual is an O(1) difference here."""
+    from oracle import orca_oracle as O
+    from orca_amd import orca_modules as pm
+    from tests.util import synth_sd
+    dt = torch.bfloat16 if precision == "bf16" else torch.float16
+    kw = {"upsample_mode": "nearest"} if kind == "Decoder" else {}
+    nblocks = 28 if kind == "Decoder" else 19
+    rs = np.random.RandomState(7)
+    sd = _identity_blocks(synth_sd(kind, 3, **kw), [i for i in range(1 if kind == "Decoder" else 0, nblocks) if i not in active])
+    pre = [f"{p}.{i}." for i in active for p in ("lconvtwos", "convtwos")] + (["lcombinerD.", "combinerD.", "lcombiner.", "combiner."] if kind == "Decoder" else [])
+    sd = _integer_blocks(sd, pre, rs)
+    dec = getattr(pm, kind)(precision=precision, **kw)
+    dec.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    dec.eval()
+    convs = dec._fold_sequentials(dec._conv_items())
+    rs = np.random.RandomState(5)
+    x = torch.from_numpy(rs.randint(0, 2, (1, 128, n)).astype(np.float32))
+    de = torch.from_numpy(rs.randint(-2, 3, (1, 1, n, n)).astype(np.float32))
+    y = torch.from_numpy(rs.randint(-2, 3, (1, 1, n // 2, n // 2)).astype(np.float32))
+    # precondition (CPU, on the 8-bit plane: the 11-bit one holds whatever that holds): with the plane's rounding at every rounding point
+    # nothing changes - no activation needs more bits than it has (to the fp32 round-off of two CPU runs of the real-valued `final` head)
+    if precision == "bf16":
+        assert maxabs(_emulate(kind, convs, sd, x, de, y, dt, "nearest"), _emulate(kind, convs, sd, x, de, y, torch.float32, "nearest")) < 1e-6
+    if kind == "Decoder":
+        out = dec(x.to(cuda), de.to(cuda), y.to(cuda))[0, 0].cpu().numpy()
+        ref = O.decoder_forward(sd, x, de, y, "nearest")[0, 0].numpy()
+    else:
+        out = dec(x.to(cuda))[0, 0].cpu().numpy()
+        ref = O.decoder_1m_forward(sd, x)[0, 0].numpy()
+    scale = float(np.abs(ref).max())
+    assert scale > 1.0 and float(np.std(ref)) > 0.1
+    assert maxabs(out, ref) <= 2e-6 * scale, (kind, active, precision, maxabs(out, ref), scale)
+
+
+@pytest.mark.parametrize("precision,min_equal", [("bf16", 0.9995), ("f16", 0.995)])
+def test_single_plane_layers_equal_rounding_point_emulation(cuda, precision, min_equal):
+    """Layer by layer, teacher-forced, on a Decoder_1m's real-valued synthetic weights and the activations they produce (blocks with
+    dilations 1, 2, 4, 8): the HIP conv on single 16-bit planes against torch fp32 on the same rounded operands, rounded once at the end.
+    All but 0.01-0.2 % of the elements are EQUAL; the rest differ by one unit in the last place (summation order)."""
+    import torch.nn.functional as F
+    from orca_amd import engine
+    from tests.util import product_module
+    dt = torch.bfloat16 if precision == "bf16" else torch.float16
+    dec = product_module("Decoder_1m", 3, precision=precision)
+    convs = dec._fold_sequentials(dec._conv_items())
+    rs = np.random.RandomState(5)
+    x = torch.from_numpy((rs.rand(1, 128, 250) * 0.5).astype(np.float32))
+    cur = _q(x[:, :, :, None] + x[:, :, None, :], dt)
+    t = oth = None
+    for i in range(4):
+        for j in range(4):
+            c = convs[4 * i + j]
+            inp, res = ((cur, None), (t, cur if i > 0 else None), (oth, None), (t, oth))[j]
+            got = engine.conv2d_m16(inp.to(cuda), c["w"], c["b"], c["dil"], j >= 2, None if res is None else res.to(cuda), precision=precision).cpu()
+            ref = F.conv2d(inp, _q(torch.from_numpy(c["w"]), dt), torch.from_numpy(c["b"]), padding=c["dil"], dilation=c["dil"])
+            ref = F.relu(ref) if j >= 2 else ref
+            ref = _q(ref if res is None else ref + res, dt)
+            eq = float((got == ref).float().mean())
+            ulp = 2.0 ** (-7 if precision == "bf16" else -10)
+            # (2 ulp: at a binade edge one unit of the upper binade is two of the lower)
+            # (... and the fp16 conversion on the device flushes results below the smallest normal number, 6.1e-5)
+            slack = 2.0 ** -14 if precision == "f16" else 0.0
+            assert eq >= min_equal and bool(((got - ref).abs() <= 2 * ulp * ref.abs().clamp_min(2.0 ** -14) + slack).all()), (i, j, c["dil"], eq)
+            if j in (0, 2):
+                t = ref
+            elif j == 1:
+                oth = ref
+            else:
+                cur = ref
