@@ -278,6 +278,8 @@ def inst_rooflines(recs):
         # its ALGORITHMIC work is the pair's (SURVEY 8d counts the reference's convolutions)
         # (25 taps from the bases = conv1.a composed with lconv1: the launch carries conv1.a's 64 -> 64 work, lconv1's is on the 17-tap launch)
         g["flop"] += 2.0 * 9 * (cout * cout if ksize == 25 else cin * cout + (cout * cout if ksize == 17 else 0)) * n * batch
+        # what the launch EXECUTES: a composed launch runs its 17 / 25 taps, not the pair's 2 x 9
+        g["xflop"] = g.get("xflop", 0.0) + 2.0 * (25 * 4 * cout if ksize == 25 else ksize * cin * cout) * n * batch
         g["bytes"] += float(cin + cout) * n * batch      # x elements in + out; bytes per element applied per arithmetic below
     PREC = {0: ("f32", "conv1d_k9_kernel", PEAK_F32_MFMA_TFLOPS, 1, 4), 1: ("bf16", "conv1d_k9_bf16s_kernel", PEAK_16BIT_MFMA_TFLOPS, 1, 4),
             2: ("bf16x2", "conv1d_k9_bf16s_kernel", PEAK_16BIT_MFMA_TFLOPS, 3, 4), 3: ("bf16x3", "conv1d_k9_bf16s_kernel", PEAK_16BIT_MFMA_TFLOPS, 6, 4),
@@ -285,7 +287,7 @@ def inst_rooflines(recs):
             5: ("f16x2", "conv1d_k9_p16_kernel", PEAK_16BIT_MFMA_TFLOPS, 3, 4), 6: ("bf16", "conv1d_k9_p16_kernel", PEAK_16BIT_MFMA_TFLOPS, 1, 2),
             7: ("f16x2", "conv1d_k9_ws_kernel", PEAK_16BIT_MFMA_TFLOPS, 3, 4), 8: ("bf16", "conv1d_k9_ws_kernel", PEAK_16BIT_MFMA_TFLOPS, 1, 2),
             9: ("f16x2", "conv1d_k9_p16w1_kernel", PEAK_16BIT_MFMA_TFLOPS, 3, 4), 10: ("bf16", "conv1d_k9_p16w1_kernel", PEAK_16BIT_MFMA_TFLOPS, 1, 2),
-            11: ("f16x2", "conv1d_k9_p16f_kernel", PEAK_16BIT_MFMA_TFLOPS, 3, 4), 12: ("f16x2", "conv1d_k9_p16p5_kernel", PEAK_16BIT_MFMA_TFLOPS, 3, 4), 13: ("bf16", "conv1d_k9_p16p5_kernel", PEAK_16BIT_MFMA_TFLOPS, 1, 2), 14: ("f16x2", "conv1d_k9_p16x_kernel", PEAK_16BIT_MFMA_TFLOPS, 3, 4)}
+            12: ("f16x2", "conv1d_k9_p16p5_kernel", PEAK_16BIT_MFMA_TFLOPS, 3, 4), 13: ("bf16", "conv1d_k9_p16p5_kernel", PEAK_16BIT_MFMA_TFLOPS, 1, 2), 14: ("f16x2", "conv1d_k9_p16x_kernel", PEAK_16BIT_MFMA_TFLOPS, 3, 4)}
     inst = {}
     for (cout, cin, tile, ksize), g in groups.items():
         prec = -tile if tile < 0 else 0
@@ -295,8 +297,8 @@ def inst_rooflines(recs):
         elif ksize == 25:
             kname = "conv1d_first_mfma_p16_kernel[25 taps: conv1.a o lconv1]"
         key = f"{kname}<cout={cout},{pname}>" if prec else f"{kname}<cout={cout},kc={4 if cin == 4 else 8},tile={tile}>"
-        d = inst.setdefault(key, {"ms": 0.0, "launches": 0, "flop": 0.0, "bytes": 0.0, "peak": peak, "nprod": nprod, "arith": pname})
-        for k in ("ms", "launches", "flop"):
+        d = inst.setdefault(key, {"ms": 0.0, "launches": 0, "flop": 0.0, "xflop": 0.0, "bytes": 0.0, "peak": peak, "nprod": nprod, "arith": pname})
+        for k in ("ms", "launches", "flop", "xflop"):
             d[k] += g[k]
         d["bytes"] += g["bytes"] * bpe
     return inst
@@ -599,6 +601,8 @@ def main():
                     "traffic_measured_in_run": False,     # replayed from the committed rocprofv3 --pmc passes of the same kernel (tools/profile_run.sh)
                     "arithmetic": d["arith"], "mfma_products_per_algorithmic_mac": d["nprod"],
                     "mfma_pipe_frac": round(achieved * d["nprod"] / d["peak"], 4),
+                    "achieved_is": "ALGORITHMIC FLOP (the reference's convolutions, SURVEY 8d) / HIP-event time",
+                    "executed_tflops": round(d["xflop"] / (d["ms"] * 1e-3) / 1e12, 2), "executed_frac": round(d["xflop"] / (d["ms"] * 1e-3) / 1e12 / d["peak"], 4),
                     "frac_of_f32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
                     "avg_launch_ms": round(d["ms"] / d["launches"], 4), "launches": d["launches"],
                     "flop_per_launch": d["flop"] / d["launches"],
@@ -691,12 +695,12 @@ def main():
         torch.cuda.synchronize(dev)
         dms = e0.elapsed_time(e1) / 10
         dtf = 2 * DEC_TFLOP["withy"] / (dms * 1e-3)
-        res["roofline_decoder"] = {"kernel": "conv2d_3x3_m16_kernel<32|64,2,1> (dilation 1-8, 72 launches) + conv2d_dblock_kernel<2,1> (dilation 16-64, 12 launches of 4 convs) "
+        res["roofline_decoder"] = {"kernel": "conv2d_3x3_m16q_kernel<32|64,2,1> (dilation 1-8, 72 launches: four-row tiles, both strands in one round) + conv2d_dblock_kernel<2,1> (dilation 16-64, 12 launches of 4 convs) "
                                              "= one Decoder forward with y at B = 2 (the two strands)", "bound": "mfma", "ms_per_forward": round(dms, 3),
                                    "achieved": round(dtf, 1), "peak": PEAK_16BIT_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(dtf / PEAK_16BIT_MFMA_TFLOPS, 4),
                                    "mfma_products_per_algorithmic_mac": 3, "mfma_pipe_frac": round(3 * dtf / PEAK_16BIT_MFMA_TFLOPS, 4),
                                    "decoders_share_of_step": round(7 * dms / ms_per_step, 3),
-                                   "mfma_busy_source": "profiles/r03_pmc_dec_sq.txt (SQ_VALU_MFMA_BUSY_CYCLES / SIMD cycles per kernel)"}
+                                   "mfma_busy_source": "profiles/r04_pmc_dec_sq.txt (SQ_VALU_MFMA_BUSY_CYCLES / SIMD cycles per kernel)"}
         del xd, yd, ded
     strands = outs = None
     engine.get_context(dev).release_workspace()

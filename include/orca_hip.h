@@ -101,7 +101,7 @@ int orca_ctx_release_workspace(orca_ctx* ctx);
  * clears the log. */
 typedef struct orca_kernel_time {
   int32_t cout, cin, tile, batch; /* tile > 0: position tile of the exact-fp32 kernel; < 0: kernel family = -1..-4 conv_bf16s.h (bf16, bf16x2, bf16x3, f16x2),
-                                   * -5 / -6 conv_p16.h (P16 / B16), -7 / -8 conv_ws.h, -9 / -10 conv_p16w1.h (P16 / B16), -11 conv_p16f.h, -12 / -13 conv_p16p5.h (P16 / B16) */
+                                   * -5 / -6 conv_p16.h (P16 / B16), -7 / -8 conv_ws.h, -9 / -10 conv_p16w1.h (P16 / B16), -12 / -13 conv_p16p5.h (P16 / B16), -14 conv_p16x.h */
   int64_t n;      /* positions per batch row            */
   float ms;       /* elapsed between the two HIP events */
   int32_t ksize;  /* taps of the launch: 9, or 17 = a composed linear pair (its algorithmic FLOPs are the pair's) */

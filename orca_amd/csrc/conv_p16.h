@@ -6,8 +6,8 @@
 //     8 channels 8p..8p+7;  unit(p, s, pos) at  base + ((2p + s) * PLEN + P16_GUARD + pos) * 16 bytes.
 //   Same 4 bytes per element as fp32, but it IS the MFMA operand image: a conv's input tile is a set of
 //   contiguous 16-byte runs that `global_load_lds` (LDS-DMA) drops straight into the LDS operand image - no
-//   staging registers, no VALU conversion, no ds_write pass.  Each plane carries 4 guard units on the left and
-//   >= 4 on the right that are kept ZERO (p16_zero_pads_kernel + producers), so the conv's zero padding and the
+//   staging registers, no VALU conversion, no ds_write pass.  Each plane carries P16_GUARD (8) guard units on the left and
+//   >= 24 on the right that are kept ZERO (p16_zero_pads_kernel + producers), so the conv's zero padding and the
 //   ragged last tile need no predication at all.
 //
 // Kernel: persistent workgroups, 8 waves, (tile, chunk) stream as in conv_bf16s.h, but with TWO LDS buffers:
@@ -216,7 +216,7 @@ __device__ __forceinline__ void p16_lds_wait(f16x8 (&a)[2][MW], f16x8 (&b)[2][NW
 //   product, 32 input channels per step.  The LDS image of a step has the same shape in both formats - the split index
 //   s of P16 becomes the k-pair index of B16 (channels 16 s + 8 g + e of the step's 32) - so the DMA geometry, the
 //   fragment reads and the counted waits are shared; only the product list and the epilogue differ.
-//   B16 planes: unit(p = ch/8, pos) at base + (p * PLEN + 4 + pos) * 16 bytes, guards as in P16.
+//   B16 planes: unit(p = ch/8, pos) at base + (p * PLEN + P16_GUARD + pos) * 16 bytes, guards as in P16.
 //   B16 weight pack: [cin/32][2 k-pairs][9][2][cout][8] bf16.
 // RL (conv1.b of stage 1, packed input): the residual `lout1` is not LOADED from a stored tensor but COMPUTED in the epilogue - lout1 is
 //   the 17-tap composed conv of the bases (see conv1d_first_mfma_p16_kernel, NTAP = 17), i.e. per 32 x 32 accumulator tile a K = 80 GEMM of
@@ -748,7 +748,7 @@ __global__ __launch_bounds__(WM * 64, WM / 4) void conv1d_k9_p16_kernel(ConvP16A
   if (FMT == 0 && OM != 2 && vmax > 65504.f && a.flag) *a.flag = 1u;
 }
 
-// zero the guard / tail units of every plane: [0,4) and [4 + n_valid, plen)
+// zero the guard / tail units of every plane: [0, P16_GUARD) and [P16_GUARD + n_valid, plen)
 __global__ void p16_zero_pads_kernel(f32x4* __restrict__ base, long plen, long n_valid) {
   f32x4* pl = base + (long)blockIdx.x * plen;
   const long tail0 = P16_GUARD + n_valid;

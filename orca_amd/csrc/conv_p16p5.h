@@ -14,10 +14,8 @@
 // Epilogue per lane: bias (accumulator init), ReLU, + residual (whole 16-byte units of the lane's five positions, halves traded with lane
 // l +- 32), max over the five tiles, hi / lo split, one 16-byte store of the pooled unit; stores beyond n / 5 are masked (the ragged last
 // window is dropped as MaxPool1d does).  The argument block is ConvP16Args (out_mode 3; y_plen = plane length of the POOLED output).
-// The same geometry also runs the UNPOOLED 128-cout layers of stages 3-4 (OM = 0: P16 out, OM = 2: fp32 channel-last out; the lane stores
-// its five positions = 80 contiguous bytes per plane) and their 17-tap form (k17, as in conv_p16.h: step 2c + h = taps 9h .. 9h+8 on the
-// input shifted by 9h - 4): the input is fetched once instead of once per 64-cout block and a step needs 0.33 instead of 0.67 LDS reads per
-// MFMA (P16 only; the B16 layers keep the 64-cout tiles).
+// (Round 3 also ran the UNPOOLED 128-cout layers of stages 3-4 on this geometry: measured equal to the 64-cout tiles - 24.66 vs 24.69 ms per
+// strand - and removed in round 4; it pays only where it removes a pass.  profiles/HISTORY.md.)
 #pragma once
 #include "conv_p16.h"
 
@@ -35,9 +33,8 @@ __device__ __forceinline__ void p16p5_wait(f16x8& x0, f16x8& x1, f16x8& w0, f16x
 
 // FMT = 0: P16 (2 x fp16 split planes, 3 products, 16 input channels per step); FMT = 1: B16 (one bf16 plane per channel octet, 1 product, 32
 // input channels per step: the split index s of the images becomes the k-pair index, conv_p16.h)
-template <bool R1, int FMT = 0, int OM = 3>
+template <bool R1, int FMT = 0>
 __global__ __launch_bounds__(512, 2) void conv1d_k9_p16p5_kernel(ConvP16Args a) {
-  static_assert(OM == 3 || FMT == 0, "unpooled outputs: P16 only");
   constexpr int CT = 128, NT = 512, GP = 160, MT = 2 * GP;      // 2 position groups of 160 = 32 windows of 5
   constexpr int XROW = MT + 8;
   constexpr int XU = 2 * 2 * XROW;          // X image units [s][g][XROW]
@@ -140,22 +137,10 @@ __global__ __launch_bounds__(512, 2) void conv1d_k9_p16p5_kernel(ConvP16Args a) 
           v.x += (float)h0.x + (float)l0.x; v.y += (float)h0.y + (float)l0.y;
           v.z += (float)h1.x + (float)l1.x; v.w += (float)h1.y + (float)l1.y;
         }
-        if (OM == 2) {          // fp32 channel-last [n][cout]
-          if (p0 + r < a.n) *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(a.y) + ((p0 + r) * CT + oct * 8) * 4 + g * 16) = v;
-        } else if (OM == 0) {   // P16, full resolution: the lane's five positions are 80 contiguous bytes of the plane
-          vmax = p16_vmax3_abs(p16_vmax3_abs(vmax, v.x, v.y), v.z, v.w);
-          unsigned h0, h1, l0, l1;
-          p16_split_hl(v, h0, h1, l0, l1);
-          p16_swap32(h0, l0);
-          p16_swap32(h1, l1);
-          u32x4_t unit;
-          unit.x = h0; unit.y = h1; unit.z = l0; unit.w = l1;
-          if (p0 + r < a.n)
-            *reinterpret_cast<u32x4_t*>(reinterpret_cast<char*>(a.y) + (long)oct * 2 * ypl16 + (g ? ypl16 : 0) + (P16_GUARD + p0 + r) * 16) = unit;
-        } else if (r == 0) m = v;
+        if (r == 0) m = v;
         else { m.x = p16_vmax(m.x, v.x); m.y = p16_vmax(m.y, v.y); m.z = p16_vmax(m.z, v.z); m.w = p16_vmax(m.w, v.w); }
       }
-      if (OM == 3) {
+      {
         vmax = p16_vmax3_abs(p16_vmax3_abs(vmax, m.x, m.y), m.z, m.w);
         unsigned h0, h1, l0, l1;
         p16_split_hl(m, h0, h1, l0, l1);
@@ -294,5 +279,5 @@ __global__ __launch_bounds__(512, 2) void conv1d_k9_p16p5_kernel(ConvP16Args a) 
     cur ^= 1;
   }
   if (epi_pos >= 0) epilogue(epi_pos);
-  if (FMT == 0 && OM != 2 && vmax > 65504.f && a.flag) *a.flag = 1u;
+  if (FMT == 0 && vmax > 65504.f && a.flag) *a.flag = 1u;
 }

@@ -58,7 +58,7 @@ __device__ __forceinline__ void p16x_wait3(f16x8 (&w)[NC]) {
 // (Also measured and dropped: with 64-cout tiles two accumulator sets fit, so the finished tile's epilogue can run from a parked copy inside
 // the next tile's first step, at a different tap pair for each of a SIMD's four waves - correct, and no faster (26.61 vs 26.52 ms per strand
 // in the stored-residual form of stage 1): under the power cap an idle matrix pipe is not the loss, the energy per output is.)
-// CT = couts per workgroup tile (96: stage 2; 64: the cout blocks of the 64- / 128-cout layers - opt-in ORCA_P16X_64=1, measured equal to the
+// CT = couts per workgroup tile (96: stage 2; 64: the cout blocks of the 64- / 128-cout layers - round 3's opt-in ORCA_P16X_64, removed in round 4: measured equal to the
 // 32 x 32 x 16 tiles of conv_p16.h there: 24.65 vs 24.56 ms per strand), NC = cout tiles (of 16) per wave:
 // CT / 16 / NC cout groups x 8 position groups of waves (96 / 3 and 64 / 2: 16 waves)
 template <int OM, bool R1, int NC = 3, int CT = 96>

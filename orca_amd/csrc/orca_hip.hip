@@ -23,7 +23,6 @@
 #include "conv_p16.h"
 #include "conv_ws.h"
 #include "conv_p16w1.h"
-#include "conv_p16f.h"
 #include "conv_p16p5.h"
 #include "conv_p16x.h"
 #include "misc_kernels.h"
@@ -132,7 +131,6 @@ struct ConvLayer {
   void* d_wb16 = nullptr;   // k=9, cin%16==0: bf16 3-way split pack [cin/16][3][9][2][cout][8]
   void* d_wf16 = nullptr;   // same, fp16 2-way split pack [cin/16][2][9][2][cout][8]
   void* d_wb16p = nullptr;  // k=9, cin%32==0: plain bf16 pack [cin/32][2 k-pairs][9][2][cout][8] (B16 format of conv_p16.h)
-  void* d_wf14 = nullptr;   // k=9, cin%16==0: fast-FIR fp16 2-way split pack [cout/CT][cin/16][Hs 5 | H0 5 | H1 4 taps][2][tap][2][CT][8] (conv_p16f.h)
   bool f16_ok = true;       // all |w| < 65504
 };
 
@@ -184,44 +182,10 @@ static void free_layer(ConvLayer& L) {
   if (L.d_wb16) (void)hipFree(L.d_wb16);
   if (L.d_wf16) (void)hipFree(L.d_wf16);
   if (L.d_wb16p) (void)hipFree(L.d_wb16p);
-  if (L.d_wf14) (void)hipFree(L.d_wf14);
-  L.d_wb16 = L.d_wf16 = L.d_wb16p = L.d_wf14 = nullptr;
+  L.d_wb16 = L.d_wf16 = L.d_wb16p = nullptr;
   if (L.d_w) (void)hipFree(L.d_w);
   if (L.d_bias) (void)hipFree(L.d_bias);
   L.d_w = L.d_bias = nullptr;
-}
-
-// Fast-FIR pack of a k9 layer (conv_p16f.h): per cout block of CT (96 for the 96-cout layers, else 64) and 16 input channels the three
-// half-rate filters Hs = H0 + H1 (5 taps; summed in double, then split), H0 = even taps (5), H1 = odd taps (4), each as a weight part
-// [s = hi | lo][tap][g][CT][8] of fp16.  w: [cout][cin][9] folded fp32.
-static int make_pack_f14(const float* w, int cin, int cout, void** d_out) {
-  const int CT = cout == 96 ? 96 : 64, ncb = cout / CT, nc = cin / 16;
-  const size_t wp5 = (size_t)5 * 4 * CT * 8, wp4 = (size_t)4 * 4 * CT * 8, wch = 2 * wp5 + wp4;
-  std::vector<uint16_t> pk((size_t)ncb * nc * wch, 0);
-  auto put = [&](size_t base, int ntap, int tap, int gg, int col, int e, double v) {
-    for (int sp = 0; sp < 2; ++sp) {
-      const _Float16 h = (_Float16)v;
-      v -= (double)h;
-      uint16_t bits;
-      memcpy(&bits, &h, 2);
-      pk[base + ((((size_t)sp * ntap + tap) * 2 + gg) * CT + col) * 8 + e] = bits;
-    }
-  };
-  for (int co = 0; co < cout; ++co)
-    for (int ci = 0; ci < cin; ++ci) {
-      const float* h = w + ((size_t)co * cin + ci) * 9;
-      const int cb = co / CT, col = co % CT, c = ci / 16, gg = (ci % 16) / 8, e = ci % 8;
-      const size_t base = ((size_t)cb * nc + c) * wch;
-      for (int j = 0; j < 5; ++j) {
-        put(base, 5, j, gg, col, e, (double)h[2 * j] + (j < 4 ? (double)h[2 * j + 1] : 0.0));
-        put(base + wp5, 5, j, gg, col, e, (double)h[2 * j]);
-        if (j < 4) put(base + 2 * wp5, 4, j, gg, col, e, (double)h[2 * j + 1]);
-      }
-    }
-  hipError_t e1 = hipMalloc(d_out, pk.size() * 2);
-  if (e1 == hipSuccess) e1 = hipMemcpy(*d_out, pk.data(), pk.size() * 2, hipMemcpyHostToDevice);
-  if (e1 != hipSuccess) return fail(ORCA_EHIP, "fast-FIR weight upload failed: %s", hipGetErrorString(e1));
-  return ORCA_OK;
 }
 
 // Re-layout of reference-format weights for the MFMA kernels:
@@ -304,7 +268,6 @@ static int make_layer(const orca_conv_desc& d, ConvLayer* out) {
     e1 = hipMalloc(&L.d_wf16, pf.size() * 2);
     if (e1 == hipSuccess) e1 = hipMemcpy(L.d_wf16, pf.data(), pf.size() * 2, hipMemcpyHostToDevice);
     if (e1 != hipSuccess) { free_layer(L); return fail(ORCA_EHIP, "fp16 weight upload failed: %s", hipGetErrorString(e1)); }
-    if (L.f16_ok && make_pack_f14(d.weight_host, d.cin, d.cout, &L.d_wf14) != ORCA_OK) { free_layer(L); return ORCA_EHIP; }
   }
   if (d.ksize == 9 && d.cin % 32 == 0) {
     // plain bf16 pack for the B16 format: channel ci = 32 c + 16 kp + 8 g + e
@@ -756,11 +719,6 @@ static bool launch_p16x(hipStream_t s, const ConvP16Args& a) {      // false: th
     if (a.out_mode == 0 && !r1) launch_p16x_k<0, false, 96>(s, a);
     else if (a.out_mode == 1 && r1) launch_p16x_k<1, true, 96>(s, a);
     else return false;
-  } else if (a.cout % 64 == 0) {
-    if (a.out_mode == 0 && !r1) launch_p16x_k<0, false, 64>(s, a);
-    else if (a.out_mode == 0 && r1) launch_p16x_k<0, true, 64>(s, a);
-    else if (a.out_mode == 2 && r1) launch_p16x_k<2, true, 64>(s, a);
-    else return false;
   } else return false;
   return true;
 }
@@ -774,31 +732,15 @@ static bool launch_p16w1(hipStream_t s, const ConvP16Args& a) {     // false: th
 }
 
 // a 128-cout layer with ReLU, residual and MaxPool1d(5) fused (conv_p16p5.h): out_mode 3
-template <int FMT, int OM>
+template <int FMT>
 static void launch_p16p5(hipStream_t s, ConvP16Args a) {
   static int ncu = [] { int dev = 0, v = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev); return v; }();
   a.tiles_per_row = (a.n + 319) / 320;
   dim3 grid((unsigned)(a.tiles_per_row < ncu ? a.tiles_per_row : ncu));
-  if (a.r1) hipLaunchKernelGGL((conv1d_k9_p16p5_kernel<true, FMT, OM>), grid, dim3(512), 0, s, a);
-  else hipLaunchKernelGGL((conv1d_k9_p16p5_kernel<false, FMT, OM>), grid, dim3(512), 0, s, a);
+  if (a.r1) hipLaunchKernelGGL((conv1d_k9_p16p5_kernel<true, FMT>), grid, dim3(512), 0, s, a);
+  else hipLaunchKernelGGL((conv1d_k9_p16p5_kernel<false, FMT>), grid, dim3(512), 0, s, a);
 }
 
-// the fast-FIR form (conv_p16f.h): 14 instead of 18 tap products per output pair
-template <int CT, int OM, bool R1>
-static void launch_p16f_k(hipStream_t s, ConvP16Args a) {
-  static int ncu = [] { int dev = 0, v = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev); return v; }();
-  a.tiles_per_row = (a.n + 511) / 512;
-  const long ntiles = a.tiles_per_row * (a.cout / CT);
-  dim3 grid((unsigned)(ntiles < ncu ? ntiles : ncu));
-  hipLaunchKernelGGL((conv1d_k9_p16f_kernel<CT, OM, R1>), grid, dim3(512), 0, s, a);
-}
-template <int CT>
-static void launch_p16f(hipStream_t s, const ConvP16Args& a) {
-  const bool r1 = a.r1 != nullptr;
-  if (a.out_mode == 0) { if (r1) launch_p16f_k<CT, 0, true>(s, a); else launch_p16f_k<CT, 0, false>(s, a); }
-  else if (a.out_mode == 1) { if (r1) launch_p16f_k<CT, 1, true>(s, a); else launch_p16f_k<CT, 1, false>(s, a); }
-  else { if (r1) launch_p16f_k<CT, 2, true>(s, a); else launch_p16f_k<CT, 2, false>(s, a); }
-}
 
 // W-stationary barrier-free form (conv_ws.h): persistent, one workgroup per CU; the grid is a multiple of the number
 // of cout blocks (of 8 x that where possible: the blocks of one position range then share an XCD)
@@ -871,8 +813,7 @@ static int launch_conv1d_p16(orca_ctx* ctx, const ConvLayer& L, const float* x, 
   }
   a.f1_codes = nullptr; a.f1_codes_L = a.f1_codes_off = 0; a.f1_reverse = 0; a.f1_table = a.f1_bias = nullptr; a.stamps = nullptr; a.rl_w = nullptr;
   static const bool no_ws = getenv("ORCA_NO_WS") != nullptr;   // A/B switch: W-stationary barrier-free kernel (conv_ws.h)
-  static const bool ws_p16 = getenv("ORCA_WS_P16") != nullptr; // ... also for P16 (measured 3 % slower there: off)
-  const bool ws_ok = !no_ws && (fmt == 1 || ws_p16) && !k17;
+  const bool ws_ok = !no_ws && fmt == 1 && !k17;     // (P16: measured 3 % slower than the tiled kernel - profiles/HISTORY.md)
   int tile_tag = fmt == 1 ? -6 : -5;
   if (f1 && f1->residual) {
     if (L.cout != 64 || L.cin != 64 || out_mode != 1 || r1 || k17) return fail(ORCA_EINVAL, "residual from the bases: only stage 1's pooled 64 -> 64 planar conv");
@@ -888,24 +829,11 @@ static int launch_conv1d_p16(orca_ctx* ctx, const ConvLayer& L, const float* x, 
   } else if (ws_ok && fmt == 1 && L.cin == 64 && L.cout == 64) {
     launch_ws_t<1, 64, 64, 2, 2>(ctx->stream, a);
     tile_tag = -8;
-  } else if (ws_ok && fmt == 0 && L.cin == 64 && (L.cout == 64 || L.cout == 96)) {
-    launch_ws_t<0, 64, 32, 2, 1>(ctx->stream, a);
-    tile_tag = -7;
   } else if (out_mode == 3) {
     if (k17 || L.cout != 128) return fail(ORCA_EINVAL, "fused MaxPool1d(5): only the 128-cout k9 conv (conv_p16p5.h)");
-    if (fmt == 1) launch_p16p5<1, 3>(ctx->stream, a); else launch_p16p5<0, 3>(ctx->stream, a);
+    if (fmt == 1) launch_p16p5<1>(ctx->stream, a); else launch_p16p5<0>(ctx->stream, a);
     tile_tag = fmt == 1 ? -13 : -12;
-  } else if (fmt == 0 && L.cout == 128 && (out_mode == 0 || out_mode == 2) && n >= 65536 && getenv("ORCA_P16C128") != nullptr) {
-    // opt-in (measured equal: 24.66 vs 24.69 ms per strand): the unpooled 128-cout layers of stages 3-4 on the same 320-position x 128-cout
-    // geometry, k17 included
-    if (out_mode == 0) launch_p16p5<0, 0>(ctx->stream, a); else launch_p16p5<0, 2>(ctx->stream, a);
-    tile_tag = -12;
-  } else if (fmt == 0 && !k17 && L.d_wf14 && n >= 65536 && getenv("ORCA_FFA") != nullptr) {
-    a.w = reinterpret_cast<const f32x4*>(L.d_wf14);
-    if (L.cout == 96) launch_p16f<96>(ctx->stream, a);
-    else launch_p16f<64>(ctx->stream, a);
-    tile_tag = -11;                      // fast-FIR form (conv_p16f.h)
-  } else if ((L.cout == 96 || (L.cout % 64 == 0 && getenv("ORCA_P16X_64") != nullptr)) && n >= 65536 && fmt == 0 && getenv("ORCA_NO_P16X") == nullptr &&
+  } else if (L.cout == 96 && n >= 65536 && fmt == 0 && getenv("ORCA_NO_P16X") == nullptr &&
              launch_p16x(ctx->stream, a)) {
     tile_tag = -14;                      // 16 x 16 x 32 matrix instruction (conv_p16x.h)
   } else if (L.cout == 96 && n >= 65536 && getenv("ORCA_NO_P16W1") == nullptr && (fmt == 1 ? launch_p16w1<1>(ctx->stream, a) : launch_p16w1<0>(ctx->stream, a))) {

@@ -209,7 +209,10 @@ def sv_driver_genome():
     return PackedGenome.random({"chrS": 40_000_000, "chrT": 36_000_000}, seed=5, n_runs=3)
 
 
-def summarize_outputs(outputs):
+SV_REAL_CASE = ("chrS", 20_000_000, 20_400_000)      # tests/golden/G22: process_del with the reference's real networks
+
+
+def summarize_outputs(outputs, stride=10):
     """Compact, comparable summary of a tuple of genomepredict dicts (fixtures keep these, not the 1.5 MB maps)."""
     d = {}
     outs = outputs if isinstance(outputs, (tuple, list)) else (outputs,)
@@ -223,7 +226,7 @@ def summarize_outputs(outputs):
             for j, p in enumerate(preds):
                 p = np.asarray(p, dtype=np.float64)
                 d[f"o{k}_m{m}_stats_{j}"] = np.array([p.sum(), (p * p).sum(), np.abs(p).max()])
-                d[f"o{k}_m{m}_sub_{j}"] = p[::10, ::10].astype(np.float32)
+                d[f"o{k}_m{m}_sub_{j}"] = p[::stride, ::stride].astype(np.float32)
     return d
 
 

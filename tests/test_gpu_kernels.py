@@ -155,50 +155,6 @@ def test_conv1d_p16_96_couts_on_32x32x16(cuda, monkeypatch, cin, k, n, out_mode,
         assert err < 2e-5, (cin, k, n, out_mode, envs, err)
 
 
-@pytest.mark.parametrize("cin,cout,k,n", [(64, 64, 9, 131072), (96, 128, 9, 66001), (96, 128, 17, 70003)])
-@pytest.mark.parametrize("out_mode", [0, 2])
-def test_conv1d_p16_64_cout_blocks_on_16x16x32(cuda, monkeypatch, cin, cout, k, n, out_mode):
-    """conv_p16x.h with 64-cout workgroup tiles (opt-in ORCA_P16X_64=1: measured equal to the 32 x 32 x 16 tiles of conv_p16.h on stages 3-4:
-    24.65 vs 24.56 ms per strand): cout blocks, strided weight rows, P16 and fp32 outputs, 9 and 17 taps, against torch fp32."""
-    monkeypatch.setenv("ORCA_P16X_64", "1")
-    rs = np.random.RandomState(cin + cout + k + n + out_mode)
-    x = torch.from_numpy(rs.randn(1, cin, n).astype(np.float32))
-    w = (rs.randn(cout, cin, k) / np.sqrt(cin * k)).astype(np.float32)
-    b = rs.randn(cout).astype(np.float32) * 0.1
-    r1 = torch.from_numpy(rs.randn(1, cout, n).astype(np.float32))
-    for relu, ra in [(False, None), (True, r1)]:
-        y = engine.conv1d_p16(x[0].t().contiguous().to(cuda), w, b, relu, None if ra is None else ra[0].t().contiguous().to(cuda), out_mode)
-        ref = F.conv1d(x.double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(), padding=k // 2)
-        if relu:
-            ref = F.relu(ref)
-        if ra is not None:
-            ref = ref + ra.double()
-        err = float((y.cpu().t()[None].double() - ref).abs().max())
-        assert err < 2e-5, (cin, cout, k, n, out_mode, relu, err)
-
-
-@pytest.mark.parametrize("cin,k,n", [(128, 9, 70001), (96, 17, 66003)])
-@pytest.mark.parametrize("out_mode", [0, 2])
-def test_conv1d_p16_128_couts_one_workgroup(cuda, monkeypatch, cin, k, n, out_mode):
-    """conv_p16p5.h without the pool (opt-in ORCA_P16C128=1: the geometry pays only where it removes the MaxPool1d(5) pass): P16 and fp32
-    channel-last outputs, 9 and 17 taps, with and without residual, against torch fp32."""
-    monkeypatch.setenv("ORCA_P16C128", "1")
-    rs = np.random.RandomState(cin + k + n + out_mode)
-    x = torch.from_numpy(rs.randn(1, cin, n).astype(np.float32))
-    w = (rs.randn(128, cin, k) / np.sqrt(cin * k)).astype(np.float32)
-    b = rs.randn(128).astype(np.float32) * 0.1
-    r1 = torch.from_numpy(rs.randn(1, 128, n).astype(np.float32))
-    for relu, ra in [(False, None), (True, r1)]:
-        y = engine.conv1d_p16(x[0].t().contiguous().to(cuda), w, b, relu, None if ra is None else ra[0].t().contiguous().to(cuda), out_mode)
-        ref = F.conv1d(x.double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(), padding=k // 2)
-        if relu:
-            ref = F.relu(ref)
-        if ra is not None:
-            ref = ref + ra.double()
-        err = float((y.cpu().t()[None].double() - ref).abs().max())
-        assert err < 2e-5, (cin, k, n, out_mode, relu, err)
-
-
 @pytest.mark.parametrize("cin,n", [(128, 2000), (128, 323), (96, 1603), (128, 200004), (128, 4)])
 @pytest.mark.parametrize("fmt", ["p16", "b16"])
 def test_conv1d_p16_pool5_fused(cuda, cin, n, fmt):
@@ -225,28 +181,6 @@ def test_conv1d_p16_pool5_fused(cuda, cin, n, fmt):
             d = (y.cpu().t()[None] - ref).abs()
             bound = 2e-5 + (ref.abs() * 2.0 ** -8 if fmt == "b16" else 0.0)
             assert bool((d <= bound).all()), (cin, n, fmt, relu, float(d.max()))
-
-
-@pytest.mark.parametrize("cin,cout,n", [(96, 96, 300001), (64, 96, 70000), (96, 128, 66001), (64, 64, 131072)])
-@pytest.mark.parametrize("out_mode", [0, 1, 2])
-def test_conv1d_p16_fast_fir(cuda, monkeypatch, cin, cout, n, out_mode):
-    """conv_p16f.h (opt-in, ORCA_FFA=1): the k9 conv as a 2-parallel fast FIR - three half-rate filters on X1, X0 - X1 and X0' - X1 with
-    the tap sums H0 + H1, H0, H1 (14 instead of 18 tap products per output pair) - against torch fp32: same bound as the plain planar
-    kernel (the differences and tap sums are exact in fp32 / fp64 before they are split into 2 x fp16 again)."""
-    monkeypatch.setenv("ORCA_FFA", "1")
-    rs = np.random.RandomState(cin + cout + n + out_mode)
-    x = torch.from_numpy(rs.randn(1, cin, n).astype(np.float32))
-    w = (rs.randn(cout, cin, 9) / np.sqrt(cin * 9)).astype(np.float32)
-    b = rs.randn(cout).astype(np.float32) * 0.1
-    r1 = torch.from_numpy(rs.randn(1, cout, n).astype(np.float32))
-    for relu, ra in [(False, None), (True, r1)]:
-        y = engine.conv1d_p16(x[0].t().contiguous().to(cuda), w, b, relu, None if ra is None else ra[0].t().contiguous().to(cuda), out_mode)
-        ref = _ref_conv1d(x, w, b, relu, ra, None)
-        if out_mode == 1:
-            ref = F.max_pool1d(ref, 4, 4)
-        assert y.shape[0] == ref.shape[2]
-        err = float((y.cpu().t()[None] - ref).abs().max())
-        assert err < 2e-5, (cin, cout, n, out_mode, relu, err)
 
 
 @pytest.mark.parametrize("cin,cout,n", [(64, 96, 1500), (96, 128, 1031), (64, 64, 4097), (64, 96, 300000), (96, 128, 70003)])

@@ -112,7 +112,7 @@ def test_encoder_weight_seed_and_gain_sweep_vs_oracle(cuda, monkeypatch, seed, g
         scale = max(1.0, float(np.abs(ref).max()))
         assert maxabs(y, ref) < 1e-4 * scale and pearson(y, ref) > 0.999999, (seed, gain, rev, maxabs(y, ref), scale)
         if seed == 1:   # stage 2 runs at 114 000 positions here: its kernel variants (256-position tiles / the fast-FIR form) on the same input
-            for switch in ("ORCA_NO_P16X", "ORCA_NO_P16W1", "ORCA_FFA", "ORCA_NO_POOL5_FUSE", "ORCA_P16C128"):
+            for switch in ("ORCA_NO_P16X", "ORCA_NO_P16W1", "ORCA_NO_POOL5_FUSE"):
                 monkeypatch.setenv(switch, "1")
                 y2 = enc.forward_codes(codes, reverse=rev).cpu().numpy()
                 monkeypatch.delenv(switch)
@@ -125,7 +125,7 @@ def test_encoder_default_dispatch_reaches_the_current_kernels(cuda):
     tiles of conv_p16.h (-5), as recorded by the per-launch HIP-event timing (launches over >= 65 536 positions)."""
     import os
     from orca_amd import engine
-    assert not [k for k in os.environ if k.startswith("ORCA_NO_") or k in ("ORCA_FFA", "ORCA_P16C128", "ORCA_P16X_64")], "a kernel-variant switch is set"
+    assert not [k for k in os.environ if k.startswith("ORCA_NO_")], "a kernel-variant switch is set"
     enc = product_module("Encoder", 0)
     codes, ok = engine.pack_sequence(torch.from_numpy(synth.synth_sequence(4000 * 300, seed=5)).transpose(1, 2).to(cuda))
     assert ok

@@ -88,6 +88,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full32m", action="store_true")
     ap.add_argument("--config3", action="store_true", help="G17: rows 0 and 5 of BASELINE config 3 (HFF-shaped model, 8 x 32 Mb), ~10 min of CPU")
+    ap.add_argument("--svreal", action="store_true", help="G22: the reference's process_del with the real orca_modules networks at 32 Mb, ~13 min of CPU")
     ap.add_argument("--only", default="")
     args = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
@@ -416,19 +417,33 @@ def main():
                 json.dump(scripts, f)
             print("G12 done", len(scripts))
 
+        class Full(torch.nn.Module):
+            """The reference's own sub-networks (orca_modules) in the container shape genomepredict expects, synthetic weights."""
+
+            def __init__(self, seed):
+                super().__init__()
+                self.net0 = load_synth(om.Encoder(), seed=seed)
+                self.net = load_synth(om.Encoder2(), seed=seed)
+                self.denets = {lv: load_synth(om.Decoder(upsample_mode="bilinear"), seed=seed + lv)
+                               for lv in (1, 2, 4, 8, 16, 32)}
+                self.denet_1_pt = load_synth(om.Decoder_1m(), seed=seed)
+                self.normmats, self.epss = synth.synth_normmats_32m()
+
+        # ---- G22: ONE structural-variant driver of the reference - process_del - with the REAL networks at full size (three
+        #      genomepredict calls: both reference-allele views and the alternative allele; ~13 min of CPU) ------------------
+        if args.svreal and want("G22"):
+            import orca_predict as op
+            genome = synth.sv_driver_genome()
+            t = time.time()
+            outs = op.process_del(*synth.SV_REAL_CASE, genome, custom_models=[Full(0)], target=False, use_cuda=False)
+            d = {f"del.{k}": v for k, v in synth.summarize_outputs(outs, stride=5).items()}
+            d["t_cpu_s"] = np.array([time.time() - t])
+            np.savez_compressed(os.path.join(GOLD, "G22_sv_del_real_nets.npz"), **d)
+            print("G22 done %.1fs" % (time.time() - t), len(outs), "views")
+
         # ---- G8: one full 32 Mb H1-ESC-shaped forward, both strands ---------------
         if args.full32m and want("G8"):
             import orca_predict as op
-
-            class Full(torch.nn.Module):
-                def __init__(self, seed):
-                    super().__init__()
-                    self.net0 = load_synth(om.Encoder(), seed=seed)
-                    self.net = load_synth(om.Encoder2(), seed=seed)
-                    self.denets = {lv: load_synth(om.Decoder(upsample_mode="bilinear"), seed=seed + lv)
-                                   for lv in (1, 2, 4, 8, 16, 32)}
-                    self.denet_1_pt = load_synth(om.Decoder_1m(), seed=seed)
-                    self.normmats, self.epss = synth.synth_normmats_32m()
 
             model = Full(0)
             seq = synth.synth_sequence(32000000, seed=1)
