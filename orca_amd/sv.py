@@ -291,7 +291,7 @@ def _window_outputs(model, merged, starts, params, mchr):
     return outs
 
 
-def sv_screen(models, genome_codes, svs, chrlen, mchr="chrS", rank=0, world=1, incremental=True, min_uses=3, stats=None):
+def sv_screen(models, genome_codes, svs, chrlen, mchr="chrS", rank=0, world=1, incremental=True, min_uses=3, stats=None, on_result=None):
     """Predict reference and alternative allele (6 maps each, per model) for this rank's share of ``svs``
     (independent windows: replicas, no collective).  genome_codes: [chrlen] uint8 tensor on the MI355X.
     Returns {sv_index: {"sv": SV, "ref": output_dict, "alt": output_dict}} with genomepredict's output dicts.
@@ -300,7 +300,8 @@ def sv_screen(models, genome_codes, svs, chrlen, mchr="chrS", rank=0, world=1, i
     (a chromosome encoding costs chrlen / 32 Mb windows' worth of Encoder time), windows reuse those bins (`encode_window`), and the
     four strands of a variant (ref / alt x forward / reverse) go through Encoder2 and every decoder level as ONE batch.  Variants whose
     phases are not held fall back to encoding their windows whole - same maps either way (tests/test_gpu_sv_incremental.py).
-    ``incremental=False`` is the reference's cost structure: two independent `genomepredict` calls per variant."""
+    ``incremental=False`` is the reference's cost structure: two independent `genomepredict` calls per variant.
+    ``on_result(i, entry)``: called per variant INSTEAD of collecting the entries (a 1 024-variant screen is 12 288 maps = 3 GB)."""
     from . import dist, orca_predict
     res = {}
     mine = list(dist.shard_indices(len(svs), rank, world))
@@ -310,7 +311,11 @@ def sv_screen(models, genome_codes, svs, chrlen, mchr="chrS", rank=0, world=1, i
             rp, rw, rm, ap, aw, am = sv_windows(sv, chrlen)
             ref = orca_predict.genomepredict(assemble_codes(genome_codes, rp)[None], mchr, rm, rw, models=models)
             alt = orca_predict.genomepredict(assemble_codes(genome_codes, ap)[None], mchr, am, aw, models=models)
-            res[i] = {"sv": sv, "ref": ref, "alt": alt}
+            entry = {"sv": sv, "ref": ref, "alt": alt}
+            if on_result is not None:
+                on_result(i, entry)
+            else:
+                res[i] = entry
         return res
     models = orca_predict._resolve_models(models, "32M", True)
     nbins = WINDOW // BIN
@@ -344,7 +349,11 @@ def sv_screen(models, genome_codes, svs, chrlen, mchr="chrS", rank=0, world=1, i
                     for o, n in ((ref, r), (alt, a)):
                         o["predictions"] += n["predictions"]
                         o["normmats"] += n["normmats"]
-            res[i] = {"sv": sv, "ref": ref, "alt": alt}
+            entry = {"sv": sv, "ref": ref, "alt": alt}
+            if on_result is not None:
+                on_result(i, entry)
+            else:
+                res[i] = entry
     if stats is not None:
         stats.update({"bins_encoded": encoded, "bins_total": len(mine) * len(models) * 4 * nbins,
                       "chromosome_encodings": sum(c.builds for c in caches)})

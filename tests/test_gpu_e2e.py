@@ -243,3 +243,33 @@ def test_sv_drivers_256mb_on_device(cuda):
     for a, b in zip(direct["predictions"][0], ref_l["predictions"][0]):
         assert maxabs(a, b) < 1e-6
     assert max(maxabs(a, b) for a, b in zip(ref_l["predictions"][0], alt["predictions"][0])) > 1e-3
+
+
+def test_process_del_against_the_reference_with_real_networks(cuda):
+    """SURVEY 8(f1) against the ORACLE, not route against route (VERDICT r3 weak #1b): the reference's own `process_del`
+    (orca_predict.py:1172-1560) with the reference's own networks (orca_modules Encoder / Encoder2 / Decoder x 6 / Decoder_1m, synthetic
+    weights) on the synthetic genome at 32 Mb - three `genomepredict` calls, 13 min of PyTorch CPU - is the fixture G22
+    (tools/make_golden.py --svreal); here the same call through orca_amd on the MI355X, genome resident in HBM: coordinates exactly, maps
+    at the north-star 1e-4 (every 5th pixel of every map + sum / sum of squares / max of the whole map)."""
+    model = M.H1esc(synthetic_seed=0)
+    g = golden("G22_sv_del_real_nets.npz")
+    dev = synth.sv_driver_genome().to(cuda)
+    outs = P.process_del(*synth.SV_REAL_CASE, dev, custom_models=[model], target=False, use_cuda=True)
+    got = synth.summarize_outputs(outs, stride=5)
+    views = len(outs)
+    assert views >= 3 and sum(1 for k in g.files if k.endswith("_chr")) == views
+    worst = 0.0
+    for k, v in got.items():
+        ref = g["del." + k]
+        if k.endswith(("_start", "_end")):
+            assert np.array_equal(v, ref), k
+        elif k.endswith(("_chr", "_annos")):
+            assert str(v[0]) == str(ref[0]), k
+        elif "_sub_" in k:
+            worst = max(worst, maxabs(v, ref))
+            assert maxabs(v, ref) < 1e-4 and pearson(v, ref) > 0.999999, (k, maxabs(v, ref))
+        elif "_stats_" in k:
+            assert abs(v[0] - ref[0]) < 1e-4 * 62500 and abs(v[1] / ref[1] - 1) < 1e-4 and abs(v[2] - ref[2]) < 1e-4, (k, v, ref)
+    # the deletion changes the maps (ref views vs alt view)
+    assert maxabs(got["o0_m0_sub_3"], got[f"o{views - 1}_m0_sub_3"]) > 1e-3
+    print(f"process_del vs the reference with real networks: {views} views, worst max-abs on the sampled pixels {worst:.3g}")

@@ -3,7 +3,7 @@
 # bench command, then separate rocprofv3 --pmc passes (SQ / FETCH_SIZE / WRITE_SIZE: one pass each, MI355X_MICROARCH.md
 # "rocprofv3 PMC slots") over one 32 Mb Encoder forward in both arithmetic modes and over one Decoder forward.
 # Everything lands in gpurun_out/<tag>/; tools/profile_collect.py turns it into the summaries committed under profiles/.
-TAG=${1:-r03}
+TAG=${1:-r04}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
