@@ -181,6 +181,12 @@ int orca_encoder_forward_codes(orca_ctx* ctx, orca_net* net, const uint8_t* code
 int orca_encoder_forward_codes_window(orca_ctx* ctx, orca_net* net, const uint8_t* codes, int64_t sc_b, int64_t win_origin,
                                       int64_t win_len, int reverse, int B, int64_t L, int64_t bin_lo, int64_t bin_hi,
                                       float* out, int64_t so_b, int64_t so_c, int64_t chunk_bp);
+/* The same from a 2-bit genome resident in HBM (selene_utils2.py:38-272 keeps the genome as text / expands every window to float32 [L,4]
+ * on the host; orca_amd/genome.py TwoBitGenome: base j of a chromosome in bits 2 (j % 4).. of byte j / 4 of `two`, N flag in bit j % 8 of byte
+ * j / 8 of `nmask`): the sequence is bases [start, start + L) of that chromosome (B = 1).  The first-layer kernels read the two planes
+ * directly - the one-hot expansion happens in LDS as for the 1-byte codes - so no unpacked copy of the window exists. */
+int orca_encoder_forward_2bit(orca_ctx* ctx, orca_net* net, const uint8_t* two, const uint8_t* nmask, int64_t start, int reverse, int64_t L,
+                              int64_t bin_lo, int64_t bin_hi, float* out, int64_t so_c, int64_t chunk_bp);
 
 /* Number of 4 kb bins Encoder emits for an L-bp input (floor through the
  * 4,4,5,5,5,2 pooling chain). */

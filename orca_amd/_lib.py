@@ -48,6 +48,7 @@ SIGNATURES = {
     "orca_net_set_precision": (c_int, [c_void_p, c_int]),
     "orca_encoder_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_int64, c_int64,
                                      c_int64, c_void_p, c_int64, c_int64, c_int64]),
+    "orca_encoder_forward_2bit": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64]),
     "orca_pack_sequence": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, POINTER(c_int)]),
     "orca_encoder_forward_codes": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int64, c_int64, c_int64,
                                            c_void_p, c_int64, c_int64, c_int64]),

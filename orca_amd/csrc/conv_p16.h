@@ -24,6 +24,16 @@
 #define P16_GUARD 8   // zero guard units on the left of every plane (>= 8 + 16 on the right): covers the 17-tap composed convs
 #define P16_HALO 4    // half width of a k9 conv: image column i of a tile at m0 is position m0 + i - P16_HALO
 
+// Base code (0..3 = A,C,G,T, 4 = N) of forward-strand base i of a sequence that is given either as 1 byte per base (`nmask` NULL) or as a
+// window of a 2-bit genome (selene_utils2.py:216-222 expands such a store to float32 [L,4] on the host): `codes` is then the 2-bit plane -
+// base j in bits 2 (j % 4) .. of byte j / 4 -, `nmask` the N bit mask - bit j % 8 of byte j / 8 -, j = origin + i (orca_amd/genome.py).
+__device__ __forceinline__ int p16_base_at(const unsigned char* __restrict__ codes, const unsigned char* __restrict__ nmask, long origin, long i) {
+  if (!nmask) return codes[i];
+  const long j = origin + i;
+  const unsigned c = (codes[j >> 2] >> ((j & 3) * 2)) & 3u;
+  return ((nmask[j >> 3] >> (j & 7)) & 1u) ? 4 : (int)c;
+}
+
 struct ConvP16Args {
   const f32x4* x;      // P16 input, cin channels
   const f32x4* w;      // fp16 pack [cin/16][2][9][2][cout][8]  (units of 16 B)
@@ -42,7 +52,9 @@ struct ConvP16Args {
   unsigned* flag;      // raised when a value written to P16 leaves the fp16 range
   unsigned long long* stamps;   // micro-benchmark only (ABL & 128): s_memtime stamps of workgroup 0 / wave 0
   // fused first layer (template flag F1): x is not read; the input tiles are PRODUCED from the packed bases
-  const unsigned char* f1_codes;   // 1 byte per base of the whole sequence (see FirstMfmaArgs)
+  const unsigned char* f1_codes;   // 1 byte per base of the whole sequence (see FirstMfmaArgs), or a 2-bit genome plane with
+  const unsigned char* f1_nmask;   // ... its N mask (NULL: 1-byte codes) and the genome index of the sequence's base 0 (p16_base_at)
+  long f1_origin;
   long f1_codes_L, f1_codes_off;   // chunk position p is strand position codes_off + p
   int f1_reverse;
   const f32x4* rl_w;               // RL: fp16 split pack [2 splits][5 k-steps][2 g][64 couts][8] of the composed 17-tap lconv1 (K = tap*4 + ci);
@@ -282,7 +294,7 @@ __global__ __launch_bounds__(WM * 64, WM / 4) void conv1d_k9_p16_kernel(ConvP16A
   auto f1_fetch = [&](long p) -> unsigned char {
     if (p < 0 || p >= a.n) return (unsigned char)5;
     const long P = a.f1_codes_off + p;
-    return a.f1_reverse ? a.f1_codes[a.f1_codes_L - 1 - P] : a.f1_codes[P];
+    return (unsigned char)p16_base_at(a.f1_codes, a.f1_nmask, a.f1_origin, a.f1_reverse ? a.f1_codes_L - 1 - P : P);
   };
   auto f1_fix = [&](unsigned char raw) -> unsigned char {
     int cc = raw;
@@ -827,6 +839,8 @@ struct FirstMfmaArgs {
   // packed input: 1 byte per base (0..3 = A,C,G,T one-hot rows, 4 = N = 0.25 x 4, other = zero row).  The chunk's
   // position p is strand position off+p; on the reverse strand that is base L-1-(off+p), complemented (3-code).
   const unsigned char* codes;
+  const unsigned char* nmask;   // non-NULL: `codes` is a 2-bit genome plane, this its N mask, `origin` the genome index of base 0 (p16_base_at)
+  long origin;
   long codes_L, codes_off;
   int reverse;
   long n;
@@ -872,7 +886,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_first_mfma_p16_kernel(FirstMfma
     if (p < 0 || p >= a.n) return (f32x4)(0.f);
     if (!a.codes) return *reinterpret_cast<const f32x4*>(a.x + p * 4);
     const long P = a.codes_off + p;
-    int c = a.reverse ? a.codes[a.codes_L - 1 - P] : a.codes[P];
+    int c = p16_base_at(a.codes, a.nmask, a.origin, a.reverse ? a.codes_L - 1 - P : P);
     if (a.reverse && c < 4) c = 3 - c;
     f32x4 v = (f32x4)(c == 4 ? 0.25f : 0.f);   // LDS-staged one-hot expansion of the packed base
     if (c < 4) v[c] = 1.f;
@@ -1037,11 +1051,12 @@ __global__ void pack_sequence_kernel(const float* __restrict__ x, long sc, long 
   codes[i] = (unsigned char)code;
 }
 // codes -> [n][4] fp32 rows of strand positions off .. off+n-1 (used by the non-P16 arithmetic modes)
-__global__ void expand_codes_kernel(const unsigned char* __restrict__ codes, long L, long off, int reverse, long n, float* __restrict__ y) {
+__global__ void expand_codes_kernel(const unsigned char* __restrict__ codes, const unsigned char* __restrict__ nmask, long origin, long L, long off, int reverse,
+                                    long n, float* __restrict__ y) {
   const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n) return;
   const long P = off + p;
-  int c = reverse ? codes[L - 1 - P] : codes[P];
+  int c = p16_base_at(codes, nmask, origin, reverse ? L - 1 - P : P);
   if (reverse && c < 4) c = 3 - c;
   f32x4 v = (f32x4)(c == 4 ? 0.25f : 0.f);
   if (c < 4) v[c] = 1.f;
@@ -1105,7 +1120,7 @@ __global__ void p16_to_nlc_kernel(const f32x4* __restrict__ x, float* __restrict
 struct EdgeFixArgs {           // where a chunk's input comes from
   int in_mode;                 // 0: float rows (x, sc, sl; 4 channels)  1: base codes (4 channels)  2: P16 planes  3: B16 planes  (-1: scratch)
   const float* x; long sc, sl;
-  const unsigned char* codes; long codes_L, codes_off; int reverse;
+  const unsigned char* codes; const unsigned char* nmask; long origin; long codes_L, codes_off; int reverse;   // (nmask: p16_base_at)
   const f32x4* xp; long x_plen;
   long n;
 };
@@ -1121,7 +1136,7 @@ __device__ __forceinline__ float edge_fix_load(const EdgeFixArgs& a, long pos, i
   if (a.in_mode == 0) return a.x[pos * a.sl + ci * a.sc];
   if (a.in_mode == 1) {
     const long P = a.codes_off + pos;
-    int c = a.reverse ? a.codes[a.codes_L - 1 - P] : a.codes[P];
+    int c = p16_base_at(a.codes, a.nmask, a.origin, a.reverse ? a.codes_L - 1 - P : P);
     if (a.reverse && c < 4) c = 3 - c;
     return c == 4 ? 0.25f : (c == ci ? 1.f : 0.f);
   }

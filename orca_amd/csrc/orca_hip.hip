@@ -785,6 +785,8 @@ static void launch_p16_t(hipStream_t s, const ConvP16Args& a) {
 // x: P16 [cin] of n positions; y: P16 (out_mode 0: n positions, 1: n/4 pooled) or fp32 [n][cout] (2); r1: P16 [cout], n
 struct FusedFirst {   // packed bases + first-layer table: the conv's input is produced instead of read (x may be NULL)
   const unsigned char* codes = nullptr;
+  const unsigned char* nmask = nullptr;   // 2-bit genome window (conv_p16.h: p16_base_at)
+  long origin = 0;
   long codes_L = 0, codes_off = 0;
   int reverse = 0;
   const float* table = nullptr;
@@ -811,19 +813,19 @@ static int launch_conv1d_p16(orca_ctx* ctx, const ConvLayer& L, const float* x, 
     HIPCHECK(hipEventCreate(&tl.e1));
     HIPCHECK(hipEventRecord(tl.e0, ctx->stream));
   }
-  a.f1_codes = nullptr; a.f1_codes_L = a.f1_codes_off = 0; a.f1_reverse = 0; a.f1_table = a.f1_bias = nullptr; a.stamps = nullptr; a.rl_w = nullptr;
+  a.f1_codes = nullptr; a.f1_nmask = nullptr; a.f1_origin = 0; a.f1_codes_L = a.f1_codes_off = 0; a.f1_reverse = 0; a.f1_table = a.f1_bias = nullptr; a.stamps = nullptr; a.rl_w = nullptr;
   static const bool no_ws = getenv("ORCA_NO_WS") != nullptr;   // A/B switch: W-stationary barrier-free kernel (conv_ws.h)
   const bool ws_ok = !no_ws && fmt == 1 && !k17;     // (P16: measured 3 % slower than the tiled kernel - profiles/HISTORY.md)
   int tile_tag = fmt == 1 ? -6 : -5;
   if (f1 && f1->residual) {
     if (L.cout != 64 || L.cin != 64 || out_mode != 1 || r1 || k17) return fail(ORCA_EINVAL, "residual from the bases: only stage 1's pooled 64 -> 64 planar conv");
-    a.f1_codes = f1->codes; a.f1_codes_L = f1->codes_L; a.f1_codes_off = f1->codes_off; a.f1_reverse = f1->reverse;
+    a.f1_codes = f1->codes; a.f1_nmask = f1->nmask; a.f1_origin = f1->origin; a.f1_codes_L = f1->codes_L; a.f1_codes_off = f1->codes_off; a.f1_reverse = f1->reverse;
     a.rl_w = reinterpret_cast<const f32x4*>(f1->table); a.f1_bias = f1->bias;
     if (fmt == 1) launch_p16_res_bases<1>(ctx->stream, a);
     else launch_p16_res_bases<0>(ctx->stream, a);
   } else if (f1) {
     if (L.cout != 64 || L.cin != 64 || out_mode != 0 || r1 || fmt != 0 || k17) return fail(ORCA_EINVAL, "fused first layer: only the 64 -> 64 P16 conv that follows it");
-    a.f1_codes = f1->codes; a.f1_codes_L = f1->codes_L; a.f1_codes_off = f1->codes_off; a.f1_reverse = f1->reverse;
+    a.f1_codes = f1->codes; a.f1_nmask = f1->nmask; a.f1_origin = f1->origin; a.f1_codes_L = f1->codes_L; a.f1_codes_off = f1->codes_off; a.f1_reverse = f1->reverse;
     a.f1_table = f1->table; a.f1_bias = f1->bias;
     launch_p16_fused_first(ctx->stream, a);
   } else if (ws_ok && fmt == 1 && L.cin == 64 && L.cout == 64) {
@@ -1243,7 +1245,9 @@ extern "C" int64_t orca_encoder_num_bins(int64_t L) {
 struct SeqSource {            // where a chunk's input comes from: a float [.,4] view or packed base codes
   const float* x = nullptr;   // already offset to the chunk start
   long sx_c = 0, sx_l = 0;
-  const unsigned char* codes = nullptr;   // whole sequence of this batch row
+  const unsigned char* codes = nullptr;   // whole sequence of this batch row: 1 byte per base, or (nmask set) a 2-bit genome plane + N mask, the
+  const unsigned char* nmask = nullptr;   // sequence starting at genome index `origin` (conv_p16.h: p16_base_at)
+  long origin = 0;
   long codes_L = 0, codes_off = 0;
   int reverse = 0;
 };
@@ -1269,7 +1273,7 @@ static int encoder_chunk(orca_ctx* ctx, orca_net* net, const SeqSource& src, lon
   const bool compose32 = net->precision == ORCA_PRECISION_F32 && net->d_l1_f32 && getenv("ORCA_NO_COMPOSE") == nullptr && getenv("ORCA_NO_COMPOSE25") == nullptr;
   if (src.codes && !use_p16 && !compose32 && !compose_nlc) {
     // the other arithmetic modes start from float rows: expand the packed bases into buf[2] as [n][4]
-    hipLaunchKernelGGL(expand_codes_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, s, src.codes, src.codes_L, src.codes_off,
+    hipLaunchKernelGGL(expand_codes_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, s, src.codes, src.nmask, src.origin, src.codes_L, src.codes_off,
                        src.reverse, n1, buf[2]);
     LAUNCHCHECK("expand_codes_kernel");
     x = buf[2]; sx_c = 1; sx_l = 4;
@@ -1300,7 +1304,7 @@ static int encoder_chunk(orca_ctx* ctx, orca_net* net, const SeqSource& src, lon
       static const bool no_fuse1 = getenv("ORCA_NO_FUSE1") != nullptr;   // A/B switch
       const bool fuse1 = src.codes && !no_fuse1 && fmt == 0 && !compose;
       FusedFirst f1;
-      f1.codes = src.codes; f1.codes_L = src.codes_L; f1.codes_off = src.codes_off; f1.reverse = src.reverse;
+      f1.codes = src.codes; f1.nmask = src.nmask; f1.origin = src.origin; f1.codes_L = src.codes_L; f1.codes_off = src.codes_off; f1.reverse = src.reverse;
       f1.table = net->d_first_tab; f1.bias = L[0].d_bias;
       int T = 1, LO = 2, S = 0;   // buffer roles: T holds the current input
       // (guards and tails of every planar tensor are zeroed by p16_zero_pads_kernel AFTER its producer: the conv kernels
@@ -1316,7 +1320,7 @@ static int encoder_chunk(orca_ctx* ctx, orca_net* net, const SeqSource& src, lon
       // one first-layer GEMM launch: ntap 9 (lconv1.a alone), 17 (lconv1 composed), 25 (conv1.a o lconv1, + ReLU)
       auto launch_first = [&](int ntap, const void* w16, const float* bias, int relu, float* out) -> int {
         FirstMfmaArgs fm;
-        fm.codes = src.codes; fm.codes_L = src.codes_L; fm.codes_off = src.codes_off; fm.reverse = src.reverse;
+        fm.codes = src.codes; fm.nmask = src.nmask; fm.origin = src.origin; fm.codes_L = src.codes_L; fm.codes_off = src.codes_off; fm.reverse = src.reverse;
         fm.x = src.codes ? nullptr : rows; fm.n = n1;
         fm.w = reinterpret_cast<const f32x4*>(w16); fm.bias = bias; fm.relu = relu;
         fm.y = reinterpret_cast<f32x4*>(out); fm.y_plen = p16_plen(n1); fm.flag = ctx->d_flag;
@@ -1368,7 +1372,7 @@ static int encoder_chunk(orca_ctx* ctx, orca_net* net, const SeqSource& src, lon
       if (!fuse1 && !res_from_bases) ORCA_TRY(launch_p16_zero_pads(ctx, first_out, 64, n1, fmt));
       if (compose) {
         EdgeFixArgs ef{};
-        if (src.codes) { ef.in_mode = 1; ef.codes = src.codes; ef.codes_L = src.codes_L; ef.codes_off = src.codes_off; ef.reverse = src.reverse; }
+        if (src.codes) { ef.in_mode = 1; ef.codes = src.codes; ef.nmask = src.nmask; ef.origin = src.origin; ef.codes_L = src.codes_L; ef.codes_off = src.codes_off; ef.reverse = src.reverse; }
         else { ef.in_mode = 0; ef.x = x; ef.sc = sx_c; ef.sl = sx_l; }
         const ConvLayer* chain[4] = {&L[0], &L[1], &L[2], &L[3]};
         const int relus[4] = {0, 0, 1, 1};
@@ -1428,7 +1432,7 @@ static int encoder_chunk(orca_ctx* ctx, orca_net* net, const SeqSource& src, lon
         }
         if (st0 == 0 && res_from_bases) {
           FusedFirst rl;     // relu(.) + lout1 computed from the bases in the epilogue, MaxPool1d(4)
-          rl.codes = src.codes; rl.codes_L = src.codes_L; rl.codes_off = src.codes_off; rl.reverse = src.reverse;
+          rl.codes = src.codes; rl.nmask = src.nmask; rl.origin = src.origin; rl.codes_L = src.codes_L; rl.codes_off = src.codes_off; rl.reverse = src.reverse;
           rl.table = reinterpret_cast<const float*>(net->d_l1_w16); rl.bias = net->d_l1_bias; rl.residual = true;
           ORCA_TRY(launch_conv1d_p16(ctx, Ls[3], buf[T], buf[S], nullptr, n, 1, 1, &rl, fmt));
           ORCA_TRY(launch_p16_zero_pads(ctx, buf[S], C, n / 4, fmt));
@@ -1470,7 +1474,7 @@ static int encoder_chunk(orca_ctx* ctx, orca_net* net, const SeqSource& src, lon
         // stage 1's linear groups composed here too (the fallback of the fp16-range guard runs this branch in bf16x3): lconv1 and
         // conv1.a o lconv1 as 17- / 25-tap first-layer GEMMs writing fp32 channel-last, exact ends by the edge chain
         FirstMfmaArgs fm;
-        fm.codes = src.codes; fm.codes_L = src.codes_L; fm.codes_off = src.codes_off; fm.reverse = src.reverse;
+        fm.codes = src.codes; fm.nmask = src.nmask; fm.origin = src.origin; fm.codes_L = src.codes_L; fm.codes_off = src.codes_off; fm.reverse = src.reverse;
         fm.x = src.codes ? nullptr : src.x; fm.n = n; fm.y_plen = 0; fm.flag = nullptr;
         const long nt = (n + 255) / 256;
         const dim3 grid((unsigned)(nt < 2048 ? nt : 2048));
@@ -1480,7 +1484,7 @@ static int encoder_chunk(orca_ctx* ctx, orca_net* net, const SeqSource& src, lon
         hipLaunchKernelGGL((conv1d_first_mfma_p16_kernel<0, 2, 25>), grid, dim3(256), 0, s, fm);
         LAUNCHCHECK("conv1d_first_mfma_p16_kernel");
         EdgeFixArgs ef{};
-        if (src.codes) { ef.in_mode = 1; ef.codes = src.codes; ef.codes_L = src.codes_L; ef.codes_off = src.codes_off; ef.reverse = src.reverse; }
+        if (src.codes) { ef.in_mode = 1; ef.codes = src.codes; ef.nmask = src.nmask; ef.origin = src.origin; ef.codes_L = src.codes_L; ef.codes_off = src.codes_off; ef.reverse = src.reverse; }
         else { ef.in_mode = 0; ef.x = src.x; ef.sc = src.sx_c; ef.sl = src.sx_l; }
         const ConvLayer* chain[3] = {&L[0], &L[1], &L[2]};
         const int relus[3] = {0, 0, 1};
@@ -1512,7 +1516,7 @@ static int encoder_chunk(orca_ctx* ctx, orca_net* net, const SeqSource& src, lon
     if (st == 0 && compose32) {
       // lconv1 (17 taps) and conv1.a o lconv1 (25 taps + ReLU) straight from the source, fp32 FMAs; exact ends by the edge chain
       FirstF32Args fa{};
-      if (src.codes) { fa.in.in_mode = 1; fa.in.codes = src.codes; fa.in.codes_L = src.codes_L; fa.in.codes_off = src.codes_off; fa.in.reverse = src.reverse; }
+      if (src.codes) { fa.in.in_mode = 1; fa.in.codes = src.codes; fa.in.nmask = src.nmask; fa.in.origin = src.origin; fa.in.codes_L = src.codes_L; fa.in.codes_off = src.codes_off; fa.in.reverse = src.reverse; }
       else { fa.in.in_mode = 0; fa.in.x = src.x; fa.in.sc = src.sx_c; fa.in.sl = src.sx_l; }
       fa.in.n = n; fa.ldy = ld;
       const long nt = (n + 127) / 128;
@@ -1542,7 +1546,8 @@ static int encoder_chunk(orca_ctx* ctx, orca_net* net, const SeqSource& src, lon
 static int encoder_forward_impl(orca_ctx* ctx, orca_net* net, const float* x, int64_t sx_b, int64_t sx_c, int64_t sx_l,
                                 const unsigned char* codes, int64_t sc_b, int reverse,
                                 int B, int64_t L, int64_t bin_lo, int64_t bin_hi, float* out, int64_t so_b,
-                                int64_t so_c, int64_t chunk_bp, int64_t win_origin = 0, int64_t win_len = -1) {
+                                int64_t so_c, int64_t chunk_bp, int64_t win_origin = 0, int64_t win_len = -1,
+                                const unsigned char* nmask = nullptr, int64_t two_origin = 0) {
   if (!ctx || !net || (!x && !codes) || !out) return fail(ORCA_EINVAL, "orca_encoder_forward: NULL argument");
   if (net->kind != ORCA_NET_ENCODER) return fail(ORCA_EINVAL, "orca_encoder_forward: net is not an Encoder");
   HIPCHECK(hipSetDevice(ctx->device));
@@ -1583,7 +1588,7 @@ static int encoder_forward_impl(orca_ctx* ctx, orca_net* net, const float* x, in
           return fail(ORCA_EINVAL, "code window [%ld,%ld) does not cover bases [%ld,%ld) needed for bins [%ld,%ld) (112 kb halo included)",
                       (long)win_origin, (long)(win_origin + win_len), b0, b1, (long)cb0, (long)cb1);
       }
-      if (codes) { src.codes = codes + (long)b * sc_b - win_origin; src.codes_L = L; src.codes_off = lo; src.reverse = reverse; }
+      if (codes) { src.codes = codes + (nmask ? 0 : (long)b * sc_b - win_origin); src.nmask = nmask; src.origin = two_origin; src.codes_L = L; src.codes_off = lo; src.reverse = reverse; }
       else { src.x = x + (long)b * sx_b + lo * sx_l; src.sx_c = sx_c; src.sx_l = sx_l; }
       ORCA_TRY(encoder_chunk(ctx, net, src, hi - lo, buf, ru4(hi - lo), &res, &rld, &rn));
       const long keep = cb0 - lo / kBinBp;
@@ -1614,6 +1619,16 @@ extern "C" int orca_encoder_forward_codes_window(orca_ctx* ctx, orca_net* net, c
                                                  int64_t so_c, int64_t chunk_bp) {
   if (win_origin < 0 || win_len < 0 || win_origin + win_len > L) return fail(ORCA_EINVAL, "code window [%ld,+%ld) outside the %ld-base sequence", (long)win_origin, (long)win_len, (long)L);
   return encoder_forward_impl(ctx, net, nullptr, 0, 0, 0, codes, sc_b, reverse, B, L, bin_lo, bin_hi, out, so_b, so_c, chunk_bp, win_origin, win_len);
+}
+
+// Encoder straight from a 2-bit genome resident in HBM (orca_amd/genome.py TwoBitGenome: 2 bits per base + 1 N bit = 3/8 byte per base):
+// the sequence is bases [start, start + L) of the chromosome whose planes are `two` / `nmask`; the one-hot expansion of a base happens
+// where the 1-byte codes are expanded - in LDS inside the first-layer kernels / the residual-from-the-bases epilogue (conv_p16.h:
+// p16_base_at) - so neither the unpack pass (orca_genome_unpack_2bit) nor the 1 byte/base window ever exists.
+extern "C" int orca_encoder_forward_2bit(orca_ctx* ctx, orca_net* net, const uint8_t* two, const uint8_t* nmask, int64_t start, int reverse,
+                                         int64_t L, int64_t bin_lo, int64_t bin_hi, float* out, int64_t so_c, int64_t chunk_bp) {
+  if (!two || !nmask || start < 0) return fail(ORCA_EINVAL, "orca_encoder_forward_2bit: NULL plane or negative start");
+  return encoder_forward_impl(ctx, net, nullptr, 0, 0, 0, two, 0, reverse, 1, L, bin_lo, bin_hi, out, 0, so_c, chunk_bp, 0, -1, nmask, start);
 }
 
 extern "C" int orca_pack_sequence(orca_ctx* ctx, const float* x, int64_t sx_c, int64_t sx_l, int64_t L, uint8_t* codes, int* packable) {

@@ -303,6 +303,25 @@ def encoder_forward_codes(net, codes, reverse=False, bin_lo=0, bin_hi=0, chunk_b
     return out
 
 
+def encoder_forward_2bit(net, two, nmask, start, L, reverse=False, bin_lo=0, bin_hi=0, chunk_bp=0, out=None):
+    """Encoder on bases [start, start + L) of a chromosome stored as 2 bits per base + N mask in HBM (genome.TwoBitGenome planes): no
+    unpacked window is made (orca_encoder_forward_2bit).  Returns [1,128,bins]."""
+    if not (two.is_cuda and nmask.is_cuda and two.dtype == torch.uint8 and nmask.dtype == torch.uint8 and two.is_contiguous() and nmask.is_contiguous()):
+        raise ValueError("two / nmask: contiguous uint8 ROCm tensors")
+    if start < 0 or (start + L + 3) // 4 > two.numel() or (start + L + 7) // 8 > nmask.numel():
+        raise ValueError("2-bit window outside the chromosome")
+    total = encoder_num_bins(L)
+    hi = total if bin_hi <= 0 else bin_hi
+    if out is None:
+        out = torch.empty((1, 128, hi - bin_lo), dtype=torch.float32, device=two.device)
+    elif tuple(out.shape) != (1, 128, hi - bin_lo) or out.stride(2) != 1:
+        raise ValueError(f"out must be a [1,128,{hi - bin_lo}] view with unit stride along the bins")
+    net.ctx.sync_stream()
+    check(_lib.load().orca_encoder_forward_2bit(net.ctx.handle, net.handle, _p(two), _p(nmask), int(start), 1 if reverse else 0, int(L), bin_lo, hi,
+                                                _p(out), out.stride(1), chunk_bp), "orca_encoder_forward_2bit")
+    return out
+
+
 def unet_forward(net, x, nlev):
     x = _f32_cuda(x, "x")
     if x.dim() != 3 or x.shape[1] != 128:

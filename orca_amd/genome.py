@@ -265,6 +265,12 @@ class TwoBitGenome(PackedGenome):
     def _length(self, chrom):
         return self._host[chrom][2]
 
+    def planes(self, chrom):
+        """(2-bit plane, N mask) of a chromosome in HBM - what `Encoder.forward_2bit` reads in place."""
+        if chrom not in self._dev:
+            raise ValueError("TwoBitGenome.planes: the genome is not resident on a device (.to(device) first)")
+        return self._dev[chrom]
+
     def _slice(self, chrom, qs, qe, on_dev):
         if not on_dev:
             t, m, _ = self._host[chrom]

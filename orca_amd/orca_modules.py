@@ -174,6 +174,13 @@ class Encoder(_HipModule):
 
     forward_codes.__doc__ += "  (Replaces the float [B,4,L] input of orca_predict.py:334.)"
 
+    def forward_2bit(self, genome, chrom, start, end, reverse=False, bin_lo=0, bin_hi=0, out=None):
+        """Encoder on `chrom`[start:end) of a genome.TwoBitGenome resident on the MI355X, read in place: 2 bits per base + N mask straight
+        into the first-layer kernels (one-hot expansion in LDS) - no unpacked 1 byte/base window, no float window (selene_utils2.py:216-222)."""
+        two, nmask = genome.planes(chrom)
+        net = self._net(two.device)
+        return self._run_guarded(net, lambda: engine.encoder_forward_2bit(net, two, nmask, start, end - start, reverse, bin_lo, bin_hi, 0, out), "bf16x3")
+
 
 def _unet_precision(precision):
     p = precision or os.environ.get("ORCA_ENCODER2_PRECISION", "f16x2")
