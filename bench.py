@@ -77,15 +77,17 @@ def usable_cores():
     return max(1, n)
 
 
-def cpu_baseline(seed):
+def cpu_baseline(seed, sample_bp=8_000_000):
     """Reference-architecture PyTorch-CPU fp32 forward (oracle/orca_oracle.py = the torch ops the
-    reference dispatches with use_cuda=False) on a bounded sample of the same workload."""
+    reference dispatches with use_cuda=False) on a bounded sample of the same workload: the Encoder on `sample_bp` bases, EXTRAPOLATED to the
+    strand (its 800 kb blocks are independent and equal: orca_modules.py:955-977), everything after it in full.  `--cpu-full-strand` (or
+    tools/run_configs.py cpu_full) times the whole 32 Mb strand once: profiles/r04_cpu_full_strand.json."""
     from oracle import orca_oracle as O
     from orca_amd import synth
     from tests.util import synth_sd
     ncores = usable_cores()
     torch.set_num_threads(ncores)
-    sample_bp = 8_000_000   # 10 reference blocks: ~13 s on the GPU box's 16 host cores, ~15 s with the rest
+    # default: 10 reference blocks, ~13 s on the GPU box's 16 host cores, ~15 s with the rest
     x = torch.from_numpy(synth.synth_sequence(sample_bp, seed=1)).transpose(1, 2)
     sd0 = synth_sd("Encoder", seed)
     O.encoder_forward(sd0, x[:, :, :912000])  # warm-up
@@ -106,8 +108,9 @@ def cpu_baseline(seed):
     t_rest = time.perf_counter() - t
     t_strand = t_enc * (L_BP / sample_bp) + t_rest
     return {"value": round(L_BP / 1e6 / t_strand, 4), "unit": "Mb/s", "cores": ncores, "kind": "port",
-            "sample": f"Encoder on {sample_bp // 1000000} Mb ({sample_bp // 800000} reference blocks, {t_enc:.1f}s, scaled x{L_BP // sample_bp}) + "
-                      f"Encoder2(8000 bins) + 6 Decoder + Decoder_1m ({t_rest:.1f}s), torch CPU fp32, {ncores} threads",
+            "extrapolated": sample_bp < L_BP,
+            "sample": (f"Encoder on {sample_bp // 1000000} Mb ({sample_bp // 800000} reference blocks, {t_enc:.1f}s" + (f", EXTRAPOLATED x{L_BP // sample_bp}" if sample_bp < L_BP else ", the whole strand") + ") + "
+                       f"Encoder2(8000 bins) + 6 Decoder + Decoder_1m ({t_rest:.1f}s), torch CPU fp32, {ncores} threads"),
             "t_encoder_sample_s": round(t_enc, 2), "t_decoders_s": round(t_rest, 2)}
 
 
@@ -508,6 +511,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-full-strand", action="store_true", help="only: time the CPU baseline on the WHOLE 32 Mb strand (about a minute of CPU), print it and exit")
     ap.add_argument("--seq-mb", type=int, default=32, help="debug only: shorter sequence (invalidates the metric)")
     ap.add_argument("--float-input", action="store_true", help="keep the strands as float32 [1,4,L] views (the reference's input form)")
     ap.add_argument("--no-sharded", action="store_true", help="skip the 256 Mb sharded-encoder section")
@@ -517,6 +521,9 @@ def main():
     ap.add_argument("--torch-collective", action="store_true", help="256 Mb section: torch.distributed all-gather instead of the C ABI's RCCL communicator")
     args = ap.parse_args()
 
+    if args.cpu_full_strand:
+        print(json.dumps({"cpu_baseline_full_strand": cpu_baseline(0, L_BP)}))
+        return
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
