@@ -10,8 +10,8 @@
 // no recompute, no intermediate map in HBM, the result written IN PLACE - 1 launch and 1 read + 1 write of the map
 // instead of 4 launches and 4 reads (each 3x) + 4 writes.
 //
-// LDS: A = 64-channel operand image [split][8 octets][256 px + zero unit], B = the 32-channel one, W ring of three pieces
-// [split][9 taps][2][32 couts]; 154 KB in f16x2, 77 KB in bf16.  The gather is LDS-DMA straight from the M16 planes (the
+// LDS: A = 64-channel operand image [split][8 octets][256 px + 16 zero units], B = the 32-channel one, W ring of three pieces
+// [split][9 taps][2][32 couts]; 157 KB in f16x2, 79 KB in bf16.  The gather is LDS-DMA straight from the M16 planes (the
 // units ARE the operand image; a pixel outside the map is fetched from a zero pad pixel).  A lane's operand for tap (dy, dx)
 // is the unit of pixel p + dy*S + dx of its sub-image (S = side) or the zero unit when that leaves the sub-image: the padding
 // costs one address select per read.  The residuals (cur for lm, oth for m) are read back from the A image in the MFMA
@@ -34,7 +34,7 @@ struct DBlockArgs {
 template <int NS, int DT, int ABL = 0>
 __global__ __launch_bounds__(512, NS == 1 ? 4 : 2) void conv2d_dblock_kernel(DBlockArgs a) {   // bf16: 77 KB of LDS, two workgroups per CU if <= 128 VGPRs
   constexpr int WNS = DT == 1 ? 2 : 1;               // splits in the weight pack (the fp16 pack always carries hi and lo)
-  constexpr int NT = 512, PXW = 257;                 // 256 pixels + the zero unit
+  constexpr int NT = 512, PXW = 256 + 16;            // 256 pixels + 16 zero units (one per bank slot of a 16-lane read group, see nb16)
   constexpr int AU = NS * 8 * PXW, BU = NS * 4 * PXW; // operand images (16-byte units)
   constexpr int WP = NS * 9 * 2 * 32;                // one weight piece: 16 input channels x 32 couts
   constexpr int NPIECE = 16;
@@ -77,8 +77,8 @@ __global__ __launch_bounds__(512, NS == 1 ? 4 : 2) void conv2d_dblock_kernel(DBl
   }
 
   // ---- zero units: BEFORE the first DMA (a visible LDS store behind a pending DMA makes the compiler wait for it) ----
-  if (tid >= 256 && tid < 256 + NS * 8) As[(tid - 256) * PXW + 256] = (f32x4)(0.f);
-  if (tid >= 320 && tid < 320 + NS * 4) Bs[(tid - 320) * PXW + 256] = (f32x4)(0.f);
+  if (tid < NS * 8 * 16) As[(tid >> 4) * PXW + 256 + (tid & 15)] = (f32x4)(0.f);
+  if (tid >= 256 && tid < 256 + NS * 4 * 16) Bs[((tid - 256) >> 4) * PXW + 256 + (tid & 15)] = (f32x4)(0.f);
   __syncthreads();
   // ---- the four biases [32 | 64 | 32 | 64] by ONE DMA instruction of wave 0 (48 lanes x 16 bytes, per-lane sources): a register-staged
   // copy put a global-load round trip in front of the gather.  It is the wave's oldest transfer: every counted wait below covers it ----
@@ -127,12 +127,15 @@ __global__ __launch_bounds__(512, NS == 1 ? 4 : 2) void conv2d_dblock_kernel(DBl
   pix(p, prow, pcol, pr, pc);
   const bool pvalid = prow < H && pcol < W;
   const long poff = (long)prow * M16_PX + pcol;
-  unsigned nb16[9];                                 // byte offset of the tap's source unit within a plane (256 = the zero unit)
+  // byte offset of the tap's source unit within a plane.  Outside the sub-image: a zero unit - the one in the SAME bank slot as the unit the
+  // lane would have read (256 + (q & 15)): the 16 lanes of a ds_read_b128 group read 16 consecutive units = all 64 banks, so a single zero
+  // unit collided with one of them whenever a group mixed inside and outside lanes (SQ_LDS_BANK_CONFLICT 18.7 % of SQ_LDS_IDX_ACTIVE, round 4)
+  unsigned nb16[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) {
     const int dy = t / 3 - 1, dx = t % 3 - 1;
     const bool in = (unsigned)(pr + dy) < (unsigned)S && (unsigned)(pc + dx) < (unsigned)S;
-    nb16[t] = (in ? (unsigned)(p + dy * S + dx) : 256u) * 16u;
+    nb16[t] = (in ? (unsigned)(p + dy * S + dx) : 256u + ((unsigned)(p + dy * S + dx) & 15u)) * 16u;
   }
 
   f32x16 acc[2];
