@@ -154,7 +154,7 @@ __device__ __forceinline__ void m16q_vmwait() { asm volatile("s_waitcnt vmcnt(%0
 #define M16Q_SPREAD 1
 #endif
 #ifndef M16Q_ABL
-#define M16Q_ABL 0   // timing-only ablations (tools/microbench_m16q.hip): 1 no MFMA, 2 no fragment reads, 4 no epilogue, 8 / 16 X / W DMA of the first piece only
+#define M16Q_ABL 0   // timing-only ablations (tools/microbench_m16q.hip): 1 no MFMA, 2 no fragment reads, 4 no epilogue, 8 / 16 X / W DMA of the first piece only, 32 no wait for a piece's first fragments
 #endif
 #ifdef M16Q_STAMPS   // tools/microbench_m16q.hip: s_memtime stamps of every wave of ONE workgroup [wave][16]
 __device__ unsigned long long m16q_stamp_buf[8 * 16];
@@ -333,7 +333,8 @@ __global__ __launch_bounds__(512, 1) void conv2d_3x3_m16q_kernel(ConvM16QArgs aq
         if (n < 8) { const int n1 = n + 1, t1 = (n1 % 3) * 3 + n1 / 3; M16Q_READ_W(wv[fb ^ 1], t1); }
         if (ky == 0 && kx < 2) M16Q_READ_X(xr[xq ^ 1], kx + 1);
         if (ky == 0) {
-          if (kx < 2) m16q_wait_xw<5 * NS, NS>(xr[xq], wv[fb]);
+          if (kx == 0 && (M16Q_ABL & 32)) m16q_wait_xw<15, NS>(xr[xq], wv[fb]);      // timing only: the piece's first fragments as if prefetched
+          else if (kx < 2) m16q_wait_xw<5 * NS, NS>(xr[xq], wv[fb]);
           else m16q_wait_xw<NS, NS>(xr[xq], wv[fb]);
         } else {
           if (n < 8) m16q_wait_w<NS, NS>(wv[fb]);
