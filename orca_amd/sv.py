@@ -194,11 +194,20 @@ def reuse_plan(pieces, chrlen, nbins):
     return out
 
 
-def encode_windows(cache, pieces_list, win_codes, out, merge_gap=2 * RF_BINS, build=True):
+POOL_MAX_BINS = 500     # longer runs (whole windows: phases that are not held) stay on the caller's stream - they fill the chip on their own
+
+
+def encode_windows(cache, pieces_list, win_codes, out, merge_gap=2 * RF_BINS, build=True, pool=None, defer_join=False):
     """Both strands of W allele windows into ``out`` [2W,128,nbins] (window w: row 2w forward, row 2w + 1 reverse complement): bins whose
     receptive field lies inside one piece are copied from `cache` (ChromEncodings), the rest - window ends, junctions, pieces of a
     phase that is not held - go through the Encoder's bin-range form on ``win_codes`` [W,L] (the assembled windows).  Bin ranges that
-    several windows have in common (the window ends, as a rule) are ONE batched call.  Returns the number of bins encoded (of 2W * nbins)."""
+    several windows have in common (the window ends, as a rule) are ONE batched call.  Returns the number of bins encoded (of 2W * nbins).
+
+    ``pool`` (engine.ContextPool): the bin-range calls are independent of each other and small (220-440 kb of bases, ~50 launches each: one
+    host thread issues them about as fast as the GPU runs them, ~14 us per launch) - each (window, strand, range) becomes a job of its own,
+    the jobs are dealt to the pool's worker threads (own context and stream), longest first; their launch streams are issued in parallel
+    and their kernels run side by side; the caller's stream continues behind all of them (``defer_join``: it does not - the caller orders
+    a stream behind them later with pool.wait_join: `sv_screen` issues a variant's local encodes under the previous variant's decoders)."""
     nbins = out.shape[2]
     C = cache.C
     W = len(pieces_list)
@@ -228,14 +237,29 @@ def encode_windows(cache, pieces_list, win_codes, out, merge_gap=2 * RF_BINS, bu
                     merged.append(r)
             for lo, hi in merged:
                 runs.setdefault((rev, lo, hi), []).append(w)
-    encoded = 0
+    encoded = sum((hi - lo) * len(ws) for (rev, lo, hi), ws in runs.items())
+    if pool is not None and len(pool) > 0:
+        jobs = sorted(((hi - lo, rev, lo, hi, w) for (rev, lo, hi), ws in runs.items() for w in ws), reverse=True)
+        pool.fork()                                                     # the windows' codes are complete on the caller's stream
+        k = 0
+        for n_, rev, lo, hi, w in jobs:
+            row = 2 * w + int(rev)
+            if n_ > POOL_MAX_BINS:
+                cache.net0.forward_codes(win_codes[w:w + 1], reverse=rev, bin_lo=lo, bin_hi=hi, out=out[row:row + 1, :, lo:hi])
+                continue
+            pool.run(k, lambda w=w, rev=rev, lo=lo, hi=hi, row=row: cache.net0.forward_codes(win_codes[w:w + 1], reverse=rev, bin_lo=lo, bin_hi=hi,
+                                                                                         out=out[row:row + 1, :, lo:hi]))
+            k += 1
+        pool.host_join()
+        if not defer_join:
+            pool.wait_join()
+        return encoded
     for (rev, lo, hi), ws in runs.items():
         if len(ws) == W and W > 1:                                      # every window: the rows of one strand are a strided view of `out`
             cache.net0.forward_codes(win_codes, reverse=rev, bin_lo=lo, bin_hi=hi, out=out[int(rev)::2, :, lo:hi])
         else:
             for w in ws:
                 cache.net0.forward_codes(win_codes[w:w + 1], reverse=rev, bin_lo=lo, bin_hi=hi, out=out[2 * w + int(rev):2 * w + int(rev) + 1, :, lo:hi])
-        encoded += (hi - lo) * len(ws)
     return encoded
 
 
@@ -291,7 +315,8 @@ def _window_outputs(model, merged, starts, params, mchr):
     return outs
 
 
-def sv_screen(models, genome_codes, svs, chrlen, mchr="chrS", rank=0, world=1, incremental=True, min_uses=3, stats=None, on_result=None):
+def sv_screen(models, genome_codes, svs, chrlen, mchr="chrS", rank=0, world=1, incremental=True, min_uses=3, stats=None, on_result=None,
+              streams=None):
     """Predict reference and alternative allele (6 maps each, per model) for this rank's share of ``svs``
     (independent windows: replicas, no collective).  genome_codes: [chrlen] uint8 tensor on the MI355X.
     Returns {sv_index: {"sv": SV, "ref": output_dict, "alt": output_dict}} with genomepredict's output dicts.
@@ -301,7 +326,10 @@ def sv_screen(models, genome_codes, svs, chrlen, mchr="chrS", rank=0, world=1, i
     four strands of a variant (ref / alt x forward / reverse) go through Encoder2 and every decoder level as ONE batch.  Variants whose
     phases are not held fall back to encoding their windows whole - same maps either way (tests/test_gpu_sv_incremental.py).
     ``incremental=False`` is the reference's cost structure: two independent `genomepredict` calls per variant.
-    ``on_result(i, entry)``: called per variant INSTEAD of collecting the entries (a 1 024-variant screen is 12 288 maps = 3 GB)."""
+    ``on_result(i, entry)``: called per variant INSTEAD of collecting the entries (a 1 024-variant screen is 12 288 maps = 3 GB).
+    ``streams``: auxiliary contexts the local re-encodes of a variant are dealt to (`encode_windows`; default $ORCA_SV_STREAMS or 4, 0 = all
+    on the caller's stream)."""
+    import os
     from . import dist, orca_predict
     res = {}
     mine = list(dist.shard_indices(len(svs), rank, world))
@@ -328,32 +356,81 @@ def sv_screen(models, genome_codes, svs, chrlen, mchr="chrS", rank=0, world=1, i
                 if n >= min_uses:
                     cache.get(*key)
             caches.append(cache)
-        enc0 = torch.empty((4, 128, nbins), dtype=torch.float32, device=genome_codes.device)
         encoded = 0
-        for i in mine:
-            sv = svs[i]
-            rp, rw, rm, ap, aw, am = sv_windows(sv, chrlen)
-            codes = torch.stack([assemble_codes(genome_codes, rp), assemble_codes(genome_codes, ap)])
-            ref = alt = None
-            for model, cache in zip(models, caches):
-                def forward(model=model, cache=cache):
-                    n = encode_windows(cache, [rp, ap], codes, enc0, build=False)
-                    return _cascade_windows(model, enc0, [(rm, rw), (am, aw)]), n
+        if streams is None:
+            streams = int(os.environ.get("ORCA_SV_STREAMS", "4"))
+        pool = engine.context_pool(genome_codes.device, streams) if (streams > 0 and genome_codes.is_cuda) else None
+        dev = genome_codes.device
+        units = [(i, mi) for i in mine for mi in range(len(models))]          # one (variant, model) per pass of the pipeline below
+        slots = [{"enc0": torch.empty((4, 128, nbins), dtype=torch.float32, device=dev), "ev": torch.cuda.Event() if pool else None} for _ in range(2)]
+        plans = {}
 
-                (merged, starts), n = engine.run_with_overflow_retry(forward, genome_codes.device)     # ONE fp16-range check per variant
-                encoded += n
-                r, a = _window_outputs(model, merged, starts, [(rm, rw), (am, aw)], mchr)
-                if ref is None:
-                    ref, alt = r, a
+        def plan(i):
+            if i not in plans:
+                plans.clear()
+                rp, rw, rm, ap, aw, am = sv_windows(svs[i], chrlen)
+                plans[i] = {"rp": rp, "ap": ap, "params": [(rm, rw), (am, aw)], "codes": torch.stack([assemble_codes(genome_codes, rp), assemble_codes(genome_codes, ap)])}
+            return plans[i]
+
+        def prep(k):
+            """Issue unit k's Encoder outputs into slot k % 2: on the pool's side stream and workers when there is a pool (the caller's
+            stream - the previous unit's decoders - is not involved), else right here."""
+            i, mi = units[k]
+            slot = slots[k % 2]
+            if pool is None:
+                pl = plan(i)
+                slot["n"] = encode_windows(caches[mi], [pl["rp"], pl["ap"]], pl["codes"], slot["enc0"], build=False)
+                return
+            with torch.cuda.stream(pool.side):
+                pl = plan(i)
+                slot["n"] = encode_windows(caches[mi], [pl["rp"], pl["ap"]], pl["codes"], slot["enc0"], build=False, pool=pool, defer_join=True)
+                slot["ev"].record(pool.side)
+
+        ctx = engine.get_context(dev) if genome_codes.is_cuda else None
+        main = torch.cuda.current_stream(dev) if pool else None
+        entry = None
+        with engine.defer_overflow_guard():                   # ONE fp16-range check per unit (below), not one per module forward
+            if pool is not None:
+                pool.side.wait_stream(main)                   # the chromosome encodings above
+            if units:
+                prep(0)
+            enc_over = pool.take_overflow() if pool else False
+            for k, (i, mi) in enumerate(units):
+                model, slot, pl = models[mi], slots[k % 2], plan(units[k][0])
+                if pool is not None:
+                    main.wait_event(slot["ev"])
+                    pool.wait_join(main)
+                merged, starts = _cascade_windows(model, slot["enc0"], pl["params"])
+                # the NEXT unit's local encodes are issued now: they run on the pool's streams while this unit's decoders (a chain of
+                # launches with ramps and tails, matrix pipe busy a quarter of the time) hold the caller's stream
+                nxt_over = False
+                if pool is not None and k + 1 < len(units):
+                    prep(k + 1)
+                    nxt_over = pool.take_overflow()            # (waits for those encodes: the host has nothing else to issue)
+                over = (ctx.take_overflow() if ctx is not None else False) or enc_over
+                enc_over = nxt_over
+                if over:                                      # an activation left the fp16 range: this unit again, range-safe arithmetic
+                    import warnings
+                    warnings.warn("orca_amd: an activation left the fp16 range; recomputing with range-safe arithmetic (bf16x3 / f32)")
+                    with engine.force_safe_precision():
+                        slot["n"] = encode_windows(caches[mi], [pl["rp"], pl["ap"]], pl["codes"], slot["enc0"], build=False)
+                        merged, starts = _cascade_windows(model, slot["enc0"], pl["params"])
+                    ctx.take_overflow()
+                encoded += slot["n"]
+                r, a = _window_outputs(model, merged, starts, pl["params"], mchr)
+                if mi == 0:
+                    entry = {"sv": svs[i], "ref": r, "alt": a}
                 else:
-                    for o, n in ((ref, r), (alt, a)):
+                    for o, n in ((entry["ref"], r), (entry["alt"], a)):
                         o["predictions"] += n["predictions"]
                         o["normmats"] += n["normmats"]
-            entry = {"sv": sv, "ref": ref, "alt": alt}
-            if on_result is not None:
-                on_result(i, entry)
-            else:
-                res[i] = entry
+                if pool is None and k + 1 < len(units):
+                    prep(k + 1)
+                if mi == len(models) - 1:
+                    if on_result is not None:
+                        on_result(i, entry)
+                    else:
+                        res[i] = entry
     if stats is not None:
         stats.update({"bins_encoded": encoded, "bins_total": len(mine) * len(models) * 4 * nbins,
                       "chromosome_encodings": sum(c.builds for c in caches)})

@@ -67,3 +67,55 @@ def test_screen_falls_back_when_phases_are_not_held(setup):
         for j in range(6):
             # (not 0: the four strands of a variant are 32 000 Encoder2 positions - its split-operand kernels - where a window's two run the exact-fp32 ones)
             assert float(np.abs(inc[0][allele]["predictions"][0][j] - full[0][allele]["predictions"][0][j]).max()) <= 2e-5
+
+
+def test_local_encodes_on_a_context_pool_equal_the_one_stream_path(setup):
+    """engine.ContextPool: the (window, strand, range) jobs of encode_windows dealt to four auxiliary contexts (own stream, workspace,
+    edge scratch, range flag) - the same kernels on the same inputs, so the encodings are equal bit for bit; repeated, so that a
+    race between overlapping calls (a shared buffer, a missing fork / join edge) would show; and the screen gives the same maps."""
+    from orca_amd import engine
+    model, genome = setup
+    cache = sv.ChromEncodings(model.net0, genome, max_entries=16)
+    pool = engine.context_pool(genome.device, 4)
+    for v in VARIANTS[:3]:
+        rp, rw, rm, ap, aw, am = sv.sv_windows(v, CHR)
+        codes = torch.stack([sv.assemble_codes(genome, rp), sv.assemble_codes(genome, ap)])
+        one = torch.full((4, 128, 8000), float("nan"), device=genome.device)
+        n1 = sv.encode_windows(cache, [rp, ap], codes, one)
+        for _ in range(3):
+            out = torch.full((4, 128, 8000), float("nan"), device=genome.device)
+            n2 = sv.encode_windows(cache, [rp, ap], codes, out, pool=pool)
+            assert n1 == n2 and torch.equal(out, one), v
+    assert not pool.take_overflow()
+    a = sv.sv_screen([model], genome, VARIANTS[:2], CHR, min_uses=1, streams=4)
+    b = sv.sv_screen([model], genome, VARIANTS[:2], CHR, min_uses=1, streams=0)
+    for i in range(2):
+        for allele in ("ref", "alt"):
+            for j in range(6):
+                assert np.array_equal(a[i][allele]["predictions"][0][j], b[i][allele]["predictions"][0][j])
+
+
+def test_pipelined_screen_redoes_a_unit_whose_encodes_left_the_fp16_range(setup, monkeypatch):
+    """The screen issues unit k + 1's local encodes under unit k's decoders; their range flags are read per unit and attributed to the unit
+    they belong to.  Forced here (the pool reports a raised flag once, for the SECOND variant's encodes): that unit alone is redone in the
+    range-safe arithmetic (bf16x3 Encoder calls, f32 Decoders: maps equal within the 1e-4 parity bar), the others are bit-identical."""
+    from orca_amd import engine
+    model, genome = setup
+    base = sv.sv_screen([model], genome, VARIANTS[:3], CHR, min_uses=1, streams=4)
+    calls = {"n": 0}
+    real = engine.ContextPool.take_overflow
+
+    def fake(self):
+        calls["n"] += 1
+        return bool(real(self)) or calls["n"] == 2          # call 1: after prep(0); call 2: unit 1's encodes, issued under unit 0's decoders
+    monkeypatch.setattr(engine.ContextPool, "take_overflow", fake)
+    with pytest.warns(UserWarning, match="fp16 range"):
+        redo = sv.sv_screen([model], genome, VARIANTS[:3], CHR, min_uses=1, streams=4)
+    for i in range(3):
+        for allele in ("ref", "alt"):
+            for j in range(6):
+                a, b = redo[i][allele]["predictions"][0][j], base[i][allele]["predictions"][0][j]
+                if i == 1:
+                    assert float(np.abs(a - b).max()) <= 1e-4 and not np.array_equal(a, b)
+                else:
+                    assert np.array_equal(a, b)
