@@ -67,12 +67,14 @@ def get_context(device):
         idx = device.index if device.index is not None else torch.cuda.current_device()
     else:
         idx = int(device)
-    ctxs = getattr(_tls, "ctxs", None)
-    if ctxs is None:
-        ctxs = _tls.ctxs = {}
-    if idx not in ctxs:
-        ctxs[idx] = Context(idx)
-    ctx = ctxs[idx]
+    ctx = getattr(_tls, "override", None)          # ContextPool.run: an auxiliary context is current on this thread
+    if ctx is None or ctx.device_index != idx:
+        ctxs = getattr(_tls, "ctxs", None)
+        if ctxs is None:
+            ctxs = _tls.ctxs = {}
+        if idx not in ctxs:
+            ctxs[idx] = Context(idx)
+        ctx = ctxs[idx]
     ctx.sync_stream()
     return ctx
 
@@ -126,68 +128,50 @@ def force_safe_precision():
 
 
 class ContextPool:
-    """K worker threads on one device, each with its own engine Context (HIP stream, workspace arena, edge-fix scratch, fp16-range flag,
-    weights) installed as THAT thread's context - for INDEPENDENT short calls that are bound by the host's launch rate and whose
-    launches fill a fraction of the chip each: the local re-encodes of an SV allele window (sv.encode_windows: ~650 launches in 9 ms
-    from one thread, the GPU keeping pace).  The C calls release the GIL, so the workers' launch streams are issued in parallel and
-    their kernels run side by side.  fork() orders the workers' streams behind the caller's current stream, run(i, fn) queues fn() on
-    worker i (under the caller's fp16-range guard policy), join() waits for the workers' host work, re-raises their exceptions and
-    orders the caller's stream behind their streams."""
+    """K auxiliary contexts on one device, each with its own HIP stream, workspace arena, edge-fix scratch, fp16-range flag and weight
+    upload (a context's arena is reused by every call, so calls that are to overlap need a context each) - for INDEPENDENT short calls
+    whose launches fill a fraction of the chip each: the local re-encodes of an SV allele window (sv.encode_windows: 14 calls of ~50
+    dependent launches, 0.65 ms of GPU time each in stream order against 0.15 ms of host time to issue one).  All issued from the
+    CALLER's thread: run(i, fn) makes context i the thread's current context (get_context) and its stream torch's current stream while
+    fn() runs.  fork() orders the pool's streams behind a stream of the caller's, host_join() marks the end of what has been issued,
+    wait_join() orders a stream behind those marks (join() = both, now); `side` is one more stream of the caller's for preparation
+    work.  (Worker THREADS per context were measured too: 42.0 against 40.6 ms per variant - the host is not the bound.)"""
 
     def __init__(self, device, k):
-        from concurrent.futures import ThreadPoolExecutor
         self.index = device.index if isinstance(device, torch.device) and device.index is not None else torch.cuda.current_device()
-        self._workers = [ThreadPoolExecutor(max_workers=1, thread_name_prefix=f"orca-pool{i}") for i in range(k)]
-        made = [w.submit(self._init_worker) for w in self._workers]
-        self.ctxs, self.streams = (list(t) for t in zip(*[f.result() for f in made])) if k else ([], [])
+        self.streams = [torch.cuda.Stream(device=self.index) for _ in range(k)]
+        self.ctxs = []
+        for s in self.streams:
+            with torch.cuda.stream(s):
+                self.ctxs.append(Context(self.index))
         self._fork = torch.cuda.Event()
         self._join = [torch.cuda.Event() for _ in range(k)]
-        self._pending = []
-        self.side = torch.cuda.Stream(device=self.index)     # a stream of the CALLER's thread beside its current one (preparation work)
-
-    def _init_worker(self):
-        torch.cuda.set_device(self.index)
-        stream = torch.cuda.Stream(device=self.index)
-        with torch.cuda.stream(stream):
-            ctx = Context(self.index)
-        _tls.ctxs = {self.index: ctx}          # get_context() of this thread: the worker's own context ...
-        _tls.pool_stream = stream              # ... on the worker's own stream
-        return ctx, stream
-
-    @staticmethod
-    def _job(fn, defer, force_safe):
-        with _guard_scope("defer", defer), _guard_scope("force_safe", force_safe), torch.cuda.stream(_tls.pool_stream):
-            return fn()
+        self.side = torch.cuda.Stream(device=self.index)     # a stream beside the caller's current one (preparation work)
 
     def __len__(self):
-        return len(self._workers)
+        return len(self.ctxs)
 
     def fork(self, stream=None):
-        """The workers' streams continue behind ``stream`` (default: the caller's current stream)."""
+        """The pool's streams continue behind ``stream`` (default: the caller's current stream)."""
         self._fork.record(stream or torch.cuda.current_stream(self.index))
         for s in self.streams:
             s.wait_event(self._fork)
 
     def run(self, i, fn):
-        self._pending.append(self._workers[i % len(self._workers)].submit(self._job, fn, _guard.defer, _guard.force_safe))
+        i %= len(self.ctxs)
+        prev = getattr(_tls, "override", None)
+        _tls.override = self.ctxs[i]
+        try:
+            with torch.cuda.stream(self.streams[i]):
+                return fn()
+        finally:
+            _tls.override = prev
 
     def host_join(self):
-        """Wait until every queued job has ISSUED its work (not until the GPU is done with it), re-raise a job's exception, and mark the
-        end of that work on the workers' streams (wait_join orders a stream behind those marks - now or later, e.g. after more
-        work has been issued on it: sv.sv_screen issues a variant's local encodes under the previous variant's decoders)."""
-        pending, self._pending = self._pending, []
-        err = None
-        results = []
-        for f in pending:                      # every job's host work, whatever happens to one of them
-            try:
-                results.append(f.result())
-            except BaseException as e:         # noqa: BLE001 - re-raised below
-                err = err or e
+        """Mark the end of the work issued so far on the pool's streams (wait_join orders a stream behind those marks - now or later,
+        e.g. after more work has been issued on it: sv.sv_screen issues a variant's local encodes under the previous variant's decoders)."""
         for s, ev in zip(self.streams, self._join):
             ev.record(s)
-        if err is not None:
-            raise err
-        return results
 
     def wait_join(self, stream=None):
         cur = stream or torch.cuda.current_stream(self.index)
@@ -195,23 +179,18 @@ class ContextPool:
             cur.wait_event(ev)
 
     def join(self):
-        results = self.host_join()
+        self.host_join()
         self.wait_join()
-        return results
 
     def take_overflow(self):
         return any([c.take_overflow() for c in self.ctxs])      # a list: every flag is read (and cleared)
-
-    def close(self):
-        for w in self._workers:
-            w.shutdown(wait=True)
 
 
 _pools = {}
 
 
 def context_pool(device, k):
-    """THE pool of k worker contexts of a device (made once per process: modules cache a weight upload per context they ran on)."""
+    """THE pool of k auxiliary contexts of a device (made once per process: modules cache a weight upload per context they ran on)."""
     idx = device.index if isinstance(device, torch.device) and device.index is not None else torch.cuda.current_device()
     if (idx, k) not in _pools:
         _pools[(idx, k)] = ContextPool(torch.device("cuda", idx), k)

@@ -203,11 +203,11 @@ def encode_windows(cache, pieces_list, win_codes, out, merge_gap=2 * RF_BINS, bu
     phase that is not held - go through the Encoder's bin-range form on ``win_codes`` [W,L] (the assembled windows).  Bin ranges that
     several windows have in common (the window ends, as a rule) are ONE batched call.  Returns the number of bins encoded (of 2W * nbins).
 
-    ``pool`` (engine.ContextPool): the bin-range calls are independent of each other and small (220-440 kb of bases, ~50 launches each: one
-    host thread issues them about as fast as the GPU runs them, ~14 us per launch) - each (window, strand, range) becomes a job of its own,
-    the jobs are dealt to the pool's worker threads (own context and stream), longest first; their launch streams are issued in parallel
-    and their kernels run side by side; the caller's stream continues behind all of them (``defer_join``: it does not - the caller orders
-    a stream behind them later with pool.wait_join: `sv_screen` issues a variant's local encodes under the previous variant's decoders)."""
+    ``pool`` (engine.ContextPool): the bin-range calls are independent of each other and small (220-440 kb of bases: ~50 dependent launches,
+    0.65-0.9 ms of GPU time in stream order, most of them on a fraction of the chip) - each (window, strand, range) becomes a job of its own,
+    the jobs are dealt to the pool's contexts (own stream and workspace), longest first, and their kernels run side by side (9.1 -> 5.4 ms
+    per variant); the caller's stream continues behind all of them (``defer_join``: it does not - the caller orders a stream behind them
+    later with pool.wait_join: `sv_screen` issues a variant's local encodes under the previous variant's decoders)."""
     nbins = out.shape[2]
     C = cache.C
     W = len(pieces_list)
@@ -373,7 +373,7 @@ def sv_screen(models, genome_codes, svs, chrlen, mchr="chrS", rank=0, world=1, i
             return plans[i]
 
         def prep(k):
-            """Issue unit k's Encoder outputs into slot k % 2: on the pool's side stream and workers when there is a pool (the caller's
+            """Issue unit k's Encoder outputs into slot k % 2: on the pool's side stream and contexts when there is a pool (the caller's
             stream - the previous unit's decoders - is not involved), else right here."""
             i, mi = units[k]
             slot = slots[k % 2]

@@ -22,7 +22,8 @@ torch.cuda.synchronize()
 print("MARK")
 import time
 t = time.perf_counter()
-n = sv.encode_windows(cache, [rp, ap], codes, enc0, build=False, pool=pool)
+with engine.defer_overflow_guard():      # as in sv_screen: no range check (= stream sync) per call
+    n = sv.encode_windows(cache, [rp, ap], codes, enc0, build=False, pool=pool)
 t_host = time.perf_counter() - t
 torch.cuda.synchronize()
 print(v, n, "bins", "streams", ns, "host enqueue", round(t_host * 1e3, 2), "ms, done after", round((time.perf_counter() - t) * 1e3, 2), "ms")

@@ -35,9 +35,11 @@ if inc:   # where a variant's time goes
         torch.cuda.synchronize(); t = T.perf_counter()
         codes = torch.stack([sv.assemble_codes(genome, rp), sv.assemble_codes(genome, ap)])
         torch.cuda.synchronize(); acc["assemble"] += T.perf_counter() - t; t = T.perf_counter()
-        sv.encode_windows(cache, [rp, ap], codes, enc0, build=False, pool=pool)
+        with engine.defer_overflow_guard():      # as in sv_screen: no range check (= stream sync) per call
+            sv.encode_windows(cache, [rp, ap], codes, enc0, build=False, pool=pool)
         torch.cuda.synchronize(); acc["encode_window"] += T.perf_counter() - t; t = T.perf_counter()
-        merged, starts = sv._cascade_windows(h1, enc0, [(rm, rw), (am, aw)])
+        with engine.defer_overflow_guard():
+            merged, starts = sv._cascade_windows(h1, enc0, [(rm, rw), (am, aw)])
         torch.cuda.synchronize(); acc["cascade"] += T.perf_counter() - t; t = T.perf_counter()
         sv._window_outputs(h1, merged, starts, [(rm, rw), (am, aw)], "c")
         acc["to_host"] += T.perf_counter() - t
