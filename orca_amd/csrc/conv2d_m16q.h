@@ -16,6 +16,10 @@
 //     (the one-row kernel: 500 workgroups of 160 KB, two rounds, each with its own cold prologue).
 //   * out-of-map source rows, halo pixels left of pixel 0 / right of the row pitch come from a zero unit by per-lane address
 //     select in the DMA: no margin is zeroed, no tap is skipped, every group runs the same instruction stream.
+//   * batches of more than one round (the SV screen's four strands, config 3's eight): the grid holds ONE round and a workgroup walks
+//     the maps b, b + gridDim.y, ... of its tile - the weights' pieces and the X geometry are the same for each - requesting the next
+//     map's first weight piece and X image under the LAST piece of the current one (ring slot and buffer 0 are free then: the piece
+//     count and the chunk count of such a launch are even), so only a workgroup's first map pays the cold first fill.
 // Every layer shape of a Decoder goes through it (16- to 144-channel inputs, 32 / 64 couts, the table-fed first conv).
 #pragma once
 #include <type_traits>
@@ -25,6 +29,7 @@ struct ConvM16QArgs {
   ConvM16Args c;
   const f32x4* zero;   // one 16-byte unit of zeros in global memory
   int ngroups;         // row groups per map = ceil(H / 4d) * d (group p = (q, r) = (p / d, p % d) holds rows 4dq + r + {0, d, 2d, 3d})
+  int nb;              // maps of the batch: the workgroup at blockIdx.y takes maps blockIdx.y, blockIdx.y + gridDim.y, ... (gridDim.y < nb only with an even nchunks)
 };
 
 // fp16 pair (hi part, lo part) of a stored value -> fp32, exactly: hi + lo has at most 22 significant bits (one v_fma_mix_f32 per value)
@@ -183,7 +188,9 @@ __global__ __launch_bounds__(512, 1) void conv2d_3x3_m16q_kernel(ConvM16QArgs aq
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, g = lane >> 5;
-  const int H = a.H, d = a.dil, b = blockIdx.y;
+  const int H = a.H, d = a.dil;
+  int b = blockIdx.y;
+  const int nb = aq.nb, bstep = gridDim.y;
   // Workgroups go to the XCDs round-robin (blockIdx.x % 8; the grid's x extent is a multiple of 8).  Tiles are ordered residue class r,
   // chain position q, half, and XCD j takes a CONTIGUOUS run of them: neighbouring groups of a chain share two of their six source rows,
   // the halves of a group 16 pixels of each - those are then fetched into ONE L2 (d = 8: XCD r holds class r; d = 1: XCD j rows 32j ..)
@@ -209,42 +216,51 @@ __global__ __launch_bounds__(512, 1) void conv2d_3x3_m16q_kernel(ConvM16QArgs aq
     const bool ok = ys >= 0 && ys < H && px >= 0 && px < M16_PX;
     xoff[it] = ok ? (int)(m16_plane(gg, s, NS, H) + (long)ys * M16_PX + px) : -1;
   }
-  const f32x4* const xb = a.x + (long)b * a.x_bs;
-  auto issue_x1 = [&](int k, int buf, int it) {      // one of the XIT transfers of chunk k's X image
-    if (it + 1 < XIT || wave < XFULL) p16_glds16(xoff[it] >= 0 ? xb + m16_plane(2 * k, 0, NS, H) + xoff[it] : aq.zero, Xs + buf * XB + it * NT + wave * 64);
+  const f32x4* xb = a.x + (long)b * a.x_bs;
+  auto issue_x1 = [&](const f32x4* xm, int k, int buf, int it) {      // one of the XIT transfers of chunk k's X image of the map at xm
+    if (it + 1 < XIT || wave < XFULL) p16_glds16(xoff[it] >= 0 ? xm + m16_plane(2 * k, 0, NS, H) + xoff[it] : aq.zero, Xs + buf * XB + it * NT + wave * 64);
   };
-  auto issue_w1 = [&](int i, int it) {               // one of the WIT transfers of weight piece i = (k, h) -> ring slot i & 1
+  auto issue_w1 = [&](int i, int slot, int it) {     // one of the WIT transfers of weight piece i = (k, h) -> ring slot `slot`
     const int k = i / NH, h = i - k * NH;
     const int u = tid + it * NT;
     if (it + 1 < WIT || wave < WFULL)
-      p16_glds16(reinterpret_cast<const f32x4*>(a.w) + ((long)k * (WNS * 9 * 2) + (u >> 5)) * COUT + h * 32 + (u & 31), Ws + (i & 1) * WP + it * NT + wave * 64);
+      p16_glds16(reinterpret_cast<const f32x4*>(a.w) + ((long)k * (WNS * 9 * 2) + (u >> 5)) * COUT + h * 32 + (u & 31), Ws + slot * WP + it * NT + wave * 64);
   };
-  auto issue_x = [&](int k, int buf) {
+  auto issue_x = [&](const f32x4* xm, int k, int buf) {
 #pragma unroll
-    for (int it = 0; it < XIT; ++it) issue_x1(k, buf, it);
+    for (int it = 0; it < XIT; ++it) issue_x1(xm, k, buf, it);
   };
-  auto issue_w = [&](int i) {
+  auto issue_w = [&](int i, int slot) {
 #pragma unroll
-    for (int it = 0; it < WIT; ++it) issue_w1(i, it);
+    for (int it = 0; it < WIT; ++it) issue_w1(i, slot, it);
   };
 
-  issue_w(0);
-  issue_x(0, 0);
+  issue_w(0, 0);
+  issue_x(xb, 0, 0);
   M16Q_STAMP(1);
+  const unsigned ws_lds = p16_lds_addr(Ws + g * 32 + l31);
+  const unsigned xs_lds = p16_lds_addr(Xs + (g * SR + r0) * ROWP + 8 + wpx + l31);
+  const int px = px0 + wpx + l31;
+  const int yr0 = y0 + r0 * d, yr1 = yr0 + d;
+  float vmax = 0.f;
+
+  while (true) {       // the maps of this workgroup: b, b + bstep, ...
+  const bool has_next = b + bstep < nb;
+  const f32x4* const xb_next = xb + (long)bstep * a.x_bs;
 
   // accumulators [row of the pair][cout half] start from the bias: register group q of a lane = couts 8q + 4g .. + 3 of the half
   // (the loads' round trip runs under the first piece's transfer)
   f32x16 acc[2][NH];
+  int gb_ = g;                     // (opaque per map: the bias loads are invariant over the map loop - hoisted, their 16 / 32 registers would stay live)
+  asm volatile("" : "+v"(gb_));
 #pragma unroll
   for (int h = 0; h < NH; ++h)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + h * 32 + 8 * q + 4 * g);
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + h * 32 + 8 * q + 4 * gb_);
 #pragma unroll
       for (int j = 0; j < 2; ++j) { acc[j][h][4 * q + 0] = b4.x; acc[j][h][4 * q + 1] = b4.y; acc[j][h][4 * q + 2] = b4.z; acc[j][h][4 * q + 3] = b4.w; }
     }
-  const unsigned ws_lds = p16_lds_addr(Ws + g * 32 + l31);
-  const unsigned xs_lds = p16_lds_addr(Xs + (g * SR + r0) * ROWP + 8 + wpx + l31);
 
   // residual units (f16x2) of the pair's FIRST row are requested when the last piece starts (their round trip runs under its MFMAs), the
   // second row's under the last kernel column of that piece (the other X fragment buffer is dead by then).  (Measured alternative for the
@@ -253,8 +269,6 @@ __global__ __launch_bounds__(512, 1) void conv2d_3x3_m16q_kernel(ConvM16QArgs aq
   // matrix pipe has nothing to cover it.)
   constexpr int NRU = NS == 2 ? NH * 4 : 1;
   u32x4_t ru[NRU], ru1[NRU];
-  const int px = px0 + wpx + l31;
-  const int yr0 = y0 + r0 * d, yr1 = yr0 + d;
   const f32x4* const rb = a.r ? a.r + (long)b * a.r_bs : nullptr;
   const bool res_late = rb != nullptr;
 
@@ -289,26 +303,40 @@ __global__ __launch_bounds__(512, 1) void conv2d_3x3_m16q_kernel(ConvM16QArgs aq
     M16Q_STAMP(3 + 2 * (i < 4 ? i : 3));
     if constexpr (NS == 2 && LASTP) {
       if (res_late && yr0 < H) {
+        // (the lane's coordinates from opaque copies, here and in the epilogue: per-lane addresses that are invariant over the map loop
+        // would be hoisted out of it and sit in ~60 registers through every piece - the kernel then spills)
+        int px_ = px, g_ = g;
+        asm volatile("" : "+v"(px_), "+v"(g_));
 #pragma unroll
-        for (int j = 0; j < NRU; ++j) ru[j] = reinterpret_cast<const u32x4_t*>(rb)[m16_plane(j, g, NS, H) + (long)yr0 * M16_PX + px];
+        for (int j = 0; j < NRU; ++j) ru[j] = reinterpret_cast<const u32x4_t*>(rb)[m16_plane(j, g_, NS, H) + (long)yr0 * M16_PX + px_];
+      } else {      // defined on every path: a value left from the workgroup's previous map would otherwise be live through the whole map loop
+#pragma unroll
+        for (int j = 0; j < NRU; ++j) ru[j] = (u32x4_t)(0u);
       }
     }
     // the next piece's weights, then (first half of a chunk) the next chunk's X image: in a block here, or (M16Q_SPREAD) one transfer per tap
     // between the MFMA groups - a block of 10 transfers per wave stalls the issuing waves until the load path has taken them (~1 400 cycles
     // per piece with the matrix pipe idle); spread, each costs its issue slot under the other wave's MFMAs
-    const bool dow = !LASTP && !(M16Q_ABL & 16), dox = !LASTP && h == 0 && k + 1 < a.nchunks && !(M16Q_ABL & 8);
+    // (the workgroup's NEXT map: its weight piece 0 is requested under the LAST piece (slot 0), its first X image (buffer 0) under the last
+    // piece too with 32 couts, under the first half of the last chunk with 64 - that half has no X transfer of its own, and the last piece
+    // of a 64-cout layer holds the residual units: the X offsets must not be live beside them)
+    const bool lastk = k + 1 == a.nchunks;
+    const bool dow = (LASTP ? has_next : true) && !(M16Q_ABL & 16);
+    const bool dox = (LASTP ? (NH == 1 && has_next) : (h == 0 && (lastk ? (NH == 2 && has_next) : true))) && !(M16Q_ABL & 8);
+    const int i_nx = LASTP ? 0 : i + 1, k_nx = (LASTP || lastk) ? 0 : k + 1;
+    const f32x4* const x_nx = (LASTP || lastk) ? xb_next : xb;
     static_assert(WIT + XIT <= 10, "transfer slots of a piece");
 #define M16Q_DMA_SLOT(n_)                                                                              \
   {                                                                                                    \
     const int first_ = (n_) == 0 ? 0 : (n_) + 1, cnt_ = (n_) == 0 ? 2 : 1;                              \
     _Pragma("unroll") for (int q_ = first_; q_ < first_ + cnt_; ++q_) {                                 \
-      if (q_ < WIT) { if (dow) issue_w1(i + 1, q_); }                                                   \
-      else if (q_ - WIT < XIT) { if (dox) issue_x1(k + 1, (k + 1) & 1, q_ - WIT); }                     \
+      if (q_ < WIT) { if (dow) issue_w1(i_nx, (i + 1) & 1, q_); }                                       \
+      else if (q_ - WIT < XIT) { if (dox) issue_x1(x_nx, k_nx, (k + 1) & 1, q_ - WIT); }                \
     }                                                                                                  \
   }
     if (!M16Q_SPREAD) {
-      if (dow) issue_w(i + 1);
-      if (dox) issue_x(k + 1, (k + 1) & 1);
+      if (dow) issue_w(i_nx, (i + 1) & 1);
+      if (dox) issue_x(x_nx, k_nx, (k + 1) & 1);
     }
     const unsigned wrow = ws_lds + (unsigned)((i & 1) * WP * 16);
     unsigned xcol[3];
@@ -323,11 +351,16 @@ __global__ __launch_bounds__(512, 1) void conv2d_3x3_m16q_kernel(ConvM16QArgs aq
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky) {
         const int n = kx * 3 + ky, fb = n & 1, xq = kx & 1;
-        if (M16Q_SPREAD && !LASTP) M16Q_DMA_SLOT(n);
+        if (M16Q_SPREAD) M16Q_DMA_SLOT(n);
         if constexpr (NS == 2 && LASTP) {       // the second row's residual units: from here on the other X fragment buffer is dead
           if (kx == 2 && ky == 0 && res_late && yr1 < H) {
+            int px_ = px, g_ = g;
+            asm volatile("" : "+v"(px_), "+v"(g_));
 #pragma unroll
-            for (int j = 0; j < NRU; ++j) ru1[j] = reinterpret_cast<const u32x4_t*>(rb)[m16_plane(j, g, NS, H) + (long)yr1 * M16_PX + px];
+            for (int j = 0; j < NRU; ++j) ru1[j] = reinterpret_cast<const u32x4_t*>(rb)[m16_plane(j, g_, NS, H) + (long)yr1 * M16_PX + px_];
+          } else if (kx == 2 && ky == 0) {
+#pragma unroll
+            for (int j = 0; j < NRU; ++j) ru1[j] = (u32x4_t)(0u);
           }
         }
         if (n < 8) { const int n1 = n + 1, t1 = (n1 % 3) * 3 + n1 / 3; M16Q_READ_W(wv[fb ^ 1], t1); }
@@ -356,17 +389,24 @@ __global__ __launch_bounds__(512, 1) void conv2d_3x3_m16q_kernel(ConvM16QArgs aq
     piece(a.nchunks - 1, H0_(), std::false_type());
     piece(a.nchunks - 1, H1_(), std::true_type());
   } else piece(a.nchunks - 1, H0_(), std::true_type());
+
+  // ---- epilogue: the pair's two rows
+  M16Q_STAMP(10);
+  if constexpr (M16Q_ABL & 4) { if (acc[0][0][0] != 0.12345f) return; }
+  {
+    int px_ = px, g_ = g;
+    asm volatile("" : "+v"(px_), "+v"(g_));
+    if (yr0 < H) m16_tile_epilogue<COUT, NS, DT>(a, acc[0], b, yr0, px_, g_, ru, res_late, vmax);
+    if (yr1 < H) m16_tile_epilogue<COUT, NS, DT>(a, acc[1], b, yr1, px_, g_, ru1, res_late, vmax);
+  }
+  M16Q_STAMP(11);
+  if (!has_next) break;
+  b += bstep;
+  xb = xb_next;
+  }   // maps
 #undef M16Q_READ_X
 #undef M16Q_READ_W
 #undef M16Q_MFMA
 #undef M16Q_DMA_SLOT
-
-  // ---- epilogue: the pair's two rows
-  M16Q_STAMP(10);
-  float vmax = 0.f;
-  if constexpr (M16Q_ABL & 4) { if (acc[0][0][0] != 0.12345f) return; }
-  if (yr0 < H) m16_tile_epilogue<COUT, NS, DT>(a, acc[0], b, yr0, px, g, ru, res_late, vmax);
-  if (yr1 < H) m16_tile_epilogue<COUT, NS, DT>(a, acc[1], b, yr1, px, g, ru1, res_late, vmax);
   if (DT == 1 && vmax > 65504.f && a.flag) *a.flag = 1u;
-  M16Q_STAMP(11);
 }

@@ -495,7 +495,16 @@ static int launch_conv2d_m16(orca_ctx* ctx, const ConvLayer& L, const f32x4* x, 
     ConvM16QArgs aq;
     aq.c = a; aq.c.banded = 0; aq.zero = reinterpret_cast<const f32x4*>(ctx->d_zero);
     aq.ngroups = ((n + 4 * L.dil - 1) / (4 * L.dil)) * L.dil;
-    dim3 gridq((unsigned)((aq.ngroups * 2 + 7) / 8 * 8), (unsigned)B);
+    aq.nb = B;
+    // batches of more than one round (SV screen: 4 strands, config 3: 8): the grid is ONE round, a workgroup walks the maps b, b + grid.y, ...
+    // of its tile and requests the next map's first piece under the last piece of the current one (needs an even chunk count: the heads'
+    // 16- / 80- / 144-channel layers keep one workgroup per map and tile).  ORCA_NO_M16Q_WALK=1 (read per call): the A/B and parity switch
+    static int ncu = [] { int dev = 0, v = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev); return v; }();
+    const int gx = (aq.ngroups * 2 + 7) / 8 * 8;
+    int gy = B;
+    if (a.nchunks % 2 == 0 && gx * B > ncu && getenv("ORCA_NO_M16Q_WALK") == nullptr) gy = ncu / gx > 1 ? ncu / gx : 1;
+    if (gy > B) gy = B;
+    dim3 gridq((unsigned)gx, (unsigned)gy);
     if (bf16) {
       if (L.cout == 64) hipLaunchKernelGGL((conv2d_3x3_m16q_kernel<64, 1, 0>), gridq, dim3(512), 0, ctx->stream, aq);
       else hipLaunchKernelGGL((conv2d_3x3_m16q_kernel<32, 1, 0>), gridq, dim3(512), 0, ctx->stream, aq);

@@ -255,6 +255,29 @@ def test_decoder_four_row_kernel_vs_one_row_kernel(cuda, precision, monkeypatch)
     assert torch.equal(p1, ref1) and torch.equal(p3, ref3)      # bit for bit: a batch size must not change a map (multi-GPU strand tails run B = 1)
 
 
+@pytest.mark.parametrize("precision", ["f16x2", "f16", "bf16"])
+def test_decoder_batches_of_several_rounds_walk_the_maps(cuda, precision, monkeypatch):
+    """Batches of more than one round of workgroups (the SV screen's 4 strands, config 3's 8): the four-row kernel's grid holds one round and a
+    workgroup walks the maps b, b + grid.y, ... of its tile, requesting the next map's first piece under the last piece of the current one
+    (conv2d_m16q.h).  Same arithmetic per map: batches of 5 (odd: the walkers have 3 and 2 maps) and 8 equal the one-workgroup-per-map
+    launches (ORCA_NO_M16Q_WALK=1) and the single-map forward bit for bit, with and without the coarse prediction."""
+    nm, _ = synth.synth_normmats_32m()
+    rs = np.random.RandomState(77)
+    x = torch.from_numpy((rs.rand(8, 128, 250) * 0.5).astype(np.float32)).to(cuda)
+    de = torch.log(torch.from_numpy(nm[8][None, None].astype(np.float32))).to(cuda)
+    yc = torch.from_numpy(rs.randn(8, 1, 125, 125).astype(np.float32)).to(cuda)
+    dec = product_module("Decoder", 0, upsample_mode="bilinear", precision=precision)
+    for B in (5, 8):
+        for y in (yc[:B], None):
+            walk = dec(x[:B], de.expand(B, -1, -1, -1), y)
+            monkeypatch.setenv("ORCA_NO_M16Q_WALK", "1")
+            flat = dec(x[:B], de.expand(B, -1, -1, -1), y)
+            monkeypatch.delenv("ORCA_NO_M16Q_WALK")
+            assert torch.equal(walk, flat), (B, y is None)
+    one = dec(x[4:5], de, yc[4:5])
+    assert torch.equal(dec(x[:5], de.expand(5, -1, -1, -1), yc[:5])[4:5], one)
+
+
 @pytest.mark.parametrize("precision", ["f16x2", "f32"])
 def test_decoder_batch_sliced_input_vs_oracle(cuda, precision, monkeypatch):
     monkeypatch.setenv("ORCA_DECODER_PRECISION", precision)

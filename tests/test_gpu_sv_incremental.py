@@ -119,3 +119,21 @@ def test_pipelined_screen_redoes_a_unit_whose_encodes_left_the_fp16_range(setup,
                     assert float(np.abs(a - b).max()) <= 1e-4 and not np.array_equal(a, b)
                 else:
                     assert np.array_equal(a, b)
+
+
+def test_pipelined_screen_with_two_models(setup):
+    """Units of the pipeline are (variant, model) pairs: two models on two variants - the entries carry both models' maps in model order and
+    equal the one-stream screen's bit for bit."""
+    model, genome = setup
+    hff = orca_models.Hff(synthetic_seed=1)
+    a = sv.sv_screen([model, hff], genome, VARIANTS[:2], CHR, min_uses=1, streams=4)
+    b = sv.sv_screen([model, hff], genome, VARIANTS[:2], CHR, min_uses=1, streams=0)
+    one = sv.sv_screen([hff], genome, VARIANTS[:1], CHR, min_uses=1, streams=0)
+    for i in range(2):
+        for allele in ("ref", "alt"):
+            assert len(a[i][allele]["predictions"]) == 2 and len(a[i][allele]["normmats"]) == 2
+            for m in range(2):
+                for j in range(6):
+                    assert np.array_equal(a[i][allele]["predictions"][m][j], b[i][allele]["predictions"][m][j])
+    for j in range(6):
+        assert np.array_equal(a[0]["alt"]["predictions"][1][j], one[0]["alt"]["predictions"][0][j])
