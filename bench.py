@@ -26,6 +26,7 @@ Also measured in the same run, OUTSIDE the timed region, and reported in the sam
   * `parity` (N = 1): the timed steps' own six maps against the shipped fixture tests/golden/G8_full32m.npz - the
     REFERENCE's genomepredict on CPU for exactly this sequence, weights and zoom position.
   * `exact_f32` (N = 1): a short second loop with every module on the exact fp32 MFMA kernels.
+  * `concurrent_strands` (N = 1): the opt-in mode ORCA_STRAND_STREAMS=1 (both strands' Encoders side by side on two streams), 5 steps.
   * `roofline_decoder` (N = 1): one Decoder forward (118 Conv2d) at B = 2 under HIP events.
   * `config3` (N = 1): BASELINE configs[2] - HFF-shaped model, batch of 8, bf16 Encoder + fp16-plane Decoders, 2 timed batches,
     roofline of its dominant kernel, parity against the reference rows of G17.
@@ -669,6 +670,26 @@ def main():
         res["parity"] = {"against": "tests/golden/G8_full32m.npz = the reference's genomepredict (PyTorch CPU fp32) on this sequence, these weights, this zoom position",
                          "max_abs_per_level": [round(e, 8) for e in errs], "pearson_min": round(min(rs), 9), "tolerance": 1e-4,
                          "ok": bool(max(errs) < 1e-4)}
+
+    # ---- opt-in mode: the reverse strand's Encoder on an auxiliary context beside the forward strand's (engine.strand_streams()).  NOT the
+    # timed configuration: with two persistent launches sharing the chip a kernel's duration no longer measures the kernel, and `roofline`
+    # above is defined on launches that have the chip to themselves.  Same kernels, same data: the maps must equal the timed region's.
+    if world == 1 and Lbp == L_BP and not args.float_input:
+        os.environ["ORCA_STRAND_STREAMS"] = "1"
+        try:
+            for _ in range(2):
+                step()
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                outs2 = step()
+            sync()
+            t2 = (time.perf_counter() - t0) / 5
+            res["concurrent_strands"] = {"what": "ORCA_STRAND_STREAMS=1 (opt-in): the two strands' Encoders on two HIP streams / contexts; 5 steps after the timed region",
+                                         "ms_per_step": round(t2 * 1e3, 3), "Mb_per_s": round(2 * Lbp / 1e6 / t2, 2),
+                                         "maps_equal_timed_region": bool(all(torch.equal(a, b) for a, b in zip(outs, outs2)))}
+        finally:
+            os.environ.pop("ORCA_STRAND_STREAMS", None)
 
     # ---- exact fp32 MFMA everywhere: short second loop (N = 1)
     if world == 1 and Lbp == L_BP:

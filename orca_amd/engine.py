@@ -147,6 +147,7 @@ class ContextPool:
         self._fork = torch.cuda.Event()
         self._join = [torch.cuda.Event() for _ in range(k)]
         self.side = torch.cuda.Stream(device=self.index)     # a stream beside the caller's current one (preparation work)
+        self._dirty = set()                                   # contexts that ran something since their range flag was last read
 
     def __len__(self):
         return len(self.ctxs)
@@ -159,6 +160,7 @@ class ContextPool:
 
     def run(self, i, fn):
         i %= len(self.ctxs)
+        self._dirty.add(i)
         prev = getattr(_tls, "override", None)
         _tls.override = self.ctxs[i]
         try:
@@ -183,7 +185,10 @@ class ContextPool:
         self.wait_join()
 
     def take_overflow(self):
-        return any([c.take_overflow() for c in self.ctxs])      # a list: every flag is read (and cleared)
+        """True if an activation left the fp16 range in a call run on one of the pool's contexts since the last check (reads - stream
+        sync - and clears the flags of the contexts used since then)."""
+        dirty, self._dirty = sorted(self._dirty), set()
+        return any([self.ctxs[i].take_overflow() for i in dirty])      # a list: every flag is read (and cleared)
 
 
 _pools = {}
@@ -197,6 +202,16 @@ def context_pool(device, k):
     return _pools[(idx, k)]
 
 
+def strand_streams():
+    """$ORCA_STRAND_STREAMS=1: `genomepredict` / `cascade_32m` encode the reverse strand on an auxiliary context while the forward strand
+    runs on the caller's stream.  The two Encoders' launches then share the chip (two persistent kernels side by side, each about twice as
+    long): a first layer bound by HBM writes runs beside a conv bound by the matrix pipe, the small launches of stages 5-7 beside full ones -
+    63.8 against 65.4 ms per step (same box, alternating).  Opt-in: a kernel's duration no longer says what the kernel can do (the bench's
+    per-kernel roofline is defined on launches that have the chip to themselves), and the second context holds its own 25 GB workspace."""
+    import os
+    return os.environ.get("ORCA_STRAND_STREAMS", "0") == "1"
+
+
 def run_with_overflow_retry(fn, device, pool=None):
     """Run fn() (a chain of module forwards on ``device``) with ONE fp16-range check at the end instead of one
     per module; if an activation left the fp16 range anywhere, redo the whole chain in the range-safe arithmetic.
@@ -207,8 +222,8 @@ def run_with_overflow_retry(fn, device, pool=None):
     with defer_overflow_guard():
         out = fn()
     over = ctx.take_overflow()
-    if pool is not None:
-        over = pool.take_overflow() or over
+    for p in ([pool] if pool is not None else []) + [q for q in _pools.values() if q is not pool and q.index == ctx.device_index]:
+        over = p.take_overflow() or over          # auxiliary contexts fn() ran on (e.g. the reverse strand's Encoder, strand_streams())
     if over:
         import warnings
         warnings.warn("orca_amd: an activation left the fp16 range; recomputing with range-safe arithmetic (bf16x3 / f32)")

@@ -121,11 +121,24 @@ class _StrandInputs:
             if isinstance(net0, Encoder):     # both strands straight into the halves of one [2B,128,bins] tensor
                 B, L = self._codes.shape
                 enc0 = torch.empty((2 * B, 128, engine.encoder_num_bins(L)), dtype=torch.float32, device=self._codes.device)
-                net0.forward_codes(self._codes, reverse=False, out=enc0[:B])
-                net0.forward_codes(self._codes, reverse=True, out=enc0[B:])
+                _encode_two_strands(lambda rev, out: net0.forward_codes(self._codes, reverse=rev, out=out), enc0, B)
                 return enc0
             return torch.cat([net0.forward_codes(self._codes, reverse=False), net0.forward_codes(self._codes, reverse=True)], dim=0)
         return torch.cat([net0(self.fwd), net0(self.rev)], dim=0)
+
+
+def _encode_two_strands(encode, enc0, B):
+    """encode(reverse, out) for the forward strand into enc0[:B] and the reverse complement into enc0[B:]: one after the other on the
+    caller's stream, or (engine.strand_streams(), opt-in) the reverse strand on an auxiliary context beside the forward one."""
+    if engine.strand_streams() and enc0.is_cuda:
+        pool = engine.context_pool(enc0.device, 1)
+        pool.fork()
+        pool.run(0, lambda: encode(True, enc0[B:]))
+        encode(False, enc0[:B])
+        pool.join()
+    else:
+        encode(False, enc0[:B])
+        encode(True, enc0[B:])
 
 
 def _log_background(bg, batch, use_cuda, flip=False):
@@ -396,8 +409,11 @@ def cascade_32m(model, xs, mpos, wpos, reverse_flags, distencs=None, merge=False
         if len(xs) > 1 and all(x.dtype == torch.uint8 for x in xs) and hasattr(model.net0, "_net"):
             # packed strands: each is encoded straight into its rows of one [S*B,128,bins] tensor
             enc0 = torch.empty((len(xs) * B, 128, engine.encoder_num_bins(xs[0].shape[1])), dtype=torch.float32, device=xs[0].device)
-            for k, (x, r) in enumerate(zip(xs, reverse_flags)):
-                encode(x, r, enc0[k * B:(k + 1) * B])
+            if len(xs) == 2 and xs[0] is xs[1] and list(reverse_flags) == [False, True]:
+                _encode_two_strands(lambda rev, out: encode(xs[0], rev, out), enc0, B)
+            else:
+                for k, (x, r) in enumerate(zip(xs, reverse_flags)):
+                    encode(x, r, enc0[k * B:(k + 1) * B])
         else:
             enc0 = torch.cat([encode(x, r) for x, r in zip(xs, reverse_flags)], dim=0) if len(xs) > 1 else encode(xs[0], reverse_flags[0])
         encodings = dict(zip([1, 2, 4, 8, 16, 32], model.net(enc0)))

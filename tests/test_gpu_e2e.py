@@ -2,6 +2,8 @@
 real reference's genomepredict on CPU for one full 32 Mb H1-ESC-shaped forward (G8,
 both strands, ~3 min of CPU in the build container) and (b) the cascade fixtures G7.
 North-star tolerance: 1e-4 max-abs per level, plus Pearson r."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -32,6 +34,15 @@ def test_full_32mb_genomepredict_vs_reference(cuda):
         assert p.shape == (250, 250) and p.dtype == np.float32
         assert maxabs(p, ref) < TOL, (j, maxabs(p, ref))
         assert pearson(p, ref) > 0.999999
+    # opt-in mode: the reverse strand's Encoder on an auxiliary context beside the forward strand's (engine.strand_streams()) - same kernels,
+    # same data: the maps are bit-identical, and the auxiliary context's range flag is part of the call's one range check
+    os.environ["ORCA_STRAND_STREAMS"] = "1"
+    try:
+        out2 = P.genomepredict(seq, "chrS", 16000000 + 1234567, 16000000, models=[model], use_cuda=True)
+    finally:
+        del os.environ["ORCA_STRAND_STREAMS"]
+    for p, q in zip(out["predictions"][0], out2["predictions"][0]):
+        assert np.array_equal(p, q)
     # invariant: a strand-averaged map of a reverse-palindromic input is flip-symmetric
     half = synth.synth_sequence(160000, seed=3)
     pal = np.concatenate([half, half[:, ::-1, ::-1]], axis=1)
