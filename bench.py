@@ -690,6 +690,7 @@ def main():
                                          "maps_equal_timed_region": bool(all(torch.equal(a, b) for a, b in zip(outs, outs2)))}
         finally:
             os.environ.pop("ORCA_STRAND_STREAMS", None)
+            engine.context_pool(dev, 1).release_workspaces()
 
     # ---- exact fp32 MFMA everywhere: short second loop (N = 1)
     if world == 1 and Lbp == L_BP:

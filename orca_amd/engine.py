@@ -184,6 +184,11 @@ class ContextPool:
         self.host_join()
         self.wait_join()
 
+    def release_workspaces(self):
+        """Free the contexts' workspace arenas (they grow again on demand): a whole-strand Encoder call leaves 25 GB in its context."""
+        for c in self.ctxs:
+            c.release_workspace()
+
     def take_overflow(self):
         """True if an activation left the fp16 range in a call run on one of the pool's contexts since the last check (reads - stream
         sync - and clears the flags of the contexts used since then)."""
