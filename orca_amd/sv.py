@@ -194,7 +194,7 @@ def reuse_plan(pieces, chrlen, nbins):
     return out
 
 
-POOL_MAX_BINS = 500     # longer runs (whole windows: phases that are not held) stay on the caller's stream - they fill the chip on their own
+POOL_MAX_BINS = 500     # longer runs (whole windows: phases that are not held) are not spread over the pool's contexts - they fill the chip on their own
 
 
 def encode_windows(cache, pieces_list, win_codes, out, merge_gap=2 * RF_BINS, build=True, pool=None, defer_join=False):
@@ -244,8 +244,9 @@ def encode_windows(cache, pieces_list, win_codes, out, merge_gap=2 * RF_BINS, bu
         k = 0
         for n_, rev, lo, hi, w in jobs:
             row = 2 * w + int(rev)
-            if n_ > POOL_MAX_BINS:
-                cache.net0.forward_codes(win_codes[w:w + 1], reverse=rev, bin_lo=lo, bin_hi=hi, out=out[row:row + 1, :, lo:hi])
+            if n_ > POOL_MAX_BINS:      # all on context 0, one after the other (one 25 GB workspace; the range flag stays with the pool's)
+                pool.run(0, lambda w=w, rev=rev, lo=lo, hi=hi, row=row: cache.net0.forward_codes(win_codes[w:w + 1], reverse=rev, bin_lo=lo, bin_hi=hi,
+                                                                                             out=out[row:row + 1, :, lo:hi]))
                 continue
             pool.run(k, lambda w=w, rev=rev, lo=lo, hi=hi, row=row: cache.net0.forward_codes(win_codes[w:w + 1], reverse=rev, bin_lo=lo, bin_hi=hi,
                                                                                          out=out[row:row + 1, :, lo:hi]))
@@ -407,6 +408,8 @@ def sv_screen(models, genome_codes, svs, chrlen, mchr="chrS", rank=0, world=1, i
                 if pool is not None and k + 1 < len(units):
                     prep(k + 1)
                     nxt_over = pool.take_overflow()            # (waits for those encodes: the host has nothing else to issue)
+                if ctx is not None:
+                    ctx.sync_stream()                          # (a whole-window fallback in prep() ran this context on the side stream)
                 over = (ctx.take_overflow() if ctx is not None else False) or enc_over
                 enc_over = nxt_over
                 if over:                                      # an activation left the fp16 range: this unit again, range-safe arithmetic
