@@ -154,7 +154,7 @@ int orca_ctx_take_overflow(orca_ctx* ctx, int* flag);
  * (4000 bp each; bin_hi<=0 means "to the end") and writes
  * out[b*so_b + c*so_c + (bin-bin_lo)], c<128.  A sub-range is how the
  * independent sequence blocks shard across GPUs.
- * chunk_bp: internal processing chunk (multiple of 4000; <=0 = default);
+ * chunk_bp: internal processing chunk (multiple of 4000; <=0 = default: the whole input up to 32 Mb, 128 Mb chunks beyond - workspace = 768 B per chunk base);
  * chunks carry a 112 kb input halo each side exactly like the reference's
  * 800 kb blocks, so results do not depend on it. */
 int orca_encoder_forward(orca_ctx* ctx, orca_net* net, const float* x, int64_t sx_b, int64_t sx_c,

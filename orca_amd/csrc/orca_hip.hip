@@ -1565,8 +1565,21 @@ static int encoder_forward_impl(orca_ctx* ctx, orca_net* net, const float* x, in
   if (bin_lo < 0 || bin_lo > bin_hi || bin_hi > total) return fail(ORCA_EINVAL, "bin range [%ld,%ld) outside [0,%ld)", (long)bin_lo, (long)bin_hi, total);
   if (bin_lo == bin_hi || B <= 0) return ORCA_OK;
   if (chunk_bp <= 0) {
+    // a 32 Mb window is one chunk; longer inputs (the 256 Mb models) run in 128 Mb chunks: 98 GB of workspace (3 x 64 channels x 4 B per base) of
+    // the 288 GB, a quarter of the chunk seams (each costs a 224 kb halo and one latency-bound pass through stages 5-7): 418 -> 406 ms per
+    // genomepredict_256Mb call against 32 Mb chunks, 412 with 64 Mb (same box).  $ORCA_ENCODER_CHUNK_BP overrides.
+    // The chunk size does not change a result (every bin sees the same bases through the same kernels); it is taken as large as the device's
+    // FREE memory allows - 128, 64 or 32 Mb with the workspace at most 45 % of what is free (several ranks sharing one GPU, as the tests do).
     const char* e = getenv("ORCA_ENCODER_CHUNK_BP");
     chunk_bp = e ? atol(e) : 32000000L;
+    if (!e && L > 32000000L) {
+      size_t fr = 0, tot = 0;
+      if (hipMemGetInfo(&fr, &tot) == hipSuccess) {
+        fr += ctx->ws_bytes;                       // the arena would be replaced, not added to
+        for (long c : {128000000L, 64000000L})
+          if ((double)(c + 2 * kHaloBp + 4096) * 768.0 <= 0.45 * (double)fr) { chunk_bp = c; break; }
+      }
+    }
   }
   if (chunk_bp % kBinBp) return fail(ORCA_EINVAL, "chunk_bp must be a multiple of 4000");
   const long chunk_bins = chunk_bp / kBinBp;
