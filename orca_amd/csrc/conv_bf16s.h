@@ -62,6 +62,7 @@ struct ConvB16Args {
   int stagger;      // units of 4096 cycles by which half of the resident workgroups start late
   unsigned* flag;   // fp16 mode: set to 1 if an activation exceeds the fp16 range (result then invalid)
   int pool4;        // fuse nn.MaxPool1d(4,4) into the epilogue: y is [n/4][COUT], y_bs its batch stride
+  int cout;         // output channels of the layer (conv_small.h: its workgroups take 32-cout blocks; the kernel below has it as COUT)
 };
 
 __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {

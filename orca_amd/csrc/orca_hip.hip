@@ -25,6 +25,7 @@
 #include "conv_p16w1.h"
 #include "conv_p16p5.h"
 #include "conv_p16x.h"
+#include "conv_small.h"
 #include "misc_kernels.h"
 #include "coarsegrain.h"
 #include "orca_hip.h"
@@ -609,6 +610,19 @@ static int launch_conv1d_b16(orca_ctx* ctx, const ConvLayer& L, int precision, c
     HIPCHECK(hipEventRecord(tl.e0, ctx->stream));
   }
   int rc;
+  a.cout = L.cout;
+  // short rows (the Encoder's stages 5-7 of a local re-encode, one- to three-bin inputs): the K-chunks of a tile side by side, one global
+  // round trip and one barrier per launch instead of a chain of eight (conv_small.h: ~6 against 23-27 us).  A function of n alone, so that
+  // a row's result never depends on the batch it is computed in; ORCA_NO_SMALL_CONV=1 (read per call): the A/B and parity switch
+  if (n <= 2048 && !pool4 && L.cout % 32 == 0 && L.cin % 16 == 0 && getenv("ORCA_NO_SMALL_CONV") == nullptr) {
+    const dim3 grid((unsigned)(((n + 31) / 32) * (L.cout / 32)), (unsigned)B);
+    if (precision == ORCA_PRECISION_BF16X3) hipLaunchKernelGGL((conv1d_k9_small_kernel<3, 0>), grid, dim3(512), 0, ctx->stream, a);
+    else if (precision == ORCA_PRECISION_BF16X2) hipLaunchKernelGGL((conv1d_k9_small_kernel<2, 0>), grid, dim3(512), 0, ctx->stream, a);
+    else if (precision == ORCA_PRECISION_F16X2) hipLaunchKernelGGL((conv1d_k9_small_kernel<2, 1>), grid, dim3(512), 0, ctx->stream, a);
+    else hipLaunchKernelGGL((conv1d_k9_small_kernel<1, 0>), grid, dim3(512), 0, ctx->stream, a);
+    LAUNCHCHECK("conv1d_k9_small_kernel");
+    return ORCA_OK;
+  }
   if (precision == ORCA_PRECISION_BF16X3) rc = launch_conv1d_b16_ns<3, 0>(ctx, L, a, B);
   else if (precision == ORCA_PRECISION_BF16X2) rc = launch_conv1d_b16_ns<2, 0>(ctx, L, a, B);
   else if (precision == ORCA_PRECISION_F16X2) rc = launch_conv1d_b16_ns<2, 1>(ctx, L, a, B);
@@ -1741,11 +1755,13 @@ extern "C" int orca_unet_forward(orca_ctx* ctx, orca_net* net, const float* x, i
   if (n_outs != nlev + 1) return fail(ORCA_EINVAL, "expected %d output pointers, got %d", nlev + 1, n_outs);
   if (n <= 0 || (n % (1 << nlev))) return fail(ORCA_EINVAL, "length %d not divisible by %d", n, 1 << nlev);
   if (B <= 0) return ORCA_OK;
-  // The split-operand path pays off from ~32 K positions per launch (256 Mb model: 2 x 64 000 bins, tail 14.6 -> 13.1 ms); below that the
-  // 128-position tiles of conv_bf16s.h leave most CUs idle and the exact fp32 kernels with their small tiles are faster (32 Mb model,
-  // 2 x 8 000 bins: 94.8 vs 95.4 ms per bench step) - and at least as accurate, so they serve every precision there.
-  const char* nlc_env = getenv("ORCA_UNET_NLC_MIN");      // read per call: the tests force the split-operand path at small sizes
-  const long nlc_min = nlc_env ? atol(nlc_env) : 32000;
+  // Every precision but "f32" runs the channel-last split-operand path: levels of <= 2048 positions on conv_small.h (the K-chunks of a tile
+  // side by side: ~7 us per launch where the exact fp32 kernel's latency chain took 31 - 28 of an Encoder2's 40 convs at 8 000 bins), the
+  // longer ones on conv_bf16s.h.  65.6 against 66.4 ms per bench step (same box, alternating); until round 4 the exact fp32 kernels
+  // served every precision below 32 000 positions per launch - which also made a row's bits depend on the batch it was computed in.
+  // $ORCA_UNET_NLC_MIN (positions per launch below which the exact kernels run; read per call) restores that for A/B checks.
+  const char* nlc_env = getenv("ORCA_UNET_NLC_MIN");
+  const long nlc_min = nlc_env ? atol(nlc_env) : 0;
   if (net->precision != ORCA_PRECISION_F32 && (long)B * n >= nlc_min) return unet_forward_nlc(ctx, net, x, sx_b, sx_c, sx_l, B, n, outs, nlev, up_only);
   const size_t full = (size_t)B * 128 * n;
   size_t need = 0;

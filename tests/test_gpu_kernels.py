@@ -101,6 +101,32 @@ def test_conv1d_split_bf16_channel_last(cuda, cin, cout, n, precision, tol):
         assert err < tol, (cin, cout, n, precision, relu, err)
 
 
+@pytest.mark.parametrize("cin,cout,n", [(128, 128, 1), (128, 128, 7), (128, 128, 33), (128, 128, 55), (128, 128, 275), (128, 128, 2048), (64, 96, 100), (96, 64, 513)])
+@pytest.mark.parametrize("precision,tol", [("bf16x3", 2e-5), ("f16x2", 2e-5), ("bf16x2", 3e-4), ("bf16", 5e-2)])
+def test_conv1d_short_rows_channel_last(cuda, cin, cout, n, precision, tol, monkeypatch):
+    """conv_small.h: rows of <= 2048 positions (the Encoder's stages 5-7 of a local re-encode) run the K-chunks of a tile side by side - against
+    torch fp32, and against the chunk-after-chunk kernel of conv_bf16s.h (ORCA_NO_SMALL_CONV=1) on the same inputs: same operand splits and
+    products, another fp32 summation order (per-chunk partials) - equal to fp32 rounding.  A batch row must not depend on the batch."""
+    rs = np.random.RandomState(cin + cout + n)
+    B = 3
+    x = torch.from_numpy(rs.randn(B, cin, n).astype(np.float32))
+    w = (rs.randn(cout, cin, 9) / np.sqrt(cin * 9)).astype(np.float32)
+    b = rs.randn(cout).astype(np.float32) * 0.1
+    r1 = torch.from_numpy(rs.randn(B, cout, n).astype(np.float32))
+    xd, rd = x.transpose(1, 2).contiguous().to(cuda), r1.transpose(1, 2).contiguous().to(cuda)
+    for relu, ra, rad in [(False, None, None), (True, r1, rd)]:
+        y = engine.conv1d_nlc(xd, w, b, precision, relu, rad)
+        ref = _ref_conv1d(x, w, b, relu, ra, None)
+        err = float((y.cpu().transpose(1, 2) - ref).abs().max())
+        assert err < tol, (cin, cout, n, precision, relu, err)
+        monkeypatch.setenv("ORCA_NO_SMALL_CONV", "1")
+        y0 = engine.conv1d_nlc(xd, w, b, precision, relu, rad)
+        monkeypatch.delenv("ORCA_NO_SMALL_CONV")
+        assert float((y - y0).abs().max()) < 2e-5
+        one = engine.conv1d_nlc(xd[1:2].contiguous(), w, b, precision, relu, None if rad is None else rad[1:2].contiguous())
+        assert torch.equal(one, y[1:2])
+
+
 def test_conv1d_split_bf16_wide_dynamic_range(cuda):
     """3-way split keeps fp32 exponent range: inputs spanning 1e-6..1e4 stay fp32-accurate (relative)."""
     rs = np.random.RandomState(0)

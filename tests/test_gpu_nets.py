@@ -26,7 +26,7 @@ def test_encoder_vs_golden_and_chunking(cuda, precision, tol):
     assert maxabs(y, g["y"]) < TOL and pearson(y, g["y"]) > 0.99999
     # internal chunking (halo 112 kb) must not change the result: 400 kb chunks vs one chunk
     y2 = enc(x, chunk_bp=400000)[0].cpu().numpy()
-    assert maxabs(y2, y) < 2e-5
+    assert maxabs(y2, y) < max(2e-5, 0.05 * tol)       # (stages 5-7 of a 400 kb chunk are short rows: conv_small.h, another fp32 summation order; bf16x2 is a 3e-5-class mode)
     # bin sub-range (multi-GPU shard) equals the slice of the full result
     y3 = enc(x, bin_lo=100, bin_hi=300)[0].cpu().numpy()
     assert maxabs(y3, y[:, 100:300]) < 2e-5
@@ -168,7 +168,7 @@ def test_encoder_composed_weights_outside_fp16_keep_the_two_conv_form(cuda, monk
 
 @pytest.mark.parametrize("precision", ["f16x2", "f32", "bf16x3"])
 def test_encoder2_encoder3_vs_golden(cuda, precision, monkeypatch):
-    monkeypatch.setenv("ORCA_UNET_NLC_MIN", "0")     # the split-operand path also below its pay-off size (default: >= 32 000 positions)
+    monkeypatch.setenv("ORCA_UNET_NLC_MIN", "0")     # (the default since round 4: the channel-last split-operand path at every size, short levels on conv_small.h)
     g = golden("G3_encoder23.npz")
     e2 = product_module("Encoder2", 0, precision=precision)
     x = torch.from_numpy((np.random.RandomState(21).rand(1, 128, 800) * 0.5).astype(np.float32)).to(cuda)
