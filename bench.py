@@ -642,8 +642,8 @@ def main():
         "value": round(mb_per_s, 3), "unit": "Mb/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": f"Encoder Conv1d stages 1-7: {enc_prec} = {ARITH[enc_prec]}; Decoder / Decoder_1m Conv2d: {dec_prec} = {ARITH[dec_prec]}; "
-                 f"Encoder2 Conv1d: exact fp32 MFMA kernels (requested {getattr(model.net, 'precision', 'f32')}; 2 strands x 8000 bins is below the 32 000 positions "
-                 "from which the split-operand kernels run); 1x1 heads, pools, upsampling, merges: fp32",
+                 f"Encoder2 Conv1d: {getattr(model.net, 'precision', 'f32')} = {ARITH[getattr(model.net, 'precision', 'f32')]}; "
+                 "1x1 heads, pools, upsampling, merges: fp32",
         "data": "synthetic",
         "config": {"workload": f"H1-ESC 32Mb model forward, single random {args.seq_mb}Mb sequence, fp32-class ({enc_prec} split operands on the 16-bit matrix "
                                "cores, see dtype; parity vs the reference's fp32 in `parity`), both strands (genomepredict-equivalent, 1 model): "
