@@ -87,20 +87,6 @@ __global__ __launch_bounds__(512, NS == 1 ? 4 : 2) void conv2d_dblock_kernel(DBl
     p16_glds16(reinterpret_cast<const f32x4*>(src), smem + AU + BU + 3 * WP);
   }
 
-  // ---- gather: the units of the workgroup's 256 pixels, all 8 octets x NS planes, by LDS-DMA; a pixel outside the map is
-  // fetched from pad pixel 255 of row 0 (zero; maps with W = 256 have no outside pixels) ----
-  {
-    int row, col, r_, c_;
-    pix(tid & 255, row, col, r_, c_);
-    const bool ok = row < H && col < W;
-    const long off = ok ? (long)row * M16_PX + col : 255;
-#pragma unroll
-    for (int it = 0; it < GIT; ++it) {
-      const int plane = 2 * it + (wave >> 2);            // = s*8 + o
-      const int s_ = plane >> 3, o_ = plane & 7;
-      if (!(ABL & 4)) p16_glds16(cur + m16_plane(o_, s_, NS, H) + off, As + plane * PXW + (wave & 3) * 64);
-    }
-  }
   // ---- weight pieces: piece i = (layer, K-chunk k, cout half h) ------------------------------------------------
   // layers 0 / 2 (64 -> 32): pieces k = 0..3;  layers 1 / 3 (32 -> 64): h = 0: k = 0, 1;  h = 1: k = 0, 1
   auto piece_src = [&](int i, int u) -> const f32x4* {
@@ -118,8 +104,25 @@ __global__ __launch_bounds__(512, NS == 1 ? 4 : 2) void conv2d_dblock_kernel(DBl
       if (u < WP) p16_glds16(piece_src(i, u), dst + it * NT + wave * 64);
     }
   };
-  issue_piece(0);
-  issue_piece(1);
+  // ---- gather: the units of the workgroup's 256 pixels, all 8 octets x NS planes, by LDS-DMA; a pixel outside the map is
+  // fetched from pad pixel 255 of row 0 (zero; maps with W = 256 have no outside pixels).  Issued K-CHUNK BY K-CHUNK of the first layer
+  // (octets 2k, 2k + 1 of every split), the first three weight pieces in between: piece k of layer 0 waits for chunk k alone (counted
+  // waits in DB_LAYER), so three quarters of the cold gather run under the first pieces' MFMAs ----
+  {
+    int row, col, r_, c_;
+    pix(tid & 255, row, col, r_, c_);
+    const bool ok = row < H && col < W;
+    const long off = ok ? (long)row * M16_PX + col : 255;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+      for (int s_ = 0; s_ < NS; ++s_) {
+        const int plane = s_ * 8 + 2 * k + (wave >> 2);            // = s*8 + o
+        if (!(ABL & 4)) p16_glds16(cur + m16_plane(plane & 7, s_, NS, H) + off, As + plane * PXW + (wave & 3) * 64);
+      }
+      if (k < 3) issue_piece(k);
+    }
+  }
 
   // ---- this lane's pixel in the MFMA layout and its neighbour units -----------------------------------------------
   const int p = wave * 32 + l31;
@@ -156,8 +159,18 @@ __global__ __launch_bounds__(512, NS == 1 ? 4 : 2) void conv2d_dblock_kernel(DBl
       constexpr bool wide_ = WIDE;                                                                                \
       const int k = wide_ ? (j & 1) : j;                                                                          \
       const int h = wide_ ? (j >> 1) : 0;                                                                         \
-      /* this piece's weights (and the gather) have landed; the next piece's may still be in flight */            \
-      if (piece + 1 < NPIECE) {                                                                                   \
+      /* this piece's weights (and, pieces 0-2, its K-chunk of the gather) have landed; what was issued behind them may still be  */ \
+      /* in flight: G1 W1 G2 W2 G3 behind piece 0, G2 W2 G3 behind piece 1, G3 W3 behind piece 2, then the next piece's weights    */ \
+      if (piece == 0) {                                                                                           \
+        if (wave < EXTRA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NS + 2 * WIT) : "memory");                \
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NS + 2 * (WIT - 1)) : "memory");                       \
+      } else if (piece == 1) {                                                                                    \
+        if (wave < EXTRA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NS + WIT) : "memory");                    \
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NS + WIT - 1) : "memory");                             \
+      } else if (piece == 2) {                                                                                    \
+        if (wave < EXTRA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS + WIT) : "memory");                        \
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS + WIT - 1) : "memory");                                 \
+      } else if (piece + 1 < NPIECE) {                                                                            \
         if (wave < EXTRA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WIT) : "memory");                             \
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WIT - 1) : "memory");                                      \
       } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                     \
@@ -165,7 +178,7 @@ __global__ __launch_bounds__(512, NS == 1 ? 4 : 2) void conv2d_dblock_kernel(DBl
       /* traffic (the `put`s of the previous layer): __syncthreads() compiles to s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier and   */ \
       /* retired the weight piece in flight at every piece (conv2d_m16.h)                                                          */ \
       if (!(ABL & 16) || j == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                   \
-      if (piece + 2 < NPIECE && !(ABL & 2)) issue_piece(piece + 2);                                               \
+      if (piece >= 1 && piece + 2 < NPIECE && !(ABL & 2)) issue_piece(piece + 2);   /* (pieces 0-2 went out with the gather) */ \
       const unsigned wrow = ws_lds + (unsigned)((piece % 3) * WP * 16);                                           \
       const unsigned xrow = (XLDS) + (unsigned)((2 * k + g) * PXW * 16);                                          \
       f16x8 xv[2][NS], wv[2][NS];                                                                                 \
