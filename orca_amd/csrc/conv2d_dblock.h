@@ -39,7 +39,7 @@ __global__ __launch_bounds__(512, NS == 1 ? 4 : 2) void conv2d_dblock_kernel(DBl
   constexpr int WP = NS * 9 * 2 * 32;                // one weight piece: 16 input channels x 32 couts
   constexpr int NPIECE = 16;
   constexpr int WIT = (WP + NT - 1) / NT;
-  constexpr int GIT = NS * 8 * 256 / NT;             // gather DMA instructions per thread (the same for every wave)
+  static_assert(NS * 8 * 256 / NT == 4 * NS, "gather: NS DMA instructions per thread and K-chunk of the first layer (the same for every wave)");
   constexpr int EXTRA = (WP - (WIT - 1) * NT + 63) / 64;     // waves that issue WIT (the others WIT - 1) DMA instructions per piece
   __shared__ f32x4 smem[AU + BU + 3 * WP + 48];
   f32x4* const As = smem;
