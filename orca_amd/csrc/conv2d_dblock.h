@@ -272,7 +272,7 @@ __global__ __launch_bounds__(512, NS == 1 ? 4 : 2) void conv2d_dblock_kernel(DBl
         p16_swap32(h1_, l1_);
         u32x4_t unit_;
         unit_.x = h0_; unit_.y = h1_; unit_.z = l0_; unit_.w = l1_;
-        if (pvalid) reinterpret_cast<u32x4_t*>(cur)[m16_plane(h * 4 + q, g, NS, H) + poff] = unit_;
+        if (pvalid) m16_store_unit(reinterpret_cast<u32x4_t*>(cur) + m16_plane(h * 4 + q, g, NS, H) + poff, unit_);
       }
     if (pvalid && vmax > 65504.f) overflow = true;
   } else {
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(512, NS == 1 ? 4 : 2) void conv2d_dblock_kernel(DBl
         p16_swap32(a1_, b1_);
         u32x4_t unit_;
         unit_.x = a0_; unit_.y = a1_; unit_.z = b0_; unit_.w = b1_;
-        if (pvalid) reinterpret_cast<u32x4_t*>(cur)[m16_plane(h * 4 + 2 * qp + g, 0, NS, H) + poff] = unit_;
+        if (pvalid) m16_store_unit(reinterpret_cast<u32x4_t*>(cur) + m16_plane(h * 4 + 2 * qp + g, 0, NS, H) + poff, unit_);
       }
     if (DT == 1 && pvalid && vmax > 65504.f) overflow = true;
   }

@@ -28,6 +28,23 @@
 
 __device__ __forceinline__ long m16_plane(int o, int s, int NS, int H) { return (long)(o * NS + s) * H * M16_PX; }   // in units
 
+// Store of one whole 16-byte unit of a map by the conv epilogues: WRITE-THROUGH (sc0 sc1).  A layer's output then leaves the XCD's L2 while the
+// kernel still runs instead of sitting there dirty until the end-of-kernel write-back (8-33 MB per launch, MI355X_MICROARCH.md "boundary":
+// + B / 6 TB/s per dependent launch); round 5, tools/microbench_m16q.hip, dependent chain at B = 2 / 4: 64 -> 32 19.5-20.4 -> 18.6-19.2 us,
+// 32 -> 64 + residual 23.3 -> 23.3, B = 4 32.0 / 43.3 -> 30.6 / 40.8; `nt` instead: slower.  M16_STORE_WT=0 (compile time): plain stores.
+#ifndef M16_STORE_WT
+#define M16_STORE_WT 1
+#endif
+__device__ __forceinline__ void m16_store_unit(u32x4_t* p, const u32x4_t& v) {
+#if M16_STORE_WT == 1
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+#elif M16_STORE_WT == 2
+  asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+#else
+  *p = v;
+#endif
+}
+
 // 8 consecutive channels of one pixel -> NS units
 template <int NS, int DT>
 __device__ __forceinline__ void m16_pack8(const f32x4 lo4, const f32x4 hi4, u32x4_t (&out)[NS], bool& ovf) {
@@ -610,7 +627,7 @@ __global__ __launch_bounds__(512, 2) void conv2d_3x3_m16_kernel(ConvM16Args a) {
         p16_swap32(h1_, l1_);
         u32x4_t unit_;
         unit_.x = h0_; unit_.y = h1_; unit_.z = l0_; unit_.w = l1_;
-        if (!(M16_ABL & 4) || unit_.x == 0x12345u) reinterpret_cast<u32x4_t*>(yb)[m16_plane(o, g, NS, H) + rowoff] = unit_;
+        if (!(M16_ABL & 4) || unit_.x == 0x12345u) m16_store_unit(reinterpret_cast<u32x4_t*>(yb) + m16_plane(o, g, NS, H) + rowoff, unit_);
       }
     if (vmax > 65504.f && a.flag) *a.flag = 1u;
   } else {
@@ -651,7 +668,7 @@ __global__ __launch_bounds__(512, 2) void conv2d_3x3_m16_kernel(ConvM16Args a) {
         p16_swap32(a1_, b1_);
         u32x4_t unit_;
         unit_.x = a0_; unit_.y = a1_; unit_.z = b0_; unit_.w = b1_;
-        reinterpret_cast<u32x4_t*>(yb)[m16_plane(o + g, 0, NS, H) + rowoff] = unit_;
+        m16_store_unit(reinterpret_cast<u32x4_t*>(yb) + m16_plane(o + g, 0, NS, H) + rowoff, unit_);
       }
     if (DT == 1 && vmax > 65504.f && a.flag) *a.flag = 1u;
   }

@@ -44,6 +44,7 @@ __device__ __forceinline__ float m16_hl_hi(unsigned h, unsigned l) {
   return r;
 }
 
+
 // epilogue of one 32-pixel x COUT accumulator tile (the accumulators started from the bias): separable-part tables, ReLU, residual, back to
 // M16 units (the P16 / B16 recipe: after v_permlane32_swap every lane holds one whole 16-byte unit; 512 contiguous bytes per half wave)
 template <int COUT, int NS, int DT>
@@ -93,7 +94,7 @@ __device__ __forceinline__ void m16_tile_epilogue(const ConvM16Args& a, f32x16 (
         p16_swap32(h1_, l1_);
         u32x4_t unit_;
         unit_.x = h0_; unit_.y = h1_; unit_.z = l0_; unit_.w = l1_;
-        reinterpret_cast<u32x4_t*>(yb)[m16_plane(o, g, NS, H) + rowoff] = unit_;
+        m16_store_unit(reinterpret_cast<u32x4_t*>(yb) + m16_plane(o, g, NS, H) + rowoff, unit_);
       }
   } else {
 #pragma unroll
@@ -133,7 +134,7 @@ __device__ __forceinline__ void m16_tile_epilogue(const ConvM16Args& a, f32x16 (
         p16_swap32(a1_, b1_);
         u32x4_t unit_;
         unit_.x = a0_; unit_.y = a1_; unit_.z = b0_; unit_.w = b1_;
-        reinterpret_cast<u32x4_t*>(yb)[m16_plane(o + g, 0, NS, H) + rowoff] = unit_;
+        m16_store_unit(reinterpret_cast<u32x4_t*>(yb) + m16_plane(o + g, 0, NS, H) + rowoff, unit_);
       }
   }
 }

@@ -13,6 +13,20 @@ static void run(ConvM16QArgs a, ConvM16QArgs b2, int B, int gy, const char* what
   a.nb = b2.nb = B;       // gy < B: a workgroup walks the maps b, b + gy, ... of its tile (one resident round)
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   float best = 1e9;
+#ifdef M16Q_TWO_QUEUES   // timing only: consecutive launches on alternating streams with NO dependency between them - the upper bound of what
+                         // overlapping a layer's ramp with its predecessor's tail could give (results are wrong: races)
+  static hipStream_t qs[2] = {nullptr, nullptr};
+  if (!qs[0]) { hipStreamCreateWithFlags(&qs[0], hipStreamNonBlocking); hipStreamCreateWithFlags(&qs[1], hipStreamNonBlocking); }
+  for (int r = 0; r < 6; ++r) {
+    hipDeviceSynchronize();
+    hipEventRecord(e0, qs[0]);
+    for (int k = 0; k < 20; ++k)
+      hipLaunchKernelGGL((conv2d_3x3_m16q_kernel<COUT, 2, 1>), dim3((a.ngroups * 2 + 7) / 8 * 8, gy), dim3(512), 0, qs[k & 1], (k & 1) ? b2 : a);
+    hipStreamSynchronize(qs[1]);
+    hipEventRecord(e1, qs[0]); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms *= 0.5f; if (r > 0 && ms < best) best = ms;
+  }
+#else
   for (int r = 0; r < 6; ++r) {
     hipEventRecord(e0, 0);
     for (int k = 0; k < 10; ++k)       // ping-pong: every launch reads what the previous one wrote
@@ -20,6 +34,7 @@ static void run(ConvM16QArgs a, ConvM16QArgs b2, int B, int gy, const char* what
     hipEventRecord(e1, 0); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); if (r > 0 && ms < best) best = ms;
   }
+#endif
   printf("cout=%d cin=%d d=%d B=%d grid.y=%d res=%d (%s): %.2f us per launch  [%s]\n", COUT, a.c.nchunks * 16, a.c.dil, B, gy, a.c.r != nullptr, what, best * 100.f, hipGetErrorString(hipGetLastError()));
 #ifdef M16Q_STAMPS
   unsigned long long h[128]; hipMemcpyFromSymbol(h, HIP_SYMBOL(m16q_stamp_buf), sizeof h);
