@@ -532,6 +532,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
     if os.environ.get("ORCA_BENCH_ONE_DEVICE"):      # test hook: all ranks on cuda:0 (control-flow check of the N > 1 path on a 1-GPU box;
         local_rank = 0                               # needs ORCA_BENCH_BACKEND=gloo - RCCL refuses two ranks on one device)
+        os.environ.setdefault("ORCA_RANKS_PER_DEVICE", str(world))    # the Encoder sizes its chunks (workspace) for `world` ranks on this GPU
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None

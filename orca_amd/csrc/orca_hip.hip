@@ -1582,17 +1582,19 @@ static int encoder_forward_impl(orca_ctx* ctx, orca_net* net, const float* x, in
     // a 32 Mb window is one chunk; longer inputs (the 256 Mb models) run in 128 Mb chunks: 98 GB of workspace (3 x 64 channels x 4 B per base) of
     // the 288 GB, a quarter of the chunk seams (each costs a 224 kb halo and one latency-bound pass through stages 5-7): 418 -> 406 ms per
     // genomepredict_256Mb call against 32 Mb chunks, 412 with 64 Mb (same box).  $ORCA_ENCODER_CHUNK_BP overrides.
-    // The chunk size does not change a result (every bin sees the same bases through the same kernels); it is taken as large as the device's
-    // FREE memory allows - 128, 64 or 32 Mb with the workspace at most 45 % of what is free (several ranks sharing one GPU, as the tests do).
+    // The chunk size does not change a result beyond fp32 round-off of the last stages (tests/test_gpu_e2e.py::test_encoder_256mb_chunk_sizes).
+    // The choice is DETERMINISTIC (free memory varies per rank and per run and does not count what torch's allocator holds): the
+    // largest of 128 / 64 / 32 Mb whose workspace (768 B per base) stays under 40 % of the device's TOTAL memory divided by
+    // $ORCA_RANKS_PER_DEVICE (default 1; bench.py and the tests set it when several ranks share one GPU).
     const char* e = getenv("ORCA_ENCODER_CHUNK_BP");
     chunk_bp = e ? atol(e) : 32000000L;
     if (!e && L > 32000000L) {
       size_t fr = 0, tot = 0;
-      if (hipMemGetInfo(&fr, &tot) == hipSuccess) {
-        fr += ctx->ws_bytes;                       // the arena would be replaced, not added to
+      const char* r = getenv("ORCA_RANKS_PER_DEVICE");
+      const long rpd = r && atol(r) > 0 ? atol(r) : 1;
+      if (hipMemGetInfo(&fr, &tot) == hipSuccess)
         for (long c : {128000000L, 64000000L})
-          if ((double)(c + 2 * kHaloBp + 4096) * 768.0 <= 0.45 * (double)fr) { chunk_bp = c; break; }
-      }
+          if ((double)(c + 2 * kHaloBp + 4096) * 768.0 <= 0.40 * (double)tot / (double)rpd) { chunk_bp = c; break; }
     }
   }
   if (chunk_bp % kBinBp) return fail(ORCA_EINVAL, "chunk_bp must be a multiple of 4000");

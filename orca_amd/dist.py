@@ -16,6 +16,7 @@ The reference's only multi-GPU mechanism is nn.DataParallel's batch split
   replicas: `shard_indices` deals them out, no data-path collective.
 """
 import os
+import sys
 
 import torch
 import torch.distributed as dist
@@ -94,10 +95,9 @@ class AbiComm:
     def __del__(self):
         # Prefer close() / the context manager.  At interpreter shutdown the HIP context, the stream or the peer ranks may be gone already and
         # ncclCommDestroy can hang or crash there: the handle is then left to the process exit.
-        import sys
-        if sys is None or sys.is_finalizing():
-            return
         try:
+            if sys is None or sys.is_finalizing():
+                return
             self.close()
         except Exception:
             pass
@@ -214,15 +214,11 @@ def strand_parallel_cascade_256m(model, enc0, mpos, wpos, chrlen, normmat, group
             try:
                 slab = strand_tail_256m(model, enc0, rank, mpos, wpos, chrlen, normmat)
             except Exception as e:      # stay in step with the other ranks (they would block in the all-gather); all raise after it
-                err, slab = e, torch.full((4, C, 250, 250), float("nan"), dtype=torch.float32, device=enc0.device)
+                err, slab = e, torch.zeros((4, C, 250, 250), dtype=torch.float32, device=enc0.device)
         else:       # the tail is one dependent chain per strand: ranks 2.. have nothing to add and only receive the maps
             slab = torch.zeros((4, C, 250, 250), dtype=torch.float32, device=enc0.device)
-        allm = _all_gather(slab, world, group, comm)
-        bad = bool(torch.isnan(allm[:2]).any())
-        if err is not None:
-            raise err
-        if bad:
-            raise RuntimeError("strand_parallel_cascade_256m: another rank failed in its strand's tail (its maps arrived as NaN)")
+        allm, failed = _all_gather_status(slab, err is not None, world, group, comm)
+        _raise_failed("strand_parallel_cascade_256m", err, failed)
         fwd, rev = allm[0], allm[1]      # ranks 0 and 1 hold one strand each; the other ranks' slabs are placeholders
     return [torch.stack([engine.strand_merge(fwd[j, c], rev[j, c]) for c in range(fwd.shape[1])]) for j in range(fwd.shape[0])]
 
@@ -243,6 +239,29 @@ def _all_gather(slab, world, group, comm):
     out = torch.empty((world,) + tuple(slab.shape), dtype=slab.dtype, device=slab.device)
     dist.all_gather_into_tensor(out.view(-1), slab.view(-1), group=group)
     return out
+
+
+def _all_gather_status(slab, failed, world, group, comm):
+    """_all_gather of ``slab`` with an explicit STATUS word per rank riding behind the payload (four floats, so that the payload rows stay
+    16-byte aligned): 1.0 = that rank's rank-local work raised.  A rank that fails still takes part in the collective (the others would
+    block in it) with whatever its slab holds; every rank then learns WHO failed from the status words - not from scanning the payload for
+    NaN, which a genuine NaN in a map (bad weights, a bad background) would trigger on every rank.  Returns ([world, *shape]
+    view of the payloads, [failed ranks]); the read-back is `world` floats."""
+    n = slab.numel()
+    assert n % 4 == 0
+    flat = torch.empty(n + 4, dtype=torch.float32, device=slab.device)
+    flat[:n] = slab.reshape(-1)
+    flat[n:] = 1.0 if failed else 0.0
+    out = _all_gather(flat, world, group, comm)                    # [world, n + 4]
+    status = out[:, n].tolist()
+    return out[:, :n].reshape((world,) + tuple(slab.shape)), [r for r, v in enumerate(status) if v != 0.0]
+
+
+def _raise_failed(what, err, failed):
+    if err is not None:
+        raise err
+    if failed:
+        raise RuntimeError(f"{what}: rank(s) {failed} failed in their rank-local work (status word of the all-gather)")
 
 
 def unit_plan(n_units, total_bins, rank, world):
@@ -274,8 +293,9 @@ def units_sharded_32m(models, codes, mpos, wpos, distencs=None, group=None, comm
     Returns per model the six merged [C,250,250] maps (on every rank).  Replaces nn.DataParallel around the sub-networks
     (orca_models.py:44-50), which only splits batches.
 
-    A rank whose local work raises does NOT leave the others blocked in the collectives: it contributes NaN slabs, every rank finds them
-    after the map gather, and all raise together.
+    A rank whose local work raises does NOT leave the others blocked in the collectives: it still takes part, with a STATUS word behind its
+    payload (`_all_gather_status`), every rank reads the status words behind that collective and all raise together - the failing rank its own
+    error, the others a RuntimeError naming it (ADVICE rounds 3-4; a genuine NaN in a map is no longer mistaken for a failed peer).
     ``local_only``: run the whole job on this rank whatever the process group (the N = 1 time inside an N-rank bench run);
     ``marks``: a list that receives (phase, torch.cuda.Event) after "encode", "gather", "tails", "maps" (bench.py's per-phase times)."""
     from . import engine, orca_predict
@@ -310,12 +330,12 @@ def units_sharded_32m(models, codes, mpos, wpos, distencs=None, group=None, comm
         try:
             for i, (u, lo, hi) in enumerate(enc_plan):
                 slab[i, :, :, : hi - lo] = local(u, lo, hi)
-        except Exception as e:                       # stay in step with the other ranks; raise after the last collective
+        except Exception as e:                       # stay in step with the other ranks: every rank raises behind the collective
             err = e
-            slab.fill_(float("nan"))
         mark("encode")
-        gathered = _all_gather(slab, world, group, comm)          # [world, units per rank, B, 128, width]
+        gathered, failed = _all_gather_status(slab, err is not None, world, group, comm)          # [world, units per rank, B, 128, width]
         mark("gather")
+        _raise_failed("units_sharded_32m (encode)", err, failed)
         enc = []
         for u in range(U):
             if world >= U:
@@ -346,23 +366,16 @@ def units_sharded_32m(models, codes, mpos, wpos, distencs=None, group=None, comm
         per = max(1, -(-U // world))
         slab = torch.zeros((per, 6, C, 250, 250), dtype=torch.float32, device=dev)
         try:
-            if err is None:
-                for i, u in enumerate(tail_units):
-                    slab[i] = tail(u, not offload)
-                for u in one_m_units:
-                    slab[0, 5] = orca_predict.denet1m_32m_from_enc(models[u // 2], enc[u], mpos, wpos, [bool(u & 1)])[0]
+            for i, u in enumerate(tail_units):
+                slab[i] = tail(u, not offload)
+            for u in one_m_units:
+                slab[0, 5] = orca_predict.denet1m_32m_from_enc(models[u // 2], enc[u], mpos, wpos, [bool(u & 1)])[0]
         except Exception as e:
             err = e
-        if err is not None:
-            slab.fill_(float("nan"))
         mark("tails")
-        allm = _all_gather(slab, world, group, comm)              # [world, per, 6, C, 250, 250]
+        allm, failed = _all_gather_status(slab, err is not None, world, group, comm)              # [world, per, 6, C, 250, 250]
         mark("maps")
-        bad = bool(torch.isnan(allm).any())                      # (the maps leave for the host next anyway)
-        if err is not None:
-            raise err
-        if bad:
-            raise RuntimeError("units_sharded_32m: another rank failed in its rank-local work (its slabs arrived as NaN)")
+        _raise_failed("units_sharded_32m (tails)", err, failed)
         maps = []
         for u in range(U):
             mu = allm[u % world, u // world] if world < U else allm[u, 0]

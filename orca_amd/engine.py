@@ -196,15 +196,23 @@ class ContextPool:
         return any([self.ctxs[i].take_overflow() for i in dirty])      # a list: every flag is read (and cleared)
 
 
-_pools = {}
+def _thread_pools():
+    pools = getattr(_tls, "pools", None)
+    if pools is None:
+        pools = _tls.pools = {}
+    return pools
 
 
 def context_pool(device, k):
-    """THE pool of k auxiliary contexts of a device (made once per process: modules cache a weight upload per context they ran on)."""
+    """THE pool of k auxiliary contexts of a device FOR THE CALLING THREAD (made once per thread: modules cache a weight upload per
+    context they ran on).  Per thread like every other context (`_tls.ctxs`): a pool's workspace arenas, edge scratch, streams, `_dirty`
+    set and fork / join events belong to one chain of calls; two threads sharing them would overwrite each other's workspace and drain
+    each other's fp16-range flags."""
     idx = device.index if isinstance(device, torch.device) and device.index is not None else torch.cuda.current_device()
-    if (idx, k) not in _pools:
-        _pools[(idx, k)] = ContextPool(torch.device("cuda", idx), k)
-    return _pools[(idx, k)]
+    pools = _thread_pools()
+    if (idx, k) not in pools:
+        pools[(idx, k)] = ContextPool(torch.device("cuda", idx), k)
+    return pools[(idx, k)]
 
 
 def strand_streams():
@@ -227,8 +235,8 @@ def run_with_overflow_retry(fn, device, pool=None):
     with defer_overflow_guard():
         out = fn()
     over = ctx.take_overflow()
-    for p in ([pool] if pool is not None else []) + [q for q in _pools.values() if q is not pool and q.index == ctx.device_index]:
-        over = p.take_overflow() or over          # auxiliary contexts fn() ran on (e.g. the reverse strand's Encoder, strand_streams())
+    for p in ([pool] if pool is not None else []) + [q for q in _thread_pools().values() if q is not pool and q.index == ctx.device_index]:
+        over = p.take_overflow() or over          # THIS thread's auxiliary contexts fn() ran on (e.g. the reverse strand's Encoder, strand_streams())
     if over:
         import warnings
         warnings.warn("orca_amd: an activation left the fp16 range; recomputing with range-safe arithmetic (bf16x3 / f32)")

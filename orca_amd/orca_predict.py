@@ -210,6 +210,8 @@ class Background256:
     8000 x 8000 matrix crosses PCIe or the host's caches per call.  NaNs are filled with the smallest finite entry, in place,
     exactly once (:664-667).  Callable as run_cascade's ``background(level, k, start)`` for the strands ``reverse_flags``."""
 
+    _nan_filled = {}      # data_ptr -> (data_ptr, shape, _version) of resident matrices whose NaNs have been filled
+
     def __init__(self, normmat, reverse_flags=(False, True), use_cuda=True):
         self.on_device = isinstance(normmat, torch.Tensor) and normmat.is_cuda
         if self.on_device and normmat.dtype != torch.float64:
@@ -229,12 +231,17 @@ class Background256:
         if self.on_device:
             # in place, as the reference does (:664-667) - and ONCE per tensor: callers hand the same resident 8000 x 8000 matrix to every call
             # (bench.py, dist.strand_tail_256m), and the isnan pass over its 512 MB plus the host sync of `.any()` sat inside every timed tail
-            if getattr(m, "_orca_nan_filled", False):
+            # (the "already filled" state is keyed by the STORAGE and its version counter, not kept as an attribute of the caller's tensor: an
+            # in-place refill with a matrix that holds NaN bumps `_version` and is filled again; views and `.to()` copies cannot lose it)
+            key = (m.data_ptr(), tuple(m.shape), m._version)
+            if Background256._nan_filled.get(m.data_ptr()) == key:
                 return
             nan = torch.isnan(m)
             if bool(nan.any()):
                 m[nan] = m[~nan].min()
-            m._orca_nan_filled = True
+            if len(Background256._nan_filled) > 64:
+                Background256._nan_filled.clear()
+            Background256._nan_filled[m.data_ptr()] = (m.data_ptr(), tuple(m.shape), m._version)
         else:
             isnan = np.isnan(m)
             if np.any(isnan):

@@ -126,16 +126,43 @@ BIN = 4000
 
 
 class ChromEncodings:
-    """Encoder outputs of a whole packed chromosome, per strand and 4 kb phase, computed on demand and kept in HBM
-    (128 x chrlen/4000 floats: 5 MB per entry for 40 Mb).  Strand '+', phase p: bins of chrom[p:], bin i = bases [p + 4000 i, ..);
-    strand '-', phase p: bins of revcomp(chrom)[p:] in reverse-complement coordinates (q = chrlen - 1 - forward position)."""
+    """Encoder outputs of a packed chromosome that are held in HBM for reuse, per strand and 4 kb phase:
+    * ENTRIES - the whole chromosome (128 x chrlen/4000 floats: 5 MB per entry for 40 Mb), built on demand.  Strand '+', phase p: bins of
+      chrom[p:], bin i = bases [p + 4000 i, ..); strand '-', phase p: bins of revcomp(chrom)[p:] in reverse-complement coordinates
+      (q = chrlen - 1 - forward position);
+    * SEGMENTS (round 5) - the Encoder output of a WINDOW that some call has encoded anyway (`add_segment`: a reference-allele view of a
+      structural-variant driver, both strands): the bins of strand coordinates [c0, c0 + 4000 n).  A later window - the alternative allele
+      of the same call, or a later call at the same phase - takes its bins from there.
+    A bin is served from a source only if the source's phase matches and the bin lies RF_BINS bins inside it (the bins next to a source's
+    ends saw its zero padding).  ``codes``: the chromosome's [chrlen] uint8 tensor, or a callable returning it (a 2-bit genome unpacks
+    only when an entry is really built); ``chrlen`` is then required."""
 
-    def __init__(self, net0, codes, max_entries=8):
-        if not (isinstance(codes, torch.Tensor) and codes.dtype == torch.uint8 and codes.dim() == 1):
-            raise ValueError("codes: a [chrlen] uint8 tensor (on the MI355X for an orca_amd Encoder)")
-        self.net0, self.codes, self.C, self.max_entries = net0, codes, int(codes.shape[0]), max_entries
+    def __init__(self, net0, codes, max_entries=8, chrlen=None, max_segments=24):
+        if callable(codes):
+            if chrlen is None:
+                raise ValueError("ChromEncodings: chrlen is required with a codes callable")
+            self._codes, self._codes_fn, self.C = None, codes, int(chrlen)
+        else:
+            if not (isinstance(codes, torch.Tensor) and codes.dtype == torch.uint8 and codes.dim() == 1):
+                raise ValueError("codes: a [chrlen] uint8 tensor (on the MI355X for an orca_amd Encoder)")
+            self._codes, self._codes_fn, self.C = codes, None, int(codes.shape[0])
+        self.net0, self.max_entries, self.max_segments = net0, max_entries, max_segments
         self.entries = {}
+        self.segments = []        # [strand, c0, tensor [128, n]], least recently used first
+        self.miss_bins = 1000     # bins a run must miss to count as a request for a chromosome encoding (an eighth of a 32 Mb window)
+        self.requests = {}        # (strand, phase) -> window-sized runs that no source could serve so far (`build="auto"`)
         self.builds = 0
+
+    @property
+    def codes(self):
+        if self._codes is None:
+            self._codes = self._codes_fn()
+        return self._codes
+
+    def auto_threshold(self):
+        """Unserved window-sized runs of one (strand, phase) after which the whole chromosome is encoded at that phase: an entry costs
+        chrlen / 32 Mb windows' worth of Encoder time and saves about one window's worth per run from then on."""
+        return max(2, -(-self.C // WINDOW))
 
     def get(self, strand, phase, build=True):
         key = (strand, int(phase))
@@ -152,42 +179,120 @@ class ChromEncodings:
             self.builds += 1
         return e
 
+    def add_segment(self, strand, c0, enc):
+        """Keep ``enc`` [128, n] = the bins of strand coordinates [c0, c0 + 4000 n) (a copy is NOT made: hand over a tensor of your own)."""
+        if enc.shape[1] > 2 * RF_BINS:
+            self.segments.append([strand, int(c0), enc])
+            del self.segments[: max(0, len(self.segments) - self.max_segments)]
+
+    def cover(self, strand, coord, nbins, build=True, extra=()):
+        """What the held sources can serve of the ``nbins`` bins starting at strand coordinate ``coord``: [(a, b, view [128, b - a])] with
+        0 <= a < b <= nbins, ascending and disjoint.  ``build``: True = encode the chromosome at this phase if it is not held, False = never,
+        "auto" = once `auto_threshold()` window-sized runs of this (strand, phase) went unserved.  ``extra``: more segments (a call's own)."""
+        phase = coord % BIN
+        key = (strand, phase)
+        got = []                                             # (a, b, tensor, first bin of the tensor to take)
+
+        def offer(c0, t):
+            i0 = (coord - c0) // BIN
+            a, b = max(0, RF_BINS - i0), min(nbins, t.shape[1] - RF_BINS - i0)
+            if b > a:
+                got.append((a, b, t, i0 + a))
+
+        def entry(bld):
+            e = self.get(strand, phase, bld)
+            if e is not None:
+                offer(phase, e)
+        entry(build is True)
+        used = []
+        for k, seg in enumerate(list(self.segments) + list(extra)):
+            if seg[0] == strand and (coord - seg[1]) % BIN == 0:
+                n0 = len(got)
+                offer(seg[1], seg[2])
+                if len(got) > n0 and k < len(self.segments):
+                    used.append(k)
+        if used:                                             # used: most recent (by identity: the lists hold tensors)
+            self.segments = [g for k, g in enumerate(self.segments) if k not in used] + [self.segments[k] for k in used]
+        got.sort(key=lambda g: (g[0], -g[1]))
+        out, pos = [], 0
+        for a, b, t, j in got:
+            if b <= pos:
+                continue
+            if a < pos:
+                j, a = j + (pos - a), pos
+            out.append((a, b, t[:, j: j + (b - a)]))
+            pos = b
+        if build == "auto" and key not in self.entries:
+            missing = nbins - sum(b - a for a, b, _ in out)
+            if missing >= self.miss_bins:                       # a window-sized miss
+                self.requests[key] = self.requests.get(key, 0) + 1
+                if self.requests[key] >= self.auto_threshold() and len(self.entries) < self.max_entries:
+                    return self.cover(strand, coord, nbins, True, extra)
+        return out
+
     def lookup(self, strand, coord, nbins, build=True):
         """[128, nbins] view of the bins starting at strand coordinate ``coord`` (forward position, or reverse-complement coordinate for
-        '-'), or None when no encoding of that phase is held / may be built, or the range touches the RF_BINS bins at an end of the
-        chromosome encoding (those saw the zero padding of the chromosome's ends)."""
-        phase = coord % BIN
-        e = self.get(strand, phase, build)
-        if e is None:
-            return None
-        i0 = (coord - phase) // BIN
-        if i0 < RF_BINS or i0 + nbins > e.shape[1] - RF_BINS:
-            return None
-        return e[:, i0: i0 + nbins]
+        '-') when ONE source holds all of them, else None (no source of that phase is held / may be built, or the range touches the
+        RF_BINS bins at an end of a source: those saw its zero padding)."""
+        for a, b, v in self.cover(strand, coord, nbins, build):
+            if a == 0 and b == nbins:
+                return v
+        return None
+
+
+class GenomeEncodings:
+    """`ChromEncodings` per chromosome of one genome for one Encoder: what `encode_windows` looks pieces `(chrom, start, length, strand)`
+    up in.  ``chrom_codes(chrom)`` -> the chromosome's [chrlen] uint8 codes on the device; ``chrlens``: {chrom: length}."""
+
+    def __init__(self, net0, chrom_codes, chrlens, max_entries=4):
+        self.net0, self.chrom_codes, self.chrlens, self.max_entries = net0, chrom_codes, dict(chrlens), max_entries
+        self.chroms = {}
+
+    def of(self, chrom):
+        if chrom not in self.chrlens:
+            return None                                        # an inserted sequence, padding: nothing to reuse
+        c = self.chroms.get(chrom)
+        if c is None:
+            c = self.chroms[chrom] = ChromEncodings(self.net0, lambda chrom=chrom: self.chrom_codes(chrom), self.max_entries, chrlen=self.chrlens[chrom])
+        return c
+
+    @property
+    def builds(self):
+        return sum(c.builds for c in self.chroms.values())
+
+
+def _p4(piece):
+    """Pieces are `(src_start, length, strand)` of ONE chromosome (the screen) or `(chrom, src_start, length, strand)` (the drivers)."""
+    return piece if len(piece) == 4 else (None,) + tuple(piece)
 
 
 def strand_coord(piece, chrlen):
     """Strand coordinate of the first base a piece contributes: forward position for '+', reverse-complement coordinate for '-'."""
-    src, ln, strand = piece
+    _, src, ln, strand = _p4(piece)
     return src if strand == "+" else chrlen - src - ln
 
 
 def revcomp_pieces(pieces):
     """The pieces of the reverse complement of a sequence given by ``pieces``."""
-    return [(src, ln, "-" if strand == "+" else "+") for src, ln, strand in reversed(pieces)]
+    return [p[:-1] + ("-" if p[-1] == "+" else "+",) for p in reversed([tuple(q) for q in pieces])]
 
 
 def reuse_plan(pieces, chrlen, nbins):
     """For a sequence of ``nbins`` * 4000 bases given as pieces: [(bin_lo, bin_hi, strand, coord)] - runs of bins whose receptive field
-    lies inside one piece (and off the sequence's ends), with the strand coordinate of bin_lo's first base."""
+    lies inside one piece (and off the sequence's ends), with the strand coordinate of bin_lo's first base.  With 4-tuple pieces
+    `(chrom, start, length, strand)` and ``chrlen`` a {chrom: length} mapping: [(bin_lo, bin_hi, strand, coord, chrom)], pieces of
+    anything that is not a chromosome of the mapping (an inserted string, padding) left out."""
     out, o = [], 0
     L = nbins * BIN
     for piece in pieces:
-        ln = piece[1]
+        chrom, src, ln, strand = _p4(piece)
         lo = max(-(-(o + RF_BINS * BIN) // BIN), RF_BINS)                          # ceil
         hi = min((o + ln - RF_BINS * BIN) // BIN, nbins - RF_BINS)                 # exclusive
         if hi > lo:
-            out.append((lo, hi, piece[2], strand_coord(piece, chrlen) + lo * BIN - o))
+            if len(piece) == 3:
+                out.append((lo, hi, strand, strand_coord(piece, chrlen) + lo * BIN - o))
+            elif chrom in chrlen:
+                out.append((lo, hi, strand, strand_coord(piece, chrlen[chrom]) + lo * BIN - o, chrom))
         o += ln
     if o != L:
         raise ValueError("pieces do not add up to the window")
@@ -197,30 +302,35 @@ def reuse_plan(pieces, chrlen, nbins):
 POOL_MAX_BINS = 500     # longer runs (whole windows: phases that are not held) are not spread over the pool's contexts - they fill the chip on their own
 
 
-def encode_windows(cache, pieces_list, win_codes, out, merge_gap=2 * RF_BINS, build=True, pool=None, defer_join=False):
+def encode_windows(cache, pieces_list, win_codes, out, merge_gap=2 * RF_BINS, build=True, pool=None, defer_join=False, extra=None, big_on_caller=False):
     """Both strands of W allele windows into ``out`` [2W,128,nbins] (window w: row 2w forward, row 2w + 1 reverse complement): bins whose
-    receptive field lies inside one piece are copied from `cache` (ChromEncodings), the rest - window ends, junctions, pieces of a
-    phase that is not held - go through the Encoder's bin-range form on ``win_codes`` [W,L] (the assembled windows).  Bin ranges that
-    several windows have in common (the window ends, as a rule) are ONE batched call.  Returns the number of bins encoded (of 2W * nbins).
+    receptive field lies inside one piece are copied from `cache` (ChromEncodings; GenomeEncodings for pieces that name their chromosome),
+    the rest - window ends, junctions, pieces of a phase that is not held - go through the Encoder's bin-range form on ``win_codes`` [W,L]
+    (the assembled windows).  Bin ranges that several windows have in common (the window ends, as a rule) are ONE batched call.  Returns
+    the number of bins encoded (of 2W * nbins).  ``extra``: {chrom: [segment]} - segments of the caller's own beside the cache's.
 
     ``pool`` (engine.ContextPool): the bin-range calls are independent of each other and small (220-440 kb of bases: ~50 dependent launches,
     0.65-0.9 ms of GPU time in stream order, most of them on a fraction of the chip) - each (window, strand, range) becomes a job of its own,
     the jobs are dealt to the pool's contexts (own stream and workspace), longest first, and their kernels run side by side (9.1 -> 5.4 ms
     per variant); the caller's stream continues behind all of them (``defer_join``: it does not - the caller orders a stream behind them
-    later with pool.wait_join: `sv_screen` issues a variant's local encodes under the previous variant's decoders)."""
+    later with pool.wait_join: `sv_screen` issues a variant's local encodes under the previous variant's decoders).  Runs longer than
+    POOL_MAX_BINS (whole windows) go to the pool's context 0 one after the other, or (``big_on_caller``) stay on the caller's context."""
     nbins = out.shape[2]
-    C = cache.C
+    multi = isinstance(cache, GenomeEncodings)
     W = len(pieces_list)
     runs = {}                                                           # (reverse, lo, hi) -> [window]
     for w, pieces in enumerate(pieces_list):
         for rev, pcs in ((False, pieces), (True, revcomp_pieces(pieces))):
             row = 2 * w + int(rev)
             have = []
-            for lo, hi, strand, coord in reuse_plan(pcs, C, nbins):
-                src = cache.lookup(strand, coord, hi - lo, build)
-                if src is not None:
-                    out[row, :, lo:hi].copy_(src)
-                    have.append((lo, hi))
+            for run in reuse_plan(pcs, cache.chrlens if multi else cache.C, nbins):
+                lo, hi, strand, coord = run[:4]
+                ce = cache.of(run[4]) if multi else cache
+                if ce is None:
+                    continue
+                for a, b, src in ce.cover(strand, coord, hi - lo, build, (extra or {}).get(run[4] if multi else None, ())):
+                    out[row, :, lo + a: lo + b].copy_(src)
+                    have.append((lo + a, lo + b))
             # the complement: runs of bins still to encode; runs closer than merge_gap are encoded as one (a call costs ~40 launches)
             todo, pos = [], 0
             for lo, hi in have:
@@ -244,6 +354,9 @@ def encode_windows(cache, pieces_list, win_codes, out, merge_gap=2 * RF_BINS, bu
         k = 0
         for n_, rev, lo, hi, w in jobs:
             row = 2 * w + int(rev)
+            if n_ > POOL_MAX_BINS and big_on_caller:      # a whole window fills the chip on its own: the caller's context and stream
+                cache.net0.forward_codes(win_codes[w:w + 1], reverse=rev, bin_lo=lo, bin_hi=hi, out=out[row:row + 1, :, lo:hi])
+                continue
             if n_ > POOL_MAX_BINS:      # all on context 0, one after the other (one 25 GB workspace; the range flag stays with the pool's)
                 pool.run(0, lambda w=w, rev=rev, lo=lo, hi=hi, row=row: cache.net0.forward_codes(win_codes[w:w + 1], reverse=rev, bin_lo=lo, bin_hi=hi,
                                                                                              out=out[row:row + 1, :, lo:hi]))
@@ -285,7 +398,8 @@ def needed_phases(svs, chrlen, length=WINDOW):
 def _cascade_windows(model, enc0, params):
     """Encoder2 + the six decoder levels for W windows whose Encoder outputs are given: ``enc0`` [2W,128,8000] (window w: forward strand
     in row 2w, reverse complement in row 2w + 1), params[w] = (mpos, wpos).  ONE cascade: every decoder level is a batch of 2W maps.
-    Returns (strand-merged maps [W,6,250,250] on the device, starts[k][6])."""
+    Returns (strand-merged maps [W,6,C,250,250] on the device - every target channel of a multi-target model, as `genomepredict`
+    keeps them -, starts[k][6])."""
     from . import orca_predict as OP
     W = len(params)
     flags = [bool(k & 1) for k in range(2 * W)]
@@ -299,7 +413,8 @@ def _cascade_windows(model, enc0, params):
 
     encodings = dict(zip([1, 2, 4, 8, 16, 32], model.net(enc0)))
     preds, starts = OP.run_cascade(model, encodings, [32, 16, 8, 4, 2, 1], lambda lv: lv, 1, flags, background, zooms, add_1m_level=1)
-    merged = [torch.stack([engine.strand_merge(p[2 * w, 0], p[2 * w + 1, 0]) for p in preds]) for w in range(W)]
+    merged = [torch.stack([torch.stack([engine.strand_merge(p[2 * w, c], p[2 * w + 1, c]) for c in range(p.shape[1])]) for p in preds])
+              for w in range(W)]
     return torch.stack(merged), starts
 
 
@@ -310,7 +425,8 @@ def _window_outputs(model, merged, starts, params, mchr):
     outs = []
     for w, (mpos, wpos) in enumerate(params):
         sc = [wpos - 16000000 + s * 4000 for s in starts[2 * w]]
-        outs.append({"predictions": [[host[w, j] for j in range(6)]], "experiments": None, "start_coords": sc,
+        # [250,250] per level for single-target models, [C,250,250] otherwise (orca_predict.py:510-523)
+        outs.append({"predictions": [[host[w, j, 0] if host.shape[2] == 1 else host[w, j] for j in range(6)]], "experiments": None, "start_coords": sc,
                      "end_coords": [int(sc[ii] + 32000000 / 2 ** ii) for ii in range(6)], "chr": mchr, "annos": None,
                      "normmats": [[model.normmats[ii] for ii in levels]]})
     return outs

@@ -10,6 +10,7 @@ import torch
 
 from oracle import orca_oracle as O
 from orca_amd import orca_predict as P
+from tests import standins
 from orca_amd import synth
 from tests.util import golden, maxabs, stats, synth_sd
 
@@ -17,7 +18,7 @@ from tests.util import golden, maxabs, stats, synth_sd
 class OracleModel32(torch.nn.Module):
     def __init__(self, seed):
         super().__init__()
-        self.net0 = synth.FakeNet0(nbins=8000, seed=seed)
+        self.net0 = standins.FakeNet0(nbins=8000, seed=seed)
         self.net = O.OracleModule(O.encoder2_forward, synth_sd("Encoder2", seed))
         self.denets = {lv: O.OracleModule(O.decoder_forward, synth_sd("Decoder", seed + lv, upsample_mode="bilinear"),
                                           upsample_mode="bilinear") for lv in (1, 2, 4, 8, 16, 32)}
@@ -28,7 +29,7 @@ class OracleModel32(torch.nn.Module):
 class OracleModel256(torch.nn.Module):
     def __init__(self, seed):
         super().__init__()
-        self.net0 = synth.FakeNet0(nbins=64000, seed=seed)
+        self.net0 = standins.FakeNet0(nbins=64000, seed=seed)
         self.net1 = O.OracleModule(O.encoder2_forward, synth_sd("Encoder2", seed))
         self.net = O.OracleModule(O.encoder3_forward, synth_sd("Encoder3", seed))
         self.denets = {lv: O.OracleModule(O.decoder_forward, synth_sd("Decoder", seed + lv, upsample_mode="bilinear"),

@@ -61,8 +61,7 @@ def test_config3_default_arithmetic_vs_reference(setup):
     assert max(maxabs(m[0], m[5]) for m in maps) > 1e-3
 
 
-@pytest.mark.parametrize("dec_precision,tol,rmin", [("bf16", 0.6, 0.999), ("f16", 0.1, 0.99999)])   # (the structure of these modes: the two tests below)
-def test_config3_bf16_throughput_mode_vs_reference(setup, dec_precision, tol, rmin):
+def _config3_vs_reference(setup, dec_precision, tol, rmin):
     model, codes, de = setup
     g = golden("G17_config3.npz")
     enc0, maps, starts = _forward(model, codes, de, "bf16", dec_precision)
@@ -75,6 +74,19 @@ def test_config3_bf16_throughput_mode_vs_reference(setup, dec_precision, tol, rm
             assert err < tol and r > rmin, (b, j, err, r)
     print(f"config 3, Encoder bf16 / Decoders {dec_precision} vs reference: worst max-abs {worst[0]:.4g}, worst Pearson {worst[1]:.6f}")
     _forward(model, codes, de, "f16x2")   # leave the module-scoped model in its default arithmetic
+
+
+def test_config3_throughput_mode_vs_reference(setup):
+    """THE config-3 mode of bench.py: Encoder on bf16 planes, Decoders on single fp16 planes - stated tolerance 0.1 / 0.99999 vs the
+    reference's own rows (G17).  (The structure of the single-plane modes: the two tests below.)"""
+    _config3_vs_reference(setup, "f16", 0.1, 0.99999)
+
+
+def test_lossy_all_bf16_decoder_mode_smoke(setup):
+    """NOT a parity claim and not a benchmarked mode: Decoders on single bf16 planes round their residual stream to 8 bits 56 times
+    (measured 0.37-0.40 max-abs on maps of range +-3, Pearson 0.9997).  Kept as a documented lossy mode; this only checks that it runs,
+    follows the same zoom path and stays inside a loose envelope (a mis-packed weight chunk shows in the integer-network test below)."""
+    _config3_vs_reference(setup, "bf16", 0.6, 0.999)
 
 
 def _q(t, dt):

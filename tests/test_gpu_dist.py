@@ -10,6 +10,7 @@ import sys
 import numpy as np
 import pytest
 import torch
+from tests import standins
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -59,7 +60,7 @@ def test_strand_parallel_tail_equals_genomepredict_256mb_fixture(cuda):
     from tests.util import golden, maxabs
     g = golden("G9_cascade256.npz")
     model = orca_models.H1esc_256M(synthetic_seed=0)
-    net0 = synth.FakeNet0(nbins=64000, seed=0).to(cuda)
+    net0 = standins.FakeNet0(nbins=64000, seed=0).to(cuda)
     seq = synth.synth_sequence(512000, seed=51)
     x = torch.from_numpy(seq).to(cuda).transpose(1, 2)
     xr = torch.from_numpy(np.ascontiguousarray(seq[:, ::-1, ::-1])).to(cuda).transpose(1, 2)

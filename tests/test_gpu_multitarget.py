@@ -6,6 +6,7 @@ import torch
 
 from oracle import orca_oracle as O
 from orca_amd import orca_leukemia as L
+from tests import standins
 from orca_amd import orca_predict as P
 from orca_amd import synth
 
@@ -75,7 +76,7 @@ def test_wrong_channel_counts_are_rejected(cuda):
 class _FakeEncoderLeukemia(torch.nn.Module):
     def __init__(self, full):
         super().__init__()
-        self.net0 = synth.FakeNet0(nbins=8000, seed=0).cuda()
+        self.net0 = standins.FakeNet0(nbins=8000, seed=0).cuda()
         self.net, self.denets, self.denet_1_pt = full.net, full.denets, full.denet_1_pt
         self.normmats, self.epss = full.normmats, full.epss
 
@@ -92,7 +93,7 @@ def test_genomepredict_with_multitarget_model_vs_oracle(cuda):
     assert len(preds) == 6 and all(p.shape == (2, 250, 250) for p in preds)
     # oracle cascade (orca_predict.py:316-523), composed from the pinned pieces
     sds = {"net": _sd(full.net, 4), "pt": _sd(full.denet_1_pt, 4), "d": {lv: _sd(full.denets[lv], 4 + lv) for lv in full.levels}}
-    fake = synth.FakeNet0(nbins=8000, seed=0)
+    fake = standins.FakeNet0(nbins=8000, seed=0)
     allp, starts0 = [], None
     for k, s in enumerate([seq, seq[:, ::-1, ::-1].copy()]):
         enc0 = fake(torch.from_numpy(np.ascontiguousarray(s)).transpose(1, 2))

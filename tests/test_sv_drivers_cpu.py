@@ -4,7 +4,7 @@
 The drivers' numerics are `genomepredict`'s (pinned by G7/G8); what is pinned here is everything around it: the
 coordinate algebra of the mutated chromosome, window clipping, piece-wise sequence assembly incl. reverse
 complements, inserted strings and 'N' padding, anchors, labels and scaled annotations.  Both sides run the same cheap
-stand-in models (`orca_amd.synth.FakeModel32`) on the CPU.
+stand-in models (`orca_amd.standins.FakeModel32`) on the CPU.
 """
 import json
 import os
@@ -13,6 +13,7 @@ import numpy as np
 import pytest
 
 from orca_amd import orca_predict, orca_utils, synth
+from tests import standins
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
@@ -79,8 +80,8 @@ def test_packed_genome_selene_semantics():
 @pytest.fixture(scope="module")
 def sv_setup():
     saved = dict(orca_predict.model_dict_global)
-    orca_predict.model_dict_global["h1esc"] = synth.FakeModel32(0)
-    orca_predict.model_dict_global["hff"] = synth.FakeModel32(1)
+    orca_predict.model_dict_global["h1esc"] = standins.FakeModel32(0)
+    orca_predict.model_dict_global["hff"] = standins.FakeModel32(1)
     yield synth.sv_driver_genome(), np.load(os.path.join(GOLD, "G11_sv_drivers.npz"))
     orca_predict.model_dict_global.clear()
     orca_predict.model_dict_global.update(saved)
@@ -108,9 +109,9 @@ def test_sv_driver_matches_reference(sv_setup, case):
 @pytest.fixture(scope="module")
 def sv_setup_256():
     saved, saved_fn = dict(orca_predict.model_dict_global), orca_predict.genomepredict_256Mb
-    orca_predict.model_dict_global["h1esc_256m"] = synth.Background256(0)
-    orca_predict.model_dict_global["hff_256m"] = synth.Background256(1)
-    rec = synth.Recorder256()
+    orca_predict.model_dict_global["h1esc_256m"] = standins.Background256(0)
+    orca_predict.model_dict_global["hff_256m"] = standins.Background256(1)
+    rec = standins.Recorder256()
     orca_predict.genomepredict_256Mb = rec
     # .to("cpu"): the drivers take their packed-codes route (what they do with the genome in HBM), on the host
     yield synth.sv_driver_genome_256().to("cpu"), np.load(os.path.join(GOLD, "G13_sv_drivers_256.npz")), rec
@@ -127,7 +128,7 @@ def test_sv_driver_256mb_views_match_reference(sv_setup_256, case):
     genome, gold, rec = sv_setup_256
     name, fn, a, kw = next(c for c in synth.sv_driver_cases_256() if c[0] == case)
     first = len(rec.calls)
-    tgt = [synth.FakeTarget256()] if fn == "process_del" else False    # the reference's process_del needs targets at 256 Mb
+    tgt = [standins.FakeTarget256()] if fn == "process_del" else False    # the reference's process_del needs targets at 256 Mb
     outs = getattr(orca_predict, fn)(*a, genome, custom_models=[object(), object()], target=tgt,
                                      use_cuda=True, window_radius=128000000, padding_chr="chr1", **kw)
     got = rec.summary(first)
@@ -164,12 +165,12 @@ def test_process_seqstr_matches_reference(monkeypatch):
     monkeypatch.setitem(sys.modules, "seqstr", None)                     # not installed
     with pytest.raises(ImportError, match="Seqstr is not installed"):
         orca_predict.process_seqstr("[32000000,41]")
-    monkeypatch.setitem(sys.modules, "seqstr", types.SimpleNamespace(seqstr=synth.FakeSeqstr()))
+    monkeypatch.setitem(sys.modules, "seqstr", types.SimpleNamespace(seqstr=standins.FakeSeqstr()))
     with pytest.raises(ValueError, match="at least 32Mb"):
-        orca_predict.process_seqstr("[31999999,1]", custom_models=[synth.FakeModel32(0)], use_cuda=False)
+        orca_predict.process_seqstr("[31999999,1]", custom_models=[standins.FakeModel32(0)], use_cuda=False)
     with pytest.raises(NotImplementedError):
-        orca_predict.process_seqstr("[32000000,41]", file="x", custom_models=[synth.FakeModel32(0)], use_cuda=False)
-    h1 = synth.FakeModel32(0)
+        orca_predict.process_seqstr("[32000000,41]", file="x", custom_models=[standins.FakeModel32(0)], use_cuda=False)
+    h1 = standins.FakeModel32(0)
     for name, spec, mpos in synth.seqstr_cases():
         got = synth.summarize_outputs(orca_predict.process_seqstr(spec, mpos=mpos, custom_models=[h1], use_cuda=False))
         keys = [k for k in gold.files if k.startswith(name + ".")]

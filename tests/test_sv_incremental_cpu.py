@@ -85,3 +85,76 @@ def test_reuse_plan_and_phases():
     assert [p[2] for p in rplan] == ["-", "+", "-"]
     want = sv.needed_phases([v, sv.SV("del", 1_001_234, 1_203_210)], C, LEN)
     assert all(0 <= ph < 4000 for _, ph in want) and sum(want.values()) >= 12
+
+
+def _driver_views(variant, chrlen, length):
+    """The views a structural-variant driver lists (orca_amd/sv_drivers.py): reference windows anchored at the variant's two ends, then
+    the alternative allele(s) - as 4-tuple pieces (chrom, start, length, strand) of chromosome "c"."""
+    r = length // 2
+    s, e = variant.start, variant.end
+    ref = [[("c", sv.coord_clip(a, chrlen, window_radius=r) - r, length, "+")] for a in (s, e)]
+    alt_pieces = sv.allele_pieces(variant, chrlen)
+    alt_len = sum(p[1] for p in alt_pieces)
+    anchors = {"del": [s], "dup": [e], "inv": [s, e]}[variant.kind]
+    alts = [[("c",) + p for p in sv.window_pieces(alt_pieces, sv.coord_clip(a, alt_len, window_radius=r) - r, length)] for a in anchors]
+    return ref, alts
+
+
+@pytest.mark.parametrize("variant", [sv.SV("del", 1_001_234, 1_203_210), sv.SV("inv", 801_111, 1_399_007), sv.SV("dup", 900_000, 1_140_000),
+                                     sv.SV("inv", 1_000_000, 1_012_000), sv.SV("dup", 1_100_777, 1_108_001)])
+def test_alternative_alleles_from_the_reference_views_of_the_same_call(variant):
+    """Round 5 (sv_drivers._run_views): no chromosome encoding at all - the reference views of a call are encoded whole and kept as
+    segments (both strands), the alternative allele takes its bins from them (the inverted segment from the OTHER strand's segment of the
+    view whose phase agrees) and only window ends and junctions are encoded.  Exact on the integer toy Encoder, coordinates off the grid."""
+    rs = np.random.RandomState(4)
+    codes = torch.from_numpy(rs.randint(0, 5, C).astype(np.uint8))
+    net = ToyNet0()
+    store = sv.GenomeEncodings(net, lambda c: codes, {"c": C})
+    nb = LEN // 4000
+    refs, alts = _driver_views(variant, C, LEN)
+    own = {}
+    for pieces in refs:
+        w = sv.assemble_codes(codes, [p[1:] for p in pieces])
+        out = torch.full((2, 128, nb), -1.0, dtype=torch.float64)
+        sv.encode_windows(store, [pieces], w[None], out, build=False, extra=own)
+        assert torch.equal(out, _window_whole(ToyNet0(), codes, [p[1:] for p in pieces])[0])
+        _, start, ln, _ = pieces[0]
+        own.setdefault("c", []).extend([["+", start, out[0].clone()], ["-", C - start - ln, out[1].clone()]])
+    for pieces in alts:
+        w = sv.assemble_codes(codes, [p[1:] for p in pieces])
+        out = torch.full((2, 128, nb), -1.0, dtype=torch.float64)
+        n = sv.encode_windows(store, [pieces], w[None], out, build=False, extra=own)
+        assert torch.equal(out, _window_whole(ToyNet0(), codes, [p[1:] for p in pieces])[0]), (variant, pieces)
+        assert n < 0.6 * 2 * nb, (variant, n, 2 * nb)                # most of the alternative allele came from the reference views
+    assert store.builds == 0
+
+
+def test_segments_persist_and_a_repeated_phase_gets_a_chromosome_encoding():
+    rs = np.random.RandomState(5)
+    codes = torch.from_numpy(rs.randint(0, 5, C).astype(np.uint8))
+    net = ToyNet0()
+    store = sv.GenomeEncodings(net, lambda c: codes, {"c": C})
+    nb = LEN // 4000
+    ce = store.of("c")
+    assert store.of("ins0") is None and ce.auto_threshold() == 2
+    ce.miss_bins = 50             # (the toy window is 400 bins; 1 000 of a real window's 8 000)
+    pieces = [("c", 400_000, LEN, "+")]
+    w = sv.assemble_codes(codes, [p[1:] for p in pieces])
+    out = torch.zeros((2, 128, nb), dtype=torch.float64)
+    assert sv.encode_windows(store, [pieces], w[None], out, build="auto") == 2 * nb          # nothing held: one miss per strand counted
+    ce.add_segment("+", 400_000, out[0].clone())
+    ce.add_segment("-", C - 400_000 - LEN, out[1].clone())
+    # the same window again: only its ends are encoded; a window shifted by 40 bins: the overlap comes from the segment
+    out2 = torch.zeros_like(out)
+    assert sv.encode_windows(store, [pieces], w[None], out2, build="auto") == 2 * 2 * sv.RF_BINS and torch.equal(out2, out)
+    shifted = [("c", 560_000, LEN, "+")]
+    w3 = sv.assemble_codes(codes, [p[1:] for p in shifted])
+    out3 = torch.zeros_like(out)
+    n3 = sv.encode_windows(store, [shifted], w3[None], out3, build="auto")
+    assert n3 < 2 * nb and torch.equal(out3, _window_whole(ToyNet0(), codes, [p[1:] for p in shifted])[0])
+    assert store.builds == 0
+    # a second window-sized miss at the same phase elsewhere on the chromosome: the whole chromosome is encoded at that phase
+    far = [("c", 4_000, LEN, "+")]
+    out4 = torch.zeros_like(out)
+    sv.encode_windows(store, [far], sv.assemble_codes(codes, [p[1:] for p in far])[None], out4, build="auto")
+    assert store.builds == 2 and torch.equal(out4, _window_whole(ToyNet0(), codes, [p[1:] for p in far])[0])

@@ -30,6 +30,7 @@ sys.path.insert(0, REF)
 warnings.filterwarnings("ignore")
 
 from orca_amd import synth  # noqa: E402
+from tests import standins
 
 GOLD = os.path.join(REPO, "tests", "golden")
 
@@ -176,7 +177,7 @@ def main():
             class Container(torch.nn.Module):
                 def __init__(self, seed):
                     super().__init__()
-                    self.net0 = synth.FakeNet0(nbins=8000, seed=seed)
+                    self.net0 = standins.FakeNet0(nbins=8000, seed=seed)
                     self.net = load_synth(om.Encoder2(), seed=seed)
                     self.denets = {lv: load_synth(om.Decoder(upsample_mode="bilinear"), seed=seed + lv)
                                    for lv in (1, 2, 4, 8, 16, 32)}
@@ -218,7 +219,7 @@ def main():
             class Container256(torch.nn.Module):
                 def __init__(self, seed):
                     super().__init__()
-                    self.net0 = synth.FakeNet0(nbins=64000, seed=seed)
+                    self.net0 = standins.FakeNet0(nbins=64000, seed=seed)
                     self.net1 = load_synth(om.Encoder2(), seed=seed)
                     self.net = load_synth(om.Encoder3(), seed=seed)
                     self.denets = {lv: load_synth(om.Decoder(upsample_mode="bilinear"), seed=seed + lv)
@@ -261,8 +262,8 @@ def main():
         if want("G11"):
             import orca_predict as op
             genome = synth.sv_driver_genome()
-            op.model_dict_global["h1esc"] = synth.FakeModel32(0)
-            op.model_dict_global["hff"] = synth.FakeModel32(1)
+            op.model_dict_global["h1esc"] = standins.FakeModel32(0)
+            op.model_dict_global["hff"] = standins.FakeModel32(1)
             d = {}
             for name, fn, a, kw in synth.sv_driver_cases():
                 t = time.time()
@@ -279,8 +280,8 @@ def main():
         # ---- G19: process_seqstr through the REAL orca_predict.process_seqstr (the `seqstr` package replaced by a stand-in) ----
         if want("G19"):
             import orca_predict as op
-            op.seqstr = synth.FakeSeqstr()
-            h1 = synth.FakeModel32(0)
+            op.seqstr = standins.FakeSeqstr()
+            h1 = standins.FakeModel32(0)
             d = {}
             for name, spec, mpos in synth.seqstr_cases():
                 t = time.time()
@@ -350,11 +351,11 @@ def main():
         if want("G13"):
             import orca_predict as op
             genome = synth.sv_driver_genome_256()
-            op.h1esc_256m, op.hff_256m = synth.Background256(0), synth.Background256(1)   # what _retrieve_multi reads
-            rec = synth.Recorder256()
+            op.h1esc_256m, op.hff_256m = standins.Background256(0), standins.Background256(1)   # what _retrieve_multi reads
+            rec = standins.Recorder256()
             op.genomepredict_256Mb = rec
             op.genomeplot_256Mb = lambda *a, **k: None       # process_dup needs a file name at 256 Mb (:1365-1367)
-            op.target_dict_global["fake"] = type("T", (synth.FakeTarget256, op.Genomic2DFeatures), {"__init__": lambda self: None})()
+            op.target_dict_global["fake"] = type("T", (standins.FakeTarget256, op.Genomic2DFeatures), {"__init__": lambda self: None})()
             d = {}
             for name, fn, a, kw in synth.sv_driver_cases_256():
                 t = time.time()
@@ -440,6 +441,23 @@ def main():
             d["t_cpu_s"] = np.array([time.time() - t])
             np.savez_compressed(os.path.join(GOLD, "G22_sv_del_real_nets.npz"), **d)
             print("G22 done %.1fs" % (time.time() - t), len(outs), "views")
+
+        # ---- G23: process_dup and process_inv of the reference with the REAL networks (3 + 4 genomepredict calls, ~17 min of CPU):
+        #      the alternative alleles whose windows repeat a segment / take it from the other strand -------------------------------
+        if args.svreal and want("G23"):
+            import orca_predict as op
+            genome = synth.sv_driver_genome()
+            t = time.time()
+            d = {}
+            model = Full(0)
+            for name, fn, a in synth.SV_REAL_CASES_G23:
+                t1 = time.time()
+                outs = getattr(op, fn)(*a, genome, custom_models=[model], target=False, use_cuda=False)
+                d.update({f"{name}.{k}": v for k, v in synth.summarize_outputs(outs, stride=5).items()})
+                d[f"{name}.t_cpu_s"] = np.array([time.time() - t1])
+                print("G23", name, len(outs), "views %.1fs" % (time.time() - t1), flush=True)
+            np.savez_compressed(os.path.join(GOLD, "G23_sv_dup_inv_real_nets.npz"), **d)
+            print("G23 done %.1fs" % (time.time() - t))
 
         # ---- G8: one full 32 Mb H1-ESC-shaped forward, both strands ---------------
         if args.full32m and want("G8"):
