@@ -25,14 +25,14 @@ Also measured in the same run, OUTSIDE the timed region, and reported in the sam
     shards (orca_amd.dist.strand_bin_sharded_32m), with `parity` against G8.
   * `parity` (N = 1): the timed steps' own six maps against the shipped fixture tests/golden/G8_full32m.npz - the
     REFERENCE's genomepredict on CPU for exactly this sequence, weights and zoom position.
-  * `exact_f32` (N = 1): a short second loop with every module on the exact fp32 MFMA kernels.
+  * `exact_f32`, `bf16x3` (N = 1): short loops with every module on the exact fp32 MFMA kernels / in the range-safe fallback arithmetic, each with its parity vs G8.
   * `concurrent_strands` (N = 1): the opt-in mode ORCA_STRAND_STREAMS=1 (both strands' Encoders side by side on two streams), 5 steps.
-  * `roofline_decoder` (N = 1): one Decoder forward (118 Conv2d) at B = 2 under HIP events.
+  * `roofline_decoder` (N = 1): one Decoder forward (118 Conv2d) at B = 2 and at B = 4 under HIP events.
   * `config3` (N = 1): BASELINE configs[2] - HFF-shaped model, batch of 8, bf16 Encoder + fp16-plane Decoders, 2 timed batches,
     roofline of its dominant kernel, parity against the reference rows of G17.
-  * `config5` (N = 1): BASELINE configs[4] - 64 of the 1024 synthetic SVs through orca_amd.sv.sv_screen (incremental encoding; 8 of them
-    also as two whole genomepredict calls; the full screen: tools/run_configs.py config5_1024, profiles/r04_config5_1024.json).
-  * `cpu_baseline` (N = 1): the oracle (= the torch CPU ops the reference dispatches) on a bounded sample.
+  * `config5` (N = 1): BASELINE configs[4] - 256 of the 1024 synthetic SVs through orca_amd.sv.sv_screen (incremental encoding; 16 of them
+    also as two whole genomepredict calls; the full screen: tools/run_configs.py config5_1024, profiles/r05_config5_1024.json).
+  * `cpu_baseline` (N = 1): the oracle (= the torch CPU ops the reference dispatches) on ONE WHOLE 32 Mb strand (+ the 8 Mb sample of rounds 1-4).
 
 Prints ONE JSON line (rank 0).  value = strand-Mb of sequence encoded AND decoded per second over the whole job
 (2 strands x 32 Mb per step per rank).
@@ -155,6 +155,29 @@ def section_roofline(enc_strand_mb_per_rank, enc_ms, gather_bytes_received, gath
     return out
 
 
+def encoder_kernels_of(dev, net0, codes, reverse, lo, hi, L):
+    """Which kernel families ONE rank-local Encoder call runs on (launch counters of the C ABI's context, orca_ctx_launch_counts): the short last
+    stages of a small shard move to conv_small.h (rows of <= 2 048 positions) - another fp32 summation order than the whole window's kernels."""
+    from orca_amd import engine
+    ctx = engine.get_context(dev)
+    c0 = ctx.launch_counts()
+    net0.forward_codes(codes, reverse=reverse, bin_lo=lo, bin_hi=hi)
+    torch.cuda.synchronize(dev)
+    c1 = ctx.launch_counts()
+    b0, b1 = max(0, lo * 4000 - 112000), min(L, hi * 4000 + 112000)
+    return {"bins": [int(lo), int(hi)], "stage7_positions_with_halo": int((b1 - b0) // 4000),
+            "launches": {k: c1[k] - c0[k] for k in ("planar", "conv_bf16s", "conv_small")},
+            "stage7_kernel": "conv_small.h" if c1["conv_small"] > c0["conv_small"] else "conv_bf16s.h"}
+
+
+def projection(n1_ms, enc_ms, tail_ms, n, units_tails=2, tail_b1_factor=0.6):
+    """PROJECTED (not measured) time of an N-rank job from the N = 1 phases of this run: Encoder / N (the 224 kb halo per shard is < 3 % at
+    8 ranks) + one unit's tail (a rank runs one strand's maps at B = 1: ~0.6 of the two-strand batch, tools/time_decoder.py) + ~0.3 ms of
+    collectives.  The tail does not shard - it is the serial fraction."""
+    ms = enc_ms / n + tail_ms * tail_b1_factor * max(1.0, units_tails / n) + 0.3
+    return {"n": n, "ms": round(ms, 2), "efficiency": round(n1_ms / (n * ms), 3), "projected": True}
+
+
 def sharded_256mb(args, rank, world, dev, dist, comm=None, collective="none (single rank)"):
     """BASELINE config 4 / north star: the 256 Mb model with the Encoder's bins sharded over the ranks."""
     from orca_amd import dist as odist, engine, orca_models, orca_predict, synth
@@ -268,6 +291,8 @@ def sharded_256mb(args, rank, world, dev, dist, comm=None, collective="none (sin
             "encoder_ms_per_rank_max": round(float(parts[0]), 2), "allgather_ms_max": round(float(parts[1]), 3), "tail_ms_max": round(float(parts[2]), 2),
             "encoder_Mb_per_s": round(2 * 256 / (float(parts[0]) * 1e-3), 1), "n1_ms_same_run": round(n1_ms, 2), "efficiency_vs_n1": round(n1_ms / (world * ms), 4),
             "roofline": section_roofline(2 * 256 / world, float(parts[0]), recv, float(parts[1])), "maps_checksum": round(chk, 4), "parity": parity,
+            "encoder_kernels_this_rank": encoder_kernels_of(dev, model.net0, wins[0], False, lo, hi, L256),
+            "projection_n8": projection(n1_ms, float(parts[0]), float(parts[2]), 8) if world == 1 else None,
             "bins_this_rank": [int(lo), int(hi)], "sequence_bytes_on_this_rank": int(sum(w.codes.numel() if isinstance(w, engine.CodeWindow) else w.numel() for w in (wins if world > 1 else wins[:1])))}
 
 
@@ -368,11 +393,11 @@ def config3_section(dev):
     return out
 
 
-def config5_section(dev, n_svs=64):
-    """BASELINE.json configs[4] on this rank: `n_svs` of the 1024 synthetic structural variants (orca_amd.sv.synth_svs: del / dup / inv,
+def config5_section(dev, n_svs=256):
+    """BASELINE.json configs[4] on this rank: `n_svs` (256) of the 1024 synthetic structural variants (orca_amd.sv.synth_svs: del / dup / inv,
     10 kb - 5 Mb) x reference + alternative allele, 6 maps each, from a packed 40 Mb chromosome in HBM.  Incremental screen
     (orca_amd/sv.py): the chromosome's strands are encoded once per 4 kb phase, a window re-encodes only its ends and junctions, the four
-    strands of a variant are one decoder batch; 8 of the variants are also run as the reference does it - two whole `genomepredict` calls
+    strands of a variant are one decoder batch; 16 of the variants are also run as the reference does it - two whole `genomepredict` calls
     each - for the speed-up and the agreement of the maps.  Variants are independent: N GPUs take every N-th (replicas, no collective)."""
     from orca_amd import engine, orca_models, sv
     h1 = orca_models.H1esc(synthetic_seed=0)
@@ -386,7 +411,7 @@ def config5_section(dev, n_svs=64):
     res = sv.sv_screen([h1], genome, svs[2:], 40_000_000, stats=stats)     # includes the chromosome encodings (4 here)
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
-    n_full = min(8, n_svs)
+    n_full = min(16, n_svs)
     sv.sv_screen([h1], genome, svs[2:3], 40_000_000, incremental=False)
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
@@ -403,7 +428,9 @@ def config5_section(dev, n_svs=64):
            "as_the_reference_does_it": {"svs": n_full, "s_per_sv": round(dt_full / n_full, 4), "svs_per_s": round(n_full / dt_full, 2),
                                         "what": "two whole genomepredict calls per variant (every window through the whole Encoder)"},
            "speedup": round((dt_full / n_full) / (dt / n_svs), 2), "max_abs_vs_whole_window_encoding": diff,
-           "kinds": "".join(v.kind[0] for v in svs[2:]), "level32_maps_checksum": round(chk, 3)}
+           "kinds": "".join(v.kind[0] for v in svs[2:]), "level32_maps_checksum": round(chk, 3),
+           "note": "a sample of the 1024: the whole screen on one GPU is profiles/r05_config5_1024.json (tools/run_configs.py config5_1024); per-variant time varies with "
+                   "the variant's size and kind (junction count), so 64-, 256- and 1024-variant figures differ by a few per cent - and by +-2 % from box to box"}
     del genome, res, full, h1
     engine.get_context(dev).release_workspace()
     torch.cuda.empty_cache()
@@ -482,6 +509,11 @@ def sharded_32mb(args, rank, world, dev, dist, comm, collective, n_models=1):
            "map_gather_ms_max": round(float(ph[3]), 3), "n1_ms_same_run": round(n1 * 1e3, 3), "efficiency_vs_n1": round(n1 / (world * el), 4),
            "roofline": section_roofline(n_models * 2 * 32 / world, float(ph[0]), recv, float(ph[1])),
            "maps_checksum": round(float(sum(float(o.double().sum()) for mo in outs for o in mo)), 4)}
+    u0, lo0, hi0 = (odist.unit_plan(U, total, rank, world)[0] if world > 1 else [(0, 0, total)])[0]
+    out["encoder_kernels_this_rank"] = dict(encoder_kernels_of(dev, models[u0 // 2].net0, codes, bool(u0 & 1), lo0, hi0, L_BP), unit=int(u0))
+    out["sequence_bytes_on_this_rank"] = int(codes.codes.numel() if isinstance(codes, engine.CodeWindow) else codes.numel())
+    if world == 1:
+        out["projection_n8"] = projection(el * 1e3, float(ph[0]), float(ph[2]), 8, units_tails=U)
     g8 = os.path.join(ROOT, "tests", "golden", "G8_full32m.npz")
     if rank == 0 and os.path.exists(g8):
         g = np.load(g8)
@@ -512,6 +544,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-only", action="store_true", help="CPU baseline from the 8 Mb sample alone (extrapolated), as in rounds 1-4: saves a minute")
     ap.add_argument("--cpu-full-strand", action="store_true", help="only: time the CPU baseline on the WHOLE 32 Mb strand (about a minute of CPU), print it and exit")
     ap.add_argument("--seq-mb", type=int, default=32, help="debug only: shorter sequence (invalidates the metric)")
     ap.add_argument("--float-input", action="store_true", help="keep the strands as float32 [1,4,L] views (the reference's input form)")
@@ -693,44 +726,68 @@ def main():
             os.environ.pop("ORCA_STRAND_STREAMS", None)
             engine.context_pool(dev, 1).release_workspaces()
 
-    # ---- exact fp32 MFMA everywhere: short second loop (N = 1)
+    # ---- the strict-fp32 readings of the same step (N = 1), each with its OWN parity against the reference's G8 on the full cascade:
+    #      exact fp32 MFMA everywhere, and the range-safe arithmetic the fp16 guard falls back to (bf16x3 Encoders, fp32 Decoders)
     if world == 1 and Lbp == L_BP:
         mods = [model.net0, model.net] + [model.denets[lv] for lv in model.levels] + [model.denet_1_pt]
         old = [m.precision for m in mods]
-        for m in mods:
-            m.precision = "f32"
-        step(); sync()
-        t0 = time.perf_counter()
-        for _ in range(2):
-            step()
-        sync()
-        t32 = (time.perf_counter() - t0) / 2
+        g8p = os.path.join(ROOT, "tests", "golden", "G8_full32m.npz")
+
+        def parity_of(maps):
+            if not os.path.exists(g8p):
+                return None
+            g = np.load(g8p)
+            errs, rs = [], []
+            for j, o in enumerate(maps):
+                a, b = o.cpu().numpy().astype(np.float64), g[f"pred_{j}"].astype(np.float64)
+                errs.append(float(np.abs(a - b).max()))
+                rs.append(float(np.corrcoef(a.ravel(), b.ravel())[0, 1]))
+            return {"against": "tests/golden/G8_full32m.npz (the reference's genomepredict, PyTorch CPU fp32)", "max_abs_per_level": [round(e, 8) for e in errs],
+                    "pearson_min": round(min(rs), 9), "tolerance": 1e-4, "ok": bool(max(errs) < 1e-4)}
+
+        for key, precs, nsteps in (("exact_f32", ["f32"] * len(mods), 2), ("bf16x3", ["bf16x3", "bf16x3"] + ["f32"] * (len(mods) - 2), 2)):
+            for m, p_ in zip(mods, precs):
+                m.precision = p_
+            step(); sync()
+            t0 = time.perf_counter()
+            for _ in range(nsteps):
+                o32 = step()
+            sync()
+            t32 = (time.perf_counter() - t0) / nsteps
+            res[key] = {"arithmetic": "every module on the exact fp32 MFMA kernels (v_mfma_f32_32x32x2_f32)" if key == "exact_f32" else
+                        "Encoder + Encoder2 on 3-way split bf16 (6 MFMA products, exact for every finite fp32), Decoders on the exact fp32 kernels - what the fp16-range guard falls back to",
+                        "ms_per_step": round(t32 * 1e3, 2), "Mb_per_s": round(2 * Lbp / 1e6 / t32, 2), "whole_step_tflops": round(step_flops() / t32, 2),
+                        "frac_of_157TF_fp32_mfma_peak": round(step_flops() / t32 / PEAK_F32_MFMA_TFLOPS, 4), "parity": parity_of(o32)}
         for m, p_ in zip(mods, old):
             m.precision = p_
-        res["exact_f32"] = {"ms_per_step": round(t32 * 1e3, 2), "Mb_per_s": round(2 * Lbp / 1e6 / t32, 2), "whole_step_tflops": round(step_flops() / t32, 2),
-                            "frac_of_157TF_fp32_mfma_peak": round(step_flops() / t32 / PEAK_F32_MFMA_TFLOPS, 4)}
+        del o32
     # ---- the Decoders' share: one Decoder forward (118 Conv2d, both strands batched as in the step) under HIP events
     if world == 1 and Lbp == L_BP:
         dec = model.denets[16]
-        xd = torch.from_numpy((np.random.RandomState(31).rand(2, 128, 250) * 0.5).astype(np.float32)).to(dev)
-        yd = torch.from_numpy(np.random.RandomState(32).randn(2, 1, 125, 125).astype(np.float32)).to(dev)
-        ded = distencs[16].expand(2, -1, -1, -1)
-        dec(xd, ded, yd)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize(dev)
-        e0.record()
-        for _ in range(10):
+        for Bd in (2, 4):
+            xd = torch.from_numpy((np.random.RandomState(31).rand(Bd, 128, 250) * 0.5).astype(np.float32)).to(dev)
+            yd = torch.from_numpy(np.random.RandomState(32).randn(Bd, 1, 125, 125).astype(np.float32)).to(dev)
+            ded = distencs[16].expand(Bd, -1, -1, -1)
             dec(xd, ded, yd)
-        e1.record()
-        torch.cuda.synchronize(dev)
-        dms = e0.elapsed_time(e1) / 10
-        dtf = 2 * DEC_TFLOP["withy"] / (dms * 1e-3)
-        res["roofline_decoder"] = {"kernel": "conv2d_3x3_m16q_kernel<32|64,2,1> (dilation 1-8, 72 launches: four-row tiles, both strands in one round) + conv2d_dblock_kernel<2,1> (dilation 16-64, 12 launches of 4 convs) "
-                                             "= one Decoder forward with y at B = 2 (the two strands)", "bound": "mfma", "ms_per_forward": round(dms, 3),
-                                   "achieved": round(dtf, 1), "peak": PEAK_16BIT_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(dtf / PEAK_16BIT_MFMA_TFLOPS, 4),
-                                   "mfma_products_per_algorithmic_mac": 3, "mfma_pipe_frac": round(3 * dtf / PEAK_16BIT_MFMA_TFLOPS, 4),
-                                   "decoders_share_of_step": round(7 * dms / ms_per_step, 3),
-                                   "mfma_busy_source": "profiles/r04_pmc_dec_sq.txt (SQ_VALU_MFMA_BUSY_CYCLES / SIMD cycles per kernel)"}
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize(dev)
+            e0.record()
+            for _ in range(10):
+                dec(xd, ded, yd)
+            e1.record()
+            torch.cuda.synchronize(dev)
+            dms = e0.elapsed_time(e1) / 10
+            dtf = Bd * DEC_TFLOP["withy"] / (dms * 1e-3)
+            if Bd == 2:
+                res["roofline_decoder"] = {"kernel": "conv2d_3x3_m16q_kernel<32|64,2,1> (dilation 1-8, 72 launches: four-row tiles, both strands in one round) + conv2d_dblock_kernel<2,1> (dilation 16-64, 12 launches of 4 convs) "
+                                                     "= one Decoder forward with y at B = 2 (the two strands)", "bound": "mfma", "ms_per_forward": round(dms, 3),
+                                           "achieved": round(dtf, 1), "peak": PEAK_16BIT_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(dtf / PEAK_16BIT_MFMA_TFLOPS, 4),
+                                           "mfma_products_per_algorithmic_mac": 3, "mfma_pipe_frac": round(3 * dtf / PEAK_16BIT_MFMA_TFLOPS, 4),
+                                           "decoders_share_of_step": round(7 * dms / ms_per_step, 3),
+                                           "mfma_busy_source": "profiles/r05_pmc_dec_sq.txt (SQ_VALU_MFMA_BUSY_CYCLES / SIMD cycles per kernel)"}
+            else:      # the SV drivers' and the screen's batch: ref + alt x two strands (workgroups of one resident round walk the maps)
+                res["roofline_decoder"]["batch_of_4"] = {"ms_per_forward": round(dms, 3), "achieved": round(dtf, 1), "frac": round(dtf / PEAK_16BIT_MFMA_TFLOPS, 4),
+                                                         "ms_per_map": round(dms / 4, 3)}
         del xd, yd, ded
     strands = outs = None
     engine.get_context(dev).release_workspace()
@@ -781,9 +838,21 @@ def main():
         res["strong_scaling"] = {k: {f: res[k].get(f) for f in ("n_gpus", "ms_per_step", "Mb_per_s", "n1_ms_same_run", "efficiency_vs_n1")}
                                  for k in ("sharded_256mb", "sharded_32mb", "sharded_32mb_two_models") if isinstance(res.get(k), dict) and "ms_per_step" in res[k]}
         res["strong_scaling"]["note"] = ("`value` above is replica mode (independent 32 Mb windows per rank, weak scaling, no collective); these are the north star's "
-                                         "one-job curves: efficiency_vs_n1 = the N = 1 time measured in THIS run / (N x this time)")
+                                         "one-job curves: efficiency_vs_n1 = the N = 1 time measured in THIS run / (N x this time).  Only the ENCODER shards: the tail "
+                                         "(Encoder2 -> decoder levels, one dependent chain per strand) is the serial fraction.  256 Mb: the Encoder is 97 % of the job, "
+                                         "so the curve is near-linear (projected 0.85-0.92 at N = 8: `projection_n8`); the 32 Mb window is TAIL-BOUND by design - 50 ms "
+                                         "of Encoder against 15 ms of tails at N = 1 leaves ~6 + 9 ms at N = 8, efficiency ~0.5-0.6 (one model; two models have four "
+                                         "tails: better from 4 ranks on).  Near-linear scaling is a property of the 256 Mb encoder only.")
+        if world == 1:
+            res["strong_scaling"]["projection_n8"] = {k: res[k].get("projection_n8") for k in ("sharded_256mb", "sharded_32mb", "sharded_32mb_two_models")
+                                                      if isinstance(res.get(k), dict)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        res["cpu_baseline"] = cpu_baseline(0)
+        # the reference's CPU path on ONE WHOLE 32 Mb strand, timed on this box in this run (north star; about a minute on the 16-core quota),
+        # and - first, while the cores are cool - the 8 Mb sample of rounds 1-4 scaled x4 (kept as a second field: the two differ by what the
+        # host does under sustained load)
+        sample = cpu_baseline(0)
+        res["cpu_baseline"] = cpu_baseline(0, L_BP) if not args.cpu_sample_only else sample
+        res["cpu_baseline"]["sample_8mb_scaled"] = {k: sample[k] for k in ("value", "unit", "extrapolated", "sample")}
         res["speedup_vs_cpu"] = round(res["value"] / world / res["cpu_baseline"]["value"], 1)
     emit()
     if dist is not None:

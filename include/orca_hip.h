@@ -109,6 +109,12 @@ typedef struct orca_kernel_time {
 int orca_ctx_set_timing(orca_ctx* ctx, int enable);
 int orca_ctx_get_timing(orca_ctx* ctx, orca_kernel_time* out, int max, int* n);
 
+/* Launch counters of the context since its creation, counts4 = { channel-last Conv1d launches on the short-row kernel (conv_small.h:
+ * rows of <= 2 048 positions), on the chunk-after-chunk kernel (conv_bf16s.h), planar P16 / B16 Conv1d launches, fused Decoder pair
+ * launches }.  Diagnostics only (which kernel family a shard's short last stages ran on: bench.py's N-rank sections); no reference
+ * counterpart. */
+int orca_ctx_launch_counts(orca_ctx* ctx, int64_t* counts4);
+
 /* ---- weights -------------------------------------------------------------
  * Replaces: nn.Module.load_state_dict + .cuda() of the reference containers
  * (orca_models.py:53-133).  `convs` lists the folded convolutions of the module

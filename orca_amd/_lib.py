@@ -43,6 +43,7 @@ SIGNATURES = {
     "orca_ctx_take_overflow": (c_int, [c_void_p, POINTER(c_int)]),
     "orca_ctx_set_timing": (c_int, [c_void_p, c_int]),
     "orca_ctx_get_timing": (c_int, [c_void_p, POINTER(KernelTime), c_int, POINTER(c_int)]),
+    "orca_ctx_launch_counts": (c_int, [c_void_p, POINTER(ctypes.c_int64)]),
     "orca_net_create": (c_int, [c_void_p, c_int, POINTER(ConvDesc), c_int, c_int, POINTER(c_void_p)]),
     "orca_net_free": (c_int, [c_void_p]),
     "orca_net_set_precision": (c_int, [c_void_p, c_int]),

@@ -84,6 +84,7 @@ struct orca_ctx {
   bool ws_used = false;
   bool timing = false;
   std::vector<TimedLaunch> timed;
+  long long counts[4] = {0, 0, 0, 0};   // launches since creation: conv_small.h | conv_bf16s.h (channel-last convs) | planar P16 / B16 convs | fused Decoder pairs (orca_ctx_launch_counts)
   unsigned* d_flag = nullptr;   // fp16-range overflow flag written by the f16x2 kernels
   float* d_edge = nullptr;      // 4 x 40 x 128 floats: one scratch slab per layer of the edge-fix chain (lconv_edge_layer_kernel)
   float* d_zero = nullptr;      // 256 bytes of zeros (the source of out-of-map units in conv2d_3x3_m16q_kernel)
@@ -621,6 +622,7 @@ static int launch_conv1d_b16(orca_ctx* ctx, const ConvLayer& L, int precision, c
     else if (precision == ORCA_PRECISION_F16X2) hipLaunchKernelGGL((conv1d_k9_small_kernel<2, 1>), grid, dim3(512), 0, ctx->stream, a);
     else hipLaunchKernelGGL((conv1d_k9_small_kernel<1, 0>), grid, dim3(512), 0, ctx->stream, a);
     LAUNCHCHECK("conv1d_k9_small_kernel");
+    ctx->counts[0]++;
     return ORCA_OK;
   }
   if (precision == ORCA_PRECISION_BF16X3) rc = launch_conv1d_b16_ns<3, 0>(ctx, L, a, B);
@@ -629,6 +631,7 @@ static int launch_conv1d_b16(orca_ctx* ctx, const ConvLayer& L, int precision, c
   else rc = launch_conv1d_b16_ns<1, 0>(ctx, L, a, B);
   if (rc != ORCA_OK) return rc;
   LAUNCHCHECK("conv1d_k9_bf16s_kernel");
+  ctx->counts[1]++;
   if (timed) {
     HIPCHECK(hipEventRecord(tl.e1, ctx->stream));
     tl.rec.cout = L.cout; tl.rec.cin = L.cin; tl.rec.tile = -precision; tl.rec.batch = B; tl.rec.n = n; tl.rec.ms = 0.f; tl.rec.ksize = 9;
@@ -824,6 +827,7 @@ static int launch_conv1d_p16(orca_ctx* ctx, const ConvLayer& L, const float* x, 
   if ((L.ksize != 9 && !k17) || (fmt == 0 ? !L.d_wf16 : !L.d_wb16p)) return fail(ORCA_EINVAL, "layer has no %s pack", fmt == 0 ? "fp16 split" : "bf16");
   if (fmt == 0 && !L.f16_ok) return fail(ORCA_EINVAL, "layer weights exceed the fp16 range: use ORCA_PRECISION_BF16X3");
   if (n <= 0) return ORCA_OK;
+  ctx->counts[2]++;
   ConvP16Args a;
   a.x = reinterpret_cast<const f32x4*>(x); a.w = reinterpret_cast<const f32x4*>(fmt == 0 ? L.d_wf16 : L.d_wb16p); a.bias = L.d_bias; a.y = y;
   a.r1 = reinterpret_cast<const f32x4*>(r1); a.x_plen = p16_plen(n); a.y_plen = p16_plen(out_mode == 1 ? n / 4 : out_mode == 3 ? n / 5 : n); a.n = n;
@@ -989,6 +993,12 @@ extern "C" int orca_ctx_set_stream(orca_ctx* ctx, void* hip_stream) {
 extern "C" int orca_ctx_set_timing(orca_ctx* ctx, int enable) {
   if (!ctx) return fail(ORCA_EINVAL, "ctx is NULL");
   ctx->timing = enable != 0;
+  return ORCA_OK;
+}
+
+extern "C" int orca_ctx_launch_counts(orca_ctx* ctx, int64_t* counts4) {
+  if (!ctx || !counts4) return fail(ORCA_EINVAL, "NULL argument");
+  for (int i = 0; i < 4; ++i) counts4[i] = ctx->counts[i];
   return ORCA_OK;
 }
 

@@ -56,6 +56,12 @@ class Context:
         check(_lib.load().orca_ctx_get_timing(self.handle, buf, max_records, ctypes.byref(n)))
         return [(r.cout, r.cin, r.tile, r.batch, r.n, r.ms, r.ksize) for r in buf[: min(n.value, max_records)]]
 
+    def launch_counts(self):
+        """{"conv_small": n, "conv_bf16s": n, "planar": n, "decoder_pairs": n} launches on this context since it was created."""
+        c = (ctypes.c_int64 * 4)()
+        check(_lib.load().orca_ctx_launch_counts(self.handle, c), "orca_ctx_launch_counts")
+        return dict(zip(("conv_small", "conv_bf16s", "planar", "decoder_pairs"), [int(x) for x in c]))
+
     def release_workspace(self):
         check(_lib.load().orca_ctx_release_workspace(self.handle))
 

@@ -301,3 +301,120 @@ def test_overflow_guard_policy_is_per_thread_and_immediate_around_a_sharded_enco
     assert engine._guard["defer"] is False
     assert seen["defer_in_other_thread"] is False
     assert seen["defer_inside_local_encode"] is False
+
+
+def test_unit_plan_covers_every_bin_once_up_to_16_ranks():
+    """Pure bookkeeping of the 32 Mb strong-scaling job (dist.unit_plan) at every world size the driver may use and beyond: each (unit, bin)
+    is encoded by exactly one rank, each unit's tail runs on exactly one rank, the `+ denet_1_pt` terms - from 2 x units ranks on - on the
+    next `units` ranks, and the widest shard is what `bench.py` sizes the gathered slab by."""
+    from orca_amd import dist as D
+    for n_units in (2, 4):
+        for world in (1, 2, 4, 8, 16):
+            if world % n_units and n_units % world:
+                continue
+            cover = {u: np.zeros(8000, dtype=int) for u in range(n_units)}
+            tails, ones = [], []
+            for r in range(world):
+                enc, t, o = D.unit_plan(n_units, 8000, r, world)
+                for u, lo, hi in enc:
+                    cover[u][lo:hi] += 1
+                    assert 0 <= lo < hi <= 8000
+                tails += t
+                ones += o
+            assert all((c == 1).all() for c in cover.values()), (n_units, world)
+            assert sorted(tails) == list(range(n_units))
+            assert sorted(ones) == (list(range(n_units)) if world >= 2 * n_units else [])
+    # the headline window on 8 ranks, one model: 4 bin shards of 2 000 bins per strand - the conv_small.h boundary (DESIGN section 5)
+    assert [D.unit_plan(2, 8000, r, 8)[0] for r in range(8)] == [[(r % 2, 2000 * (r // 2), 2000 * (r // 2) + 2000)] for r in range(8)]
+
+
+def _worker8(rank, world, port, q):
+    """world = 8 over gloo (what the driver's 8-GPU node will run first): the one-model job = 2 strands x 4 bin shards, tails on ranks 0 / 1,
+    `+ denet_1_pt` on ranks 2 / 3, ranks 4-7 encode only; the two-model job = 4 units x 2 bin shards, tails on ranks 0-3, `+ denet_1_pt` on
+    ranks 4-7; both against the unsharded toy result; and the 256 Mb tail (ranks 2-7 only receive)."""
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from orca_amd import dist as D
+    from orca_amd import engine, orca_predict
+    try:
+        D.init_from_env("gloo")
+        engine.strand_merge = lambda f, r: 0.5 * f + 0.5 * torch.flip(r, [0, 1])
+        calls, tails, ones = [], [], []
+        NB = 80
+
+        class _Net0:
+            def __init__(self, tag):
+                self.tag = tag
+
+            def forward_codes(self, codes, reverse=False, bin_lo=0, bin_hi=0):
+                calls.append((self.tag, bool(reverse), bin_lo, bin_hi))
+                b = torch.arange(bin_lo, bin_hi if bin_hi > 0 else NB, dtype=torch.float32)
+                return (b[None, None, :] * (1 + self.tag) + 1000.0 * float(reverse) + 0.001 * torch.arange(128.)[None, :, None]).expand(codes.shape[0], -1, -1).contiguous()
+
+        class _Model:
+            def __init__(self, tag):
+                self.tag, self.net0 = tag, _Net0(tag)
+                self.denets = {lv: type("D", (), {"num_2d": 1})() for lv in (32, 256)}
+
+        def _tail(model, enc0, mpos, wpos, flags, de=None, with_1m=True):
+            tails.append((model.tag, [bool(f) for f in flags]))
+            v = (enc0 * torch.arange(1, enc0.shape[2] + 1.)).sum(dim=(1, 2))
+            maps = [v.view(-1, 1, 1, 1) * (j + 1) * (1 + model.tag) + torch.tensor([1.0 if f else 0.0 for f in flags]).repeat_interleave(enc0.shape[0] // len(flags)).view(-1, 1, 1, 1)
+                    + torch.zeros(enc0.shape[0], 1, 250, 250) for j in range(6)]
+            if with_1m:
+                maps[5] = maps[5] + _one_m(model, enc0, mpos, wpos, flags, record=False)
+            return maps, None
+
+        def _one_m(model, enc0, mpos, wpos, flags, record=True):
+            if record:
+                ones.append((model.tag, [bool(f) for f in flags]))
+            per = enc0.shape[0] // len(flags)
+            return torch.cat([torch.full((per, 1, 250, 250), 0.5 * float(enc0[k * per:(k + 1) * per].sum()) + (7.0 if f else 3.0) + model.tag) for k, f in enumerate(flags)])
+        orca_predict.cascade_32m_from_enc = _tail
+        orca_predict.denet1m_32m_from_enc = _one_m
+        codes = torch.zeros((1, 4000 * NB), dtype=torch.uint8)
+        models = [_Model(0), _Model(1)]
+        res = {}
+        for name, ms in (("one", models[:1]), ("two", models)):
+            calls.clear(); tails.clear(); ones.clear()
+            got = D.units_sharded_32m(ms, codes, 0, 0)
+            U = 2 * len(ms)
+            u, sh = rank % U, rank // U
+            lo, hi = D.bin_range(NB, sh, 8 // U)
+            ok = calls == [(u // 2, bool(u & 1), lo, hi)]
+            ok &= tails == ([(rank // 2, [bool(rank & 1)])] if rank < U else [])
+            ok &= ones == ([((rank - U) // 2, [bool((rank - U) & 1)])] if U <= rank < 2 * U else [])
+            # against the job done by hand on this rank alone
+            t_save, o_save = list(tails), list(ones)
+            for m_i, m in enumerate(ms):
+                full = [m.net0.forward_codes(codes, bool(st), 0, NB) for st in range(2)]
+                wf, wr = _tail(m, full[0], 0, 0, [False])[0], _tail(m, full[1], 0, 0, [True])[0]
+                ok &= all(torch.allclose(got[m_i][j][0], 0.5 * wf[j][0, 0] + 0.5 * torch.flip(wr[j][0, 0], [0, 1]), rtol=1e-6, atol=0) for j in range(6))
+            res[name] = bool(ok)
+        seen = []
+        D.strand_tail_256m = lambda model, enc0, strand, *a: (seen.append(strand), torch.full((4, 1, 250, 250), float(10 + strand)))[1]
+        maps256 = D.strand_parallel_cascade_256m(models[0], torch.zeros(2, 128, 8), 0, 0, 0, None)
+        res["256"] = seen == ([rank] if rank < 2 else []) and all(torch.equal(m, torch.full((1, 250, 250), 10.5)) for m in maps256)
+        q.put((rank, res))
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+    except Exception as e:
+        import traceback
+        q.put((rank, {"error": repr(e) + traceback.format_exc()[-600:]}))
+
+
+def test_one_and_two_model_jobs_gloo_world8():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker8, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    for _ in range(8):
+        rank, res = q.get(timeout=600)
+        assert res == {"one": True, "two": True, "256": True}, (rank, res)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0

@@ -215,6 +215,22 @@ def test_bench_two_ranks_on_one_gpu_over_gloo(cuda):
             assert b[k] is not None and b[k] >= 0, (k, b)
         assert 0 < b["roofline"]["encoder"]["frac"] < 1 and a["efficiency_vs_n1"] == 1.0
     assert set(two["strong_scaling"]) >= {"sharded_256mb", "sharded_32mb", "sharded_32mb_two_models"} and s2["efficiency_vs_n1"] > 0
+    # ---- the driver's N = 1 record is self-sufficient: strict-fp32 readings with their own parity on the full cascade,
+    #      the Decoder roofline at B = 2 and B = 4, config 5 on 256 variants with the reference-style comparator on 16, projections + note
+    for key in ("exact_f32", "bf16x3"):
+        assert one[key]["parity"]["ok"] and max(one[key]["parity"]["max_abs_per_level"]) < 1e-4 and one[key]["ms_per_step"] > 0, one[key]
+    rd = one["roofline_decoder"]
+    assert rd["ms_per_forward"] > 0 and rd["batch_of_4"]["ms_per_forward"] > rd["ms_per_forward"] and 0 < rd["batch_of_4"]["frac"] < 1
+    c5 = one["config5"]
+    assert "error" not in c5 and c5["svs"] == 256 and c5["as_the_reference_does_it"]["svs"] == 16 and c5["max_abs_vs_whole_window_encoding"] < 1e-4, c5
+    assert one["config3"]["parity"]["ok"], one["config3"]
+    note = one["strong_scaling"]["note"]
+    assert "tail" in note.lower() and "256 Mb" in note
+    pj = one["strong_scaling"]["projection_n8"]
+    assert all(pj[k]["projected"] and 0 < pj[k]["efficiency"] <= 1 for k in ("sharded_256mb", "sharded_32mb", "sharded_32mb_two_models")), pj
+    assert pj["sharded_256mb"]["efficiency"] > pj["sharded_32mb"]["efficiency"]            # the 32 Mb window is tail-bound
+    k1 = t1["encoder_kernels_this_rank"]
+    assert k1["stage7_kernel"] == "conv_bf16s.h" and k1["stage7_positions_with_halo"] == 8000 and k1["launches"]["planar"] > 0, k1
 
 
 def test_bench_four_ranks_on_one_gpu_over_gloo(cuda):
@@ -240,3 +256,38 @@ def test_bench_four_ranks_on_one_gpu_over_gloo(cuda):
         assert sec["efficiency_vs_n1"] > 0 and sec["n1_ms_same_run"] > 0 and 0 < sec["roofline"]["encoder"]["frac"] < 1, sec
     assert t["roofline"]["allgather"]["bytes_received_per_rank"] == 3 * 128 * 4000 * 4
     assert set(d["strong_scaling"]) >= {"sharded_256mb", "sharded_32mb", "sharded_32mb_two_models"}
+
+
+def test_bench_eight_ranks_on_one_gpu_over_gloo(cuda):
+    """De-risking N = 8 without the hardware: `bench.py --gpus 8` as the driver will launch it, all eight ranks on cuda:0
+    over gloo.  256 Mb: 8 000-bin shards (each rank 32 Mb of bases + the 112 kb halo, the Encoder in 32 Mb chunks: eight workspaces on one
+    GPU); 32 Mb, one model: 2 strands x 4 shards of 2 000 bins - the `conv_small.h` boundary: rank 0's shard starts at the window's end
+    (2 028 positions at stage 7 with its one halo: the short-row kernel), interior shards have 2 056 (the chunk-after-chunk kernel); two
+    models: 4 units x 2 shards, the `+ denet_1_pt` terms on ranks 4-7.  Every section must reproduce the reference's fixtures at 1e-4; the
+    maps of the N = 8 job are NOT bit-equal to N = 1 where a shard's stage 7 changed kernels (another fp32 summation order, ~1e-6) - the
+    checksum relation asserted here is the one that is true: relative 1e-6."""
+    env = dict(os.environ, ORCA_BENCH_ONE_DEVICE="1", ORCA_BENCH_BACKEND="gloo")
+    base = [os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--sharded-steps", "1", "--no-cpu-baseline", "--no-configs", "--sharded-timeout", "1500"]
+    p1 = subprocess.run([sys.executable] + base + ["--gpus", "1"], env=env, capture_output=True, text=True, timeout=900)
+    assert p1.returncode == 0, p1.stderr[-2000:]
+    one = json.loads([l for l in p1.stdout.splitlines() if l.startswith("{")][-1])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1",
+           "--master-port", str(29900 + os.getpid() % 90)] + base + ["--gpus", "8"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=2400)
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-1500:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    s, t, m = d["sharded_256mb"], d["sharded_32mb"], d["sharded_32mb_two_models"]
+    assert d["n_gpus"] == 8 and all("error" not in x and "skipped" not in x for x in (s, t, m)), (s, t, m)
+    assert s["bins_this_rank"] == [0, 8000] and s["sequence_bytes_on_this_rank"] == 2 * (32_000_000 + 112_000)
+    assert s["parity"]["ok"] and t["parity"]["ok"] and m["parity"]["ok"], (s["parity"], t["parity"], m["parity"])
+    ks, kt, km = s["encoder_kernels_this_rank"], t["encoder_kernels_this_rank"], m["encoder_kernels_this_rank"]
+    assert ks["stage7_positions_with_halo"] == 8028 and ks["stage7_kernel"] == "conv_bf16s.h", ks
+    assert kt["bins"] == [0, 2000] and kt["stage7_positions_with_halo"] == 2028 and kt["stage7_kernel"] == "conv_small.h" and kt["launches"]["conv_small"] == 4, kt
+    assert km["bins"] == [0, 4000] and km["stage7_kernel"] == "conv_bf16s.h", km
+    assert t["sequence_bytes_on_this_rank"] == 8_000_000 + 112_000 and m["sequence_bytes_on_this_rank"] == 16_000_000 + 112_000
+    assert t["roofline"]["allgather"]["bytes_received_per_rank"] == 7 * 128 * 2000 * 4
+    for a, b in ((one["sharded_256mb"], s), (one["sharded_32mb"], t), (one["sharded_32mb_two_models"], m)):
+        assert abs(a["maps_checksum"] - b["maps_checksum"]) <= 1e-6 * abs(a["maps_checksum"]), (a["maps_checksum"], b["maps_checksum"])
+        assert b["efficiency_vs_n1"] > 0 and b["n1_ms_same_run"] > 0
