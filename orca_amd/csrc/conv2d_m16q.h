@@ -47,10 +47,11 @@ __device__ __forceinline__ float m16_hl_hi(unsigned h, unsigned l) {
 
 // epilogue of one 32-pixel x COUT accumulator tile (the accumulators started from the bias): separable-part tables, ReLU, residual, back to
 // M16 units (the P16 / B16 recipe: after v_permlane32_swap every lane holds one whole 16-byte unit; 512 contiguous bytes per half wave)
-template <int COUT, int NS, int DT>
-__device__ __forceinline__ void m16_tile_epilogue(const ConvM16Args& a, f32x16 (&acc)[COUT / 32], int b, int yr, int px, int g,
+// (HB, NH: the cout halves [HB, HB + NH) of the layer are in acc[0 .. NH) / ru[0 .. 4 NH) - the whole layer by default, one half for the
+// half-by-half kernel below)
+template <int COUT, int NS, int DT, int HB = 0, int NH = COUT / 32>
+__device__ __forceinline__ void m16_tile_epilogue(const ConvM16Args& a, f32x16 (&acc)[NH], int b, int yr, int px, int g,
                                                   const u32x4_t* ru, bool res, float& vmax) {
-  constexpr int NH = COUT / 32;
   const int H = a.H, W = a.W;
   const bool pxok = px < W;
   const long rowoff = (long)yr * M16_PX + px;
@@ -70,16 +71,16 @@ __device__ __forceinline__ void m16_tile_epilogue(const ConvM16Args& a, f32x16 (
     for (int h = 0; h < NH; ++h)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int o = h * 4 + q;
+        const int o = (HB + h) * 4 + q;
         f32x4 v;
         v.x = acc[h][4 * q + 0]; v.y = acc[h][4 * q + 1]; v.z = acc[h][4 * q + 2]; v.w = acc[h][4 * q + 3];
         if (tabr) {
-          const f32x4 tr = *reinterpret_cast<const f32x4*>(tabr + h * 32 + 8 * q + 4 * g), tc = *reinterpret_cast<const f32x4*>(tabc + h * 32 + 8 * q + 4 * g);
+          const f32x4 tr = *reinterpret_cast<const f32x4*>(tabr + (HB + h) * 32 + 8 * q + 4 * g), tc = *reinterpret_cast<const f32x4*>(tabc + (HB + h) * 32 + 8 * q + 4 * g);
           v.x += tr.x + tc.x; v.y += tr.y + tc.y; v.z += tr.z + tc.z; v.w += tr.w + tc.w;
         }
         if (a.relu) { v.x = p16_vmax(v.x, 0.f); v.y = p16_vmax(v.y, 0.f); v.z = p16_vmax(v.z, 0.f); v.w = p16_vmax(v.w, 0.f); }
         if (rb) {
-          const u32x4_t u_ = ru[o];                                                                    // g = 0: the hi unit, g = 1: the lo unit
+          const u32x4_t u_ = ru[h * 4 + q];                                                            // g = 0: the hi unit, g = 1: the lo unit
           unsigned ux_ = u_.x, uy_ = u_.y, uz_ = u_.z, uw_ = u_.w;
           p16_swap32(ux_, uz_);
           p16_swap32(uy_, uw_);
@@ -101,12 +102,12 @@ __device__ __forceinline__ void m16_tile_epilogue(const ConvM16Args& a, f32x16 (
     for (int h = 0; h < NH; ++h)
 #pragma unroll
       for (int qp = 0; qp < 2; ++qp) {
-        const int o = h * 4 + 2 * qp;                 // octets o (q0 = 2 qp) and o + 1
+        const int o = (HB + h) * 4 + 2 * qp;          // octets o (q0 = 2 qp) and o + 1
         f32x4 v0, v1;
         v0.x = acc[h][8 * qp + 0]; v0.y = acc[h][8 * qp + 1]; v0.z = acc[h][8 * qp + 2]; v0.w = acc[h][8 * qp + 3];
         v1.x = acc[h][8 * qp + 4]; v1.y = acc[h][8 * qp + 5]; v1.z = acc[h][8 * qp + 6]; v1.w = acc[h][8 * qp + 7];
         if (tabr) {
-          const int co_ = h * 32 + 16 * qp + 4 * g;
+          const int co_ = (HB + h) * 32 + 16 * qp + 4 * g;
           const f32x4 r0 = *reinterpret_cast<const f32x4*>(tabr + co_), c0 = *reinterpret_cast<const f32x4*>(tabc + co_);
           const f32x4 r1 = *reinterpret_cast<const f32x4*>(tabr + co_ + 8), c1 = *reinterpret_cast<const f32x4*>(tabc + co_ + 8);
           v0.x += r0.x + c0.x; v0.y += r0.y + c0.y; v0.z += r0.z + c0.z; v0.w += r0.w + c0.w;
