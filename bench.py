@@ -174,7 +174,7 @@ def projection(n1_ms, enc_ms, tail_ms, n, units_tails=2, tail_b1_factor=0.6):
     """PROJECTED (not measured) time of an N-rank job from the N = 1 phases of this run: Encoder / N (the 224 kb halo per shard is < 3 % at
     8 ranks) + one unit's tail (a rank runs one strand's maps at B = 1: ~0.6 of the two-strand batch, tools/time_decoder.py) + ~0.3 ms of
     collectives.  The tail does not shard - it is the serial fraction."""
-    ms = enc_ms / n + tail_ms * tail_b1_factor * max(1.0, units_tails / n) + 0.3
+    ms = enc_ms / n + tail_ms * tail_b1_factor * (2.0 / units_tails) * max(1.0, units_tails / n) + 0.3      # a rank runs max(1, units / N) one-strand tails
     return {"n": n, "ms": round(ms, 2), "efficiency": round(n1_ms / (n * ms), 3), "projected": True}
 
 
