@@ -20,6 +20,7 @@
 #include "conv2d_m16.h"
 #include "conv2d_m16q.h"
 #include "conv2d_dblock.h"
+#include "conv_stage1.h"
 #include "conv_p16.h"
 #include "conv_ws.h"
 #include "conv_p16w1.h"
@@ -1348,6 +1349,9 @@ static int encoder_chunk(orca_ctx* ctx, orca_net* net, const SeqSource& src, lon
       // ... and with packed bases the residual lout1 is computed inside conv1.b's epilogue (conv_p16.h, RL) instead of being stored by a
       // 17-tap first-layer launch and re-read: ORCA_NO_RL=1 keeps the stored form
       const bool res_from_bases = compose25 && src.codes && getenv("ORCA_NO_RL") == nullptr;
+      // ... and in the throughput mode (B16 planes) the whole stage is ONE kernel from the bases (conv_stage1.h): conv1.b's input tiles are
+      // produced in LDS by the matrix cores, a1 is neither written nor re-read.  ORCA_NO_STAGE1_FUSE=1 (read per call): the two-launch form
+      const bool stage1_fused = res_from_bases && fmt == 1 && L[3].cin == 64 && L[3].cout == 64 && L[3].d_wb16p && getenv("ORCA_NO_STAGE1_FUSE") == nullptr;
       float* first_out = compose ? buf[LO] : buf[T];
       const float* rows = x;     // flat [n][4] float rows for the MFMA first-layer kernels (unused with packed input)
       // one first-layer GEMM launch: ntap 9 (lconv1.a alone), 17 (lconv1 composed), 25 (conv1.a o lconv1, + ReLU)
@@ -1394,7 +1398,7 @@ static int encoder_chunk(orca_ctx* ctx, orca_net* net, const SeqSource& src, lon
         if (res_from_bases) { /* no lout1 tensor */ }
         else if (compose) ORCA_TRY(launch_first(17, net->d_l1_w16, net->d_l1_bias, 0, buf[LO]));
         else ORCA_TRY(launch_first(9, net->d_first_w16, L[0].d_bias, 0, buf[T]));
-        if (compose25) {
+        if (compose25 && !stage1_fused) {
           ORCA_TRY(launch_first(25, net->d_c1a_w16, net->d_c1a_bias, 1, buf[T]));
           ORCA_TRY(launch_p16_zero_pads(ctx, buf[T], 64, n1, fmt));
         }
@@ -1467,7 +1471,38 @@ static int encoder_chunk(orca_ctx* ctx, orca_net* net, const SeqSource& src, lon
           FusedFirst rl;     // relu(.) + lout1 computed from the bases in the epilogue, MaxPool1d(4)
           rl.codes = src.codes; rl.nmask = src.nmask; rl.origin = src.origin; rl.codes_L = src.codes_L; rl.codes_off = src.codes_off; rl.reverse = src.reverse;
           rl.table = reinterpret_cast<const float*>(net->d_l1_w16); rl.bias = net->d_l1_bias; rl.residual = true;
-          ORCA_TRY(launch_conv1d_p16(ctx, Ls[3], buf[T], buf[S], nullptr, n, 1, 1, &rl, fmt));
+          if (stage1_fused) {
+            Stage1Args sa;
+            ConvP16Args& a1 = sa.c;
+            a1.x = nullptr; a1.w = reinterpret_cast<const f32x4*>(Ls[3].d_wb16p); a1.bias = Ls[3].d_bias; a1.y = buf[S]; a1.r1 = nullptr;
+            a1.x_plen = p16_plen(n); a1.y_plen = p16_plen(n / 4); a1.n = n; a1.tiles_per_row = (n + 63) / 64; a1.nchunks = 2; a1.cout = 64;
+            a1.relu = 1; a1.out_mode = 1; a1.k17 = 0; a1.flag = ctx->d_flag; a1.stamps = nullptr;
+            a1.f1_codes = rl.codes; a1.f1_nmask = rl.nmask; a1.f1_origin = rl.origin; a1.f1_codes_L = rl.codes_L; a1.f1_codes_off = rl.codes_off; a1.f1_reverse = rl.reverse;
+            a1.rl_w = reinterpret_cast<const f32x4*>(net->d_l1_w16); a1.f1_table = nullptr; a1.f1_bias = net->d_l1_bias;
+            sa.w25 = reinterpret_cast<const f32x4*>(net->d_c1a_w16); sa.b25 = net->d_c1a_bias;
+            sa.a1_edge = reinterpret_cast<const f32x4*>(buf[T]); sa.a1_plen = p16_plen(n);
+            static int ncu_ = [] { int dev = 0, v = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev); return v; }();
+            const long ntw_ = (n + 63) / 64;
+            const long need_ = (ntw_ + 7) / 8;
+            const bool timed_ = ctx->timing && n >= 65536;
+            TimedLaunch tl_;
+            if (timed_) {
+              HIPCHECK(hipEventCreate(&tl_.e0));
+              HIPCHECK(hipEventCreate(&tl_.e1));
+              HIPCHECK(hipEventRecord(tl_.e0, s));
+            }
+            hipLaunchKernelGGL((conv1d_stage1_b16_kernel<1>), dim3((unsigned)(need_ < ncu_ ? need_ : ncu_)), dim3(512), 0, s, sa);
+            LAUNCHCHECK("conv1d_stage1_b16_kernel");
+            ctx->counts[2]++;
+            if (timed_) {
+              HIPCHECK(hipEventRecord(tl_.e1, s));
+              // (both 64 -> 64 convs of the stage in one launch: recorded as cin = 128 so that 2 * 9 * cin * cout is the pair's algorithmic work)
+              tl_.rec.cout = 64; tl_.rec.cin = 128; tl_.rec.tile = -15; tl_.rec.batch = 1; tl_.rec.n = n; tl_.rec.ms = 0.f; tl_.rec.ksize = 9;
+              ctx->timed.push_back(tl_);
+            }
+          } else {
+            ORCA_TRY(launch_conv1d_p16(ctx, Ls[3], buf[T], buf[S], nullptr, n, 1, 1, &rl, fmt));
+          }
           ORCA_TRY(launch_p16_zero_pads(ctx, buf[S], C, n / 4, fmt));
           EdgePoolArgs ep{};
           ep.sc = ctx->d_edge + 3 * ORCA_EDGE_SLAB; ep.half_c = 8; ep.sl = ctx->d_edge + 1 * ORCA_EDGE_SLAB; ep.half_l = 16; ep.n = n; ep.cout = C;
