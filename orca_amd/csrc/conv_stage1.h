@@ -20,6 +20,7 @@
 // Arithmetic vs the two-launch form: the 25-tap weights enter as ONE bf16 product (there: fp16 hi + lo, two products) - a1 is rounded to
 // bf16 right after either way; the mode's parity is the one stated for config 3 (tests/test_gpu_config3.py, bench.py `config3.parity`).
 #pragma once
+#include <type_traits>
 #include "conv_ws.h"
 
 struct Stage1Args {
@@ -48,9 +49,13 @@ __global__ __launch_bounds__(512, 2) void conv1d_stage1_b16_kernel(Stage1Args sa
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, g = lane >> 5;
-  const long TW = (long)gridDim.x * WM;
+  // every wave takes a CONTIGUOUS run of wave tiles: the last 8 columns of a tile's slice are the first 8 of the next tile's (the conv's
+  // halo), so only a run's first tile produces 72 + positions - the others copy 8 columns and produce 64 (two position tiles instead of three)
   const long ntw = (a.n + MTW - 1) / MTW;
-  long tile = (long)blockIdx.x * WM + wave;
+  const long nwv = (long)gridDim.x * WM;
+  const long run = (ntw + nwv - 1) / nwv;
+  long tile = ((long)blockIdx.x * WM + wave) * run;
+  const long tile_end = tile + run < ntw ? tile + run : ntw;
 
   f32x4* const w25s = smem + WU + WM * NCH * SLOT;
   unsigned char* const xbase = reinterpret_cast<unsigned char*>(smem + WU + WM * NCH * SLOT + W25U);
@@ -69,7 +74,7 @@ __global__ __launch_bounds__(512, 2) void conv1d_stage1_b16_kernel(Stage1Args sa
     oh16[tid] = v;
   }
   __syncthreads();                             // the only barrier of the kernel
-  if (tile >= ntw) return;
+  if (tile >= tile_end) return;
 
   f32x4* const slice = smem + WU + wave * (NCH * SLOT);
   // base code at chunk position p (5 = outside the chunk: the composed first layer's zero padding), reverse complement applied
@@ -102,93 +107,112 @@ __global__ __launch_bounds__(512, 2) void conv1d_stage1_b16_kernel(Stage1Args sa
       acc[i][j][4 * q + 0] += b_.x; acc[i][j][4 * q + 1] += b_.y; acc[i][j][4 * q + 2] += b_.z; acc[i][j][4 * q + 3] += b_.w; \
     }                                                                                                            \
     const unsigned char* win_ = win + 8 + l31 + 2 * g;                                                           \
-    f32x4 wa_[2][2][NW];                                                                                         \
-    _Pragma("unroll") for (int sp = 0; sp < 2; ++sp) _Pragma("unroll") for (int j = 0; j < NW; ++j) wa_[0][sp][j] = a.rl_w[((sp * 5 + 0) * 2 + g) * 64 + j * 32 + l31]; \
+    f32x4 wa_[3][2][NW];       /* the pack's units for k-step kk, requested two k-steps ahead (L1 / L2 round trips) */    \
+    _Pragma("unroll") for (int k0 = 0; k0 < 2; ++k0) _Pragma("unroll") for (int sp = 0; sp < 2; ++sp) _Pragma("unroll") for (int j = 0; j < NW; ++j) \
+      wa_[k0][sp][j] = a.rl_w[((sp * 5 + k0) * 2 + g) * 64 + j * 32 + l31];                                      \
     _Pragma("unroll") for (int kk = 0; kk < 5; ++kk) {                                                           \
-      if (kk + 1 < 5) { _Pragma("unroll") for (int sp = 0; sp < 2; ++sp) _Pragma("unroll") for (int j = 0; j < NW; ++j)                      \
-          wa_[(kk + 1) & 1][sp][j] = a.rl_w[((sp * 5 + kk + 1) * 2 + g) * 64 + j * 32 + l31]; }                  \
+      if (kk + 2 < 5) { _Pragma("unroll") for (int sp = 0; sp < 2; ++sp) _Pragma("unroll") for (int j = 0; j < NW; ++j)                      \
+          wa_[(kk + 2) % 3][sp][j] = a.rl_w[((sp * 5 + kk + 2) * 2 + g) * 64 + j * 32 + l31]; }                  \
+      f16x8 xf_[MW];                                                                                             \
       _Pragma("unroll") for (int i = 0; i < MW; ++i) {                                                           \
         const u32x2 o0_ = oh16[win_[i * 32 + 4 * kk]], o1_ = oh16[win_[i * 32 + 4 * kk + 1]];                    \
         u32x4_t u_;                                                                                              \
         u_.x = o0_.x; u_.y = o0_.y; u_.z = o1_.x; u_.w = o1_.y;                                                  \
-        const f16x8 xf_ = __builtin_bit_cast(f16x8, u_);                                                         \
-        _Pragma("unroll") for (int sp = 1; sp >= 0; --sp) _Pragma("unroll") for (int j = 0; j < NW; ++j)         \
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wa_[kk & 1][sp][j]), xf_, acc[i][j], 0, 0, 0); \
+        xf_[i] = __builtin_bit_cast(f16x8, u_);                                                                  \
       }                                                                                                          \
+      /* (split-major: consecutive instructions go to the four different accumulators) */                        \
+      _Pragma("unroll") for (int sp = 1; sp >= 0; --sp) _Pragma("unroll") for (int i = 0; i < MW; ++i) _Pragma("unroll") for (int j = 0; j < NW; ++j) \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wa_[kk % 3][sp][j]), xf_[i], acc[i][j], 0, 0, 0); \
     }                                                                                                            \
   }
 
-  for (; tile < ntw; tile += TW) {
-    const long m0 = tile * MTW;
-    // ---- 1. the tile's bases -> the wave's window (the previous tile's epilogue has read its window: same wave, program order) ----
-    {
-      const unsigned char c0 = base_at(m0 - 16 + lane), c1 = base_at(m0 - 16 + 64 + lane);
-      win[lane] = c0;
-      win[64 + lane] = c1;
+  // the producer of NPI position tiles: columns col0 + 32 pi + l31 of the slice = a1 at positions m0 - 4 + column
+  auto produce = [&](const long m0, auto npi_c, auto col0_c) __attribute__((always_inline)) {
+    constexpr int NPI = decltype(npi_c)::value, COL0 = decltype(col0_c)::value;
+    f32x16 pacc[2][NPI];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 b_ = *reinterpret_cast<const f32x4*>(bias_s + 64 + j * 32 + 8 * q + 4 * g);
+#pragma unroll
+        for (int pi = 0; pi < NPI; ++pi) { pacc[j][pi][4 * q + 0] = b_.x; pacc[j][pi][4 * q + 1] = b_.y; pacc[j][pi][4 * q + 2] = b_.z; pacc[j][pi][4 * q + 3] = b_.w; }
+      }
+    const unsigned char* wp = win + COL0 + l31 + 2 * g;        // base of tap t of a column: window index column + t (t = 4 kk + 2 g, + 1)
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+      f16x8 xb[NPI];
+#pragma unroll
+      for (int pi = 0; pi < NPI; ++pi) {
+        const u32x2 o0 = oh16[wp[32 * pi + 4 * kk]], o1 = oh16[wp[32 * pi + 4 * kk + 1]];
+        u32x4_t u;
+        u.x = o0.x; u.y = o0.y; u.z = o1.x; u.w = o1.y;
+        xb[pi] = __builtin_bit_cast(f16x8, u);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const f16x8 wv = __builtin_bit_cast(f16x8, w25s[(kk * 2 + g) * 64 + j * 32 + l31]);
+#pragma unroll
+        for (int pi = 0; pi < NPI; ++pi) pacc[j][pi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wv, xb[pi], pacc[j][pi], 0, 0, 0);
+      }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    // ---- 2. producer: a1 = relu(25-tap conv of the bases) at positions m0 - 4 + col, col = 0 .. 95 (72 used), -> the slice ----
-    {
-      f32x16 pacc[2][3];
+    const bool edge = (m0 - 4 < 8) || (m0 - 4 + 104 > a.n - 8);    // wave-uniform: the tile touches an end of the chunk
+#pragma unroll
+    for (int pi = 0; pi < NPI; ++pi) {
+      const int col = COL0 + 32 * pi + l31;
+      const long p = m0 - 4 + col;
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const f32x4 b_ = *reinterpret_cast<const f32x4*>(bias_s + 64 + j * 32 + 8 * q + 4 * g);
-#pragma unroll
-          for (int pi = 0; pi < 3; ++pi) { pacc[j][pi][4 * q + 0] = b_.x; pacc[j][pi][4 * q + 1] = b_.y; pacc[j][pi][4 * q + 2] = b_.z; pacc[j][pi][4 * q + 3] = b_.w; }
-        }
-      const unsigned char* wp = win + l31 + 2 * g;        // base of tap t of column col: window index col + t (t = 4 kk + 2 g, + 1)
-#pragma unroll
-      for (int kk = 0; kk < KS; ++kk) {
-        f16x8 xb[3];
-#pragma unroll
-        for (int pi = 0; pi < 3; ++pi) {
-          const u32x2 o0 = oh16[wp[32 * pi + 4 * kk]], o1 = oh16[wp[32 * pi + 4 * kk + 1]];
-          u32x4_t u;
-          u.x = o0.x; u.y = o0.y; u.z = o1.x; u.w = o1.y;
-          xb[pi] = __builtin_bit_cast(f16x8, u);
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const f16x8 wv = __builtin_bit_cast(f16x8, w25s[(kk * 2 + g) * 64 + j * 32 + l31]);
-#pragma unroll
-          for (int pi = 0; pi < 3; ++pi) pacc[j][pi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wv, xb[pi], pacc[j][pi], 0, 0, 0);
-        }
-      }
-      const bool edge = (m0 - 4 < 8) || (m0 - 4 + 96 > a.n - 8);    // wave-uniform: the tile touches an end of the chunk
-#pragma unroll
-      for (int pi = 0; pi < 3; ++pi) {
-        const int col = 32 * pi + l31;
-        const long p = m0 - 4 + col;
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int qp = 0; qp < 2; ++qp) {
-            f32x4 v0, v1;
-            // (fmaxf, not the inline-asm v_max of the other epilogues: these reads follow the MFMA chain directly, and the compiler only
-            // inserts the MFMA -> VALU wait states in front of instructions it can see - with asm reads the first unit of a tile came out
-            // wrong in a quarter of the lanes)
-            v0.x = fmaxf(pacc[j][pi][8 * qp + 0], 0.f); v0.y = fmaxf(pacc[j][pi][8 * qp + 1], 0.f);
-            v0.z = fmaxf(pacc[j][pi][8 * qp + 2], 0.f); v0.w = fmaxf(pacc[j][pi][8 * qp + 3], 0.f);
-            v1.x = fmaxf(pacc[j][pi][8 * qp + 4], 0.f); v1.y = fmaxf(pacc[j][pi][8 * qp + 5], 0.f);
-            v1.z = fmaxf(pacc[j][pi][8 * qp + 6], 0.f); v1.w = fmaxf(pacc[j][pi][8 * qp + 7], 0.f);
-            unsigned a0 = cvt_pk_bf16(v0.x, v0.y), a1 = cvt_pk_bf16(v0.z, v0.w), b0 = cvt_pk_bf16(v1.x, v1.y), b1 = cvt_pk_bf16(v1.z, v1.w);
-            asm volatile("s_nop 1" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1));     // v_permlane32_swap: two wait states behind the (inline-asm) conversions
-            p16_swap32(a0, b0);     // g = 0: the unit of plane j*4 + 2 qp, g = 1: of plane j*4 + 2 qp + 1 (8 consecutive channels of position p)
-            p16_swap32(a1, b1);
-            u32x4_t unit;
-            unit.x = a0; unit.y = a1; unit.z = b0; unit.w = b1;
-            const int P = j * 4 + 2 * qp + g;
-            if (edge) {
-              if (p < 0 || p >= a.n) unit = (u32x4_t)(0u);                       // conv1.b's own zero padding
-              else if (p < 8 || p >= a.n - 8)                                    // the edge-fixed a1 (intermediates zero-padded as PyTorch does)
-                unit = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const char*>(sa.a1_edge) + ((long)P * sa.a1_plen + P16_GUARD + p) * 16);
-            }
-            if (col < XW) slice[(P >> 2) * SLOT + (P & 3) * XW + col] = __builtin_bit_cast(f32x4, unit);
+        for (int qp = 0; qp < 2; ++qp) {
+          f32x4 v0, v1;
+          // (fmaxf, not the inline-asm v_max of the other epilogues: these reads follow the MFMA chain directly, and the compiler only
+          // inserts the MFMA -> VALU wait states in front of instructions it can see - with asm reads the first unit of a tile came out
+          // wrong in a quarter of the lanes)
+          v0.x = fmaxf(pacc[j][pi][8 * qp + 0], 0.f); v0.y = fmaxf(pacc[j][pi][8 * qp + 1], 0.f);
+          v0.z = fmaxf(pacc[j][pi][8 * qp + 2], 0.f); v0.w = fmaxf(pacc[j][pi][8 * qp + 3], 0.f);
+          v1.x = fmaxf(pacc[j][pi][8 * qp + 4], 0.f); v1.y = fmaxf(pacc[j][pi][8 * qp + 5], 0.f);
+          v1.z = fmaxf(pacc[j][pi][8 * qp + 6], 0.f); v1.w = fmaxf(pacc[j][pi][8 * qp + 7], 0.f);
+          unsigned a0 = cvt_pk_bf16(v0.x, v0.y), a1 = cvt_pk_bf16(v0.z, v0.w), b0 = cvt_pk_bf16(v1.x, v1.y), b1 = cvt_pk_bf16(v1.z, v1.w);
+          asm volatile("s_nop 1" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1));     // v_permlane32_swap: two wait states behind the (inline-asm) conversions
+          p16_swap32(a0, b0);     // g = 0: the unit of plane j*4 + 2 qp, g = 1: of plane j*4 + 2 qp + 1 (8 consecutive channels of position p)
+          p16_swap32(a1, b1);
+          u32x4_t unit;
+          unit.x = a0; unit.y = a1; unit.z = b0; unit.w = b1;
+          const int P = j * 4 + 2 * qp + g;
+          if (edge) {
+            if (p < 0 || p >= a.n) unit = (u32x4_t)(0u);                       // conv1.b's own zero padding
+            else if (p < 8 || p >= a.n - 8)                                    // the edge-fixed a1 (intermediates zero-padded as PyTorch does)
+              unit = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const char*>(sa.a1_edge) + ((long)P * sa.a1_plen + P16_GUARD + p) * 16);
           }
-      }
+          if (col < XW) slice[(P >> 2) * SLOT + (P & 3) * XW + col] = __builtin_bit_cast(f32x4, unit);
+        }
     }
+  };
+
+  // the bases of the wave's NEXT tile travel in two registers through the current one (their round trip used to open every tile)
+  unsigned char nb0 = base_at(tile * MTW - 16 + lane), nb1 = base_at(tile * MTW - 16 + 64 + lane);
+  bool first = true;
+  // the two waves of a SIMD (w, w + 4) start half a tile apart: one builds operand units / runs its epilogue (VALU, LDS) while the other
+  // multiplies; started together they spend their first tiles in step - both on the VALU, then both queueing for the matrix pipe
+  if (wave >= 4) { __builtin_amdgcn_s_sleep(60); __builtin_amdgcn_s_sleep(60); }
+  for (; tile < tile_end; ++tile) {
+    const long m0 = tile * MTW;
+    // ---- 1. the tile's bases -> the wave's window (the previous tile's epilogue has read its window: same wave, program order) ----
+    if (!first) {   // the halo: columns 64 .. 71 of the previous tile's slice are columns 0 .. 7 of this one (8 planes x 8 columns = 64 units)
+      const int pl = lane >> 3, cc = lane & 7;
+      const f32x4 u = slice[(pl >> 2) * SLOT + (pl & 3) * XW + 64 + cc];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      slice[(pl >> 2) * SLOT + (pl & 3) * XW + cc] = u;
+    }
+    win[lane] = nb0;
+    win[64 + lane] = nb1;
+    if (tile + 1 < tile_end) { nb0 = base_at(m0 + MTW - 16 + lane); nb1 = base_at(m0 + MTW - 16 + 64 + lane); }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // ---- 2. producer: a1 = relu(25-tap conv of the bases) -> the slice ----
+    if (first) produce(m0, std::integral_constant<int, 3>(), std::integral_constant<int, 0>());
+    else produce(m0, std::integral_constant<int, 2>(), std::integral_constant<int, 8>());
+    first = false;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the slice is written (same wave: LDS operations retire in order)
     // ---- 3. conv1.b's accumulators start from its bias ----
 #pragma unroll

@@ -74,7 +74,9 @@ def test_encoder_composed_linear_pairs_vs_two_conv_form_and_oracle(cuda, precisi
         refr = O.encoder_forward(sd, xr).numpy()
         yr = enc.forward_codes(codes, reverse=True).cpu().numpy()
         assert maxabs(yr, refr) < tol, (L, "reverse codes")
-        for switch in ("ORCA_NO_COMPOSE", "ORCA_NO_COMPOSE25", "ORCA_NO_RL", "ORCA_NO_POOL5_FUSE"):   # two-conv form everywhere / conv1.a as its own launch / lout1 stored / MaxPool1d(5) as its own pass
+        # two-conv form everywhere / conv1.a as its own launch / lout1 stored / MaxPool1d(5) as its own pass / (bf16 planes) stage 1 as two launches
+        # instead of the one kernel that produces conv1.b's input tiles from the bases (conv_stage1.h)
+        for switch in ("ORCA_NO_COMPOSE", "ORCA_NO_COMPOSE25", "ORCA_NO_RL", "ORCA_NO_POOL5_FUSE", "ORCA_NO_STAGE1_FUSE"):
             monkeypatch.setenv(switch, "1")
             y2 = enc(xc).cpu().numpy()
             yc2 = enc.forward_codes(codes).cpu().numpy()
@@ -82,6 +84,8 @@ def test_encoder_composed_linear_pairs_vs_two_conv_form_and_oracle(cuda, precisi
             assert maxabs(y2, ref) < tol and maxabs(yc2, ref) < tol, switch
             if precision != "bf16":
                 assert maxabs(y, y2) < 2e-5 and maxabs(yc, yc2) < 2e-5, switch
+            elif switch == "ORCA_NO_STAGE1_FUSE":    # same products but for the 25-tap weights' lo part; a1 rounded to bf16 either way
+                assert maxabs(yc, yc2) < 0.03, (switch, maxabs(yc, yc2))
     xf = torch.from_numpy(np.random.RandomState(14).rand(1, 4, 4000 * 2).astype(np.float32))     # arbitrary float rows
     reff = O.encoder_forward(sd, xf).numpy()
     assert maxabs(enc(xf.to(cuda)).cpu().numpy(), reff) < tol
