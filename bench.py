@@ -308,15 +308,19 @@ def inst_rooflines(recs):
         # (25 taps from the bases = conv1.a composed with lconv1: the launch carries conv1.a's 64 -> 64 work, lconv1's is on the 17-tap launch)
         g["flop"] += 2.0 * 9 * (cout * cout if ksize == 25 else cin * cout + (cout * cout if ksize == 17 else 0)) * n * batch
         # what the launch EXECUTES: a composed launch runs its 17 / 25 taps, not the pair's 2 x 9
-        g["xflop"] = g.get("xflop", 0.0) + 2.0 * (25 * 4 * cout if ksize == 25 else ksize * cin * cout) * n * batch
-        g["bytes"] += float(cin + cout) * n * batch      # x elements in + out; bytes per element applied per arithmetic below
+        g["xflop"] = g.get("xflop", 0.0) + 2.0 * (25 * 4 * cout if ksize == 25 else (112 + 9 * 64 + 80) * 64 if tile == -15 else ksize * cin * cout) * n * batch
+        # x elements in + out; bytes per element applied per arithmetic below.  (tile -15 = stage 1 in one kernel from the bases, conv_stage1.h:
+        # 1 byte per base in, 64 channels x n / 4 pooled positions x 2 B out = 33 B per position, whatever `cin` says - it is recorded as 128 so
+        # that the FLOP line above counts both of the stage's 64 -> 64 convs)
+        g["bytes"] += (16.5 if tile == -15 else float(cin + cout)) * n * batch
     PREC = {0: ("f32", "conv1d_k9_kernel", PEAK_F32_MFMA_TFLOPS, 1, 4), 1: ("bf16", "conv1d_k9_bf16s_kernel", PEAK_16BIT_MFMA_TFLOPS, 1, 4),
             2: ("bf16x2", "conv1d_k9_bf16s_kernel", PEAK_16BIT_MFMA_TFLOPS, 3, 4), 3: ("bf16x3", "conv1d_k9_bf16s_kernel", PEAK_16BIT_MFMA_TFLOPS, 6, 4),
             4: ("f16x2", "conv1d_k9_bf16s_kernel", PEAK_16BIT_MFMA_TFLOPS, 3, 4),
             5: ("f16x2", "conv1d_k9_p16_kernel", PEAK_16BIT_MFMA_TFLOPS, 3, 4), 6: ("bf16", "conv1d_k9_p16_kernel", PEAK_16BIT_MFMA_TFLOPS, 1, 2),
             7: ("f16x2", "conv1d_k9_ws_kernel", PEAK_16BIT_MFMA_TFLOPS, 3, 4), 8: ("bf16", "conv1d_k9_ws_kernel", PEAK_16BIT_MFMA_TFLOPS, 1, 2),
             9: ("f16x2", "conv1d_k9_p16w1_kernel", PEAK_16BIT_MFMA_TFLOPS, 3, 4), 10: ("bf16", "conv1d_k9_p16w1_kernel", PEAK_16BIT_MFMA_TFLOPS, 1, 2),
-            12: ("f16x2", "conv1d_k9_p16p5_kernel", PEAK_16BIT_MFMA_TFLOPS, 3, 4), 13: ("bf16", "conv1d_k9_p16p5_kernel", PEAK_16BIT_MFMA_TFLOPS, 1, 2), 14: ("f16x2", "conv1d_k9_p16x_kernel", PEAK_16BIT_MFMA_TFLOPS, 3, 4)}
+            12: ("f16x2", "conv1d_k9_p16p5_kernel", PEAK_16BIT_MFMA_TFLOPS, 3, 4), 13: ("bf16", "conv1d_k9_p16p5_kernel", PEAK_16BIT_MFMA_TFLOPS, 1, 2), 14: ("f16x2", "conv1d_k9_p16x_kernel", PEAK_16BIT_MFMA_TFLOPS, 3, 4),
+            15: ("bf16", "conv1d_stage1_b16_kernel[conv1.a o lconv1 produced in LDS + conv1.b + lout1]", PEAK_16BIT_MFMA_TFLOPS, 1, 2)}
     inst = {}
     for (cout, cin, tile, ksize), g in groups.items():
         prec = -tile if tile < 0 else 0

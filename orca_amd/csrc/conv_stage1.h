@@ -7,18 +7,19 @@
 // Here a1 never exists in HBM.  The kernel is the W-STATIONARY, BARRIER-FREE form of conv_ws.h - conv1.b's 73.7 KB of bf16 weights stay in
 // LDS, every WAVE owns 64-position tiles outright - with the LDS-DMA of a wave's input slice replaced by a PRODUCER that computes it:
 //   * the wave fetches the 123 bases its tile looks at (1 byte each; reverse complement = index / code flip) into a private 128-byte window;
-//   * a1 at the tile's 64 + 8 positions = a K = 112 GEMM of the composed 25-tap weights (bf16, 14 KB of LDS) with one-hot operand units
-//     built from two window bytes each (K index = tap * 4 + channel) - 42 matrix instructions per tile beside conv1.b's 144 -, bias, ReLU,
+//   * a1 at the tile's 64 new positions (the 8 halo columns roll over from the wave's previous tile) = a K = 112 GEMM of the composed
+//     25-tap weights (fp16 hi plane, 14 KB of LDS) with one-hot operand units
+//     built from two window bytes each (K index = tap * 4 + channel) - 28 matrix instructions per tile beside conv1.b's 144 -, bias, ReLU,
 //     rounded to bf16 and written into the wave's slice in the B16 operand layout (v_permlane32_swap pairs the two half-units of a lane pair,
 //     as every B16 epilogue does);
 //   * conv1.b's 2 x 9 taps run out of that slice exactly as in conv_ws.h; its epilogue adds lout1 (K = 80 GEMM from the same window, the
-//     17-tap pack read through L1), pools by 4 and stores.
+//     17-tap pack's hi plane read through L1), pools by 4 and stores.
 // No workgroup barrier after the weight load: while one wave of a SIMD builds operand units (VALU, LDS) the other multiplies.
 // What a single convolution cannot express - PyTorch's zero padding of the INTERMEDIATE tensors at the two ends of a chunk - is patched as
 // before: the edge-fix chain (lconv_edge_layer_kernel) writes a1's first / last 8 positions into `a1_edge`, the producer takes those units
 // from there; positions outside the chunk are conv1.b's own zero padding.
-// Arithmetic vs the two-launch form: the 25-tap weights enter as ONE bf16 product (there: fp16 hi + lo, two products) - a1 is rounded to
-// bf16 right after either way; the mode's parity is the one stated for config 3 (tests/test_gpu_config3.py, bench.py `config3.parity`).
+// Arithmetic vs the two-launch form: the 25-tap and 17-tap weights enter with their fp16 hi part, ONE product each (there: hi + lo, two
+// products) - a1 and the stage's output are rounded to bf16 right after either way (measured vs exact fp32: the same error); the mode's parity is the one stated for config 3 (tests/test_gpu_config3.py, bench.py `config3.parity`).
 #pragma once
 #include <type_traits>
 #include "conv_ws.h"
@@ -98,8 +99,9 @@ __global__ __launch_bounds__(512, 2) void conv1d_stage1_b16_kernel(Stage1Args sa
   long epi_tile = -1;
 #define P16_EPI_CB 0
 #define P16_EPI_M0 (epi_tile * MTW)
-  // + lout1 of the tile's positions, straight from the bases (conv_p16.h, RL): K = 80 GEMM of the composed 17-tap pack (fp16 hi / lo, read
-  // through L1: 20 KB that do not fit beside the slices) with fp16 one-hot units from the wave's window (base of tap t of position p: p + t - 8)
+  // + lout1 of the tile's positions, straight from the bases (conv_p16.h, RL): K = 80 GEMM of the composed 17-tap pack - its fp16 hi plane,
+  // ONE product (11 significant bits: the sum is rounded to bf16 right after), read through L1 (10 KB that do not fit beside the slices) - with
+  // fp16 one-hot units from the wave's window (base of tap t of position p: p + t - 8)
 #define P16_EPI_HOOK()                                                                                           \
   {                                                                                                              \
     _Pragma("unroll") for (int i = 0; i < MW; ++i) _Pragma("unroll") for (int j = 0; j < NW; ++j) _Pragma("unroll") for (int q = 0; q < 4; ++q) { \
@@ -107,12 +109,11 @@ __global__ __launch_bounds__(512, 2) void conv1d_stage1_b16_kernel(Stage1Args sa
       acc[i][j][4 * q + 0] += b_.x; acc[i][j][4 * q + 1] += b_.y; acc[i][j][4 * q + 2] += b_.z; acc[i][j][4 * q + 3] += b_.w; \
     }                                                                                                            \
     const unsigned char* win_ = win + 8 + l31 + 2 * g;                                                           \
-    f32x4 wa_[3][2][NW];       /* the pack's units for k-step kk, requested two k-steps ahead (L1 / L2 round trips) */    \
-    _Pragma("unroll") for (int k0 = 0; k0 < 2; ++k0) _Pragma("unroll") for (int sp = 0; sp < 2; ++sp) _Pragma("unroll") for (int j = 0; j < NW; ++j) \
-      wa_[k0][sp][j] = a.rl_w[((sp * 5 + k0) * 2 + g) * 64 + j * 32 + l31];                                      \
+    f32x4 wa_[3][NW];          /* the pack's units (hi plane) for k-step kk, requested two k-steps ahead (L1 / L2 round trips) */ \
+    _Pragma("unroll") for (int k0 = 0; k0 < 2; ++k0) _Pragma("unroll") for (int j = 0; j < NW; ++j)              \
+      wa_[k0][j] = a.rl_w[(k0 * 2 + g) * 64 + j * 32 + l31];                                                     \
     _Pragma("unroll") for (int kk = 0; kk < 5; ++kk) {                                                           \
-      if (kk + 2 < 5) { _Pragma("unroll") for (int sp = 0; sp < 2; ++sp) _Pragma("unroll") for (int j = 0; j < NW; ++j)                      \
-          wa_[(kk + 2) % 3][sp][j] = a.rl_w[((sp * 5 + kk + 2) * 2 + g) * 64 + j * 32 + l31]; }                  \
+      if (kk + 2 < 5) { _Pragma("unroll") for (int j = 0; j < NW; ++j) wa_[(kk + 2) % 3][j] = a.rl_w[((kk + 2) * 2 + g) * 64 + j * 32 + l31]; } \
       f16x8 xf_[MW];                                                                                             \
       _Pragma("unroll") for (int i = 0; i < MW; ++i) {                                                           \
         const u32x2 o0_ = oh16[win_[i * 32 + 4 * kk]], o1_ = oh16[win_[i * 32 + 4 * kk + 1]];                    \
@@ -120,9 +121,8 @@ __global__ __launch_bounds__(512, 2) void conv1d_stage1_b16_kernel(Stage1Args sa
         u_.x = o0_.x; u_.y = o0_.y; u_.z = o1_.x; u_.w = o1_.y;                                                  \
         xf_[i] = __builtin_bit_cast(f16x8, u_);                                                                  \
       }                                                                                                          \
-      /* (split-major: consecutive instructions go to the four different accumulators) */                        \
-      _Pragma("unroll") for (int sp = 1; sp >= 0; --sp) _Pragma("unroll") for (int i = 0; i < MW; ++i) _Pragma("unroll") for (int j = 0; j < NW; ++j) \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wa_[kk % 3][sp][j]), xf_[i], acc[i][j], 0, 0, 0); \
+      _Pragma("unroll") for (int i = 0; i < MW; ++i) _Pragma("unroll") for (int j = 0; j < NW; ++j)              \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wa_[kk % 3][j]), xf_[i], acc[i][j], 0, 0, 0); \
     }                                                                                                            \
   }
 
