@@ -505,7 +505,10 @@ static int launch_conv2d_m16(orca_ctx* ctx, const ConvLayer& L, const f32x4* x, 
     static int ncu = [] { int dev = 0, v = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev); return v; }();
     const int gx = (aq.ngroups * 2 + 7) / 8 * 8;
     int gy = B;
-    if (a.nchunks % 2 == 0 && gx * B > ncu && getenv("ORCA_NO_M16Q_WALK") == nullptr) gy = ncu / gx > 1 ? ncu / gx : 1;
+    // (single-plane modes, 32 couts: 73.7 KB of LDS and 111 VGPRs - TWO workgroups fit a CU, one's transfers and epilogue under the other's
+    // MFMAs: the resident round is twice as large.  ORCA_M16Q_ONE_PER_CU=1: the A/B switch)
+    const int res = (mode != 0 && L.cout == 32 && getenv("ORCA_M16Q_ONE_PER_CU") == nullptr) ? 2 * ncu : ncu;
+    if (a.nchunks % 2 == 0 && gx * B > res && getenv("ORCA_NO_M16Q_WALK") == nullptr) gy = res / gx > 1 ? res / gx : 1;
     if (gy > B) gy = B;
     dim3 gridq((unsigned)gx, (unsigned)gy);
     if (bf16) {

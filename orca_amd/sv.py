@@ -442,6 +442,11 @@ def sv_screen(models, genome_codes, svs, chrlen, mchr="chrS", rank=0, world=1, i
     (a chromosome encoding costs chrlen / 32 Mb windows' worth of Encoder time), windows reuse those bins (`encode_window`), and the
     four strands of a variant (ref / alt x forward / reverse) go through Encoder2 and every decoder level as ONE batch.  Variants whose
     phases are not held fall back to encoding their windows whole - same maps either way (tests/test_gpu_sv_incremental.py).
+    LIMIT: reuse needs window runs that SHARE a 4 kb phase - coordinates on one 4 kb grid, as `synth_svs` draws them and as
+    screens of binned calls have them.  Variants at arbitrary base positions have a phase of their own each: they take the whole-window
+    route (`stats["bins_encoded"] / stats["bins_total"]` says how much of the screen did; `stats["whole_window_runs"]` counts the runs),
+    and the quoted ~30 SV/s does not apply to them - the structural-variant drivers (`sv_drivers._run_views`) then still share work between
+    the views of one call (1.3-1.6x).
     ``incremental=False`` is the reference's cost structure: two independent `genomepredict` calls per variant.
     ``on_result(i, entry)``: called per variant INSTEAD of collecting the entries (a 1 024-variant screen is 12 288 maps = 3 GB).
     ``streams``: auxiliary contexts the local re-encodes of a variant are dealt to (`encode_windows`; default $ORCA_SV_STREAMS or 4, 0 = all
@@ -552,5 +557,7 @@ def sv_screen(models, genome_codes, svs, chrlen, mchr="chrS", rank=0, world=1, i
                         res[i] = entry
     if stats is not None:
         stats.update({"bins_encoded": encoded, "bins_total": len(mine) * len(models) * 4 * nbins,
-                      "chromosome_encodings": sum(c.builds for c in caches)})
+                      "chromosome_encodings": sum(c.builds for c in caches),
+                      "phases_wanted": len(want), "phases_held": sum(len(c.entries) for c in caches) // max(1, len(caches)),
+                      "whole_window_runs": int(sum(n for key, n in want.items() if n < min_uses))})
     return res

@@ -1,5 +1,5 @@
 """Turn gpurun_out/<tag>/ (tools/profile_run.sh) into the summaries committed under profiles/:
-   <tag>_bench_kernel_stats.csv        rocprofv3 --kernel-trace --stats of `python bench.py --no-cpu-baseline`
+   <tag>_bench_kernel_stats.csv        rocprofv3 --kernel-trace --stats of `python bench.py --no-cpu-baseline --no-configs`
    <tag>_bench_dominant_launches.txt   every n = 32 M launch of the dominant kernel's instantiations (us) + averages
    <tag>_bench.json / _bench_under_rocprof.json
    <tag>_pmc_<run>.txt                 per-kernel sums of the counter passes (tools/pmc_summary.py format)
@@ -28,7 +28,7 @@ for r in rows:
     if n.startswith("void conv1d_k9_p16_kernel<") or n.startswith("void conv1d_k9_p16w1_kernel<") or n.startswith("void conv1d_k9_p16x_kernel<") or n.startswith("void conv1d_k9_p16p5_kernel<") or n.startswith("void conv1d_k9_ws_kernel") or n.startswith("void conv1d_first_mfma_p16_kernel"):
         by[n.replace("void ", "").split("(")[0]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 with open(os.path.join(dst, f"{tag}_bench_dominant_launches.txt"), "w") as f:
-    f.write("# rocprofv3 --kernel-trace of `python bench.py --no-cpu-baseline`: launches of the planar conv kernels (bench.py's `roofline` names the\n"
+    f.write("# rocprofv3 --kernel-trace of `python bench.py --no-cpu-baseline --no-configs`: launches of the planar conv kernels (bench.py's `roofline` names the\n"
             "# instantiation with the largest time share), split by problem size; template arguments <CT, MW, NW, WM, out_mode, residual, ABL,\n"
             "# fused-first-layer, format, residual-from-bases> (conv_p16w1.h: <out_mode, residual, format>).  'big' = launches >= 2.5 ms (stage 1 at n = 32 M, stage 2 at n = 8 M of a 32 Mb strand\n"
             "# or chunk), the rest are stages 3-4.\n")

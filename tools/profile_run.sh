@@ -3,12 +3,12 @@
 # bench command, then separate rocprofv3 --pmc passes (SQ / FETCH_SIZE / WRITE_SIZE: one pass each, MI355X_MICROARCH.md
 # "rocprofv3 PMC slots") over one 32 Mb Encoder forward in both arithmetic modes and over one Decoder forward.
 # Everything lands in gpurun_out/<tag>/; tools/profile_collect.py turns it into the summaries committed under profiles/.
-TAG=${1:-r04}
+TAG=${1:-r05}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -o bench -- python $ROOT/bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -o bench -- python $ROOT/bench.py --no-cpu-baseline --no-configs > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
 python $ROOT/bench.py > $OUT/bench.json 2> $OUT/bench.err
 SQ="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"
 for mode in f16x2 bf16; do
