@@ -11,6 +11,8 @@ H2D/D2H copies at the ends.  ``use_cuda=False`` simply leaves tensors on the
 host, which the orca_amd modules refuse (no CPU path) - it exists so that the
 cascade bookkeeping can be exercised with foreign ``torch.nn.Module`` models.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -50,6 +52,29 @@ def _resolve_models(models, group, use_cuda):
                 load_resources(models=[group], use_cuda=use_cuda)
             objs.append(model_dict_global[m])
     return objs
+
+
+import contextlib as _contextlib
+import threading as _threading
+
+_enc_scope = _threading.local()
+
+
+@_contextlib.contextmanager
+def shared_encodings():
+    """Within this scope (one thread) `genomepredict_256Mb` keeps the Encoder output of a packed sequence per (sequence storage, Encoder) and
+    reuses it when the SAME sequence comes again: the structural-variant drivers predict one 256 Mb sequence at two anchors (the reference
+    chromosome at the variant's left and right end, `orca_predict.py:1335 / :1389`; both views of an inversion) - the reference encodes it
+    twice, 2 x 128 Mb strand pairs of Encoder work each.  Nothing outlives the scope."""
+    prev = getattr(_enc_scope, "cache", None)
+    if os.environ.get("ORCA_NO_SHARED_ENCODINGS"):       # A/B switch (read per call)
+        yield
+        return
+    _enc_scope.cache = {} if prev is None else prev
+    try:
+        yield
+    finally:
+        _enc_scope.cache = prev
 
 
 class _StrandInputs:
@@ -120,8 +145,14 @@ class _StrandInputs:
         if self.use_cuda and isinstance(net0, (Encoder, ShardedEncoder)) and self._pack():
             if isinstance(net0, Encoder):     # both strands straight into the halves of one [2B,128,bins] tensor
                 B, L = self._codes.shape
+                cache = getattr(_enc_scope, "cache", None)          # `shared_encodings()`: the same packed sequence at another anchor
+                key = (self._codes.data_ptr(), tuple(self._codes.shape), self._codes._version, id(net0), net0.precision, engine._guard["force_safe"])
+                if cache is not None and key in cache:
+                    return cache[key][1]
                 enc0 = torch.empty((2 * B, 128, engine.encoder_num_bins(L)), dtype=torch.float32, device=self._codes.device)
                 _encode_two_strands(lambda rev, out: net0.forward_codes(self._codes, reverse=rev, out=out), enc0, B)
+                if cache is not None:
+                    cache[key] = (self._codes, enc0)      # (the codes tensor is HELD: its storage - the key - cannot be handed to another sequence meanwhile)
                 return enc0
             return torch.cat([net0.forward_codes(self._codes, reverse=False), net0.forward_codes(self._codes, reverse=True)], dim=0)
         return torch.cat([net0(self.fwd), net0(self.rev)], dim=0)

@@ -389,6 +389,19 @@ def _alt_view_256(genome, sc, mchr, anchor, chrlen_alt, anno_regions, models, pa
     return _predict256(seq, mchr, normmats, alt_round, anchor, wpos, models, anno, padding_chr, None, use_cuda)
 
 
+def _shares_encodings(fn):
+    """A driver call runs inside `orca_predict.shared_encodings()`: at 256 Mb the same packed sequence predicted at two anchors is encoded once."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*a, **k):
+        from .orca_predict import shared_encodings
+        with shared_encodings():
+            return fn(*a, **k)
+    return wrapped
+
+
+@_shares_encodings
 def process_region(mchr, mstart, mend, genome, file=None, custom_models=None, target=True, show_genes=True, show_tracks=False,
                    window_radius=16000000, padding_chr="chr1", model_labels=None, use_cuda=True):
     """Multiscale prediction centred on a region (`orca_predict.py:983-1169`)."""
@@ -412,6 +425,7 @@ def _ref_pair(genome, mchr, mstart, mend, models, target, use_cuda, window_radiu
     return ref_l, ref_r, None
 
 
+@_shares_encodings
 def process_dup(mchr, mstart, mend, genome, file=None, custom_models=None, target=True, show_genes=True, show_tracks=False,
                 window_radius=16000000, padding_chr="chr1", model_labels=None, use_cuda=True):
     """Tandem duplication of [mstart, mend) (`orca_predict.py:1172-1507`): ref.l, ref.r, alt (anchored at the
@@ -433,6 +447,7 @@ def process_dup(mchr, mstart, mend, genome, file=None, custom_models=None, targe
     return tuple(_run_views(genome, [ref_l, ref_r, alt], models, use_cuda))
 
 
+@_shares_encodings
 def process_del(mchr, mstart, mend, genome, cmap=None, file=None, custom_models=None, target=True, show_genes=True,
                 show_tracks=False, window_radius=16000000, padding_chr="chr1", model_labels=None, use_cuda=True):
     """Deletion of [mstart, mend) (`orca_predict.py:1510-1817`): ref.l, ref.r, alt at the breakpoint."""
@@ -449,6 +464,7 @@ def process_del(mchr, mstart, mend, genome, cmap=None, file=None, custom_models=
     return tuple(_run_views(genome, [ref_l, ref_r, alt], models, use_cuda))
 
 
+@_shares_encodings
 def process_inv(mchr, mstart, mend, genome, file=None, custom_models=None, target=True, show_genes=True, show_tracks=False,
                 window_radius=16000000, padding_chr="chr1", model_labels=None, use_cuda=True):
     """Inversion of [mstart, mend) (`orca_predict.py:1820-2175`): ref.l, ref.r, alt.l, alt.r."""
@@ -518,6 +534,7 @@ def process_custom(region_list, ref_region_list, mpos, genome, ref_mpos_list=Non
     return (outs[-2] if len(outs) > 1 else None), outs[-1]
 
 
+@_shares_encodings
 def process_single_breakpoint(chr1, pos1, chr2, pos2, orientation1, orientation2, genome, custom_models=None, target=True,
                               file=None, show_genes=True, show_tracks=False, window_radius=16000000, padding_chr="chr1",
                               model_labels=None, use_cuda=True):
