@@ -276,6 +276,22 @@ def test_sv_drivers_256mb_on_device(cuda):
     for a, b in zip(direct["predictions"][0], ref_l["predictions"][0]):
         assert maxabs(a, b) < 1e-6
     assert max(maxabs(a, b) for a, b in zip(ref_l["predictions"][0], alt["predictions"][0])) > 1e-3
+    # round 5: ref.l and ref.r predict the SAME 256 Mb sequence at two anchors - one Encoder pass serves both (orca_predict.shared_encodings):
+    # a third fewer planar conv launches than with every view encoded, identical maps
+    from orca_amd import engine
+    ctx = engine.get_context(cuda)
+    c0 = ctx.launch_counts()["planar"]
+    again = P.process_del("chrL", mstart, mend, g, custom_models=[model], target=False, window_radius=128000000, padding_chr="chr1")
+    c1 = ctx.launch_counts()["planar"]
+    os.environ["ORCA_NO_SHARED_ENCODINGS"] = "1"
+    try:
+        each = P.process_del("chrL", mstart, mend, g, custom_models=[model], target=False, window_radius=128000000, padding_chr="chr1")
+    finally:
+        del os.environ["ORCA_NO_SHARED_ENCODINGS"]
+    c2 = ctx.launch_counts()["planar"]
+    assert 0 < (c1 - c0) * 3 == (c2 - c1) * 2, (c1 - c0, c2 - c1)
+    for oa, ob in zip(again, each):
+        assert all(np.array_equal(x, y) for x, y in zip(oa["predictions"][0], ob["predictions"][0]))
 
 
 def test_process_del_against_the_reference_with_real_networks(cuda):
