@@ -32,6 +32,7 @@ Also measured in the same run, OUTSIDE the timed region, and reported in the sam
     roofline of its dominant kernel, parity against the reference rows of G17.
   * `config5` (N = 1): BASELINE configs[4] - 256 of the 1024 synthetic SVs through orca_amd.sv.sv_screen (incremental encoding; 16 of them
     also as two whole genomepredict calls; the full screen: tools/run_configs.py config5_1024, profiles/r05_config5_1024.json).
+  * `roofline.traffic` (N = 1): measured in the run by two rocprofv3 counter passes over the same Encoder launches in child processes.
   * `cpu_baseline` (N = 1): the oracle (= the torch CPU ops the reference dispatches) on ONE WHOLE 32 Mb strand (+ the 8 Mb sample of rounds 1-4).
 
 Prints ONE JSON line (rank 0).  value = strand-Mb of sequence encoded AND decoded per second over the whole job
@@ -113,6 +114,43 @@ def cpu_baseline(seed, sample_bp=8_000_000):
             "sample": (f"Encoder on {sample_bp // 1000000} Mb ({sample_bp // 800000} reference blocks, {t_enc:.1f}s" + (f", EXTRAPOLATED x{L_BP // sample_bp}" if sample_bp < L_BP else ", the whole strand") + ") + "
                        f"Encoder2(8000 bins) + 6 Decoder + Decoder_1m ({t_rest:.1f}s), torch CPU fp32, {ncores} threads"),
             "t_encoder_sample_s": round(t_enc, 2), "t_decoders_s": round(t_rest, 2)}
+
+
+def measure_traffic_in_run(kernel_name, timeout_s=240):
+    """HBM traffic of the dominant kernel measured IN THIS RUN: two separate `rocprofv3 --kernel-trace --pmc` passes
+    (FETCH_SIZE, WRITE_SIZE: one counter per pass, MI355X_MICROARCH.md 'rocprofv3 PMC slots') over `tools/prof_encoder.py 32 f16x2 1 codes`
+    (two forwards of a 32 Mb strand - the launches of the timed region, same kernels, same sizes) in child processes; bytes per launch =
+    (2 x FETCH_SIZE + WRITE_SIZE) x 1024 / launches - FETCH_SIZE doubled per the guide's gfx950 correction, both counters in KiB.  Returns
+    (bytes_per_launch, launches) or (None, reason): any failure (no rocprofv3, a timeout, an unknown kernel) leaves the committed number in place."""
+    import csv, glob, re, shutil, subprocess, tempfile
+    table = {"conv1d_k9_p16_kernel<cout=64,f16x2>": (re.compile(r"^void conv1d_k9_p16_kernel<64,"), 4000.0),
+             "conv1d_k9_p16x_kernel<cout=96,f16x2>": (re.compile(r"^void conv1d_k9_p16x_kernel<\d, (true|false), 3, 96>"), 2500.0),
+             "conv1d_first_mfma_p16_kernel<0,0,25>": (re.compile(r"^void conv1d_first_mfma_p16_kernel<0, 0, 25>"), 800.0)}
+    if kernel_name not in table or shutil.which("rocprofv3") is None:
+        return None, "no rocprofv3 on this box" if kernel_name in table else f"no counter recipe for {kernel_name}"
+    rx, min_us = table[kernel_name]
+    sums = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="orca_pmc_", dir="/tmp")
+        try:
+            subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable,
+                            os.path.join(ROOT, "tools", "prof_encoder.py"), "32", "f16x2", "1", "codes"], cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"),
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=True)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            tot, disp = 0.0, set()
+            for r in csv.DictReader(open(files[0])):
+                if r["Counter_Name"] == counter and rx.search(r["Kernel_Name"]) and (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 >= min_us:
+                    tot += float(r["Counter_Value"])
+                    disp.add(r["Dispatch_Id"])
+            sums[counter] = (tot, len(disp))
+        except Exception as e:
+            return None, f"{counter} pass failed: {type(e).__name__}"
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    (fe, n1), (wr, n2) = sums["FETCH_SIZE"], sums["WRITE_SIZE"]
+    if not n1 or n1 != n2:
+        return None, f"launch counts of the two passes differ ({n1}, {n2})"
+    return (2 * fe + wr) * 1024 / n1, n1
 
 
 XGMI_LINK_GB_S, XGMI_LINKS = 153.0, 7     # MI355X: 7 point-to-point xGMI links per GPU
@@ -548,6 +586,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true", help="do not measure the dominant kernel's HBM traffic with rocprofv3 counter passes in child processes (about a minute); the committed profiles/pmc_traffic.json is quoted instead")
     ap.add_argument("--cpu-sample-only", action="store_true", help="CPU baseline from the 8 Mb sample alone (extrapolated), as in rounds 1-4: saves a minute")
     ap.add_argument("--cpu-full-strand", action="store_true", help="only: time the CPU baseline on the WHOLE 32 Mb strand (about a minute of CPU), print it and exit")
     ap.add_argument("--seq-mb", type=int, default=32, help="debug only: shorter sequence (invalidates the metric)")
@@ -651,7 +690,7 @@ def main():
                     "executed_tflops": round(d["xflop"] / (d["ms"] * 1e-3) / 1e12, 2), "executed_frac": round(d["xflop"] / (d["ms"] * 1e-3) / 1e12 / d["peak"], 4),
                     "frac_of_f32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
                     "avg_launch_ms": round(d["ms"] / d["launches"], 4), "launches": d["launches"],
-                    "flop_per_launch": d["flop"] / d["launches"],
+                    "flop_per_launch": d["flop"] / d["launches"], "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
                     "conv1d_time_share_of_step": round(tot_ms / (elapsed * 1e3), 4),
                     "all_conv1d_tflops": round(sum(v["flop"] for v in inst.values()) / (tot_ms * 1e-3) / 1e12, 2)}
 
@@ -850,6 +889,18 @@ def main():
         if world == 1:
             res["strong_scaling"]["projection_n8"] = {k: res[k].get("projection_n8") for k in ("sharded_256mb", "sharded_32mb", "sharded_32mb_two_models")
                                                       if isinstance(res.get(k), dict)}
+    if rank == 0 and world == 1 and not args.no_traffic and Lbp == L_BP and isinstance(res.get("roofline"), dict):
+        # (this process holds no workspace any more; the child processes run the Encoder on their own)
+        engine.get_context(dev).release_workspace()
+        torch.cuda.empty_cache()
+        got, info = measure_traffic_in_run(res["roofline"]["kernel"])
+        if got is not None:
+            res["roofline"].update({"traffic": got, "traffic_measured_in_run": True, "traffic_launches": info,
+                                    "traffic_source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (two passes) over tools/prof_encoder.py 32 f16x2 1 codes, child processes of this run",
+                                    "traffic_committed": res["roofline"].get("traffic"),
+                                    "traffic_over_algorithmic": round(got / res["roofline"]["algorithmic_bytes_per_launch"], 3)})
+        else:
+            res["roofline"]["traffic_not_measured_because"] = info
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # the reference's CPU path on ONE WHOLE 32 Mb strand, timed on this box in this run (north star; about a minute on the 16-core quota),
         # and - first, while the cores are cool - the 8 Mb sample of rounds 1-4 scaled x4 (kept as a second field: the two differ by what the

@@ -244,21 +244,25 @@ class GenomeEncodings:
     """`ChromEncodings` per chromosome of one genome for one Encoder: what `encode_windows` looks pieces `(chrom, start, length, strand)`
     up in.  ``chrom_codes(chrom)`` -> the chromosome's [chrlen] uint8 codes on the device; ``chrlens``: {chrom: length}."""
 
-    def __init__(self, net0, chrom_codes, chrlens, max_entries=4):
-        self.net0, self.chrom_codes, self.chrlens, self.max_entries = net0, chrom_codes, dict(chrlens), max_entries
-        self.chroms = {}
+    def __init__(self, net0, chrom_codes, chrlens, max_entries=4, max_chroms=8):
+        self.net0, self.chrom_codes, self.chrlens, self.max_entries, self.max_chroms = net0, chrom_codes, dict(chrlens), max_entries, max_chroms
+        self.chroms = {}           # least recently used first; at most max_chroms chromosomes keep encodings (<= 24 segments of 4 MB + max_entries
+        self._builds_gone = 0      # whole-chromosome encodings each: a bound on what a long session over a whole genome holds in HBM)
 
     def of(self, chrom):
         if chrom not in self.chrlens:
             return None                                        # an inserted sequence, padding: nothing to reuse
-        c = self.chroms.get(chrom)
+        c = self.chroms.pop(chrom, None)
         if c is None:
-            c = self.chroms[chrom] = ChromEncodings(self.net0, lambda chrom=chrom: self.chrom_codes(chrom), self.max_entries, chrlen=self.chrlens[chrom])
+            c = ChromEncodings(self.net0, lambda chrom=chrom: self.chrom_codes(chrom), self.max_entries, chrlen=self.chrlens[chrom])
+        self.chroms[chrom] = c
+        while len(self.chroms) > self.max_chroms:
+            self._builds_gone += self.chroms.pop(next(iter(self.chroms))).builds
         return c
 
     @property
     def builds(self):
-        return sum(c.builds for c in self.chroms.values())
+        return self._builds_gone + sum(c.builds for c in self.chroms.values())
 
 
 def _p4(piece):

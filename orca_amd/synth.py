@@ -149,6 +149,18 @@ def sv_driver_genome():
 SV_REAL_CASE = ("chrS", 20_000_000, 20_400_000)      # tests/golden/G22: process_del with the reference's real networks
 # tests/golden/G23: process_dup (three views) and process_inv (four views; the inverted segment's bins come from the OTHER strand's
 # encoding of the chromosome, coordinates off the 4 kb grid) with the reference's real networks
+# tests/golden/G24: the drivers whose alternative alleles are not pieces of ONE chromosome - an inserted string ('-' strand, with N), a
+# translocation joining two chromosomes ('+', '-' orientations: one side reverse-complemented) and a custom rearrangement - real networks
+def sv_real_cases_g24():
+    rs = np.random.RandomState(78)
+    ins_seq = "".join("ACGTN"[i] for i in rs.choice(5, 5003, p=[0.24, 0.24, 0.24, 0.24, 0.04]))
+    return [("ins", "process_ins", ("chrS", 18_000_123, ins_seq), {"strand": "-"}),
+            ("bp", "process_single_breakpoint", ("chrS", 22_000_000, "chrT", 9_000_000, "+", "-"), {}),
+            ("custom", "process_custom", ([("chrS", 1_000_000, 17_000_000, "+"), ("chrT", 4_000_000, 20_000_000, "-")],
+                                          [("chrS", 1_000_000, 33_000_000, "+")], 16_000_000),
+             {"anno_list": [[16_000_000, "double"]], "ref_anno_list": [[17_000_000, "single"]]})]
+
+
 SV_REAL_CASES_G23 = [("dup", "process_dup", ("chrS", 12_000_000, 12_700_000)), ("inv", "process_inv", ("chrS", 25_101_000, 26_403_500))]
 
 

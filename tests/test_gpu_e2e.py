@@ -357,3 +357,37 @@ def test_process_dup_inv_against_the_reference_with_real_networks(cuda, case):
                 assert abs(v[0] - ref[0]) < 1e-4 * 62500 and abs(v[1] / ref[1] - 1) < 1e-4 and abs(v[2] - ref[2]) < 1e-4, (k, v, ref)
         assert maxabs(got["o0_m0_sub_3"], got[f"o{views - 1}_m0_sub_3"]) > 1e-3
         print(f"process_{case} vs the reference with real networks (call {attempt + 1}): {views} views, worst max-abs on the sampled pixels {worst:.3g}")
+
+
+@pytest.mark.parametrize("case", ["ins", "bp", "custom"])
+def test_process_ins_breakpoint_custom_against_the_reference_with_real_networks(cuda, case):
+    """The drivers whose alternative allele is NOT pieces of one chromosome, against the reference's own calls with its real networks (fixture
+    G24, tools/make_golden.py --svreal --only G24): `process_ins` (orca_predict.py:2178-2497; a 5 kb string with N, '-' strand: the inserted
+    pieces have nothing to reuse, their neighbours do), `process_single_breakpoint` (:2684-3057; chrS joined to the reverse complement of a
+    piece of chrT: two chromosomes' kept encodings in one window) and `process_custom` (:2500-2681; a chimeric window with a '-' piece) -
+    through the incremental route, twice.  The reference's `process_ins` runs its alt.r view on the registered default pair (it forgets
+    `models=`, :2474; the fixture registered the same real model twice): model 0 is compared."""
+    from orca_amd import sv_drivers
+    model = M.H1esc(synthetic_seed=0)
+    g = golden("G24_sv_ins_bp_custom_real_nets.npz")
+    dev = synth.sv_driver_genome().to(cuda)
+    name, fn, a, kw = next(c for c in synth.sv_real_cases_g24() if c[0] == case)
+    sv_drivers.clear_encoding_cache()
+    for attempt in range(2):
+        outs = getattr(P, fn)(*a, dev, custom_models=[model], target=False, use_cuda=True, **kw)
+        got = synth.summarize_outputs(outs, stride=5)
+        views = len(outs)
+        assert sum(1 for k in g.files if k.startswith(case + ".") and k.endswith("_chr")) == views
+        worst = 0.0
+        for k, v in got.items():
+            ref = g[f"{case}.{k}"]
+            if k.endswith(("_start", "_end")):
+                assert np.array_equal(v, ref), k
+            elif k.endswith(("_chr", "_annos")):
+                assert str(v[0]) == str(ref[0]), k
+            elif "_sub_" in k:
+                worst = max(worst, maxabs(v, ref))
+                assert maxabs(v, ref) < 1e-4 and pearson(v, ref) > 0.999999, (k, attempt, maxabs(v, ref))
+            elif "_stats_" in k:
+                assert abs(v[0] - ref[0]) < 1e-4 * 62500 and abs(v[1] / ref[1] - 1) < 1e-4 and abs(v[2] - ref[2]) < 1e-4, (k, v, ref)
+        print(f"{fn} vs the reference with real networks (call {attempt + 1}): {views} views, worst max-abs on the sampled pixels {worst:.3g}")

@@ -459,6 +459,26 @@ def main():
             np.savez_compressed(os.path.join(GOLD, "G23_sv_dup_inv_real_nets.npz"), **d)
             print("G23 done %.1fs" % (time.time() - t))
 
+        # ---- G24: process_ins / process_single_breakpoint / process_custom of the reference with the REAL networks (3 + 3 + 2 genomepredict
+        #      calls, ~20 min of CPU): alternative alleles with an inserted string, pieces of two chromosomes, a '-' piece ---------------------
+        if args.svreal and want("G24"):
+            import orca_predict as op
+            genome = synth.sv_driver_genome()
+            t = time.time()
+            d = {}
+            model = Full(0)
+            # (the reference's process_ins forgets `models=` in its alt.r call, orca_predict.py:2474, and falls back to the registered default
+            # pair: both names get the same real model, the fixture's alt.r view then carries it twice - the test compares model 0)
+            op.model_dict_global["h1esc"] = op.model_dict_global["hff"] = model
+            for name, fn, a, kw in synth.sv_real_cases_g24():
+                t1 = time.time()
+                outs = getattr(op, fn)(*a, genome, custom_models=[model], target=False, use_cuda=False, **kw)
+                d.update({f"{name}.{k}": v for k, v in synth.summarize_outputs(outs, stride=5).items()})
+                d[f"{name}.t_cpu_s"] = np.array([time.time() - t1])
+                print("G24", name, len(outs), "views %.1fs" % (time.time() - t1), flush=True)
+            np.savez_compressed(os.path.join(GOLD, "G24_sv_ins_bp_custom_real_nets.npz"), **d)
+            print("G24 done %.1fs" % (time.time() - t))
+
         # ---- G8: one full 32 Mb H1-ESC-shaped forward, both strands ---------------
         if args.full32m and want("G8"):
             import orca_predict as op
