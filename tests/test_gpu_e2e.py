@@ -368,6 +368,8 @@ def test_process_ins_breakpoint_custom_against_the_reference_with_real_networks(
     through the incremental route, twice.  The reference's `process_ins` runs its alt.r view on the registered default pair (it forgets
     `models=`, :2474; the fixture registered the same real model twice): model 0 is compared."""
     from orca_amd import sv_drivers
+    if not os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "G24_sv_ins_bp_custom_real_nets.npz")):
+        pytest.skip("fixture G24 not generated (tools/make_golden.py --svreal --only G24: ~25 min of CPU next to /root/reference)")
     model = M.H1esc(synthetic_seed=0)
     g = golden("G24_sv_ins_bp_custom_real_nets.npz")
     dev = synth.sv_driver_genome().to(cuda)
