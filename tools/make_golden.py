@@ -470,13 +470,18 @@ def main():
             # (the reference's process_ins forgets `models=` in its alt.r call, orca_predict.py:2474, and falls back to the registered default
             # pair: both names get the same real model, the fixture's alt.r view then carries it twice - the test compares model 0)
             op.model_dict_global["h1esc"] = op.model_dict_global["hff"] = model
+            path24 = os.path.join(GOLD, "G24_sv_ins_bp_custom_real_nets.npz")
+            if os.path.exists(path24):                      # resumable: the file is rewritten after every case, finished cases are kept
+                d.update({k: v for k, v in np.load(path24).items()})
             for name, fn, a, kw in synth.sv_real_cases_g24():
+                if f"{name}.t_cpu_s" in d:
+                    continue
                 t1 = time.time()
                 outs = getattr(op, fn)(*a, genome, custom_models=[model], target=False, use_cuda=False, **kw)
                 d.update({f"{name}.{k}": v for k, v in synth.summarize_outputs(outs, stride=5).items()})
                 d[f"{name}.t_cpu_s"] = np.array([time.time() - t1])
                 print("G24", name, len(outs), "views %.1fs" % (time.time() - t1), flush=True)
-            np.savez_compressed(os.path.join(GOLD, "G24_sv_ins_bp_custom_real_nets.npz"), **d)
+                np.savez_compressed(path24, **d)
             print("G24 done %.1fs" % (time.time() - t))
 
         # ---- G8: one full 32 Mb H1-ESC-shaped forward, both strands ---------------
