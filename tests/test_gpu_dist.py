@@ -225,7 +225,7 @@ def test_bench_two_ranks_on_one_gpu_over_gloo(cuda):
     assert "error" not in c5 and c5["svs"] == 256 and c5["as_the_reference_does_it"]["svs"] == 16 and c5["max_abs_vs_whole_window_encoding"] < 1e-4, c5
     assert one["config3"]["parity"]["ok"], one["config3"]
     rf = one["roofline"]          # the dominant kernel's HBM traffic is measured by counter passes inside the run (child processes), not replayed
-    assert rf["traffic_measured_in_run"] is True and 0.9 < rf["traffic_over_algorithmic"] < 1.3 and rf["traffic_launches"] >= 2, rf
+    assert rf["traffic_measured_in_run"] is True and 0.5 < rf["traffic_over_algorithmic"] < 1.3 and rf["traffic_launches"] >= 2, rf      # (conv1.b pools its output: its in + out count is an upper bound)
     note = one["strong_scaling"]["note"]
     assert "tail" in note.lower() and "256 Mb" in note
     pj = one["strong_scaling"]["projection_n8"]
