@@ -253,6 +253,23 @@ def test_sv_drivers_device_genome_equals_host_route(cuda):
         assert max(maxabs(x, y) for x, y in zip(outs_d[0]["predictions"][0], outs_d[-1]["predictions"][0])) > 1e-3
 
 
+def test_sv_drivers_on_a_two_bit_genome(cuda):
+    """The drivers' incremental route on the 2-bit + N-mask genome (3/8 byte per base in HBM; windows and whole chromosomes are expanded to
+    codes on the device only where something is encoded): the same dictionaries, bit for bit, as on the 1 byte/base store."""
+    from orca_amd import sv_drivers
+    from orca_amd.genome import TwoBitGenome
+    model = M.H1esc(synthetic_seed=0)
+    g1 = synth.sv_driver_genome().to(cuda)
+    g2 = TwoBitGenome.from_packed(synth.sv_driver_genome()).to(cuda)
+    sv_drivers.clear_encoding_cache()
+    a = P.process_dup("chrS", 20_000_000, 20_404_000, g1, custom_models=[model], target=False)
+    b = P.process_dup("chrS", 20_000_000, 20_404_000, g2, custom_models=[model], target=False)
+    assert len(a) == len(b) == 3
+    for oa, ob in zip(a, b):
+        assert oa["start_coords"] == ob["start_coords"] and oa["annos"] == ob["annos"]
+        assert all(np.array_equal(x, y) for x, y in zip(oa["predictions"][0], ob["predictions"][0]))
+
+
 def test_sv_drivers_256mb_on_device(cuda):
     """window_radius=128000000 on the MI355X with a H1esc_256M-shaped model and the genome in HBM: each view of
     `process_del` equals a direct `genomepredict_256Mb` call on the same (independently gathered) codes and background,
