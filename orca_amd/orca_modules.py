@@ -63,17 +63,21 @@ class _HipModule(nn.Module):
     def __init__(self):
         super().__init__()
         self._nets = {}
+        self._wver = 0          # bumped with every change of the parameter containers: whoever caches this module's OUTPUTS keys on it (sv_drivers._store)
 
     # any change of the parameter containers invalidates the uploaded copy
     def invalidate(self):
         self._nets = {}
+        self._wver = getattr(self, "_wver", 0) + 1
 
     def _apply(self, fn, *a, **k):
         self._nets = {}
+        self._wver = getattr(self, "_wver", 0) + 1
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, state_dict, *a, **k):
         self._nets = {}
+        self._wver = getattr(self, "_wver", 0) + 1
         # tolerate the reference's DataParallel prefixes (orca_models.py:104-123)
         own = set(self.state_dict().keys())
         fixed = {}

@@ -163,7 +163,9 @@ def _store(genome, net0):
     stores = getattr(_tls, "stores", None)
     if stores is None:
         stores = _tls.stores = {}
-    key = (id(genome), id(net0))
+    # (the Encoder's arithmetic mode and the version of its weights are part of the key: kept encodings must not outlive a `precision = ...`
+    # or a `load_state_dict` on the same module object)
+    key = (id(genome), id(net0), getattr(net0, "precision", None), getattr(net0, "_wver", 0))
     hit = stores.pop(key, None)
     if hit is not None and (hit[0]() is not genome or hit[1]() is not net0):
         hit = None                                           # an id reused by another object

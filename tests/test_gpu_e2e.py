@@ -268,6 +268,17 @@ def test_sv_drivers_on_a_two_bit_genome(cuda):
     for oa, ob in zip(a, b):
         assert oa["start_coords"] == ob["start_coords"] and oa["annos"] == ob["annos"]
         assert all(np.array_equal(x, y) for x, y in zip(oa["predictions"][0], ob["predictions"][0]))
+    # kept encodings belong to (genome, Encoder, its arithmetic mode, the version of its weights): another precision starts its own store
+    n_before = len(sv_drivers._tls.stores)
+    model.net0.precision = "f32"
+    c = P.process_dup("chrS", 20_000_000, 20_404_000, g1, custom_models=[model], target=False)
+    assert len(sv_drivers._tls.stores) == n_before + 1
+    os.environ["ORCA_SV_INCREMENTAL"] = "0"
+    try:
+        cw = P.process_dup("chrS", 20_000_000, 20_404_000, g1, custom_models=[model], target=False)
+    finally:
+        del os.environ["ORCA_SV_INCREMENTAL"]
+    assert max(maxabs(x, y) for oa, ob in zip(c, cw) for x, y in zip(oa["predictions"][0], ob["predictions"][0])) < 3e-5
 
 
 def test_sv_drivers_256mb_on_device(cuda):
