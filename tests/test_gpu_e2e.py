@@ -281,6 +281,49 @@ def test_sv_drivers_on_a_two_bit_genome(cuda):
     assert max(maxabs(x, y) for oa, ob in zip(c, cw) for x, y in zip(oa["predictions"][0], ob["predictions"][0])) < 3e-5
 
 
+class _Target4kb:
+    """Observed-data stand-in at 4 kb resolution (`get_feature_data(chrom, start, end)` -> [8000, 8000] for a 32 Mb window, with a few NaN bins)."""
+
+    def get_feature_data(self, chrom, start, end):
+        n = int((end - start) / 4000)
+        a = (start + 4000.0 * np.arange(n)) / 1e6
+        m = 1.0 / (1.0 + np.abs(a[:, None] - a[None, :])) + 1e-3 * np.sin(a)[:, None] * np.cos(a)[None, :]
+        m[::997, :] = np.nan
+        return m.astype(np.float32)
+
+
+def test_sv_drivers_two_models_and_targets_through_the_incremental_route(cuda):
+    """`_run_views` bookkeeping beyond the maps: TWO models (the reference's default call shape: predictions / normmats per model, each model
+    its own kept encodings) and observed-data targets for the reference views (`experiments`: nan-aware block means of the target window at
+    every level's zoom, log-ratio to the background, orca_predict.py:404-449) - identical to what `genomepredict` builds view by view."""
+    from orca_amd import sv_drivers
+    models = [M.H1esc(synthetic_seed=0), M.Hff(synthetic_seed=1)]
+    dev = synth.sv_driver_genome().to(cuda)
+    tgt = [_Target4kb(), _Target4kb()]
+    sv_drivers.clear_encoding_cache()
+    inc = P.process_del("chrS", 20_000_000, 20_404_000, dev, custom_models=models, target=tgt)
+    os.environ["ORCA_SV_INCREMENTAL"] = "0"
+    try:
+        whole = P.process_del("chrS", 20_000_000, 20_404_000, dev, custom_models=models, target=tgt)
+    finally:
+        del os.environ["ORCA_SV_INCREMENTAL"]
+    assert len(inc) == len(whole) == 3
+    for k, (a, b) in enumerate(zip(inc, whole)):
+        assert list(a.keys()) == list(b.keys()) and a["start_coords"] == b["start_coords"] and a["annos"] == b["annos"]
+        assert len(a["predictions"]) == len(b["predictions"]) == 2 and len(a["normmats"]) == 2
+        for m in range(2):
+            assert max(maxabs(x, y) for x, y in zip(a["predictions"][m], b["predictions"][m])) < 3e-5
+            assert all(np.array_equal(x, y) for x, y in zip(a["normmats"][m], b["normmats"][m]))
+        if k < 2:       # the reference views carry the observed data; the alternative allele has none (orca_predict.py:1484-1497)
+            assert len(a["experiments"]) == 2
+            for m in range(2):
+                for x, y in zip(a["experiments"][m], b["experiments"][m]):
+                    assert x.shape == y.shape == (250, 250) and np.array_equal(np.isnan(x), np.isnan(y)) and np.allclose(x, y, rtol=0, atol=0, equal_nan=True)
+        else:
+            assert a["experiments"] is None and b["experiments"] is None
+    assert max(maxabs(x, y) for x, y in zip(inc[0]["predictions"][0], inc[0]["predictions"][1])) > 1e-3      # two different models
+
+
 def test_sv_drivers_256mb_on_device(cuda):
     """window_radius=128000000 on the MI355X with a H1esc_256M-shaped model and the genome in HBM: each view of
     `process_del` equals a direct `genomepredict_256Mb` call on the same (independently gathered) codes and background,
