@@ -126,6 +126,8 @@ def measure_traffic_in_run(kernel_name, timeout_s=240):
     table = {"conv1d_k9_p16_kernel<cout=64,f16x2>": (re.compile(r"^void conv1d_k9_p16_kernel<64,"), 4000.0),
              "conv1d_k9_p16x_kernel<cout=96,f16x2>": (re.compile(r"^void conv1d_k9_p16x_kernel<\d, (true|false), 3, 96>"), 2500.0),
              "conv1d_first_mfma_p16_kernel<0,0,25>": (re.compile(r"^void conv1d_first_mfma_p16_kernel<0, 0, 25>"), 800.0)}
+    if any(k.startswith(("ROCPROF", "ROCP_", "ROCPROFILER")) or (k == "LD_PRELOAD" and "rocprof" in v) for k, v in os.environ.items()):
+        return None, "this run is itself under a profiler (its environment would be inherited by the counter passes)"
     if kernel_name not in table or shutil.which("rocprofv3") is None:
         return None, "no rocprofv3 on this box" if kernel_name in table else f"no counter recipe for {kernel_name}"
     rx, min_us = table[kernel_name]
