@@ -29,6 +29,22 @@ struct DBlockArgs {
   unsigned* flag;
 };
 
+// The block's result goes out with PLAIN (write-back) stores, unlike the per-layer kernels' write-through ones (m16_store_unit): a workgroup's units are
+// scattered - dilation 16: 16 bytes of every 128-byte line, 32: 64 bytes - and the 8 workgroups that share a line sit on one XCD, so its L2 merges them
+// into whole lines before they leave; written through, every unit went out as its own partial line.  tools/microbench_dblock.hip, us per launch at
+// B = 2, write-through -> write-back: d = 16 66.8 -> 55.5, d = 32 74.5 -> 61.7, d = 64 52.8 -> 48.0; single fp16 plane, B = 8: 106 -> 86, 108 -> 85,
+// 84 -> 77 (round 5; DBLOCK_STORE_WT=1 at compile time: the write-through form).
+#ifndef DBLOCK_STORE_WT
+#define DBLOCK_STORE_WT 0
+#endif
+__device__ __forceinline__ void db_store_unit(u32x4_t* p, const u32x4_t& v) {
+#if DBLOCK_STORE_WT
+  m16_store_unit(p, v);
+#else
+  *p = v;
+#endif
+}
+
 // ABL (tools/microbench_dblock.hip only, 0 in the library): 1 = no MFMAs, 2 = weight pieces fetched once (no DMA in the loop),
 // 4 = no gather, 8 = no operand reads, 16 = no piece barriers (timing only: races)
 template <int NS, int DT, int ABL = 0>
@@ -272,7 +288,7 @@ __global__ __launch_bounds__(512, NS == 1 ? 4 : 2) void conv2d_dblock_kernel(DBl
         p16_swap32(h1_, l1_);
         u32x4_t unit_;
         unit_.x = h0_; unit_.y = h1_; unit_.z = l0_; unit_.w = l1_;
-        if (pvalid) m16_store_unit(reinterpret_cast<u32x4_t*>(cur) + m16_plane(h * 4 + q, g, NS, H) + poff, unit_);
+        if (pvalid) db_store_unit(reinterpret_cast<u32x4_t*>(cur) + m16_plane(h * 4 + q, g, NS, H) + poff, unit_);
       }
     if (pvalid && vmax > 65504.f) overflow = true;
   } else {
@@ -288,7 +304,7 @@ __global__ __launch_bounds__(512, NS == 1 ? 4 : 2) void conv2d_dblock_kernel(DBl
         p16_swap32(a1_, b1_);
         u32x4_t unit_;
         unit_.x = a0_; unit_.y = a1_; unit_.z = b0_; unit_.w = b1_;
-        if (pvalid) m16_store_unit(reinterpret_cast<u32x4_t*>(cur) + m16_plane(h * 4 + 2 * qp + g, 0, NS, H) + poff, unit_);
+        if (pvalid) db_store_unit(reinterpret_cast<u32x4_t*>(cur) + m16_plane(h * 4 + 2 * qp + g, 0, NS, H) + poff, unit_);
       }
     if (DT == 1 && pvalid && vmax > 65504.f) overflow = true;
   }

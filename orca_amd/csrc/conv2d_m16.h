@@ -113,9 +113,9 @@ __global__ void p16_maxpool_kernel(const f32x4* __restrict__ x, long x_plen, f32
 // grid (n rows, noct octets), block 256 (pixel j): 4 500 independent workgroups per map (one row of ALL octets per workgroup was a serial
 // chain of 18 load -> pack -> store rounds on 1 000 waves: 59 us per map).
 template <int NS, int DT>
-__global__ void outer_sum_m16_kernel(const float* __restrict__ x, long sx_c, long sx_l, const float* __restrict__ de, long sd_c, long sd_h,
-                                     long sd_w, int nt, f32x4* __restrict__ out, int n, int o0, unsigned* flag) {
-  const int j = threadIdx.x, i = blockIdx.x, o = blockIdx.y + o0;
+__device__ __forceinline__ void outer_sum_m16_body(const float* __restrict__ x, long sx_c, long sx_l, const float* __restrict__ de, long sd_c, long sd_h,
+                                                   long sd_w, int nt, f32x4* __restrict__ out, int n, int o0, unsigned* flag, int i, int oy) {
+  const int j = threadIdx.x, o = oy + o0;
   bool ovf = false;
   float v[8];
 #pragma unroll
@@ -136,18 +136,22 @@ __global__ void outer_sum_m16_kernel(const float* __restrict__ x, long sx_c, lon
   for (int s = 0; s < NS; ++s) reinterpret_cast<u32x4_t*>(out)[m16_plane(o - o0, s, NS, n) + (long)i * M16_PX + j] = u[s];
   if (DT == 1 && ovf && flag) *flag = 1u;
 }
+template <int NS, int DT>
+__global__ void outer_sum_m16_kernel(const float* __restrict__ x, long sx_c, long sx_l, const float* __restrict__ de, long sd_c, long sd_h,
+                                     long sd_w, int nt, f32x4* __restrict__ out, int n, int o0, unsigned* flag) {
+  outer_sum_m16_body<NS, DT>(x, sx_c, sx_l, de, sd_c, sd_h, sd_w, nt, out, n, o0, flag, (int)blockIdx.x, (int)blockIdx.y);
+}
 
 // The separable part of the Decoder's first conv (lcombinerD.a on mat = x_i + x_j, orca_modules.py:462-465), exact fp32:
 //   tab[which][cls][pos][co] = sum_k sum_c wsep[which][cls][k][c][co] * x[c][pos + k - 1]       (taps inside [0, n) only)
 // which = 0: the row term, indexed by the pixel's row, one table per COLUMN class (0: first column, 1: interior, 2: last column - the
 // classes differ in which kx taps were summed into wsep); which = 1: the column term per ROW class.
-__global__ __launch_bounds__(256) void sep_tables_kernel(const float* __restrict__ x, long sx_c, long sx_l, const float* __restrict__ wsep,
-                                                         float* __restrict__ tab, int n) {
+__device__ __forceinline__ void sep_tables_body(const float* __restrict__ x, long sx_c, long sx_l, const float* __restrict__ wsep,
+                                                float* __restrict__ tab, int n, int pos, int wc, float (*part)[64]) {
   // grid (n, 6), block 256 = 64 couts x 4 groups of 32 input channels (partials reduced through LDS): 96 independent-load FMAs per thread.
   // 15 us per map (the weights come from L2 once per position: 150 MB).  Measured alternatives: ten positions per workgroup 28 us (150
   // workgroups of serial loads); one-wave workgroups without LDS (to run beside the other stream's conv workgroups) 22 us.
-  __shared__ float part[4][64];
-  const int pos = blockIdx.x, wc = blockIdx.y, co = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int co = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const float* w = wsep + (size_t)wc * 3 * 128 * 64;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
   for (int k = 0; k < 3; ++k) {
@@ -165,13 +169,18 @@ __global__ __launch_bounds__(256) void sep_tables_kernel(const float* __restrict
   __syncthreads();
   if (grp == 0) tab[((size_t)wc * n + pos) * 64 + co] = (part[0][co] + part[1][co]) + (part[2][co] + part[3][co]);
 }
+__global__ __launch_bounds__(256) void sep_tables_kernel(const float* __restrict__ x, long sx_c, long sx_l, const float* __restrict__ wsep,
+                                                         float* __restrict__ tab, int n) {
+  __shared__ float part[4][64];
+  sep_tables_body(x, sx_c, sx_l, wsep, tab, n, (int)blockIdx.x, (int)blockIdx.y, part);
+}
 
 // bilinear / nearest x2 upsample of y [nt][n/2][n/2] into octet o0 (channels 8*o0 .. +nt-1; the rest of the octet and octet
 // o0 + 1 = 0) of an M16 map.  grid n, block 256
 template <int NS, int DT>
-__global__ void upsample2d_m16_kernel(const float* __restrict__ y, long sy_c, long sy_h, long sy_w, int nt, f32x4* __restrict__ out, int n,
-                                      int o0, int bilinear, unsigned* flag) {
-  const int j = threadIdx.x, i = blockIdx.x, h = n / 2;
+__device__ __forceinline__ void upsample2d_m16_body(const float* __restrict__ y, long sy_c, long sy_h, long sy_w, int nt, f32x4* __restrict__ out, int n,
+                                                    int o0, int bilinear, unsigned* flag, int i) {
+  const int j = threadIdx.x, h = n / 2;
   float v[8];
 #pragma unroll
   for (int t = 0; t < 8; ++t) v[t] = 0.f;
@@ -201,6 +210,41 @@ __global__ void upsample2d_m16_kernel(const float* __restrict__ y, long sy_c, lo
     reinterpret_cast<u32x4_t*>(out)[m16_plane(o0 + 1, s, NS, n) + (long)i * M16_PX + j] = (u32x4_t)(0u);
   }
   if (DT == 1 && ovf && flag) *flag = 1u;
+}
+template <int NS, int DT>
+__global__ void upsample2d_m16_kernel(const float* __restrict__ y, long sy_c, long sy_h, long sy_w, int nt, f32x4* __restrict__ out, int n,
+                                      int o0, int bilinear, unsigned* flag) {
+  upsample2d_m16_body<NS, DT>(y, sy_c, sy_h, sy_w, nt, out, n, o0, bilinear, flag, (int)blockIdx.x);
+}
+
+// Everything a Decoder forward computes from its INPUTS alone, for up to 8 maps of the batch, in ONE launch (VERDICT r4 #1 iii: until round 5 three
+// launches per map - 44 us + five launch gaps per forward at B = 2): grid (n, roles, maps), block 256; role = blockIdx.y:
+//   [0, noct)          outer_sum_m16_body: octet role of IN (the Decoder's distenc chunk / Decoder_1m's 16 outer-sum octets)
+//   [noct, noct + 6)   sep_tables_body: table role - noct of the separable part of lcombinerD.a          (nsep = 6, Decoder only)
+//   noct + nsep        upsample2d_m16_body: the coarse prediction into octets 8, 9 of A                    (when y is given)
+// The roles write disjoint buffers (IN, TAB, octets 8-9 of A; the convs that fill A's octets 0-7 come later and do not touch 8-9).
+struct M16HeadArgs {
+  const float* x[8];
+  const float* de[8];
+  const float* y[8];
+  long sx_c, sx_l, sd_c, sd_h, sd_w, sy_c, sy_h, sy_w;
+  f32x4* in; long in_bs;      // IN maps (units per map)
+  float* tab; long tab_bs;    // tables (floats per map)
+  f32x4* a; long a_bs;        // A maps
+  const float* wsep;
+  int nt, n, o0, noct, nsep, bilinear;
+  unsigned* flag;
+};
+template <int NS, int DT>
+__global__ __launch_bounds__(256) void decoder_head_m16_kernel(M16HeadArgs a) {
+  __shared__ float part[4][64];
+  const int i = blockIdx.x, role = blockIdx.y, b = blockIdx.z;
+  if (role < a.noct)
+    outer_sum_m16_body<NS, DT>(a.x[b], a.sx_c, a.sx_l, a.de[b], a.sd_c, a.sd_h, a.sd_w, a.nt, a.in + b * a.in_bs, a.n, a.o0, a.flag, i, role);
+  else if (role < a.noct + a.nsep)
+    sep_tables_body(a.x[b], a.sx_c, a.sx_l, a.wsep, a.tab + b * a.tab_bs, a.n, i, role - a.noct, part);
+  else
+    upsample2d_m16_body<NS, DT>(a.y[b], a.sy_c, a.sy_h, a.sy_w, a.nt, a.a + b * a.a_bs, a.n, 8, a.bilinear, a.flag, i);
 }
 
 // `final` head + symmetrisation on a 64-channel M16 map (see final_sym_kernel); a.cur = the map's units, a.cur_bs in units.

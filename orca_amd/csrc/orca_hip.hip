@@ -1917,14 +1917,21 @@ static int decoder_m16(orca_ctx* ctx, orca_net* net, const RowSrc& x, long sx_c,
     f32x4* T = T0 + b0 * sz32;
     hipStream_t s = ctx->stream;
     float* TAB = is1m ? nullptr : TAB0 + b0 * tabsz;
-    for (int b = 0; b < nb; ++b) {
-      hipLaunchKernelGGL((outer_sum_m16_kernel<NS, DT>), dim3((unsigned)n, (unsigned)oIN), dim3(ORCA_LDW), 0, s, x.at(b0 + b), sx_c, sx_l, de.at(b0 + b), sd_c, sd_h,
-                         sd_w, nt2, IN + b * szIN, n, is1m ? 0 : 16, ctx->d_flag);
-      LAUNCHCHECK("outer_sum_m16_kernel");
-      if (!is1m) {
-        hipLaunchKernelGGL(sep_tables_kernel, dim3((unsigned)n, 6u), dim3(256), 0, s, x.at(b0 + b), sx_c, sx_l, net->d_sep, TAB + b * tabsz, n);
-        LAUNCHCHECK("sep_tables_kernel");
-      }
+    // everything computed from the inputs alone - IN (outer sum / distenc chunk), the separable tables, the upsampled coarse prediction - in one
+    // launch per 8 maps (decoder_head_m16_kernel)
+    for (int c0 = 0; c0 < nb; c0 += 8) {
+      const int nc = nb - c0 < 8 ? nb - c0 : 8;
+      M16HeadArgs ha{};
+      for (int b = 0; b < nc; ++b) { ha.x[b] = x.at(b0 + c0 + b); ha.de[b] = de.at(b0 + c0 + b); ha.y[b] = (!is1m && y) ? y.at(b0 + c0 + b) : nullptr; }
+      ha.sx_c = sx_c; ha.sx_l = sx_l; ha.sd_c = sd_c; ha.sd_h = sd_h; ha.sd_w = sd_w; ha.sy_c = sy_c; ha.sy_h = sy_h; ha.sy_w = sy_w;
+      ha.in = IN + c0 * szIN; ha.in_bs = (long)szIN;
+      ha.tab = is1m ? nullptr : TAB + c0 * tabsz; ha.tab_bs = (long)tabsz;
+      ha.a = A + c0 * szA; ha.a_bs = (long)szA;
+      ha.wsep = net->d_sep; ha.nt = nt2; ha.n = n; ha.o0 = is1m ? 0 : 16; ha.noct = oIN; ha.nsep = is1m ? 0 : 6;
+      ha.bilinear = net->upsample_mode == ORCA_UPSAMPLE_BILINEAR ? 1 : 0; ha.flag = ctx->d_flag;
+      const unsigned roles = (unsigned)(oIN + ha.nsep + ((!is1m && y) ? 1 : 0));
+      hipLaunchKernelGGL((decoder_head_m16_kernel<NS, DT>), dim3((unsigned)n, roles, (unsigned)nc), dim3(256), 0, s, ha);
+      LAUNCHCHECK("decoder_head_m16_kernel");
     }
     const ConvLayer* L = net->convs.data();
     const ConvLayer* pairs;
@@ -1939,11 +1946,7 @@ static int decoder_m16(orca_ctx* ctx, orca_net* net, const RowSrc& x, long sx_c,
       C2(L[3], Bf, sz64, 8, A, szA, oA, Cf, sz64, 1);           // A[octets 0..7] = combinerD(.) + .
       pairs = L + 8; npairs = 28;
       if (y) {
-        for (int b = 0; b < nb; ++b) {                            // octets 8, 9 of A: the coarse prediction
-          hipLaunchKernelGGL((upsample2d_m16_kernel<NS, DT>), dim3((unsigned)n), dim3(ORCA_LDW), 0, s, y.at(b0 + b), sy_c, sy_h, sy_w, nt2,
-                             A + b * szA, n, 8, net->upsample_mode == ORCA_UPSAMPLE_BILINEAR ? 1 : 0, ctx->d_flag);
-          LAUNCHCHECK("upsample2d_m16_kernel");
-        }
+        // (octets 8, 9 of A - the upsampled coarse prediction - were written by the head launch)
         C2(L[4], A, szA, oA, Bf, sz64, 8, nullptr, 0, 0);
         C2(L[5], Bf, sz64, 8, Cf, sz64, 8, nullptr, 0, 0);
         C2(L[6], Cf, sz64, 8, Bf, sz64, 8, nullptr, 0, 1);
