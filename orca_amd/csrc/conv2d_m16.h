@@ -110,7 +110,7 @@ __global__ void p16_maxpool_kernel(const f32x4* __restrict__ x, long x_plen, f32
 // ---- producers / consumers at the ends of a Decoder ---------------------------------------------------------------
 // mat[c][i][j] = x[c][i] + x[c][j] (c < 128); channels 128..128+nt-1 = distenc[t][i][j]; other channels and pad pixels 0.
 // `o0`: first channel octet produced (the Decoder only materialises octets 16, 17 = distenc + padding; octet o lands in plane o - o0).
-// grid (n rows, noct octets), block 256 (pixel j): 4 500 independent workgroups per map (one row of ALL octets per workgroup was a serial
+// (role of decoder_head_m16_kernel) workgroup = (row i, octet), block 256 (pixel j): 4 500 independent workgroups per map (one row of ALL octets per workgroup was a serial
 // chain of 18 load -> pack -> store rounds on 1 000 waves: 59 us per map).
 template <int NS, int DT>
 __device__ __forceinline__ void outer_sum_m16_body(const float* __restrict__ x, long sx_c, long sx_l, const float* __restrict__ de, long sd_c, long sd_h,
@@ -136,47 +136,53 @@ __device__ __forceinline__ void outer_sum_m16_body(const float* __restrict__ x, 
   for (int s = 0; s < NS; ++s) reinterpret_cast<u32x4_t*>(out)[m16_plane(o - o0, s, NS, n) + (long)i * M16_PX + j] = u[s];
   if (DT == 1 && ovf && flag) *flag = 1u;
 }
-template <int NS, int DT>
-__global__ void outer_sum_m16_kernel(const float* __restrict__ x, long sx_c, long sx_l, const float* __restrict__ de, long sd_c, long sd_h,
-                                     long sd_w, int nt, f32x4* __restrict__ out, int n, int o0, unsigned* flag) {
-  outer_sum_m16_body<NS, DT>(x, sx_c, sx_l, de, sd_c, sd_h, sd_w, nt, out, n, o0, flag, (int)blockIdx.x, (int)blockIdx.y);
-}
 
 // The separable part of the Decoder's first conv (lcombinerD.a on mat = x_i + x_j, orca_modules.py:462-465), exact fp32:
 //   tab[which][cls][pos][co] = sum_k sum_c wsep[which][cls][k][c][co] * x[c][pos + k - 1]       (taps inside [0, n) only)
 // which = 0: the row term, indexed by the pixel's row, one table per COLUMN class (0: first column, 1: interior, 2: last column - the
 // classes differ in which kx taps were summed into wsep); which = 1: the column term per ROW class.
+#define SEP_TILE 16
+struct SepSmem { float xs[128][SEP_TILE + 4]; float part[4][SEP_TILE][64]; };
 __device__ __forceinline__ void sep_tables_body(const float* __restrict__ x, long sx_c, long sx_l, const float* __restrict__ wsep,
-                                                float* __restrict__ tab, int n, int pos, int wc, float (*part)[64]) {
-  // grid (n, 6), block 256 = 64 couts x 4 groups of 32 input channels (partials reduced through LDS): 96 independent-load FMAs per thread.
-  // 15 us per map (the weights come from L2 once per position: 150 MB).  Measured alternatives: ten positions per workgroup 28 us (150
-  // workgroups of serial loads); one-wave workgroups without LDS (to run beside the other stream's conv workgroups) 22 us.
+                                                float* __restrict__ tab, int n, int tile, int wc, SepSmem& sm) {
+  // One workgroup = weight class wc x 16 positions; block 256 = 64 couts x 4 groups of 32 input channels (partials reduced through LDS).  A thread
+  // loads each of its 96 weights ONCE and uses it for the 16 positions (x tile in LDS, read as broadcast float4s): 96 workgroups per map read
+  // 9.4 MB of weights from L2.  Until round 5 a workgroup was ONE position (grid (n, 6)): 150 MB of L2 reads and 11 us per map (measured then:
+  // ten positions per workgroup with serial loads 28 us; one-wave workgroups without LDS 22 us).
+  const int t0 = tile * SEP_TILE;
+  if (t0 >= n) return;
   const int co = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  const float* w = wsep + (size_t)wc * 3 * 128 * 64;
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int k = 0; k < 3; ++k) {
-    const int p = pos + k - 1;
-    if (p < 0 || p >= n) continue;
-    const float* wk = w + ((size_t)k * 128 + grp * 32) * 64 + co;
-    const float* xk = x + (long)(grp * 32) * sx_c + (long)p * sx_l;
-#pragma unroll
-    for (int c = 0; c < 32; c += 4) {
-#pragma unroll
-      for (int u = 0; u < 4; ++u) acc[u] = fmaf(wk[(c + u) * 64], xk[(c + u) * sx_c], acc[u]);
-    }
+  for (int e = threadIdx.x; e < 128 * (SEP_TILE + 2); e += 256) {
+    const int c = e / (SEP_TILE + 2), q = e % (SEP_TILE + 2), p = t0 - 1 + q;
+    sm.xs[c][q] = (p >= 0 && p < n) ? x[(long)c * sx_c + (long)p * sx_l] : 0.f;     // taps outside [0, n) contribute 0
   }
-  part[grp][co] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
   __syncthreads();
-  if (grp == 0) tab[((size_t)wc * n + pos) * 64 + co] = (part[0][co] + part[1][co]) + (part[2][co] + part[3][co]);
-}
-__global__ __launch_bounds__(256) void sep_tables_kernel(const float* __restrict__ x, long sx_c, long sx_l, const float* __restrict__ wsep,
-                                                         float* __restrict__ tab, int n) {
-  __shared__ float part[4][64];
-  sep_tables_body(x, sx_c, sx_l, wsep, tab, n, (int)blockIdx.x, (int)blockIdx.y, part);
+  float acc[SEP_TILE];
+#pragma unroll
+  for (int p = 0; p < SEP_TILE; ++p) acc[p] = 0.f;
+  const float* w = wsep + (size_t)wc * 3 * 128 * 64 + co;
+#pragma unroll 4
+  for (int cc = 0; cc < 32; ++cc) {
+    const int c = grp * 32 + cc;
+    const float w0 = w[(size_t)(0 * 128 + c) * 64], w1 = w[(size_t)(1 * 128 + c) * 64], w2 = w[(size_t)(2 * 128 + c) * 64];
+    float xr[SEP_TILE + 4];
+#pragma unroll
+    for (int q4 = 0; q4 < (SEP_TILE + 4) / 4; ++q4) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(&sm.xs[c][4 * q4]);
+      xr[4 * q4] = v.x; xr[4 * q4 + 1] = v.y; xr[4 * q4 + 2] = v.z; xr[4 * q4 + 3] = v.w;
+    }
+#pragma unroll
+    for (int p = 0; p < SEP_TILE; ++p) acc[p] = fmaf(w2, xr[p + 2], fmaf(w1, xr[p + 1], fmaf(w0, xr[p], acc[p])));
+  }
+#pragma unroll
+  for (int p = 0; p < SEP_TILE; ++p) sm.part[grp][p][co] = acc[p];
+  __syncthreads();
+  for (int p = grp; p < SEP_TILE; p += 4)
+    if (t0 + p < n) tab[((size_t)wc * n + t0 + p) * 64 + co] = (sm.part[0][p][co] + sm.part[1][p][co]) + (sm.part[2][p][co] + sm.part[3][p][co]);
 }
 
 // bilinear / nearest x2 upsample of y [nt][n/2][n/2] into octet o0 (channels 8*o0 .. +nt-1; the rest of the octet and octet
-// o0 + 1 = 0) of an M16 map.  grid n, block 256
+// o0 + 1 = 0) of an M16 map.  (role of decoder_head_m16_kernel) workgroup = row i, block 256
 template <int NS, int DT>
 __device__ __forceinline__ void upsample2d_m16_body(const float* __restrict__ y, long sy_c, long sy_h, long sy_w, int nt, f32x4* __restrict__ out, int n,
                                                     int o0, int bilinear, unsigned* flag, int i) {
@@ -211,16 +217,11 @@ __device__ __forceinline__ void upsample2d_m16_body(const float* __restrict__ y,
   }
   if (DT == 1 && ovf && flag) *flag = 1u;
 }
-template <int NS, int DT>
-__global__ void upsample2d_m16_kernel(const float* __restrict__ y, long sy_c, long sy_h, long sy_w, int nt, f32x4* __restrict__ out, int n,
-                                      int o0, int bilinear, unsigned* flag) {
-  upsample2d_m16_body<NS, DT>(y, sy_c, sy_h, sy_w, nt, out, n, o0, bilinear, flag, (int)blockIdx.x);
-}
 
 // Everything a Decoder forward computes from its INPUTS alone, for up to 8 maps of the batch, in ONE launch (VERDICT r4 #1 iii: until round 5 three
 // launches per map - 44 us + five launch gaps per forward at B = 2): grid (n, roles, maps), block 256; role = blockIdx.y:
 //   [0, noct)          outer_sum_m16_body: octet role of IN (the Decoder's distenc chunk / Decoder_1m's 16 outer-sum octets)
-//   [noct, noct + 6)   sep_tables_body: table role - noct of the separable part of lcombinerD.a          (nsep = 6, Decoder only)
+//   [noct, noct + 6)   sep_tables_body: weight class role - noct of the separable tables, blockIdx.x = tile of 16 positions (nsep = 6, Decoder only)
 //   noct + nsep        upsample2d_m16_body: the coarse prediction into octets 8, 9 of A                    (when y is given)
 // The roles write disjoint buffers (IN, TAB, octets 8-9 of A; the convs that fill A's octets 0-7 come later and do not touch 8-9).
 struct M16HeadArgs {
@@ -237,12 +238,12 @@ struct M16HeadArgs {
 };
 template <int NS, int DT>
 __global__ __launch_bounds__(256) void decoder_head_m16_kernel(M16HeadArgs a) {
-  __shared__ float part[4][64];
+  __shared__ SepSmem sm;
   const int i = blockIdx.x, role = blockIdx.y, b = blockIdx.z;
   if (role < a.noct)
     outer_sum_m16_body<NS, DT>(a.x[b], a.sx_c, a.sx_l, a.de[b], a.sd_c, a.sd_h, a.sd_w, a.nt, a.in + b * a.in_bs, a.n, a.o0, a.flag, i, role);
   else if (role < a.noct + a.nsep)
-    sep_tables_body(a.x[b], a.sx_c, a.sx_l, a.wsep, a.tab + b * a.tab_bs, a.n, i, role - a.noct, part);
+    sep_tables_body(a.x[b], a.sx_c, a.sx_l, a.wsep, a.tab + b * a.tab_bs, a.n, i, role - a.noct, sm);   // i = tile of 16 positions (the rest exit)
   else
     upsample2d_m16_body<NS, DT>(a.y[b], a.sy_c, a.sy_h, a.sy_w, a.nt, a.a + b * a.a_bs, a.n, 8, a.bilinear, a.flag, i);
 }

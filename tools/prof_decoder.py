@@ -3,12 +3,17 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from tests.util import product_module
+# usage: prof_decoder.py [B = 2] [precision = f16x2 | f16 | bf16]
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+prec = sys.argv[2] if len(sys.argv) > 2 else None
 dev = torch.device("cuda:0")
 dec = product_module("Decoder", 0, device=dev)
+if prec:
+    dec.precision = prec
 rs = np.random.RandomState(0)
-x = torch.from_numpy(rs.randn(2, 128, 250).astype(np.float32)).to(dev)
-de = torch.from_numpy(rs.randn(2, 1, 250, 250).astype(np.float32)).to(dev)
-y = torch.from_numpy(rs.randn(2, 1, 125, 125).astype(np.float32)).to(dev)
+x = torch.from_numpy(rs.randn(B, 128, 250).astype(np.float32)).to(dev)
+de = torch.from_numpy(rs.randn(B, 1, 250, 250).astype(np.float32)).to(dev)
+y = torch.from_numpy(rs.randn(B, 1, 125, 125).astype(np.float32)).to(dev)
 for _ in range(2):
     out = dec(x, de, y)
 torch.cuda.synchronize()
@@ -17,4 +22,4 @@ ev0.record()
 for _ in range(5):
     out = dec(x, de, y)
 ev1.record(); torch.cuda.synchronize()
-print(f"decoder B=2: {ev0.elapsed_time(ev1) / 5:.3f} ms per forward")
+print(f"decoder B={B} {prec or 'f16x2'}: {ev0.elapsed_time(ev1) / 5:.3f} ms per forward")
