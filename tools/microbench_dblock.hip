@@ -72,6 +72,24 @@ int main() {
   a.dil = 16;
   for (int B : {1, 2, 4, 8}) { run<2, 1, 0>(a, B, "v1"); run2<2, 1, 256, 0>(a, B, "v2"); }
   for (int B : {2, 8}) { run<1, 1, 0>(a, B, "v1 f16"); run2<1, 1, 256, 0>(a, B, "v2 f16"); }
+  if (getenv("DBLOCK_V1_ABL")) {
+    for (int d : {16, 32, 64}) {
+      a.dil = d;
+      for (int rep = 0; rep < 2; ++rep) {
+        run<2, 1, 0>(a, 2, "v1 full");
+        run<2, 1, 1>(a, 2, "no MFMA");
+        run<2, 1, 2>(a, 2, "no W DMA in the loop");
+        run<2, 1, 4>(a, 2, "no gather");
+        run<2, 1, 8>(a, 2, "no operand reads");
+        run<2, 1, 16>(a, 2, "one barrier per layer");
+        run<2, 1, 1 + 8>(a, 2, "no MFMA, no operand reads");
+        run<2, 1, 1 + 2 + 8>(a, 2, "no MFMA, no reads, no DMA");
+        run<2, 1, 1 + 2 + 4 + 8>(a, 2, "only barriers + epilogues");
+        run<2, 1, 1 + 2 + 4 + 8 + 16>(a, 2, "only epilogues");
+      }
+    }
+    return 0;
+  }
   if (getenv("DBLOCK_V2_ABL")) {
     for (int d : {32, 64}) {
       a.dil = d;

@@ -16,7 +16,7 @@ for f in ("bench.json", "bench_under_rocprof.json"):
     lines = [l for l in open(os.path.join(src, f)).read().splitlines() if l.startswith("{")]
     open(os.path.join(dst, f"{tag}_{f}"), "w").write(lines[-1] + "\n")
 
-for f in ("configs.json", "config5_1024.json"):
+for f in ("configs.json", "config5_1024.json", "bench_gaps.txt"):
     if os.path.exists(os.path.join(src, f)) and os.path.getsize(os.path.join(src, f)) > 2:
         shutil.copy(os.path.join(src, f), os.path.join(dst, f"{tag}_{f}"))
 

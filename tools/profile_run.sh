@@ -9,6 +9,7 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -o bench -- python $ROOT/bench.py --no-cpu-baseline --no-configs > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
+python $ROOT/tools/trace_gaps.py $OUT/bench/bench_kernel_trace.csv 10 > $OUT/bench_gaps.txt 2>&1
 python $ROOT/bench.py > $OUT/bench.json 2> $OUT/bench.err
 SQ="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"
 for mode in f16x2 bf16; do
