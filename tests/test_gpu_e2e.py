@@ -464,3 +464,45 @@ def test_process_ins_breakpoint_custom_against_the_reference_with_real_networks(
             elif "_stats_" in k:
                 assert abs(v[0] - ref[0]) < 1e-4 * 62500 and abs(v[1] / ref[1] - 1) < 1e-4 and abs(v[2] - ref[2]) < 1e-4, (k, v, ref)
         print(f"{fn} vs the reference with real networks (call {attempt + 1}): {views} views, worst max-abs on the sampled pixels {worst:.3g}")
+
+
+def test_process_del_256mb_against_the_reference_with_real_networks(cuda):
+    """The 256 Mb branch of SURVEY 8(f1) against the ORACLE: the reference's own `process_del(..., window_radius=128000000)`
+    (orca_predict.py:1510-1817 -> three `genomepredict_256Mb` calls, :652-878) with the reference's own networks (orca_modules Encoder / Encoder2 /
+    Encoder3 / four Decoders, synthetic weights; the backgrounds `_retrieve_multi` reads and the targets the reference cannot do without at 256 Mb are
+    the stand-ins of G13) is the fixture G25 (tools/make_golden.py --svreal --only G25, ~75 min of PyTorch CPU); here the same call through orca_amd
+    on the MI355X with the genome resident in HBM - ref.l and ref.r from ONE Encoder pass per strand (orca_predict.shared_encodings), the alternative
+    allele assembled on the device: coordinates exactly, maps at the north-star 1e-4."""
+    from tests import standins
+    path = os.path.join(os.path.dirname(__file__), "golden", "G25_sv_del256_real_nets.npz")
+    if not os.path.exists(path):
+        pytest.skip("G25 fixture not generated")
+    g = np.load(path)
+    model = M.H1esc_256M(synthetic_seed=0)
+    saved = dict(P.model_dict_global)
+    P.model_dict_global["h1esc_256m"], P.model_dict_global["hff_256m"] = standins.Background256(0), standins.Background256(1)
+    try:
+        dev = synth.sv_driver_genome_256().to(cuda)
+        name, fn, a, kw = synth.sv_driver_cases_256()[0]
+        outs = P.process_del(*a, dev, custom_models=[model], target=[standins.FakeTarget256()], use_cuda=True, window_radius=128000000,
+                             padding_chr="chr1", **kw)
+    finally:
+        P.model_dict_global.clear()
+        P.model_dict_global.update(saved)
+    got = synth.summarize_outputs(outs, stride=5)
+    views = len(outs)
+    assert views == 3 and sum(1 for k in g.files if k.endswith("_chr")) == views
+    worst = 0.0
+    for k, v in got.items():
+        ref = g["del256." + k]
+        if k.endswith(("_start", "_end")):
+            assert np.array_equal(v, ref), k
+        elif k.endswith(("_chr", "_annos")):
+            assert str(v[0]) == str(ref[0]), k
+        elif "_sub_" in k:
+            worst = max(worst, maxabs(v, ref))
+            assert maxabs(v, ref) < 1e-4 and pearson(v, ref) > 0.999999, (k, maxabs(v, ref))
+        elif "_stats_" in k:
+            assert abs(v[0] - ref[0]) < 1e-4 * 62500 and abs(v[1] / ref[1] - 1) < 1e-4 and abs(v[2] - ref[2]) < 1e-4, (k, v, ref)
+    assert maxabs(got["o0_m0_sub_0"], got[f"o{views - 1}_m0_sub_0"]) > 1e-3      # the deletion changes the maps
+    print(f"process_del at 256 Mb vs the reference with real networks: {views} views, worst max-abs on the sampled pixels {worst:.3g}")

@@ -89,7 +89,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full32m", action="store_true")
     ap.add_argument("--config3", action="store_true", help="G17: rows 0 and 5 of BASELINE config 3 (HFF-shaped model, 8 x 32 Mb), ~10 min of CPU")
-    ap.add_argument("--svreal", action="store_true", help="G22: the reference's process_del with the real orca_modules networks at 32 Mb, ~13 min of CPU")
+    ap.add_argument("--svreal", action="store_true", help="G22-G25: the reference's process_* drivers with the real orca_modules networks (G22-24: 32 Mb, 13-20 min of CPU each; G25: process_del at 256 Mb, ~75 min)")
     ap.add_argument("--only", default="")
     args = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
@@ -483,6 +483,49 @@ def main():
                 print("G24", name, len(outs), "views %.1fs" % (time.time() - t1), flush=True)
                 np.savez_compressed(path24, **d)
             print("G24 done %.1fs" % (time.time() - t))
+
+        # ---- G25: a 256 Mb structural-variant driver of the reference - process_del with window_radius=128000000 - with the REAL networks
+        #      (orca_modules Encoder / Encoder2 / Encoder3 / four Decoders): three genomepredict_256Mb calls, ~25 min of CPU each.  Resumable
+        #      view by view (every finished genomepredict_256Mb call is kept under /tmp/g25_view<i>.pkl) ------------------------------------------
+        if args.svreal and want("G25"):
+            import pickle
+            import orca_predict as op
+            genome = synth.sv_driver_genome_256()
+            op.h1esc_256m, op.hff_256m = standins.Background256(0), standins.Background256(1)   # what _retrieve_multi reads
+            op.target_dict_global["fake"] = type("T", (standins.FakeTarget256, op.Genomic2DFeatures), {"__init__": lambda self: None})()
+
+            class Ref256(torch.nn.Module):
+                def __init__(self, seed):
+                    super().__init__()
+                    self.net0 = load_synth(om.Encoder(), seed=seed)
+                    self.net1 = load_synth(om.Encoder2(), seed=seed)
+                    self.net = load_synth(om.Encoder3(), seed=seed)
+                    self.denets = {lv: load_synth(om.Decoder(upsample_mode="bilinear"), seed=seed + lv) for lv in (32, 64, 128, 256)}
+
+            real, ncall = op.genomepredict_256Mb, [0]
+
+            def kept(*a, **k):
+                path = "/tmp/g25_view%d.pkl" % ncall[0]
+                ncall[0] += 1
+                if os.path.exists(path):
+                    return pickle.load(open(path, "rb"))
+                t1 = time.time()
+                out = real(*a, **k)
+                pickle.dump(out, open(path, "wb"))
+                print("G25 view", ncall[0] - 1, "%.1fs" % (time.time() - t1), flush=True)
+                return out
+
+            op.genomepredict_256Mb = kept
+            t = time.time()
+            name, fn, a, kw = synth.sv_driver_cases_256()[0]
+            assert fn == "process_del"
+            outs = op.process_del(*a, genome, custom_models=[Ref256(0)], target=["fake"], use_cuda=False, window_radius=128000000,
+                                  padding_chr="chr1", **kw)
+            op.genomepredict_256Mb = real
+            d = {f"del256.{k}": v for k, v in synth.summarize_outputs(outs, stride=5).items()}
+            d["t_cpu_s"] = np.array([time.time() - t])
+            np.savez_compressed(os.path.join(GOLD, "G25_sv_del256_real_nets.npz"), **d)
+            print("G25 done %.1fs" % (time.time() - t), len(outs), "views")
 
         # ---- G8: one full 32 Mb H1-ESC-shaped forward, both strands ---------------
         if args.full32m and want("G8"):
