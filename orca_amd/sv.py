@@ -437,7 +437,7 @@ def _window_outputs(model, merged, starts, params, mchr):
 
 
 def sv_screen(models, genome_codes, svs, chrlen, mchr="chrS", rank=0, world=1, incremental=True, min_uses=3, stats=None, on_result=None,
-              streams=None):
+              streams=None, group=2):
     """Predict reference and alternative allele (6 maps each, per model) for this rank's share of ``svs``
     (independent windows: replicas, no collective).  genome_codes: [chrlen] uint8 tensor on the MI355X.
     Returns {sv_index: {"sv": SV, "ref": output_dict, "alt": output_dict}} with genomepredict's output dicts.
@@ -454,7 +454,10 @@ def sv_screen(models, genome_codes, svs, chrlen, mchr="chrS", rank=0, world=1, i
     ``incremental=False`` is the reference's cost structure: two independent `genomepredict` calls per variant.
     ``on_result(i, entry)``: called per variant INSTEAD of collecting the entries (a 1 024-variant screen is 12 288 maps = 3 GB).
     ``streams``: auxiliary contexts the local re-encodes of a variant are dealt to (`encode_windows`; default $ORCA_SV_STREAMS or 4, 0 = all
-    on the caller's stream)."""
+    on the caller's stream).
+    ``group``: variants per pass of Encoder2 + decoders (default 2 = batches of 8 maps per level: a Decoder forward costs 0.97 ms per map at
+    B = 8 against 1.00 at B = 4 and 1.12 at B = 2, tools/prof_decoder.py; a map does not depend on the batch it is computed in, so the
+    results are the same bit for bit - tests/test_gpu_sv_incremental.py)."""
     import os
     from . import dist, orca_predict
     res = {}
@@ -487,46 +490,55 @@ def sv_screen(models, genome_codes, svs, chrlen, mchr="chrS", rank=0, world=1, i
             streams = int(os.environ.get("ORCA_SV_STREAMS", "4"))
         pool = engine.context_pool(genome_codes.device, streams) if (streams > 0 and genome_codes.is_cuda) else None
         dev = genome_codes.device
-        units = [(i, mi) for i in mine for mi in range(len(models))]          # one (variant, model) per pass of the pipeline below
-        slots = [{"enc0": torch.empty((4, 128, nbins), dtype=torch.float32, device=dev), "ev": torch.cuda.Event() if pool else None} for _ in range(2)]
+        group = max(1, int(group))
+        chunks = [tuple(mine[c:c + group]) for c in range(0, len(mine), group)]
+        units = [(ch, mi) for ch in chunks for mi in range(len(models))]     # one (group of variants, model) per pass of the pipeline below
+        slots = [{"enc0": torch.empty((4 * group, 128, nbins), dtype=torch.float32, device=dev), "ev": torch.cuda.Event() if pool else None} for _ in range(2)]
         plans = {}
 
-        def plan(i):
-            if i not in plans:
+        def plan(ch):
+            """windows of a group of variants: [ref, alt] of each, in order"""
+            if ch not in plans:
                 plans.clear()
-                rp, rw, rm, ap, aw, am = sv_windows(svs[i], chrlen)
-                plans[i] = {"rp": rp, "ap": ap, "params": [(rm, rw), (am, aw)], "codes": torch.stack([assemble_codes(genome_codes, rp), assemble_codes(genome_codes, ap)])}
-            return plans[i]
+                pieces, params, codes = [], [], []
+                for i in ch:
+                    rp, rw, rm, ap, aw, am = sv_windows(svs[i], chrlen)
+                    pieces += [rp, ap]
+                    params += [(rm, rw), (am, aw)]
+                    codes += [assemble_codes(genome_codes, rp), assemble_codes(genome_codes, ap)]
+                plans[ch] = {"pieces": pieces, "params": params, "codes": torch.stack(codes)}
+            return plans[ch]
 
         def prep(k):
             """Issue unit k's Encoder outputs into slot k % 2: on the pool's side stream and contexts when there is a pool (the caller's
             stream - the previous unit's decoders - is not involved), else right here."""
-            i, mi = units[k]
+            ch, mi = units[k]
             slot = slots[k % 2]
             if pool is None:
-                pl = plan(i)
-                slot["n"] = encode_windows(caches[mi], [pl["rp"], pl["ap"]], pl["codes"], slot["enc0"], build=False)
+                pl = plan(ch)
+                slot["n"] = encode_windows(caches[mi], pl["pieces"], pl["codes"], slot["enc0"][:4 * len(ch)], build=False)
                 return
             with torch.cuda.stream(pool.side):
-                pl = plan(i)
-                slot["n"] = encode_windows(caches[mi], [pl["rp"], pl["ap"]], pl["codes"], slot["enc0"], build=False, pool=pool, defer_join=True)
+                pl = plan(ch)
+                slot["n"] = encode_windows(caches[mi], pl["pieces"], pl["codes"], slot["enc0"][:4 * len(ch)], build=False, pool=pool, defer_join=True)
                 slot["ev"].record(pool.side)
 
         ctx = engine.get_context(dev) if genome_codes.is_cuda else None
         main = torch.cuda.current_stream(dev) if pool else None
-        entry = None
         with engine.defer_overflow_guard():                   # ONE fp16-range check per unit (below), not one per module forward
             if pool is not None:
                 pool.side.wait_stream(main)                   # the chromosome encodings above
             if units:
                 prep(0)
             enc_over = pool.take_overflow() if pool else False
-            for k, (i, mi) in enumerate(units):
-                model, slot, pl = models[mi], slots[k % 2], plan(units[k][0])
+            entries = {}
+            for k, (ch, mi) in enumerate(units):
+                model, slot, pl = models[mi], slots[k % 2], plan(ch)
+                enc0 = slot["enc0"][:4 * len(ch)]
                 if pool is not None:
                     main.wait_event(slot["ev"])
                     pool.wait_join(main)
-                merged, starts = _cascade_windows(model, slot["enc0"], pl["params"])
+                merged, starts = _cascade_windows(model, enc0, pl["params"])
                 # the NEXT unit's local encodes are issued now: they run on the pool's streams while this unit's decoders (a chain of
                 # launches with ramps and tails, matrix pipe busy a quarter of the time) hold the caller's stream
                 nxt_over = False
@@ -541,24 +553,28 @@ def sv_screen(models, genome_codes, svs, chrlen, mchr="chrS", rank=0, world=1, i
                     import warnings
                     warnings.warn("orca_amd: an activation left the fp16 range; recomputing with range-safe arithmetic (bf16x3 / f32)")
                     with engine.force_safe_precision():
-                        slot["n"] = encode_windows(caches[mi], [pl["rp"], pl["ap"]], pl["codes"], slot["enc0"], build=False)
-                        merged, starts = _cascade_windows(model, slot["enc0"], pl["params"])
+                        slot["n"] = encode_windows(caches[mi], pl["pieces"], pl["codes"], enc0, build=False)
+                        merged, starts = _cascade_windows(model, enc0, pl["params"])
                     ctx.take_overflow()
                 encoded += slot["n"]
-                r, a = _window_outputs(model, merged, starts, pl["params"], mchr)
-                if mi == 0:
-                    entry = {"sv": svs[i], "ref": r, "alt": a}
-                else:
-                    for o, n in ((entry["ref"], r), (entry["alt"], a)):
-                        o["predictions"] += n["predictions"]
-                        o["normmats"] += n["normmats"]
+                outs = _window_outputs(model, merged, starts, pl["params"], mchr)
+                for v, i in enumerate(ch):
+                    r, a = outs[2 * v], outs[2 * v + 1]
+                    if mi == 0:
+                        entries[i] = {"sv": svs[i], "ref": r, "alt": a}
+                    else:
+                        for o, n in ((entries[i]["ref"], r), (entries[i]["alt"], a)):
+                            o["predictions"] += n["predictions"]
+                            o["normmats"] += n["normmats"]
                 if pool is None and k + 1 < len(units):
                     prep(k + 1)
                 if mi == len(models) - 1:
-                    if on_result is not None:
-                        on_result(i, entry)
-                    else:
-                        res[i] = entry
+                    for i in ch:
+                        entry = entries.pop(i)
+                        if on_result is not None:
+                            on_result(i, entry)
+                        else:
+                            res[i] = entry
     if stats is not None:
         stats.update({"bins_encoded": encoded, "bins_total": len(mine) * len(models) * 4 * nbins,
                       "chromosome_encodings": sum(c.builds for c in caches),

@@ -101,7 +101,7 @@ def test_pipelined_screen_redoes_a_unit_whose_encodes_left_the_fp16_range(setup,
     range-safe arithmetic (bf16x3 Encoder calls, f32 Decoders: maps equal within the 1e-4 parity bar), the others are bit-identical."""
     from orca_amd import engine
     model, genome = setup
-    base = sv.sv_screen([model], genome, VARIANTS[:3], CHR, min_uses=1, streams=4)
+    base = sv.sv_screen([model], genome, VARIANTS[:3], CHR, min_uses=1, streams=4, group=1)     # unit = one variant
     calls = {"n": 0}
     real = engine.ContextPool.take_overflow
 
@@ -110,7 +110,7 @@ def test_pipelined_screen_redoes_a_unit_whose_encodes_left_the_fp16_range(setup,
         return bool(real(self)) or calls["n"] == 2          # call 1: after prep(0); call 2: unit 1's encodes, issued under unit 0's decoders
     monkeypatch.setattr(engine.ContextPool, "take_overflow", fake)
     with pytest.warns(UserWarning, match="fp16 range"):
-        redo = sv.sv_screen([model], genome, VARIANTS[:3], CHR, min_uses=1, streams=4)
+        redo = sv.sv_screen([model], genome, VARIANTS[:3], CHR, min_uses=1, streams=4, group=1)
     for i in range(3):
         for allele in ("ref", "alt"):
             for j in range(6):
@@ -137,3 +137,31 @@ def test_pipelined_screen_with_two_models(setup):
                     assert np.array_equal(a[i][allele]["predictions"][m][j], b[i][allele]["predictions"][m][j])
     for j in range(6):
         assert np.array_equal(a[0]["alt"]["predictions"][1][j], one[0]["alt"]["predictions"][0][j])
+
+
+def test_screen_groups_of_variants_per_decoder_batch_are_bit_identical(setup):
+    """`group` variants go through Encoder2 and every decoder level as ONE batch of 4 x group maps (default 2: a Decoder forward is cheaper per
+    map at B = 8 than at B = 4).  A map does not depend on the batch it is computed in: groups of 1, 2 (with an odd variant left over) and 3,
+    one and two models, with and without the auxiliary contexts - the same bits, the same entries in the same order."""
+    model, genome = setup
+    hff = orca_models.Hff(synthetic_seed=1)
+    base = sv.sv_screen([model], genome, VARIANTS[:3], CHR, min_uses=1, group=1, on_result=None)
+    for group, streams in ((2, 4), (3, 4), (2, 0)):
+        order = []
+        got = {}
+        sv.sv_screen([model], genome, VARIANTS[:3], CHR, min_uses=1, group=group, streams=streams, on_result=lambda i, e: (order.append(i), got.__setitem__(i, e)))
+        assert order == [0, 1, 2]
+        for i in range(3):
+            assert got[i]["sv"] == VARIANTS[i]
+            for allele in ("ref", "alt"):
+                assert got[i][allele]["start_coords"] == base[i][allele]["start_coords"]
+                for j in range(6):
+                    assert np.array_equal(got[i][allele]["predictions"][0][j], base[i][allele]["predictions"][0][j]), (group, streams, i, allele, j)
+    two1 = sv.sv_screen([model, hff], genome, VARIANTS[:3], CHR, min_uses=1, group=1)
+    two2 = sv.sv_screen([model, hff], genome, VARIANTS[:3], CHR, min_uses=1, group=2)
+    for i in range(3):
+        for allele in ("ref", "alt"):
+            assert len(two2[i][allele]["predictions"]) == 2
+            for m in range(2):
+                for j in range(6):
+                    assert np.array_equal(two1[i][allele]["predictions"][m][j], two2[i][allele]["predictions"][m][j])
