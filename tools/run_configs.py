@@ -26,7 +26,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "config5_1024":
     print(json.dumps({"config5_sv_screen_1024_1gpu": {"svs": 1024, "s_total": round(dt, 2), "s_per_sv_ref_plus_alt": round(dt / 1024, 4), "svs_per_s": round(1024 / dt, 2),
                                                        "strand_Mb_per_s": round(1024 * 4 * 32 / dt, 1), "kinds": kinds, "maps": 1024 * 12, "maps_checksum": round(chk, 3),
                                                        "encoder_bins_encoded_frac": round(stats["bins_encoded"] / stats["bins_total"], 4), "chromosome_encodings": stats["chromosome_encodings"],
-                                                       "mode": "incremental (orca_amd/sv.py): chromosome encoded once per strand and 4 kb phase, windows re-encode ends + junctions, ref + alt as one decoder batch"}}))
+                                                       "mode": "incremental (orca_amd/sv.py): chromosome encoded once per strand and 4 kb phase, windows re-encode ends + junctions, ref + alt of two variants as one decoder batch"}}))
     sys.exit(0)
 def rand_codes(B, L, seed):
     g = torch.Generator(device=dev).manual_seed(seed)
