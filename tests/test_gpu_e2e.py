@@ -466,35 +466,36 @@ def test_process_ins_breakpoint_custom_against_the_reference_with_real_networks(
         print(f"{fn} vs the reference with real networks (call {attempt + 1}): {views} views, worst max-abs on the sampled pixels {worst:.3g}")
 
 
-def test_process_del_256mb_against_the_reference_with_real_networks(cuda):
+@pytest.mark.parametrize("case", ["del256", "inv256"])
+def test_process_256mb_drivers_against_the_reference_with_real_networks(cuda, case):
     """The 256 Mb branch of SURVEY 8(f1) against the ORACLE: the reference's own `process_del(..., window_radius=128000000)`
-    (orca_predict.py:1510-1817 -> three `genomepredict_256Mb` calls, :652-878) with the reference's own networks (orca_modules Encoder / Encoder2 /
-    Encoder3 / four Decoders, synthetic weights; the backgrounds `_retrieve_multi` reads and the targets the reference cannot do without at 256 Mb are
-    the stand-ins of G13) is the fixture G25 (tools/make_golden.py --svreal --only G25, ~75 min of PyTorch CPU); here the same call through orca_amd
-    on the MI355X with the genome resident in HBM - ref.l and ref.r from ONE Encoder pass per strand (orca_predict.shared_encodings), the alternative
-    allele assembled on the device: coordinates exactly, maps at the north-star 1e-4."""
-    from tests import standins
+    (orca_predict.py:1510-1817 -> three `genomepredict_256Mb` calls, :652-878) and `process_inv` (:1820-2175, four calls) with the reference's own
+    networks (orca_modules Encoder / Encoder2 / Encoder3 / four Decoders, synthetic weights; the backgrounds `_retrieve_multi` reads and the targets the
+    reference's process_del cannot do without at 256 Mb are the stand-ins of G13) are the fixture G25 (tools/make_golden.py --svreal --only G25,
+    G25_CASES=del256,inv256: ~20 min of PyTorch CPU per view); here the same calls through orca_amd on the MI355X with the genome resident in HBM -
+    views that predict the same 256 Mb sequence at two anchors from ONE Encoder pass per strand (orca_predict.shared_encodings), the alternative
+    alleles assembled on the device (inv: a reverse-complemented piece): coordinates exactly, maps at the north-star 1e-4."""
     path = os.path.join(os.path.dirname(__file__), "golden", "G25_sv_del256_real_nets.npz")
-    if not os.path.exists(path):
-        pytest.skip("G25 fixture not generated")
-    g = np.load(path)
+    g = np.load(path) if os.path.exists(path) else None
+    if g is None or f"{case}.t_cpu_s" not in g.files:
+        pytest.skip(f"G25 fixture holds no {case}")
     model = M.H1esc_256M(synthetic_seed=0)
     saved = dict(P.model_dict_global)
     P.model_dict_global["h1esc_256m"], P.model_dict_global["hff_256m"] = standins.Background256(0), standins.Background256(1)
     try:
         dev = synth.sv_driver_genome_256().to(cuda)
-        name, fn, a, kw = synth.sv_driver_cases_256()[0]
-        outs = P.process_del(*a, dev, custom_models=[model], target=[standins.FakeTarget256()], use_cuda=True, window_radius=128000000,
-                             padding_chr="chr1", **kw)
+        name, fn, a, kw = next(c for c in synth.sv_driver_cases_256() if c[0] == case)
+        tgt = [standins.FakeTarget256()] if fn == "process_del" else False
+        outs = getattr(P, fn)(*a, dev, custom_models=[model], target=tgt, use_cuda=True, window_radius=128000000, padding_chr="chr1", **kw)
     finally:
         P.model_dict_global.clear()
         P.model_dict_global.update(saved)
     got = synth.summarize_outputs(outs, stride=5)
     views = len(outs)
-    assert views == 3 and sum(1 for k in g.files if k.endswith("_chr")) == views
+    assert views >= 3 and sum(1 for k in g.files if k.startswith(case + ".") and k.endswith("_chr")) == views
     worst = 0.0
     for k, v in got.items():
-        ref = g["del256." + k]
+        ref = g[case + "." + k]
         if k.endswith(("_start", "_end")):
             assert np.array_equal(v, ref), k
         elif k.endswith(("_chr", "_annos")):
@@ -504,5 +505,5 @@ def test_process_del_256mb_against_the_reference_with_real_networks(cuda):
             assert maxabs(v, ref) < 1e-4 and pearson(v, ref) > 0.999999, (k, maxabs(v, ref))
         elif "_stats_" in k:
             assert abs(v[0] - ref[0]) < 1e-4 * 62500 and abs(v[1] / ref[1] - 1) < 1e-4 and abs(v[2] - ref[2]) < 1e-4, (k, v, ref)
-    assert maxabs(got["o0_m0_sub_0"], got[f"o{views - 1}_m0_sub_0"]) > 1e-3      # the deletion changes the maps
-    print(f"process_del at 256 Mb vs the reference with real networks: {views} views, worst max-abs on the sampled pixels {worst:.3g}")
+    assert maxabs(got["o0_m0_sub_0"], got[f"o{views - 1}_m0_sub_0"]) > 1e-3      # the variant changes the maps
+    print(f"{fn} at 256 Mb vs the reference with real networks: {views} views, worst max-abs on the sampled pixels {worst:.3g}")

@@ -502,30 +502,36 @@ def main():
                     self.net = load_synth(om.Encoder3(), seed=seed)
                     self.denets = {lv: load_synth(om.Decoder(upsample_mode="bilinear"), seed=seed + lv) for lv in (32, 64, 128, 256)}
 
-            real, ncall = op.genomepredict_256Mb, [0]
+            real, ncall, case_ = op.genomepredict_256Mb, [0], [""]
 
             def kept(*a, **k):
-                path = "/tmp/g25_view%d.pkl" % ncall[0]
+                path = "/tmp/g25_%s_view%d.pkl" % (case_[0], ncall[0])
                 ncall[0] += 1
                 if os.path.exists(path):
                     return pickle.load(open(path, "rb"))
                 t1 = time.time()
                 out = real(*a, **k)
                 pickle.dump(out, open(path, "wb"))
-                print("G25 view", ncall[0] - 1, "%.1fs" % (time.time() - t1), flush=True)
+                print("G25", case_[0], "view", ncall[0] - 1, "%.1fs" % (time.time() - t1), flush=True)
                 return out
 
             op.genomepredict_256Mb = kept
-            t = time.time()
-            name, fn, a, kw = synth.sv_driver_cases_256()[0]
-            assert fn == "process_del"
-            outs = op.process_del(*a, genome, custom_models=[Ref256(0)], target=["fake"], use_cuda=False, window_radius=128000000,
-                                  padding_chr="chr1", **kw)
+            path25 = os.path.join(GOLD, "G25_sv_del256_real_nets.npz")
+            d = {k: v for k, v in np.load(path25).items()} if os.path.exists(path25) else {}
+            model = Ref256(0)
+            # $G25_CASES: names of synth.sv_driver_cases_256() (default del256; inv256 = four views, the inverted piece from the other strand)
+            for name, fn, a, kw in synth.sv_driver_cases_256():
+                if name not in os.environ.get("G25_CASES", "del256").split(",") or f"{name}.t_cpu_s" in d:
+                    continue
+                t = time.time()
+                case_[0], ncall[0] = name, 0
+                tgt = ["fake"] if fn == "process_del" else False     # the reference's process_del cannot run without targets at 256 Mb
+                outs = getattr(op, fn)(*a, genome, custom_models=[model], target=tgt, use_cuda=False, window_radius=128000000, padding_chr="chr1", **kw)
+                d.update({f"{name}.{k}": v for k, v in synth.summarize_outputs(outs, stride=5).items()})
+                d[f"{name}.t_cpu_s"] = np.array([time.time() - t])
+                np.savez_compressed(path25, **d)
+                print("G25", name, "done %.1fs" % (time.time() - t), len(outs), "views", flush=True)
             op.genomepredict_256Mb = real
-            d = {f"del256.{k}": v for k, v in synth.summarize_outputs(outs, stride=5).items()}
-            d["t_cpu_s"] = np.array([time.time() - t])
-            np.savez_compressed(os.path.join(GOLD, "G25_sv_del256_real_nets.npz"), **d)
-            print("G25 done %.1fs" % (time.time() - t), len(outs), "views")
 
         # ---- G8: one full 32 Mb H1-ESC-shaped forward, both strands ---------------
         if args.full32m and want("G8"):
