@@ -231,6 +231,21 @@ def strand_streams():
     return os.environ.get("ORCA_STRAND_STREAMS", "0") == "1"
 
 
+def batch_streams():
+    """The bf16-plane Encoder (config 3's throughput mode) runs a batch of >= 2 sequences as two halves on two contexts / HIP streams
+    (`orca_modules.Encoder.forward_codes`): stage 1's HBM-bound launch of one half beside the matrix-bound convs of the other - 74.7 -> 71.8 ms
+    per 8 strands (tools/scratch measurement, late round 5), same bits.  $ORCA_BATCH_STREAMS=0: one context (a kernel's HIP-event time then
+    measures the kernel, not its share of the chip - bench.py's config-3 roofline pass).  The fp32-class default arithmetic does not gain
+    (197.3 -> 197.6 ms) and stays on one context."""
+    import os
+    return os.environ.get("ORCA_BATCH_STREAMS", "1") != "0"
+
+
+def in_pool_run():
+    """True while the calling thread is inside ContextPool.run (its current context is one of a pool's)."""
+    return getattr(_tls, "override", None) is not None
+
+
 def run_with_overflow_retry(fn, device, pool=None):
     """Run fn() (a chain of module forwards on ``device``) with ONE fp16-range check at the end instead of one
     per module; if an activation left the fp16 range anywhere, redo the whole chain in the range-safe arithmetic.

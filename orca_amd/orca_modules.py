@@ -173,6 +173,23 @@ class Encoder(_HipModule):
     def forward_codes(self, codes, reverse=False, bin_lo=0, bin_hi=0, chunk_bp=0, out=None):
         """Encoder straight from packed bases: ``codes`` [B,L] uint8 on the MI355X (0..3 = A,C,G,T, 4 = N, see
         engine.pack_sequence).  ``reverse=True`` encodes the reverse complement of the same buffer."""
+        if (self.precision == "bf16" and isinstance(codes, torch.Tensor) and codes.is_cuda and codes.dim() == 2 and codes.shape[0] >= 2
+                and codes.shape[1] <= 64_000_000 and engine.batch_streams() and not engine.strand_streams() and not engine.in_pool_run()):
+            # throughput mode, a batch: two halves on two contexts (engine.batch_streams) - each row is computed exactly as alone
+            B, L = codes.shape
+            hi = engine.encoder_num_bins(L) if bin_hi <= 0 else bin_hi
+            if out is None:
+                out = torch.empty((B, 128, hi - bin_lo), dtype=torch.float32, device=codes.device)
+            h = (B + 1) // 2
+            pool = engine.context_pool(codes.device, 1)
+            pool.fork()
+            try:
+                pool.run(0, lambda: self.forward_codes(codes[h:], reverse, bin_lo, bin_hi, chunk_bp, out[h:]))
+                net = self._net(codes.device)
+                self._run_guarded(net, lambda: engine.encoder_forward_codes(net, codes[:h], reverse, bin_lo, bin_hi, chunk_bp, out[:h]), "bf16x3")
+            finally:
+                pool.join()          # whatever happened: the caller's stream continues behind what was issued on the pool's
+            return out
         net = self._net(codes.device)
         return self._run_guarded(net, lambda: engine.encoder_forward_codes(net, codes, reverse, bin_lo, bin_hi, chunk_bp, out), "bf16x3")
 

@@ -16,7 +16,7 @@ import pytest
 import torch
 
 from orca_amd import orca_models, orca_predict as P, synth
-from tests.util import golden, maxabs, pearson, stats
+from tests.util import golden, maxabs, pearson, product_module, stats
 
 pytestmark = pytest.mark.gpu
 CFG = {"seed": 7, "rows": (0, 5), "row_seed0": 10, "L": 32_000_000, "mpos": 17_234_567, "wpos": 16_000_000}   # = tools/make_golden.py CONFIG3
@@ -260,3 +260,35 @@ def test_single_plane_layers_equal_rounding_point_emulation(cuda, precision, min
                 oth = ref
             else:
                 cur = ref
+
+
+def test_bf16_encoder_batch_on_two_contexts_is_bit_identical(cuda, monkeypatch):
+    """`precision="bf16"` + a batch: Encoder.forward_codes runs the rows as two halves on two contexts / HIP streams (engine.batch_streams) - every row is
+    computed exactly as alone: equal to the one-context call (ORCA_BATCH_STREAMS=0) bit for bit, for even and odd batches, with a bin range, into a
+    caller's buffer; and the launch counters show that the caller's context ran only its half."""
+    from orca_amd import engine
+    enc = product_module("Encoder", 0, precision="bf16").to(cuda)
+    g = torch.Generator(device=cuda).manual_seed(5)
+    codes = torch.randint(0, 5, (5, 1_200_000), device=cuda, generator=g, dtype=torch.uint8)
+    ctx = engine.get_context(cuda)
+    for B, kw in ((2, {}), (5, {}), (4, {"bin_lo": 40, "bin_hi": 260}), (3, {"reverse": True})):
+        monkeypatch.setenv("ORCA_BATCH_STREAMS", "0")
+        c0 = ctx.launch_counts()["planar"]
+        one = enc.forward_codes(codes[:B], **kw)
+        c1 = ctx.launch_counts()["planar"]
+        monkeypatch.delenv("ORCA_BATCH_STREAMS")
+        two = enc.forward_codes(codes[:B], **kw)
+        c2 = ctx.launch_counts()["planar"]
+        assert torch.equal(one, two), (B, kw)
+        assert 0 < (c2 - c1) < (c1 - c0), (c0, c1, c2)          # the caller's context launched for ceil(B / 2) rows only
+        buf = torch.full_like(one, float("nan"))
+        assert enc.forward_codes(codes[:B], out=buf, **kw) is buf and torch.equal(buf, one)
+    # the fp32-class default arithmetic stays on one context
+    enc.precision = "f16x2"
+    c0 = ctx.launch_counts()["planar"]
+    a = enc.forward_codes(codes[:2])
+    c1 = ctx.launch_counts()["planar"]
+    monkeypatch.setenv("ORCA_BATCH_STREAMS", "0")
+    b = enc.forward_codes(codes[:2])
+    c2 = ctx.launch_counts()["planar"]
+    assert torch.equal(a, b) and c1 - c0 == c2 - c1
