@@ -448,6 +448,7 @@ def config3_section(dev):
                          "ok": bool(max(errs) < 0.1 and min(rs) > 0.99999)}
     del codes, preds, hff
     ctx.release_workspace()
+    engine.context_pool(dev, 1).release_workspaces()      # the second context the bf16 Encoder ran half of the batch on
     torch.cuda.empty_cache()
     return out
 
