@@ -505,5 +505,6 @@ def test_process_256mb_drivers_against_the_reference_with_real_networks(cuda, ca
             assert maxabs(v, ref) < 1e-4 and pearson(v, ref) > 0.999999, (k, maxabs(v, ref))
         elif "_stats_" in k:
             assert abs(v[0] - ref[0]) < 1e-4 * 62500 and abs(v[1] / ref[1] - 1) < 1e-4 and abs(v[2] - ref[2]) < 1e-4, (k, v, ref)
-    assert maxabs(got["o0_m0_sub_0"], got[f"o{views - 1}_m0_sub_0"]) > 1e-3      # the variant changes the maps
+    alt0 = views - 1 if case == "del256" else 2                                   # the alternative-allele view with ref.l's anchor
+    assert max(maxabs(got[f"o0_m0_sub_{j}"], got[f"o{alt0}_m0_sub_{j}"]) for j in range(4)) > 5e-3      # the variant changes the maps
     print(f"{fn} at 256 Mb vs the reference with real networks: {views} views, worst max-abs on the sampled pixels {worst:.3g}")
