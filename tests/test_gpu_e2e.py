@@ -466,7 +466,7 @@ def test_process_ins_breakpoint_custom_against_the_reference_with_real_networks(
         print(f"{fn} vs the reference with real networks (call {attempt + 1}): {views} views, worst max-abs on the sampled pixels {worst:.3g}")
 
 
-@pytest.mark.parametrize("case", ["del256", "inv256"])
+@pytest.mark.parametrize("case", ["del256", "inv256", "bp256_short"])
 def test_process_256mb_drivers_against_the_reference_with_real_networks(cuda, case):
     """The 256 Mb branch of SURVEY 8(f1) against the ORACLE: the reference's own `process_del(..., window_radius=128000000)`
     (orca_predict.py:1510-1817 -> three `genomepredict_256Mb` calls, :652-878) and `process_inv` (:1820-2175, four calls) with the reference's own
@@ -505,6 +505,6 @@ def test_process_256mb_drivers_against_the_reference_with_real_networks(cuda, ca
             assert maxabs(v, ref) < 1e-4 and pearson(v, ref) > 0.999999, (k, maxabs(v, ref))
         elif "_stats_" in k:
             assert abs(v[0] - ref[0]) < 1e-4 * 62500 and abs(v[1] / ref[1] - 1) < 1e-4 and abs(v[2] - ref[2]) < 1e-4, (k, v, ref)
-    alt0 = views - 1 if case == "del256" else 2                                   # the alternative-allele view with ref.l's anchor
+    alt0 = 2 if case == "inv256" else views - 1                                   # an alternative-allele view (inv: the one with ref.l's anchor)
     assert max(maxabs(got[f"o0_m0_sub_{j}"], got[f"o{alt0}_m0_sub_{j}"]) for j in range(4)) > 5e-3      # the variant changes the maps
     print(f"{fn} at 256 Mb vs the reference with real networks: {views} views, worst max-abs on the sampled pixels {worst:.3g}")

@@ -529,7 +529,8 @@ def main():
                 outs = getattr(op, fn)(*a, genome, custom_models=[model], target=tgt, use_cuda=False, window_radius=128000000, padding_chr="chr1", **kw)
                 d.update({f"{name}.{k}": v for k, v in synth.summarize_outputs(outs, stride=5).items()})
                 d[f"{name}.t_cpu_s"] = np.array([time.time() - t])
-                np.savez_compressed(path25, **d)
+                np.savez_compressed(path25 + ".tmp.npz", **d)
+                os.replace(path25 + ".tmp.npz", path25)          # (atomic: an interrupted run never leaves half a fixture)
                 print("G25", name, "done %.1fs" % (time.time() - t), len(outs), "views", flush=True)
             op.genomepredict_256Mb = real
 
