@@ -431,7 +431,11 @@ def config3_section(dev):
     if inst:
         name, d = max(inst.items(), key=lambda kv: kv[1]["ms"])
         ach = d["flop"] / (d["ms"] * 1e-3) / 1e12
+        xach = d["xflop"] * d["nprod"] / (d["ms"] * 1e-3) / 1e12
         out["roofline"] = {"kernel": name, "bound": "hbm+mfma", "achieved": round(ach, 1), "peak": d["peak"], "unit": "TFLOP/s", "frac": round(ach / d["peak"], 4),
+                           "frac_is": "ALGORITHMIC FLOP (the reference's convolutions of the stage, SURVEY 8d) / HIP-event time / peak - not pipe use",
+                           "executed_mfma_tflops": round(xach, 1), "executed_frac": round(xach / d["peak"], 4),
+                           "executed_is": "matrix-instruction FLOP the launch really issues (composed taps, products per MAC) / time / peak = matrix-pipe use",
                            "algorithmic_hbm_GBps": round(d["bytes"] / (d["ms"] * 1e-3) / 1e9, 1), "hbm_frac_of_8TBps": round(d["bytes"] / (d["ms"] * 1e-3) / 8e12, 4),
                            "avg_launch_ms": round(d["ms"] / d["launches"], 4), "launches": d["launches"]}
     g17 = os.path.join(ROOT, "tests", "golden", "G17_config3.npz")
@@ -453,45 +457,59 @@ def config3_section(dev):
     return out
 
 
-def config5_section(dev, n_svs=256):
-    """BASELINE.json configs[4] on this rank: `n_svs` (256) of the 1024 synthetic structural variants (orca_amd.sv.synth_svs: del / dup / inv,
-    10 kb - 5 Mb) x reference + alternative allele, 6 maps each, from a packed 40 Mb chromosome in HBM.  Incremental screen
-    (orca_amd/sv.py): the chromosome's strands are encoded once per 4 kb phase, a window re-encodes only its ends and junctions, the four
-    strands of a variant are one decoder batch; 16 of the variants are also run as the reference does it - two whole `genomepredict` calls
-    each - for the speed-up and the agreement of the maps.  Variants are independent: N GPUs take every N-th (replicas, no collective)."""
+def config5_section(dev, n_svs=256, n_unaligned=64):
+    """BASELINE.json configs[4] on this rank: synthetic structural variants (orca_amd.sv.synth_svs: del / dup / inv, 10 kb - 5 Mb) x reference +
+    alternative allele, 6 maps each, from a packed 40 Mb chromosome in HBM, through the screen of orca_amd/sv.py.
+    TWO sets: the workload as SURVEY 8(d) defines it - log-uniform sizes, NO alignment (`n_unaligned` of the 1024; the top-level
+    figures) - and rounds 3-5's set with every coordinate on the 4 kb grid (`aligned_4kb`, `n_svs` of the 1024).  The incremental encoder reuses a
+    chromosome encoding per 4 kb PHASE: on the grid every window shares one phase (the chromosome's strands are encoded once, a window
+    re-encodes only its ends and junctions); off the grid every window has a phase of its own and goes through the Encoder whole - what is
+    left of the screen there is the batching of the decoders (two variants = 8 maps per level).  Per set, 8 variants are also run as the
+    reference does it - two whole `genomepredict` calls each - for the speed-up and the agreement of the maps.
+    Variants are independent: N GPUs take every N-th (replicas, no collective)."""
     from orca_amd import engine, orca_models, sv
     h1 = orca_models.H1esc(synthetic_seed=0)
     g = torch.Generator(device=dev).manual_seed(5)
     genome = torch.randint(0, 4, (40_000_000,), device=dev, generator=g, dtype=torch.uint8)
-    svs = sv.synth_svs(n_svs + 2, 40_000_000)
-    sv.sv_screen([h1], genome, svs[:2], 40_000_000, min_uses=1)      # warm-up: workspace growth, both window shapes
-    torch.cuda.synchronize(dev)
-    stats = {}
-    t0 = time.perf_counter()
-    res = sv.sv_screen([h1], genome, svs[2:], 40_000_000, stats=stats)     # includes the chromosome encodings (4 here)
-    torch.cuda.synchronize(dev)
-    dt = time.perf_counter() - t0
-    n_full = min(16, n_svs)
-    sv.sv_screen([h1], genome, svs[2:3], 40_000_000, incremental=False)
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    full = sv.sv_screen([h1], genome, svs[2:2 + n_full], 40_000_000, incremental=False)
-    torch.cuda.synchronize(dev)
-    dt_full = time.perf_counter() - t0
-    diff = max(float(np.abs(res[i][a]["predictions"][0][j] - full[i][a]["predictions"][0][j]).max()) for i in range(n_full) for a in ("ref", "alt") for j in range(6))
-    chk = float(sum(float(np.sum(r[a]["predictions"][0][0], dtype=np.float64)) for r in res.values() for a in ("ref", "alt")))
-    out = {"workload": f"{n_svs} of the 1024 synthetic SVs x (reference + alternative allele) x 6 maps of a 32 Mb window (both strands), from a packed "
-                       "40 Mb chromosome in HBM; incremental screen: chromosome encoded once per strand and 4 kb phase, windows re-encode ends + junctions, "
-                       "ref + alt of TWO variants decoded as one batch of 8 maps per level", "svs": n_svs, "s_per_sv": round(dt / n_svs, 4),
-           "svs_per_s": round(n_svs / dt, 2), "window_Mb_per_s": round(n_svs * 2 * 2 * 32 / dt, 1), "projected_1024_svs_s_one_gpu": round(1024 * dt / n_svs, 1),
-           "encoder_bins_encoded_frac": round(stats["bins_encoded"] / stats["bins_total"], 4), "chromosome_encodings": stats["chromosome_encodings"],
-           "as_the_reference_does_it": {"svs": n_full, "s_per_sv": round(dt_full / n_full, 4), "svs_per_s": round(n_full / dt_full, 2),
-                                        "what": "two whole genomepredict calls per variant (every window through the whole Encoder)"},
-           "speedup": round((dt_full / n_full) / (dt / n_svs), 2), "max_abs_vs_whole_window_encoding": diff,
-           "kinds": "".join(v.kind[0] for v in svs[2:]), "level32_maps_checksum": round(chk, 3),
-           "note": "a sample of the 1024: the whole screen on one GPU is profiles/r05_config5_1024.json (tools/run_configs.py config5_1024); per-variant time varies with "
-                   "the variant's size and kind (junction count), so 64-, 256- and 1024-variant figures differ by a few per cent - and by +-2 % from box to box"}
-    del genome, res, full, h1
+
+    def run(svs, n_full=8):
+        sv.sv_screen([h1], genome, svs[:2], 40_000_000, min_uses=1)      # warm-up: workspace growth, both window shapes
+        torch.cuda.synchronize(dev)
+        stats = {}
+        t0 = time.perf_counter()
+        res = sv.sv_screen([h1], genome, svs[2:], 40_000_000, stats=stats)     # includes the chromosome encodings (4 on the grid, none off it)
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        n = len(svs) - 2
+        n_full = min(n_full, n)
+        sv.sv_screen([h1], genome, svs[2:3], 40_000_000, incremental=False)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        full = sv.sv_screen([h1], genome, svs[2:2 + n_full], 40_000_000, incremental=False)
+        torch.cuda.synchronize(dev)
+        dt_full = time.perf_counter() - t0
+        diff = max(float(np.abs(res[i][a]["predictions"][0][j] - full[i][a]["predictions"][0][j]).max()) for i in range(n_full) for a in ("ref", "alt") for j in range(6))
+        chk = float(sum(float(np.sum(r[a]["predictions"][0][0], dtype=np.float64)) for r in res.values() for a in ("ref", "alt")))
+        return {"svs": n, "s_per_sv": round(dt / n, 4), "svs_per_s": round(n / dt, 2), "window_Mb_per_s": round(n * 2 * 2 * 32 / dt, 1),
+                "projected_1024_svs_s_one_gpu": round(1024 * dt / n, 1),
+                "encoder_bins_encoded_frac": round(stats["bins_encoded"] / stats["bins_total"], 4), "chromosome_encodings": stats["chromosome_encodings"],
+                "whole_window_runs": stats.get("whole_window_runs"),
+                "as_the_reference_does_it": {"svs": n_full, "s_per_sv": round(dt_full / n_full, 4), "svs_per_s": round(n_full / dt_full, 2),
+                                             "what": "two whole genomepredict calls per variant (every window through the whole Encoder, decoders at B = 2)"},
+                "speedup": round((dt_full / n_full) / (dt / n), 2), "max_abs_vs_whole_window_encoding": diff,
+                "kinds": "".join(v.kind[0] for v in svs[2:]), "level32_maps_checksum": round(chk, 3)}
+
+    out = run(sv.synth_svs(n_unaligned + 2, 40_000_000))
+    out = {"workload": f"{n_unaligned} of the 1024 synthetic SVs AS SURVEY 8(d) DRAWS THEM (log-uniform size, arbitrary base positions: align = 1) x (reference + "
+                       "alternative allele) x 6 maps of a 32 Mb window (both strands), from a packed 40 Mb chromosome in HBM, through orca_amd.sv.sv_screen: off the 4 kb "
+                       "grid every window keeps its own phase (as the reference's windows do, orca_predict.py:1613) and is encoded whole; ref + alt of TWO variants are "
+                       "decoded as one batch of 8 maps per level", "coordinates": "unaligned (align=1)", **out}
+    out["aligned_4kb"] = {"workload": f"{n_svs} of the 1024 with every coordinate rounded down to the 4 kb grid (synth_svs(align=4000): rounds 3-5's set - the incremental "
+                                      "screen's best case: chromosome encoded once per strand and phase, windows re-encode ends + junctions only)",
+                          "coordinates": "4 kb-aligned (align=4000)", **run(sv.synth_svs(n_svs + 2, 40_000_000, align=4000))}
+    out["note"] = ("samples of the 1024: the whole screen on one GPU is profiles/r06_config5_1024.json (tools/run_configs.py config5_1024, both sets); per-variant time "
+                   "varies with the variant's size and kind, so 64-, 256- and 1024-variant figures differ by a few per cent - and by +-2 % from box to box")
+    del genome, h1
     engine.get_context(dev).release_workspace()
     torch.cuda.empty_cache()
     return out
@@ -705,7 +723,9 @@ def main():
                     "arithmetic": d["arith"], "mfma_products_per_algorithmic_mac": d["nprod"],
                     "mfma_pipe_frac": round(achieved * d["nprod"] / d["peak"], 4),
                     "achieved_is": "ALGORITHMIC FLOP (the reference's convolutions, SURVEY 8d) / HIP-event time",
-                    "executed_tflops": round(d["xflop"] / (d["ms"] * 1e-3) / 1e12, 2), "executed_frac": round(d["xflop"] / (d["ms"] * 1e-3) / 1e12 / d["peak"], 4),
+                    "executed_mfma_tflops": round(d["xflop"] * d["nprod"] / (d["ms"] * 1e-3) / 1e12, 2),
+                    "executed_frac": round(d["xflop"] * d["nprod"] / (d["ms"] * 1e-3) / 1e12 / d["peak"], 4),
+                    "executed_is": "16-bit matrix-instruction FLOP issued (taps as launched x products per MAC) / HIP-event time; executed_frac = matrix-pipe use",
                     "frac_of_f32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
                     "avg_launch_ms": round(d["ms"] / d["launches"], 4), "launches": d["launches"],
                     "flop_per_launch": d["flop"] / d["launches"], "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
@@ -736,7 +756,7 @@ def main():
         "metric": "Mb of sequence encoded+decoded per second (32Mb H1-ESC-shaped model, both strands, 6 levels)",
         "value": round(mb_per_s, 3), "unit": "Mb/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": f"Encoder Conv1d stages 1-7: {enc_prec} = {ARITH[enc_prec]}; Decoder / Decoder_1m Conv2d: {dec_prec} = {ARITH[dec_prec]}; "
+        "dtype": f"{enc_prec} | Encoder Conv1d stages 1-7: {enc_prec} = {ARITH[enc_prec]}; Decoder / Decoder_1m Conv2d: {dec_prec} = {ARITH[dec_prec]}; "
                  f"Encoder2 Conv1d: {getattr(model.net, 'precision', 'f32')} = {ARITH[getattr(model.net, 'precision', 'f32')]}; "
                  "1x1 heads, pools, upsampling, merges: fp32",
         "data": "synthetic",
@@ -786,6 +806,35 @@ def main():
         finally:
             os.environ.pop("ORCA_STRAND_STREAMS", None)
             engine.context_pool(dev, 1).release_workspaces()
+
+    # ---- the reference's CALL FORM: `genomepredict(sequence)` with the host float32 [1, 32e6, 4] array the reference's
+    #      callers hand over (orca_predict.py:231-233, :324-337) - upload over PCIe, on-device pack, both strands, six levels, maps back on the
+    #      host - and the reference's DEFAULT of two models (:231).  `value` above starts from packed bases resident in HBM; this is the
+    #      PCIe-inclusive figure, timed in the same run.
+    if world == 1 and Lbp == L_BP and not args.float_input and rank == 0:
+        try:
+            seq_host = synth.synth_sequence(Lbp, seed=1 + rank)
+            hff2 = orca_models.Hff(synthetic_seed=1)
+            o1 = orca_predict.genomepredict(seq_host, "chrS", mpos, wpos, models=[model])
+            t0 = time.perf_counter()
+            for _ in range(3):
+                o1 = orca_predict.genomepredict(seq_host, "chrS", mpos, wpos, models=[model])
+            t_one = (time.perf_counter() - t0) / 3
+            orca_predict.genomepredict(seq_host, "chrS", mpos, wpos, models=[model, hff2])
+            t0 = time.perf_counter()
+            for _ in range(2):
+                orca_predict.genomepredict(seq_host, "chrS", mpos, wpos, models=[model, hff2])
+            t_two = (time.perf_counter() - t0) / 2
+            same = bool(all(np.array_equal(np.asarray(p), o.cpu().numpy().reshape(np.asarray(p).shape)) for p, o in zip(o1["predictions"][0], outs)))
+            res["reference_call_form"] = {"what": "orca_predict.genomepredict(host float32 [1,32000000,4], mchr, mpos, wpos, models=[H1esc]) - the reference's own call: "
+                                                  "512 MB over PCIe per call, packed on the device, both strands, 6 levels, maps returned as numpy (wall clock, 3 calls)",
+                                          "ms_per_call": round(t_one * 1e3, 2), "Mb_per_s": round(2 * Lbp / 1e6 / t_one, 2),
+                                          "over_value_ms": round(t_one * 1e3 - ms_per_step, 2),
+                                          "two_models_ms": round(t_two * 1e3, 2), "two_models_what": "the reference's default models=['h1esc','hff'] (orca_predict.py:231): one upload, two models",
+                                          "maps_equal_timed_region": same}
+            del seq_host, hff2, o1
+        except Exception as e:
+            res["reference_call_form"] = {"error": f"{type(e).__name__}: {e}"}
 
     # ---- the strict-fp32 readings of the same step (N = 1), each with its OWN parity against the reference's G8 on the full cascade:
     #      exact fp32 MFMA everywhere, and the range-safe arithmetic the fp16 guard falls back to (bf16x3 Encoders, fp32 Decoders)
@@ -849,6 +898,26 @@ def main():
             else:      # the SV drivers' and the screen's batch: ref + alt x two strands (workgroups of one resident round walk the maps)
                 res["roofline_decoder"]["batch_of_4"] = {"ms_per_forward": round(dms, 3), "achieved": round(dtf, 1), "frac": round(dtf / PEAK_16BIT_MFMA_TFLOPS, 4),
                                                          "ms_per_map": round(dms / 4, 3)}
+        # config 3's Decoder mode: ONE fp16 plane per map (2 B/element, one MFMA product per MAC), batch of 8
+        old_prec, dec.precision = dec.precision, "f16"
+        try:
+            xd = torch.from_numpy((np.random.RandomState(31).rand(8, 128, 250) * 0.5).astype(np.float32)).to(dev)
+            yd = torch.from_numpy(np.random.RandomState(32).randn(8, 1, 125, 125).astype(np.float32)).to(dev)
+            ded = distencs[16].expand(8, -1, -1, -1)
+            dec(xd, ded, yd)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize(dev)
+            e0.record()
+            for _ in range(10):
+                dec(xd, ded, yd)
+            e1.record()
+            torch.cuda.synchronize(dev)
+            dms = e0.elapsed_time(e1) / 10
+            dtf = 8 * DEC_TFLOP["withy"] / (dms * 1e-3)
+            res["roofline_decoder"]["single_plane_b8"] = {"precision": "f16 (one fp16 plane per map; config 3's Decoders)", "ms_per_forward": round(dms, 3), "ms_per_map": round(dms / 8, 3),
+                                                          "achieved": round(dtf, 1), "frac": round(dtf / PEAK_16BIT_MFMA_TFLOPS, 4), "mfma_products_per_algorithmic_mac": 1}
+        finally:
+            dec.precision = old_prec
         del xd, yd, ded
     strands = outs = None
     engine.get_context(dev).release_workspace()
@@ -868,6 +937,27 @@ def main():
     def emit():
         if rank == 0 and not printed.is_set():
             printed.set()
+            # the driver's record keeps `roofline`, `config`, `cpu_baseline` and the scalar fields: the other sections' headline numbers ride in those
+            def pick(sec, *path):
+                d = res.get(sec)
+                for k in path:
+                    d = d.get(k) if isinstance(d, dict) else None
+                return d
+            if isinstance(res.get("roofline"), dict):
+                res["roofline"]["other_readings"] = {
+                    "exact_f32_ms_per_step": pick("exact_f32", "ms_per_step"), "exact_f32_frac_of_157TF": pick("exact_f32", "frac_of_157TF_fp32_mfma_peak"),
+                    "bf16x3_ms_per_step": pick("bf16x3", "ms_per_step"),
+                    "decoder_ms_per_forward_b2": pick("roofline_decoder", "ms_per_forward"), "decoder_frac": pick("roofline_decoder", "frac"),
+                    "decoder_mfma_pipe_frac": pick("roofline_decoder", "mfma_pipe_frac"),
+                    "decoder_single_plane_b8_ms": pick("roofline_decoder", "single_plane_b8", "ms_per_forward"),
+                    "hbm_bound_kernel_frac": pick("roofline_hbm_bound_kernel", "frac"),
+                    "config3_executed_frac": pick("config3", "roofline", "executed_frac")}
+            res["config"]["other_configs_in_this_line"] = {
+                "reference_call_form_ms": pick("reference_call_form", "ms_per_call"), "two_models_ms": pick("reference_call_form", "two_models_ms"),
+                "config3_strand_Mb_per_s": pick("config3", "Mb_per_s"), "config3_parity_ok": pick("config3", "parity", "ok"),
+                "config5_unaligned_svs_per_s": pick("config5", "svs_per_s"), "config5_aligned_4kb_svs_per_s": pick("config5", "aligned_4kb", "svs_per_s"),
+                "sharded_256mb_ms": pick("sharded_256mb", "ms_per_step"), "parity_ok": pick("parity", "ok"),
+                "fp16_headroom": res.get("fp16_headroom")}
             print(json.dumps(res), flush=True)
 
     def bail():

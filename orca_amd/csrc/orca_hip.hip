@@ -1626,6 +1626,7 @@ static int encoder_forward_impl(orca_ctx* ctx, orca_net* net, const float* x, in
   if (bin_hi <= 0) bin_hi = total;
   if (bin_lo < 0 || bin_lo > bin_hi || bin_hi > total) return fail(ORCA_EINVAL, "bin range [%ld,%ld) outside [0,%ld)", (long)bin_lo, (long)bin_hi, total);
   if (bin_lo == bin_hi || B <= 0) return ORCA_OK;
+  bool chunk_auto = false;
   if (chunk_bp <= 0) {
     // a 32 Mb window is one chunk; longer inputs (the 256 Mb models) run in 128 Mb chunks: 98 GB of workspace (3 x 64 channels x 4 B per base) of
     // the 288 GB, a quarter of the chunk seams (each costs a 224 kb halo and one latency-bound pass through stages 5-7): 418 -> 406 ms per
@@ -1636,6 +1637,7 @@ static int encoder_forward_impl(orca_ctx* ctx, orca_net* net, const float* x, in
     // $ORCA_RANKS_PER_DEVICE (default 1; bench.py and the tests set it when several ranks share one GPU).
     const char* e = getenv("ORCA_ENCODER_CHUNK_BP");
     chunk_bp = e ? atol(e) : 32000000L;
+    chunk_auto = !e;
     if (!e && L > 32000000L) {
       size_t fr = 0, tot = 0;
       const char* r = getenv("ORCA_RANKS_PER_DEVICE");
@@ -1646,17 +1648,25 @@ static int encoder_forward_impl(orca_ctx* ctx, orca_net* net, const float* x, in
     }
   }
   if (chunk_bp % kBinBp) return fail(ORCA_EINVAL, "chunk_bp must be a multiple of 4000");
-  const long chunk_bins = chunk_bp / kBinBp;
-  long max_n1 = 0;
-  for (long cb0 = bin_lo; cb0 < bin_hi; cb0 += chunk_bins) {
-    const long cb1 = cb0 + chunk_bins < bin_hi ? cb0 + chunk_bins : bin_hi;
-    const long lo = cb0 * kBinBp - kHaloBp > 0 ? cb0 * kBinBp - kHaloBp : 0;
-    const long hi = (cb1 == total) ? L : (cb1 * kBinBp + kHaloBp < L ? cb1 * kBinBp + kHaloBp : L);
-    if (hi - lo > max_n1) max_n1 = hi - lo;
+  long chunk_bins = 0, ld1 = 0;
+  for (;;) {
+    chunk_bins = chunk_bp / kBinBp;
+    long max_n1 = 0;
+    for (long cb0 = bin_lo; cb0 < bin_hi; cb0 += chunk_bins) {
+      const long cb1 = cb0 + chunk_bins < bin_hi ? cb0 + chunk_bins : bin_hi;
+      const long lo = cb0 * kBinBp - kHaloBp > 0 ? cb0 * kBinBp - kHaloBp : 0;
+      const long hi = (cb1 == total) ? L : (cb1 * kBinBp + kHaloBp < L ? cb1 * kBinBp + kHaloBp : L);
+      if (hi - lo > max_n1) max_n1 = hi - lo;
+    }
+    ld1 = ru4(max_n1) + 1024;   // slack: P16 planes are padded to 512 positions + guards
+    const int rc = ws_ensure(ctx, 3 * ru256((size_t)64 * ld1 * sizeof(float)));
+    if (rc == ORCA_OK) break;
+    // the deterministic choice above looks at TOTAL memory; if the device cannot give that much right now (another process, ranks
+    // sharing it without $ORCA_RANKS_PER_DEVICE, torch's allocator holding most of it) fall back chunk size by chunk size - same result
+    if (rc != ORCA_ENOMEM || !chunk_auto || chunk_bp <= 32000000L) return rc;
+    (void)hipGetLastError();
+    chunk_bp /= 2;
   }
-  const long ld1 = ru4(max_n1) + 1024;   // slack: P16 planes are padded to 512 positions + guards
-  const size_t per = ru256((size_t)64 * ld1 * sizeof(float));
-  ORCA_TRY(ws_ensure(ctx, 3 * per));
   float* buf[3];
   for (int i = 0; i < 3; ++i) buf[i] = ws_take(ctx, (size_t)64 * ld1);
   for (int b = 0; b < B; ++b) {

@@ -241,9 +241,9 @@ def _all_gather(slab, world, group, comm):
     return out
 
 
-def _all_gather_status(slab, failed, world, group, comm):
+def _all_gather_status(slab, failed, world, group, comm, defer=False):
     """_all_gather of ``slab`` with an explicit STATUS word per rank riding behind the payload (four floats, so that the payload rows stay
-    16-byte aligned): 1.0 = that rank's rank-local work raised.  A rank that fails still takes part in the collective (the others would
+    16-byte aligned): 1.0 = that rank's rank-local work raised.  ``defer``: return the status vector (device) instead of the failed ranks.  A rank that fails still takes part in the collective (the others would
     block in it) with whatever its slab holds; every rank then learns WHO failed from the status words - not from scanning the payload for
     NaN, which a genuine NaN in a map (bad weights, a bad background) would trigger on every rank.  Returns ([world, *shape]
     view of the payloads, [failed ranks]); the read-back is `world` floats."""
@@ -253,8 +253,16 @@ def _all_gather_status(slab, failed, world, group, comm):
     flat[:n] = slab.reshape(-1)
     flat[n:] = 1.0 if failed else 0.0
     out = _all_gather(flat, world, group, comm)                    # [world, n + 4]
-    status = out[:, n].tolist()
-    return out[:, :n].reshape((world,) + tuple(slab.shape)), [r for r, v in enumerate(status) if v != 0.0]
+    payload = out[:, :n].reshape((world,) + tuple(slab.shape))
+    if defer:       # the caller reads the words later, together with a following collective's (`_failed_ranks`): no host sync here
+        return payload, out[:, n]
+    return payload, _failed_ranks(out[:, n])
+
+
+def _failed_ranks(*status):
+    """Ranks whose status word is raised in any of the [world] status vectors: ONE device read for all of them."""
+    words = torch.stack([w.reshape(-1) for w in status]).tolist()
+    return [[r for r, v in enumerate(row) if v != 0.0] for row in words] if len(status) > 1 else [r for r, v in enumerate(words[0]) if v != 0.0]
 
 
 def _raise_failed(what, err, failed):
@@ -333,9 +341,11 @@ def units_sharded_32m(models, codes, mpos, wpos, distencs=None, group=None, comm
         except Exception as e:                       # stay in step with the other ranks: every rank raises behind the collective
             err = e
         mark("encode")
-        gathered, failed = _all_gather_status(slab, err is not None, world, group, comm)          # [world, units per rank, B, 128, width]
+        # (the status words of THIS collective are read together with the final one's: a read here is a host sync in front of the tails,
+        # ADVICE r5 - a rank that failed to encode still runs its tails, on zeros, and every rank raises behind the last collective)
+        gathered, enc_status = _all_gather_status(slab, err is not None, world, group, comm, defer=True)          # [world, units per rank, B, 128, width]
         mark("gather")
-        _raise_failed("units_sharded_32m (encode)", err, failed)
+        enc_err, err = err, None
         enc = []
         for u in range(U):
             if world >= U:
@@ -373,8 +383,10 @@ def units_sharded_32m(models, codes, mpos, wpos, distencs=None, group=None, comm
         except Exception as e:
             err = e
         mark("tails")
-        allm, failed = _all_gather_status(slab, err is not None, world, group, comm)              # [world, per, 6, C, 250, 250]
+        allm, tail_status = _all_gather_status(slab, err is not None, world, group, comm, defer=True)              # [world, per, 6, C, 250, 250]
         mark("maps")
+        enc_failed, failed = _failed_ranks(enc_status, tail_status)
+        _raise_failed("units_sharded_32m (encode)", enc_err, enc_failed)
         _raise_failed("units_sharded_32m (tails)", err, failed)
         maps = []
         for u in range(U):

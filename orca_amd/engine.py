@@ -246,23 +246,42 @@ def in_pool_run():
     return getattr(_tls, "override", None) is not None
 
 
+def tentative(undo):
+    """A result computed in the fp16-split arithmetic was just put where LATER calls will find it (a cached Encoder output, a
+    chromosome encoding of the SV drivers' store) while the range check of the pass that produced it is still pending
+    (`run_with_overflow_retry`: one check at the end of the chain).  ``undo()`` takes it out again; it runs if and only if that
+    check fires, before the range-safe retry.  Outside such a pass (immediate checks: the module's own retry has already
+    happened; the retry itself: range-safe arithmetic) nothing is registered."""
+    lst = getattr(_tls, "tentative", None)
+    if lst is not None and _guard.defer and not _guard.force_safe:
+        lst.append(undo)
+
+
 def run_with_overflow_retry(fn, device, pool=None):
     """Run fn() (a chain of module forwards on ``device``) with ONE fp16-range check at the end instead of one
     per module; if an activation left the fp16 range anywhere, redo the whole chain in the range-safe arithmetic.
-    ``pool``: a ContextPool fn() also launched on (its contexts carry their own range flags)."""
+    ``pool``: a ContextPool fn() also launched on (its contexts carry their own range flags).
+    Whatever fn() cached for later calls on the way (`tentative`) is dropped first when the check fires."""
     if not (isinstance(device, torch.device) and device.type == "cuda"):
         return fn()
     ctx = get_context(device)
-    with defer_overflow_guard():
-        out = fn()
-    over = ctx.take_overflow()
-    for p in ([pool] if pool is not None else []) + [q for q in _thread_pools().values() if q is not pool and q.index == ctx.device_index]:
-        over = p.take_overflow() or over          # THIS thread's auxiliary contexts fn() ran on (e.g. the reverse strand's Encoder, strand_streams())
-    if over:
-        import warnings
-        warnings.warn("orca_amd: an activation left the fp16 range; recomputing with range-safe arithmetic (bf16x3 / f32)")
-        with force_safe_precision():
+    outer, _tls.tentative = getattr(_tls, "tentative", None), []
+    try:
+        with defer_overflow_guard():
             out = fn()
+        over = ctx.take_overflow()
+        for p in ([pool] if pool is not None else []) + [q for q in _thread_pools().values() if q is not pool and q.index == ctx.device_index]:
+            over = p.take_overflow() or over          # THIS thread's auxiliary contexts fn() ran on (e.g. the reverse strand's Encoder, strand_streams())
+        if over:
+            import warnings
+            warnings.warn("orca_amd: an activation left the fp16 range; recomputing with range-safe arithmetic (bf16x3 / f32)")
+            for undo in _tls.tentative:
+                undo()
+            _tls.tentative = []
+            with force_safe_precision():
+                out = fn()
+    finally:
+        _tls.tentative = outer
     return out
 
 

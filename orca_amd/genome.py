@@ -163,15 +163,18 @@ class PackedGenome:
         return [(c, self._length(c)) for c in self.get_chrs()]
 
     def _bounds(self, chrom, start, end, pad):
+        """Clamped slice + padding counts of a query, with the reference's error behaviour (pinned by tests/golden/G26, generated
+        from `MemmapGenome.get_encoding_from_coords`, selene_utils2.py:231-262): every query that cannot yield `end - start` rows
+        fails its `assert` there - without `pad` anything beyond the chromosome (:257), with `pad` a window that does not at least
+        touch the chromosome (the padded pieces then do not add up to `end - start`, :261) and any window of negative length."""
         n = self._length(chrom)
-        if end < start:
-            raise ValueError(f"window [{start}, {end}) has negative length")
-        if pad:   # both ends clamped: a window entirely outside the chromosome is all padding ('N')
-            qs = min(max(start, 0), n)
-            qe = min(max(end, qs), n)
-            pl = min(max(-start, 0), end - start)
-            return qs, qe, pl, (end - start) - pl - (qe - qs)
-        if not (0 <= start and end <= n):   # the reference's error type (its `assert`, selene_utils2.py:257), raised explicitly: survives python -O
+        if pad:
+            if not (start <= end and start <= n and end >= 0):
+                raise AssertionError(f"window [{start}, {end}) does not touch chromosome {chrom} of length {n}: the reference's padded "
+                                     "pieces do not add up to end - start (selene_utils2.py:261)")
+            qs, qe = max(start, 0), min(end, n)
+            return qs, qe, qs - start, end - qe
+        if not (0 <= start <= end <= n):   # the reference's error type (its `assert`s, selene_utils2.py:257,261), raised explicitly: survives python -O
             raise AssertionError(f"coordinates [{start}, {end}) exceed chromosome {chrom} of length {n} (selene_utils2.py:257)")
         return start, end, 0, 0
 
@@ -201,12 +204,16 @@ class PackedGenome:
         return c
 
     def get_encoding_from_coords(self, chrom, start, end, strand="+", pad=False):
-        """float32 [end-start, 4] exactly as `MemmapGenome.get_encoding_from_coords` (`selene_utils2.py:231-262`)."""
+        """[end-start, 4] rows exactly as `MemmapGenome.get_encoding_from_coords` (`selene_utils2.py:186-262`; pinned query by query
+        by tests/golden/G26): 0.25 rows beyond either end with `pad`, '-' = both axes flipped, any other strand symbol = '+'.
+        Always float32 - the reference's padded form is float64 only because `np.ones(...) * 0.25` promotes its `hstack`
+        (:238-244); every caller converts to float32 (`torch.FloatTensor`, orca_predict.py:324)."""
         return codes_to_encoding(self.get_codes_from_coords(chrom, start, end, strand, pad, device=False))
 
     def get_encoding_from_coords_check_unk(self, chrom, start, end, strand="+", pad=False):
-        """As the reference (`selene_utils2.py:264-272`): the flag looks at the FIRST position's row only."""
-        enc = self.get_encoding_from_coords(chrom, start, end, strand=strand, pad=pad)
+        """As the reference (`selene_utils2.py:264-272`): it passes `pad=strand`, so the window is ALWAYS padded whatever the
+        caller's `pad` says, and the flag looks at the FIRST position's row only (a zero-length window has none: IndexError)."""
+        enc = self.get_encoding_from_coords(chrom, start, end, strand=strand, pad=True)
         return enc, bool(np.any(enc[0, :] == 0.25))
 
     sequence_to_encoding = staticmethod(sequence_to_encoding)

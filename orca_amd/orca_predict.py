@@ -153,6 +153,9 @@ class _StrandInputs:
                 _encode_two_strands(lambda rev, out: net0.forward_codes(self._codes, reverse=rev, out=out), enc0, B)
                 if cache is not None:
                     cache[key] = (self._codes, enc0)      # (the codes tensor is HELD: its storage - the key - cannot be handed to another sequence meanwhile)
+                    # inside a deferred range check (genomepredict_256Mb's forward) this pass is not known to be clean yet: if the check
+                    # at the end of the cascade fires, the entry goes before the range-safe retry - and before another anchor can hit it
+                    engine.tentative(lambda cache=cache, key=key: cache.pop(key, None))
                 return enc0
             return torch.cat([net0.forward_codes(self._codes, reverse=False), net0.forward_codes(self._codes, reverse=True)], dim=0)
         return torch.cat([net0(self.fwd), net0(self.rev)], dim=0)
@@ -241,8 +244,6 @@ class Background256:
     8000 x 8000 matrix crosses PCIe or the host's caches per call.  NaNs are filled with the smallest finite entry, in place,
     exactly once (:664-667).  Callable as run_cascade's ``background(level, k, start)`` for the strands ``reverse_flags``."""
 
-    _nan_filled = {}      # data_ptr -> (data_ptr, shape, _version) of resident matrices whose NaNs have been filled
-
     def __init__(self, normmat, reverse_flags=(False, True), use_cuda=True):
         self.on_device = isinstance(normmat, torch.Tensor) and normmat.is_cuda
         if self.on_device and normmat.dtype != torch.float64:
@@ -262,17 +263,17 @@ class Background256:
         if self.on_device:
             # in place, as the reference does (:664-667) - and ONCE per tensor: callers hand the same resident 8000 x 8000 matrix to every call
             # (bench.py, dist.strand_tail_256m), and the isnan pass over its 512 MB plus the host sync of `.any()` sat inside every timed tail
-            # (the "already filled" state is keyed by the STORAGE and its version counter, not kept as an attribute of the caller's tensor: an
-            # in-place refill with a matrix that holds NaN bumps `_version` and is filled again; views and `.to()` copies cannot lose it)
-            key = (m.data_ptr(), tuple(m.shape), m._version)
-            if Background256._nan_filled.get(m.data_ptr()) == key:
+            # (the "already filled" state belongs to the STORAGE and its version counter, not to the caller's tensor object: an
+            # in-place refill with a matrix that holds NaN bumps `_version` and is filled again; views cannot lose it)
+            # the state lives ON the storage object (PyTorch keeps one Python object per live storage), so it dies with the
+            # allocation - a key of (pointer, shape, version) outlived the tensor and matched the caching allocator's next block at that address
+            st = m.untyped_storage()
+            if getattr(st, "_orca_nan_filled", None) == m._version:
                 return
             nan = torch.isnan(m)
             if bool(nan.any()):
                 m[nan] = m[~nan].min()
-            if len(Background256._nan_filled) > 64:
-                Background256._nan_filled.clear()
-            Background256._nan_filled[m.data_ptr()] = (m.data_ptr(), tuple(m.shape), m._version)
+            st._orca_nan_filled = m._version
         else:
             isnan = np.isnan(m)
             if np.any(isnan):

@@ -166,14 +166,18 @@ def _store(genome, net0):
     # (the Encoder's arithmetic mode and the version of its weights are part of the key: kept encodings must not outlive a `precision = ...`
     # or a `load_state_dict` on the same module object)
     key = (id(genome), id(net0), getattr(net0, "precision", None), getattr(net0, "_wver", 0))
+    for k in [k for k, h in stores.items() if h[0]() is None or h[1]() is None]:
+        del stores[k]                                        # the genome or the Encoder is gone: its encodings (and the HBM they hold) go too
     hit = stores.pop(key, None)
     if hit is not None and (hit[0]() is not genome or hit[1]() is not net0):
         hit = None                                           # an id reused by another object
     if hit is None:
         import weakref
         chrlens = dict(genome.get_chr_lens())
-        hit = (weakref.ref(genome), weakref.ref(net0),
-               sv.GenomeEncodings(net0, lambda c: genome.get_codes_from_coords(c, 0, chrlens[c]), chrlens))
+        wg = weakref.ref(genome)
+        # the store must not keep what it is keyed on alive - the GenomeEncodings sees the Encoder through a weak proxy and the
+        # genome through a weak reference (a deleted genome's GBs of HBM, its unpacked chromosomes and segments are released with it)
+        hit = (wg, weakref.ref(net0), sv.GenomeEncodings(weakref.proxy(net0), lambda c: wg().get_codes_from_coords(c, 0, chrlens[c]), chrlens))
     stores[key] = hit                                        # most recently used last
     while len(stores) > _MAX_STORES:
         stores.pop(next(iter(stores)))

@@ -6,6 +6,7 @@ import os
 import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.multiprocessing as mp
 
@@ -418,3 +419,42 @@ def test_one_and_two_model_jobs_gloo_world8():
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
+
+
+def test_results_cached_inside_a_deferred_range_check_do_not_survive_a_fired_check(monkeypatch):
+    """`run_with_overflow_retry` checks the fp16 range ONCE, behind the whole chain; what the chain put where later calls find it
+    before that check (`engine.tentative`: a shared Encoder output of genomepredict_256Mb, an auto-built chromosome encoding of the SV
+    drivers) is taken out again when the check fires - before the range-safe retry, which caches its own result - and kept otherwise.
+    The device is faked: only the control flow is under test (the GPU suite forces the same through a real 256 Mb driver call)."""
+    from orca_amd import engine
+
+    flags = []
+
+    class Ctx:
+        device_index = 0
+
+        def take_overflow(self):
+            return flags.pop(0)
+
+    monkeypatch.setattr(engine, "get_context", lambda d: Ctx())
+    monkeypatch.setattr(engine, "_thread_pools", lambda: {})
+    cache, passes = {}, []
+
+    def chain():
+        passes.append(engine._guard["force_safe"])
+        if "enc" not in cache:
+            cache["enc"] = "bf16x3" if engine._guard["force_safe"] else "f16x2"
+            engine.tentative(lambda: cache.pop("enc", None))
+        return cache["enc"]
+
+    dev = torch.device("cuda:0")
+    flags[:] = [False]
+    assert engine.run_with_overflow_retry(chain, dev) == "f16x2" and cache == {"enc": "f16x2"} and passes == [False]
+    cache.clear(); passes.clear()
+    flags[:] = [True]
+    with pytest.warns(UserWarning, match="fp16 range"):
+        assert engine.run_with_overflow_retry(chain, dev) == "bf16x3"
+    assert cache == {"enc": "bf16x3"} and passes == [False, True]          # the overflowed entry was dropped, the retry's kept
+    # outside a deferred pass nothing is registered (immediate checks: the module has already retried)
+    engine.tentative(lambda: cache.clear())
+    assert cache == {"enc": "bf16x3"} and getattr(engine._tls, "tentative", None) is None

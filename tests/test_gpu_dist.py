@@ -221,8 +221,18 @@ def test_bench_two_ranks_on_one_gpu_over_gloo(cuda):
         assert one[key]["parity"]["ok"] and max(one[key]["parity"]["max_abs_per_level"]) < 1e-4 and one[key]["ms_per_step"] > 0, one[key]
     rd = one["roofline_decoder"]
     assert rd["ms_per_forward"] > 0 and rd["batch_of_4"]["ms_per_forward"] > rd["ms_per_forward"] and 0 < rd["batch_of_4"]["frac"] < 1
+    assert rd["single_plane_b8"]["ms_per_forward"] > 0 and rd["single_plane_b8"]["mfma_products_per_algorithmic_mac"] == 1
+    # config 5 on the workload as SURVEY 8(d) draws it (unaligned) AND on rounds 3-5's 4 kb-aligned set, each with its comparator
     c5 = one["config5"]
-    assert "error" not in c5 and c5["svs"] == 256 and c5["as_the_reference_does_it"]["svs"] == 16 and c5["max_abs_vs_whole_window_encoding"] < 1e-4, c5
+    assert "error" not in c5 and c5["coordinates"].startswith("unaligned") and c5["svs"] == 64 and c5["max_abs_vs_whole_window_encoding"] < 1e-4, c5
+    a5 = c5["aligned_4kb"]
+    assert a5["svs"] == 256 and a5["as_the_reference_does_it"]["svs"] == 8 and a5["max_abs_vs_whole_window_encoding"] < 1e-4, a5
+    assert a5["svs_per_s"] > c5["svs_per_s"] and a5["encoder_bins_encoded_frac"] < 0.1 < c5["encoder_bins_encoded_frac"]
+    rc = one["reference_call_form"]                            # the reference's call: host float32 array in, numpy maps out (PCIe inclusive)
+    assert "error" not in rc and rc["ms_per_call"] > one["ms_per_step"] and rc["two_models_ms"] > rc["ms_per_call"] and rc["maps_equal_timed_region"], rc
+    assert one["dtype"].startswith("f16x2") and one["config"]["other_configs_in_this_line"]["config5_unaligned_svs_per_s"] == c5["svs_per_s"]
+    assert one["roofline"]["other_readings"]["exact_f32_ms_per_step"] == one["exact_f32"]["ms_per_step"]
+    assert one["roofline"]["executed_frac"] >= one["roofline"]["frac"] and one["config3"]["roofline"]["executed_frac"] > 0
     assert one["config3"]["parity"]["ok"], one["config3"]
     rf = one["roofline"]          # the dominant kernel's HBM traffic is measured by counter passes inside the run (child processes), not replayed
     assert rf["traffic_measured_in_run"] is True and 0.5 < rf["traffic_over_algorithmic"] < 1.3 and rf["traffic_launches"] >= 2, rf      # (conv1.b pools its output: its in + out count is an upper bound)

@@ -253,6 +253,57 @@ def test_sv_drivers_device_genome_equals_host_route(cuda):
         assert max(maxabs(x, y) for x, y in zip(outs_d[0]["predictions"][0], outs_d[-1]["predictions"][0])) > 1e-3
 
 
+def test_chromosome_encoding_built_in_a_pass_whose_range_check_fires_is_dropped(cuda, monkeypatch):
+    """the drivers' store builds a whole-chromosome encoding (`build="auto"`) INSIDE the call's deferred fp16-range check and keeps
+    it for every later call.  Forced here: the call in which the entries are built reports a raised range flag - the entries of that pass
+    must be gone (the range-safe retry builds its own), later calls stay at the parity bar of the undisturbed store, and a store dies
+    with its genome (it used to keep the genome - and its HBM - alive through its own closure)."""
+    import gc
+    import weakref
+    from orca_amd import engine, sv_drivers
+    model = M.H1esc(synthetic_seed=0)
+    g = synth.sv_driver_genome().to(cuda)
+    args, kw = ("chrS", 20_000_000, 20_404_000, g), dict(custom_models=[model], target=False)
+    sv_drivers.clear_encoding_cache()
+    base = [P.process_del(*args, **kw) for _ in range(3)][-1]        # the store's steady state: chromosome encodings of this phase held
+    store = sv_drivers._store(g, model.net0)
+    held = {k: id(v) for k, v in store.of("chrS").entries.items()}
+    assert held and store.builds == len(held)
+    sv_drivers.clear_encoding_cache()
+    P.process_del(*args, **kw)                                         # call 1: segments only
+    store = sv_drivers._store(g, model.net0)
+    assert not store.of("chrS").entries
+    real, calls, seen = engine.Context.take_overflow, {"n": 0}, {}
+
+    def fake(self):
+        calls["n"] += 1
+        if calls["n"] == 1:
+            seen["entries_at_check"] = dict(store.of("chrS").entries)  # built by the pass under check
+            return True
+        return bool(real(self))
+    with monkeypatch.context() as mp_, pytest.warns(UserWarning, match="fp16 range"):
+        mp_.setattr(engine.Context, "take_overflow", fake)
+        redo = P.process_del(*args, **kw)                              # call 2: the entries are built - and the check fires
+    assert seen["entries_at_check"], "the pass under check built no chromosome encoding: the test no longer forces the case"
+    now = store.of("chrS").entries
+    assert all(now.get(k) is not t for k, t in seen["entries_at_check"].items())      # none of the unchecked pass's tensors is still served
+    assert store.builds == len(now)
+    later = P.process_del(*args, **kw)
+    for outs in (redo, later):
+        for oa, ob in zip(outs, base):
+            assert oa["start_coords"] == ob["start_coords"]
+            for x, y in zip(oa["predictions"][0], ob["predictions"][0]):
+                assert maxabs(x, y) < 1e-4
+    # the store holds its genome and Encoder weakly
+    wg = weakref.ref(g)
+    del g, args, store, now, seen, fake
+    gc.collect()
+    assert wg() is None
+    sv_drivers._store(synth.sv_driver_genome().to(cuda), model.net0)
+    assert all(h[0]() is not None for h in sv_drivers._tls.stores.values())
+    sv_drivers.clear_encoding_cache()
+
+
 def test_sv_drivers_on_a_two_bit_genome(cuda):
     """The drivers' incremental route on the 2-bit + N-mask genome (3/8 byte per base in HBM; windows and whole chromosomes are expanded to
     codes on the device only where something is encoded): the same dictionaries, bit for bit, as on the 1 byte/base store."""
@@ -363,6 +414,37 @@ def test_sv_drivers_256mb_on_device(cuda):
     assert 0 < (c1 - c0) * 3 == (c2 - c1) * 2, (c1 - c0, c2 - c1)
     for oa, ob in zip(again, each):
         assert all(np.array_equal(x, y) for x, y in zip(oa["predictions"][0], ob["predictions"][0]))
+
+
+def test_shared_encoding_of_a_pass_whose_range_check_fires_is_not_reused(cuda, monkeypatch):
+    """`genomepredict_256Mb` caches a packed sequence's Encoder output for the driver call's other anchor INSIDE its deferred
+    fp16-range check.  Forced here (the first check of the call reports a raised flag): the cached f16x2 output of that pass must be gone
+    before the second anchor looks it up - ref.r then encodes again (3 Encoder passes on the planar kernels instead of 2: the count
+    of a call without sharing) - and every map still agrees with the undisturbed call at the parity bar."""
+    from orca_amd import engine
+    from orca_amd import genome as G
+    model = M.H1esc_256M(synthetic_seed=0)
+    g = G.PackedGenome.random({"chrL": 150_016_000, "chr1": 120_000_000}, seed=9, fast=True).to(cuda)
+    args = ("chrL", 60_200_000, 61_850_000, g)
+    kw = dict(custom_models=[model], target=False, window_radius=128000000, padding_chr="chr1")
+    ctx = engine.get_context(cuda)
+    P.process_del(*args, **kw)                                   # warm: weights uploaded, workspaces sized
+    c0 = ctx.launch_counts()["planar"]
+    base = P.process_del(*args, **kw)
+    c1 = ctx.launch_counts()["planar"]
+    real, calls = engine.Context.take_overflow, {"n": 0}
+
+    def fake(self):
+        calls["n"] += 1
+        return bool(real(self)) or calls["n"] == 1
+    with monkeypatch.context() as mp_, pytest.warns(UserWarning, match="fp16 range"):
+        mp_.setattr(engine.Context, "take_overflow", fake)
+        redo = P.process_del(*args, **kw)
+    c2 = ctx.launch_counts()["planar"]
+    assert (c2 - c1) * 2 == (c1 - c0) * 3, (c1 - c0, c2 - c1)     # ref.l (dropped), ref.r (again), alt - the range-safe retry runs other kernels
+    for oa, ob in zip(redo, base):
+        for x, y in zip(oa["predictions"][0], ob["predictions"][0]):
+            assert maxabs(x, y) < 1e-4
 
 
 def test_process_del_against_the_reference_with_real_networks(cuda):

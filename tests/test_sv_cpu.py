@@ -42,8 +42,12 @@ def test_allele_windows_equal_explicit_editing():
 
 def test_sv_windows_are_centred_and_full_length():
     chrlen = 40_000_000
-    for v in sv.synth_svs(64, chrlen):
-        assert v.kind in ("del", "dup", "inv") and 0 < v.start < v.end < chrlen and v.start % 4000 == 0
+    off = [v for v in sv.synth_svs(64, chrlen) if v.start % 4000 or v.end % 4000]
+    assert len(off) >= 60                                     # the default set is unaligned (log-uniform sizes, no alignment)
+    old = sv.synth_svs(64, chrlen, align=4000)                # rounds 3-5's set: the same draws rounded down to the 4 kb grid
+    assert [v.kind for v in old] == [v.kind for v in sv.synth_svs(64, chrlen)] and old[0] == sv.SV("del", 30_172_000, 33_840_000)
+    for v in sv.synth_svs(64, chrlen) + old:
+        assert v.kind in ("del", "dup", "inv") and 0 < v.start < v.end < chrlen and 10_000 - 4000 < v.end - v.start <= 5_000_000
         rp, rw, rm, ap, aw, am = sv.sv_windows(v, chrlen)
         assert sum(p[1] for p in rp) == sum(p[1] for p in ap) == sv.WINDOW
         assert rw - 16_000_000 <= rm <= rw + 16_000_000 and aw - 16_000_000 <= am <= aw + 16_000_000

@@ -10,7 +10,7 @@ from orca_amd/synth.py into the reference nn.Modules, runs seeded inputs and
 stores the outputs as small .npz fixtures.  The reference source itself never
 travels: fixtures are data only (inputs are regenerated from seeds).
 
-Usage:  python tools/make_golden.py [--full32m]   (--full32m adds the ~8 min
+Usage:  python tools/make_golden.py [--full32m | --config3 | --coarsegrain | --full256m | --genome | --svreal]   (--full32m adds the ~8 min
 full 32 Mb two-strand forward, G8)
 """
 import argparse
@@ -619,6 +619,104 @@ def coarsegrain_golden():
     np.savez_compressed(os.path.join(GOLD, "G18_coarsegrain.npz"), **d)
 
 
+GENOME26 = {"seed": 26, "chroms": (("chr1", 100_003), ("chr10", 1_237), ("chr2", 64), ("chrX", 7), ("chrM", 20_000))}
+
+
+def genome26_strings():
+    """The synthetic multi-chromosome FASTA text behind G26: upper and lower case bases, N runs, IUPAC symbols."""
+    rs = np.random.RandomState(GENOME26["seed"])
+    recs = {}
+    for name, n in GENOME26["chroms"]:
+        s = rs.choice(list("ACGTacgt"), size=n, p=[0.2] * 4 + [0.05] * 4)
+        for _ in range(max(1, n // 9000)):
+            a = int(rs.randint(0, max(1, n - 3)))
+            s[a:a + int(rs.randint(1, max(2, min(700, n // 3))))] = "N"
+        for a in rs.randint(0, n, max(1, n // 400)):
+            s[a] = rs.choice(list("RYnKMswb"))
+        recs[name] = "".join(s)
+    recs["chr1"] = "N" * 11 + recs["chr1"][11:-5] + "nnnnn"      # N at both chromosome ends
+    return recs
+
+
+def genome_golden():
+    """G26 - the reference's genome store itself: `selene_utils2.MemmapGenome.get_encoding_from_coords` /
+    `get_encoding_from_coords_check_unk` (selene_utils2.py:186-272) on a synthetic multi-chromosome genome.  The object is
+    made with `object.__new__` and given the state `_unpicklable_init` (:97-157) leaves behind - `sequence_data` [4, total]
+    float32 in sorted-chromosome order, `inds`, `len_chrs`, `initialized` - because pyfaidx and selene are not installed;
+    the one-hot columns come from the build's encoder (selene's `sequence_to_encoding` is not vendored: SURVEY 8c).
+    Everything the QUERY does - slicing, 0.25 padding, the '-' strand as `[::-1, ::-1]`, the asserts, `pad=strand` in
+    `_check_unk`, the first-row unknown test - is the reference's own code."""
+    _stub_third_party()
+    import selene_utils2 as su
+    from orca_amd.genome import sequence_to_encoding
+    recs = genome26_strings()
+    g = object.__new__(su.MemmapGenome)
+    g.chrs = sorted(recs)
+    g.len_chrs = {c: len(recs[c]) for c in g.chrs}
+    g.lens = np.array([g.len_chrs[c] for c in g.chrs])
+    g.inds = {c: ind for c, ind in zip(g.chrs, np.concatenate([[0], np.cumsum(g.lens)]))}
+    g.sequence_data = np.zeros((4, int(g.lens.sum())), dtype=np.float32)
+    for c in g.chrs:
+        g.sequence_data[:, g.inds[c]: g.inds[c] + g.len_chrs[c]] = sequence_to_encoding(recs[c]).T
+    g.initialized = True
+
+    rs = np.random.RandomState(GENOME26["seed"] + 1)
+    queries = []
+    for c in g.chrs:
+        n = g.len_chrs[c]
+        span = min(n, 300)
+        fixed = [(0, n), (0, 0), (n, n), (0, min(n, 5)), (max(0, n - 5), n), (-7, min(n, 4)), (max(0, n - 3), n + 9), (-4, n + 4),
+                 (-10, 0), (n, n + 10), (-10, -2), (n + 2, n + 12), (n + 1, n + 1), (-3, -3), (5, 2), (min(n, 3), min(n, 3)),
+                 (-1, 1), (n - 1, n + 1)]
+        rnd = []
+        for _ in range(24):
+            a = int(rs.randint(-span // 4 - 2, n + span // 4 + 2))
+            rnd.append((a, a + int(rs.randint(0, span + 1))))
+        for (a, b) in fixed + rnd:
+            for strand in ("+", "-", "."):
+                for pad in (False, True):
+                    queries.append((c, int(a), int(b), strand, pad))
+    # Encoder-sized windows (whole 4 kb bins, N runs inside) for the -m gpu comparison of the HBM-resident stores and of
+    # `Encoder.forward_2bit` with the Encoder on the reference's float rows
+    for (a, b) in ((0, 96_000), (4_003, 100_003), (-2_000, 22_000), (80_003, 104_003)):
+        for strand in ("+", "-"):
+            queries.append(("chr1", a, b, strand, True))
+    queries.append(("chrM", 0, 20_000, "-", False))
+
+    d = {"chrs": np.array(g.chrs), "q_chrom": np.array([q[0] for q in queries]), "q_start": np.array([q[1] for q in queries], dtype=np.int64),
+         "q_end": np.array([q[2] for q in queries], dtype=np.int64), "q_strand": np.array([q[3] for q in queries]),
+         "q_pad": np.array([q[4] for q in queries], dtype=bool)}
+    for c in g.chrs:
+        d["seq_" + c] = np.array(recs[c])
+    status, dtypes, rows, offs, unk_status, unk_flag, unk_same = [], [], [], [0], [], [], []
+    for (c, a, b, strand, pad) in queries:
+        try:
+            enc = g.get_encoding_from_coords(c, a, b, strand=strand, pad=pad)
+            assert enc.shape == (b - a, 4)
+            status.append("ok"); dtypes.append(str(enc.dtype)); rows.append(np.asarray(enc, dtype=np.float32))
+            assert np.array_equal(rows[-1].astype(enc.dtype), enc)
+        except AssertionError:
+            status.append("AssertionError"); dtypes.append(""); rows.append(np.zeros((0, 4), np.float32))
+        except Exception as e:       # anything else the reference raises is recorded by type
+            status.append(type(e).__name__); dtypes.append(""); rows.append(np.zeros((0, 4), np.float32))
+        offs.append(offs[-1] + rows[-1].shape[0])
+        try:      # the check_unk form ignores the caller's pad (pad=strand is always true: selene_utils2.py:271)
+            enc2, unk = g.get_encoding_from_coords_check_unk(c, a, b, strand=strand, pad=pad)
+            unk_status.append("ok"); unk_flag.append(bool(unk))
+            ref_pad = g.get_encoding_from_coords(c, a, b, strand=strand, pad=True)
+            unk_same.append(bool(np.array_equal(enc2, ref_pad)))
+        except AssertionError:
+            unk_status.append("AssertionError"); unk_flag.append(False); unk_same.append(True)
+        except Exception as e:
+            unk_status.append(type(e).__name__); unk_flag.append(False); unk_same.append(True)
+    assert all(unk_same)
+    d.update(status=np.array(status), dtype=np.array(dtypes), rows=np.concatenate(rows, axis=0), row_offsets=np.array(offs, dtype=np.int64),
+             unk_status=np.array(unk_status), unk_flag=np.array(unk_flag, dtype=bool))
+    np.savez_compressed(os.path.join(GOLD, "G26_genome.npz"), **d)
+    from collections import Counter
+    print("G26 done:", len(queries), "queries;", Counter(status), Counter(unk_status), Counter(dtypes), "rows", d["rows"].shape)
+
+
 FULL256 = {"seed": 0, "seq_seed": 2, "L": 256_000_000, "chrlen": 138_368_000, "mpos": 70_000_000, "wpos": 128_000_000}
 
 
@@ -683,6 +781,8 @@ def full256_golden(om, threads):
 if __name__ == "__main__":
     if "--coarsegrain" in sys.argv:
         coarsegrain_golden()
+    elif "--genome" in sys.argv:
+        genome_golden()
     elif "--full256m" in sys.argv:
         _stub_third_party()
         import orca_modules as _om

@@ -8,7 +8,7 @@ dev = torch.device("cuda:0")
 h1 = orca_models.H1esc(synthetic_seed=0)
 g = torch.Generator(device=dev).manual_seed(5)
 genome = torch.randint(0, 4, (40_000_000,), device=dev, generator=g, dtype=torch.uint8)
-v = sv.synth_svs(4, 40_000_000)[2]
+v = sv.synth_svs(4, 40_000_000, align=4000)[2]      # an on-grid variant: the local encodes are what is measured
 cache = sv.ChromEncodings(h1.net0, genome)
 rp, rw, rm, ap, aw, am = sv.sv_windows(v, 40_000_000)
 codes = torch.stack([sv.assemble_codes(genome, rp), sv.assemble_codes(genome, ap)])

@@ -1,16 +1,17 @@
-"""SV screen timing (BASELINE configs[4]) on one GPU: python tools/time_sv_screen.py [n_svs] [incremental 0|1] [streams: auxiliary contexts of the local encodes, 0 = none]"""
+"""SV screen timing (BASELINE configs[4]) on one GPU: python tools/time_sv_screen.py [n_svs] [incremental 0|1] [streams: auxiliary contexts of the local encodes, 0 = none, -1 = default] [align: 1 = unaligned (default), 4000 = the 4 kb grid]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from orca_amd import orca_models, sv
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 inc = (sys.argv[2] != "0") if len(sys.argv) > 2 else True
-streams = int(sys.argv[3]) if len(sys.argv) > 3 else None
+streams = int(sys.argv[3]) if len(sys.argv) > 3 and int(sys.argv[3]) >= 0 else None
+align = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 dev = torch.device("cuda:0")
 h1 = orca_models.H1esc(synthetic_seed=0)
 g = torch.Generator(device=dev).manual_seed(5)
 genome = torch.randint(0, 4, (40_000_000,), device=dev, generator=g, dtype=torch.uint8)
-svs = sv.synth_svs(n + 2, 40_000_000)
+svs = sv.synth_svs(n + 2, 40_000_000, align=align)
 sv.sv_screen([h1], genome, svs[:2], 40_000_000, incremental=inc, min_uses=1, streams=streams)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
@@ -20,7 +21,7 @@ torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 print(f"incremental={inc} streams={streams} {n} SVs: {dt / n * 1e3:.1f} ms per SV = {n / dt:.2f} SV/s  {st}")
 
-if inc:   # where a variant's time goes
+if inc and align == 4000:   # where an on-grid variant's time goes
     import time as T
     cache = sv.ChromEncodings(h1.net0, genome)
     for k in (("+", 0), ("-", 0), ("+", 2000), ("-", 2000)):
