@@ -147,6 +147,21 @@ int orca_net_free(orca_net* net);
  *                         traffic of _BF16, 11 instead of 8 significant bits; fp16 range guard as _F16X2). */
 #define ORCA_PRECISION_F16 5
 int orca_net_set_precision(orca_net* net, int precision);
+/* ORCA_NET_ENCODER only: which of the ALGEBRAICALLY EQUAL forms of stage 1-3's linear groups runs (orca_modules.py:811-852: `lconv_i` is
+ * Conv-BN-Conv-BN with no nonlinearity, `conv_i`'s first conv is linear up to its ReLU; eval-mode BatchNorm is affine, so each group is ONE
+ * convolution whose weights the library composes on the host in float64).  The default runs every composed form the weights allow; a group
+ * whose composed weights leave the fp16 range keeps the reference's layer sequence by itself.  The other values FORCE a less composed form:
+ * they exist so that the parity suite can run the fallbacks on ordinary weights and compare them with the default (tests/test_gpu_nets.py).
+ *   _DEFAULT         lconv1 = 17 taps, conv1.a o lconv1 = 25 taps, both straight from the bases; with packed bases lout1 is computed in
+ *                    conv1.b's epilogue (never stored); lconv2 / lconv3 = single 17-tap convs
+ *   _STORED_RESIDUAL as _DEFAULT, lout1 written by a 17-tap first-layer launch and re-read (what float input rows get anyway)
+ *   _LCONV1_ONLY     conv1.a stays a 64 -> 64 launch of its own
+ *   _TWO_CONV        the reference's layer sequence, conv by conv */
+#define ORCA_ENCODER_FORM_DEFAULT 0
+#define ORCA_ENCODER_FORM_STORED_RESIDUAL 1
+#define ORCA_ENCODER_FORM_LCONV1_ONLY 2
+#define ORCA_ENCODER_FORM_TWO_CONV 3
+int orca_net_set_encoder_form(orca_net* net, int form);
 /* ORCA_PRECISION_F16X2 only: the kernels raise a device flag when an activation leaves the fp16
  * range (the result of that forward is then invalid).  This call waits for the context's stream,
  * returns the flag in *flag and clears it - the host falls back to ORCA_PRECISION_BF16X3. */
@@ -206,7 +221,7 @@ int64_t orca_encoder_num_bins(int64_t L);
  * contiguous [B,128,n>>i] encoding (fine -> coarse, as the reference returns).
  * Arithmetic: orca_net_set_precision (F32, F16X2, BF16X3, BF16X2, BF16).  The split-operand modes run on channel-last
  * activations from B*n >= 32000 positions on (the 256 Mb model's 64 000 bins); smaller problems use the exact fp32 kernels,
- * which are faster there, whatever the precision asked for ($ORCA_UNET_NLC_MIN overrides the threshold). */
+ * which are faster there, whatever the precision asked for. */
 int orca_unet_forward(orca_ctx* ctx, orca_net* net, const float* x, int64_t sx_b, int64_t sx_c,
                       int64_t sx_l, int B, int n, float* const* outs_host, int n_outs);
 

@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "liborca_hip.so")
 ORCA_NET_ENCODER, ORCA_NET_ENCODER2, ORCA_NET_ENCODER3, ORCA_NET_DECODER, ORCA_NET_DECODER_1M, ORCA_NET_ENCODER2B = 1, 2, 3, 4, 5, 6
 ORCA_UPSAMPLE_NEAREST, ORCA_UPSAMPLE_BILINEAR = 0, 1
 PRECISIONS = {"f32": 0, "bf16": 1, "bf16x2": 2, "bf16x3": 3, "f16x2": 4, "f16": 5}
+ENCODER_FORMS = {"default": 0, "stored_residual": 1, "lconv1_only": 2, "two_conv": 3}      # include/orca_hip.h: ORCA_ENCODER_FORM_*
 
 
 class OrcaHipError(RuntimeError):
@@ -47,6 +48,7 @@ SIGNATURES = {
     "orca_net_create": (c_int, [c_void_p, c_int, POINTER(ConvDesc), c_int, c_int, POINTER(c_void_p)]),
     "orca_net_free": (c_int, [c_void_p]),
     "orca_net_set_precision": (c_int, [c_void_p, c_int]),
+    "orca_net_set_encoder_form": (c_int, [c_void_p, c_int]),
     "orca_encoder_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_int64, c_int64,
                                      c_int64, c_void_p, c_int64, c_int64, c_int64]),
     "orca_encoder_forward_2bit": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64]),

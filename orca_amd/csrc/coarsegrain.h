@@ -11,7 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-__global__ void cg_init_kernel(const float* __restrict__ ar, const float* __restrict__ cnt, long ld_in, int n, int N, float* __restrict__ v,
+static __global__ void cg_init_kernel(const float* __restrict__ ar, const float* __restrict__ cnt, long ld_in, int n, int N, float* __restrict__ v,
                                float* __restrict__ c, int* __restrict__ m) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (long)N * N) return;
@@ -26,7 +26,7 @@ __global__ void cg_init_kernel(const float* __restrict__ ar, const float* __rest
 }
 
 // fine side F = 2M; (row 2i + row 2i+1) first, then the two columns - the order of torch.sum(axis=1) then (axis=2)
-__global__ void cg_coarsen_kernel(const float* __restrict__ v, const float* __restrict__ c, const int* __restrict__ m, int M, float* __restrict__ vo,
+static __global__ void cg_coarsen_kernel(const float* __restrict__ v, const float* __restrict__ c, const int* __restrict__ m, int M, float* __restrict__ vo,
                                   float* __restrict__ co, int* __restrict__ mo) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (long)M * M) return;
@@ -38,7 +38,7 @@ __global__ void cg_coarsen_kernel(const float* __restrict__ v, const float* __re
 }
 
 // one thread per COARSE pixel: updates its 2x2 block of the finer level in place
-__global__ void cg_refine_kernel(const float* __restrict__ v_cur, const int* __restrict__ m_cur, int M, float cutoff, float* __restrict__ v_next,
+static __global__ void cg_refine_kernel(const float* __restrict__ v_cur, const int* __restrict__ m_cur, int M, float cutoff, float* __restrict__ v_next,
                                  const float* __restrict__ c_next, const int* __restrict__ m_next) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (long)M * M) return;
@@ -58,7 +58,7 @@ __global__ void cg_refine_kernel(const float* __restrict__ v_cur, const int* __r
   }
 }
 
-__global__ void cg_finish_kernel(const float* __restrict__ v, const int* __restrict__ m, int N, int n, float* __restrict__ out, long ld_out) {
+static __global__ void cg_finish_kernel(const float* __restrict__ v, const int* __restrict__ m, int N, int n, float* __restrict__ out, long ld_out) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (long)n * n) return;
   const int i = (int)(idx / n), j = (int)(idx - (long)i * n);

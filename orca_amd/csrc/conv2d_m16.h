@@ -77,36 +77,6 @@ __device__ __forceinline__ void m16_unpack8(const u32x4_t (&u)[NS], float (&v)[8
   }
 }
 
-// ---- nn.MaxPool1d(K, K) on planar 16-bit sequence tensors (conv_p16.h: P16 = NS 2 / fp16 hi + lo planes, B16 = NS 1 / bf16) --------
-// Units are the M16 / P16 unit (8 channels of one position); plane of octet o, split s at base + (o * NS + s) * plen, positions behind
-// P16_GUARD units.  The pooled value is the max of the stored (hi + lo) values, re-split - what pooling the fp32 tensor and splitting
-// in the next conv's loader would give, up to the 2^-22 the split has already rounded away.  grid (ceil(n_out / 256), C / 8), block 256.
-template <int K, int NS, int DT>
-__global__ void p16_maxpool_kernel(const f32x4* __restrict__ x, long x_plen, f32x4* __restrict__ y, long y_plen, long n_out) {
-  const long m = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const int o = blockIdx.y;
-  if (m >= n_out) return;
-  const u32x4_t* xp = reinterpret_cast<const u32x4_t*>(x) + (long)o * NS * x_plen + P16_GUARD + m * K;
-  float best[8];
-#pragma unroll
-  for (int j = 0; j < K; ++j) {
-    u32x4_t u[NS];
-#pragma unroll
-    for (int s = 0; s < NS; ++s) u[s] = xp[(long)s * x_plen + j];
-    float v[8];
-    m16_unpack8<NS, DT>(u, v);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) best[e] = j == 0 ? v[e] : fmaxf(best[e], v[e]);
-  }
-  f32x4 a, b;
-  a.x = best[0]; a.y = best[1]; a.z = best[2]; a.w = best[3]; b.x = best[4]; b.y = best[5]; b.z = best[6]; b.w = best[7];
-  u32x4_t out[NS];
-  bool ovf = false;
-  m16_pack8<NS, DT>(a, b, out, ovf);
-#pragma unroll
-  for (int s = 0; s < NS; ++s) reinterpret_cast<u32x4_t*>(y)[((long)o * NS + s) * y_plen + P16_GUARD + m] = out[s];
-}
-
 // ---- producers / consumers at the ends of a Decoder ---------------------------------------------------------------
 // mat[c][i][j] = x[c][i] + x[c][j] (c < 128); channels 128..128+nt-1 = distenc[t][i][j]; other channels and pad pixels 0.
 // `o0`: first channel octet produced (the Decoder only materialises octets 16, 17 = distenc + padding; octet o lands in plane o - o0).

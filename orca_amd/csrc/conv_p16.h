@@ -761,7 +761,7 @@ __global__ __launch_bounds__(WM * 64, WM / 4) void conv1d_k9_p16_kernel(ConvP16A
 }
 
 // zero the guard / tail units of every plane: [0, P16_GUARD) and [P16_GUARD + n_valid, plen)
-__global__ void p16_zero_pads_kernel(f32x4* __restrict__ base, long plen, long n_valid) {
+static __global__ void p16_zero_pads_kernel(f32x4* __restrict__ base, long plen, long n_valid) {
   f32x4* pl = base + (long)blockIdx.x * plen;
   const long tail0 = P16_GUARD + n_valid;
   for (long i = threadIdx.x; i < P16_GUARD + (plen - tail0); i += blockDim.x) {
@@ -782,7 +782,7 @@ struct FirstP16Args {
   unsigned* flag;
 };
 
-__global__ __launch_bounds__(256) void conv1d_first_p16_kernel(FirstP16Args a) {
+static __global__ __launch_bounds__(256) void conv1d_first_p16_kernel(FirstP16Args a) {
   __shared__ float ws[36 * 8];   // [tap*4+ci][8 couts of this octet]
   __shared__ float bs[8];
   const int oct = blockIdx.y;
@@ -1032,7 +1032,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_first_mfma_p16_kernel(FirstMfma
 
 // ---- packed sequence helpers --------------------------------------------------------------------------------
 // [L][4] float rows (element strides sc, sl) -> 1-byte codes; *bad is raised for rows that are neither one-hot nor N
-__global__ void pack_sequence_kernel(const float* __restrict__ x, long sc, long sl, long L, unsigned char* __restrict__ codes,
+static __global__ void pack_sequence_kernel(const float* __restrict__ x, long sc, long sl, long L, unsigned char* __restrict__ codes,
                                      unsigned* __restrict__ bad) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= L) return;
@@ -1051,7 +1051,7 @@ __global__ void pack_sequence_kernel(const float* __restrict__ x, long sc, long 
   codes[i] = (unsigned char)code;
 }
 // codes -> [n][4] fp32 rows of strand positions off .. off+n-1 (used by the non-P16 arithmetic modes)
-__global__ void expand_codes_kernel(const unsigned char* __restrict__ codes, const unsigned char* __restrict__ nmask, long origin, long L, long off, int reverse,
+static __global__ void expand_codes_kernel(const unsigned char* __restrict__ codes, const unsigned char* __restrict__ nmask, long origin, long L, long off, int reverse,
                                     long n, float* __restrict__ y) {
   const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n) return;
@@ -1065,7 +1065,7 @@ __global__ void expand_codes_kernel(const unsigned char* __restrict__ codes, con
 
 // ---- converters (tests, and the stage 3 -> 4 hand-over) -------------------------------------------------
 // fp32 channel-last [n][C] -> P16
-__global__ void nlc_to_p16_kernel(const float* __restrict__ x, f32x4* __restrict__ y, long n, int C, long plen) {
+static __global__ void nlc_to_p16_kernel(const float* __restrict__ x, f32x4* __restrict__ y, long n, int C, long plen) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int c4n = C / 4;
   if (idx >= n * c4n) return;
@@ -1076,7 +1076,7 @@ __global__ void nlc_to_p16_kernel(const float* __restrict__ x, f32x4* __restrict
   p16_split_store(reinterpret_cast<char*>(y) + (long)(c4 >> 1) * 2 * plen * 16 + (P16_GUARD + pos) * 16 + (c4 & 1) * 8, plen * 16, v, true, ovf);
 }
 // fp32 channel-last [n][C] -> B16 (one bf16 plane per 8 channels), and back
-__global__ void nlc_to_b16_kernel(const float* __restrict__ x, f32x4* __restrict__ y, long n, int C, long plen) {
+static __global__ void nlc_to_b16_kernel(const float* __restrict__ x, f32x4* __restrict__ y, long n, int C, long plen) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int c4n = C / 4;
   if (idx >= n * c4n) return;
@@ -1087,7 +1087,7 @@ __global__ void nlc_to_b16_kernel(const float* __restrict__ x, f32x4* __restrict
   pk.x = cvt_pk_bf16(v.x, v.y); pk.y = cvt_pk_bf16(v.z, v.w);
   *reinterpret_cast<u32x2*>(reinterpret_cast<char*>(y) + (long)(c4 >> 1) * plen * 16 + (P16_GUARD + pos) * 16 + (c4 & 1) * 8) = pk;
 }
-__global__ void b16_to_nlc_kernel(const f32x4* __restrict__ x, float* __restrict__ y, long n, int C, long plen) {
+static __global__ void b16_to_nlc_kernel(const f32x4* __restrict__ x, float* __restrict__ y, long n, int C, long plen) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int c4n = C / 4;
   if (idx >= n * c4n) return;
@@ -1099,7 +1099,7 @@ __global__ void b16_to_nlc_kernel(const f32x4* __restrict__ x, float* __restrict
   *reinterpret_cast<f32x4*>(y + pos * C + 4 * c4) = v;
 }
 // P16 -> fp32 channel-last [n][C]
-__global__ void p16_to_nlc_kernel(const f32x4* __restrict__ x, float* __restrict__ y, long n, int C, long plen) {
+static __global__ void p16_to_nlc_kernel(const f32x4* __restrict__ x, float* __restrict__ y, long n, int C, long plen) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int c4n = C / 4;
   if (idx >= n * c4n) return;
@@ -1185,7 +1185,7 @@ __device__ __forceinline__ float edge_layer_dot(const EdgeLayerArgs& a, const fl
   return acc;
 }
 
-__global__ __launch_bounds__(512) void lconv_edge_layer_kernel(EdgeLayerArgs a) {
+static __global__ __launch_bounds__(512) void lconv_edge_layer_kernel(EdgeLayerArgs a) {
   __shared__ float xs[9][128];
   __shared__ float part[3][128];
   const int tid = threadIdx.x, co = tid & 127, th = tid >> 7;
@@ -1302,7 +1302,7 @@ struct EdgePoolArgs {
   long n; int cout;
   f32x4* y; long y_plen; int out_fmt;
 };
-__global__ __launch_bounds__(128) void lconv_edge_pool_kernel(EdgePoolArgs a) {
+static __global__ __launch_bounds__(128) void lconv_edge_pool_kernel(EdgePoolArgs a) {
   const long nw = a.n / 4;
   long w;
   if (blockIdx.x == 0) w = 0;

@@ -7,10 +7,14 @@
 
 #include "conv_kernels.h"
 
+#ifndef ORCA_MAX_TARGETS
+#define ORCA_MAX_TARGETS 8   // num_2d of the multi-target decoders (orca_leukemia.py:512-990); hidden width F = max(5, T)
+#endif
+
 // x[b] viewed as [4][L] with element strides (sc, sl)  ->  y [4][ld] channel-major.
 // The reference feeds `seq.transpose(1,2)` of a [B,L,4] array (orca_predict.py:334),
 // i.e. sc=1, sl=4: one float4 per position.
-__global__ void seq_to_channel_major_kernel(const float* __restrict__ x, long sc, long sl, long L, float* __restrict__ y, long ld) {
+static __global__ void seq_to_channel_major_kernel(const float* __restrict__ x, long sc, long sl, long L, float* __restrict__ y, long ld) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= L) return;
   float v0, v1, v2, v3;
@@ -24,7 +28,7 @@ __global__ void seq_to_channel_major_kernel(const float* __restrict__ x, long sc
 }
 
 // x viewed as [4][L] with element strides (sc, sl)  ->  y [L][4] contiguous rows (input of the first-layer MFMA kernel)
-__global__ void seq_to_rows_kernel(const float* __restrict__ x, long sc, long sl, long L, float* __restrict__ y) {
+static __global__ void seq_to_rows_kernel(const float* __restrict__ x, long sc, long sl, long L, float* __restrict__ y) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= L) return;
   float4 q;
@@ -33,7 +37,7 @@ __global__ void seq_to_rows_kernel(const float* __restrict__ x, long sc, long sl
 }
 
 // 2-bit + N-mask genome window -> 1-byte base codes (one thread = 4 consecutive output bases)
-__global__ void genome_unpack_2bit_kernel(const unsigned char* __restrict__ two, const unsigned char* __restrict__ nmask, long start, long n,
+static __global__ void genome_unpack_2bit_kernel(const unsigned char* __restrict__ two, const unsigned char* __restrict__ nmask, long start, long n,
                                           unsigned char* __restrict__ codes) {
   const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
 #pragma unroll
@@ -70,7 +74,7 @@ __global__ void maxpool1d_kernel(const float* __restrict__ x, long ldx, float* _
 }
 
 // nn.Upsample(scale_factor=2) (nearest, 1-D): y[r][m] = x[r][m>>1]
-__global__ void upsample1d_x2_kernel(const float* __restrict__ x, long ldx, float* __restrict__ y, long ldy, long n_out) {
+static __global__ void upsample1d_x2_kernel(const float* __restrict__ x, long ldx, float* __restrict__ y, long ldy, long n_out) {
   const long m = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long r = blockIdx.y;
   if (m >= n_out) return;
@@ -78,7 +82,7 @@ __global__ void upsample1d_x2_kernel(const float* __restrict__ x, long ldx, floa
 }
 
 // nn.Upsample(scale_factor=2) (nearest) on channel-last rows: y[m][:] = x[m >> 1][:]; one thread = 4 channels.  grid ceil(n_out*C/4 / 256)
-__global__ void upsample1d_x2_nlc_kernel(const float* __restrict__ x, float* __restrict__ y, long n_out, int C) {
+static __global__ void upsample1d_x2_nlc_kernel(const float* __restrict__ x, float* __restrict__ y, long n_out, int C) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int c4n = C / 4;
   if (idx >= n_out * c4n) return;
@@ -89,7 +93,7 @@ __global__ void upsample1d_x2_nlc_kernel(const float* __restrict__ x, float* __r
 
 // [rows][cols] <-> its transpose through a 32 x 33 LDS tile, both sides coalesced: dst[c * ldd + r] = src[r * lds_ + c]
 // (channel-last [n][128] <-> channel-major [128][n] hand-overs of the U-net encoders).  grid (ceil(cols/32), ceil(rows/32), batch), block (32, 8)
-__global__ void transpose2d_kernel(const float* __restrict__ src, long lds_, long src_bs, float* __restrict__ dst, long ldd, long dst_bs,
+static __global__ void transpose2d_kernel(const float* __restrict__ src, long lds_, long src_bs, float* __restrict__ dst, long ldd, long dst_bs,
                                    long rows, long cols) {
   __shared__ float tile[32][33];
   src += (long)blockIdx.z * src_bs;
@@ -109,7 +113,7 @@ __global__ void transpose2d_kernel(const float* __restrict__ src, long lds_, lon
 }
 
 // generic strided 2-D copy: dst[r*ldd + c] = src[r*lds_ + c*scol]
-__global__ void copy2d_kernel(const float* __restrict__ src, long lds_, long scol, float* __restrict__ dst, long ldd, long cols) {
+static __global__ void copy2d_kernel(const float* __restrict__ src, long lds_, long scol, float* __restrict__ dst, long ldd, long cols) {
   const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long r = blockIdx.y;
   if (c >= cols) return;
@@ -119,7 +123,7 @@ __global__ void copy2d_kernel(const float* __restrict__ src, long lds_, long sco
 // Decoder input (orca_modules.py:462-463): mat[c][i][j] = x[c][i] + x[c][j] (c<128),
 // channel 128 = distenc[i][j] (if given), remaining pad channels = 0.
 // out layout [cpad][n][256]; one thread writes a float4 of columns.
-__global__ void outer_sum_kernel(const float* __restrict__ x, long sx_c, long sx_l, const float* __restrict__ de, long sd_c, long sd_h,
+static __global__ void outer_sum_kernel(const float* __restrict__ x, long sx_c, long sx_l, const float* __restrict__ de, long sd_c, long sd_h,
                                  long sd_w, int nt, float* __restrict__ out, int n, int cpad) {
   const int j4 = threadIdx.x;  // 0..63 -> columns 4*j4..4*j4+3
   const int i = blockIdx.x;
@@ -141,7 +145,7 @@ __global__ void outer_sum_kernel(const float* __restrict__ x, long sx_c, long sx
 // nn.Upsample(scale_factor=(2,2), mode) of y [n/2][n/2] written into ONE channel plane
 // [n][256] (orca_modules.py:430,468); the 7 pad planes behind it are zeroed.
 // bilinear = PyTorch align_corners=False: src = max((dst+0.5)/2-0.5, 0).
-__global__ void upsample2d_x2_kernel(const float* __restrict__ y, long sy_c, long sy_h, long sy_w, int nt, float* __restrict__ out, int n,
+static __global__ void upsample2d_x2_kernel(const float* __restrict__ y, long sy_c, long sy_h, long sy_w, int nt, float* __restrict__ out, int n,
                                      int bilinear, int nplanes) {
   const int j = threadIdx.x;
   const int i = blockIdx.x;
@@ -167,7 +171,6 @@ __global__ void upsample2d_x2_kernel(const float* __restrict__ y, long sy_c, lon
 
 // `final` head (orca_modules.py:423-428) + symmetrisation (:488):
 // f(i,j) = w2 . relu(W1 cur[:,i,j] + b1) + b2 ; out[i][j] = 0.5 f(i,j) + 0.5 f(j,i) (+= if accumulate)
-#define ORCA_MAX_TARGETS 8   // num_2d of the multi-target decoders (orca_leukemia.py:512-990); hidden width F = max(5, T)
 struct FinalArgs {
   const float* cur;  // [64][n][256]
   const float* w1;   // [F][64] (BN folded)
@@ -209,7 +212,7 @@ __device__ __forceinline__ void final_head_store(const FinalArgs& a, const float
   }                                                                                                         \
   __syncthreads();
 
-__global__ void final_sym_kernel(FinalArgs a) {
+static __global__ void final_sym_kernel(FinalArgs a) {
   ORCA_FINAL_LOAD_HEAD();
   const int j = threadIdx.x, i = blockIdx.x, b = blockIdx.y, n = a.n;
   if (j >= n) return;
@@ -229,14 +232,14 @@ __global__ void final_sym_kernel(FinalArgs a) {
 }
 
 // strand merge (orca_predict.py:514-523): out = 0.5*fwd + 0.5*rev[::-1, ::-1]
-__global__ void strand_merge_kernel(const float* __restrict__ fwd, const float* __restrict__ rev, float* __restrict__ out, int n) {
+static __global__ void strand_merge_kernel(const float* __restrict__ fwd, const float* __restrict__ rev, float* __restrict__ out, int n) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= n * n) return;
   out[idx] = fwd[idx] * 0.5f + rev[n * n - 1 - idx] * 0.5f;
 }
 
 // [B,C,n,n] contiguous <-> padded [B,C,n,256] (single-layer conv2d entry point only)
-__global__ void pad_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int n, int to_padded) {
+static __global__ void pad_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int n, int to_padded) {
   const int j = threadIdx.x;
   const long row = blockIdx.x;  // over B*C*n
   if (to_padded) dst[row * ORCA_LDW + j] = (j < n) ? src[row * n + j] : 0.f;
@@ -245,7 +248,7 @@ __global__ void pad_rows_kernel(const float* __restrict__ src, float* __restrict
 
 // y[b][co][m] = act(bias[co] + sum_ci w[co][ci] * x[b][ci][m])  - the kernel-size-1 Conv1d layers of Net.final_1d.
 // grid (ceil(n/256), cout, B); x reads are coalesced along m, w/bias are wave-uniform (scalar loads).
-__global__ void pointwise1d_kernel(const float* __restrict__ w, const float* __restrict__ bias, int cin, const float* __restrict__ x,
+static __global__ void pointwise1d_kernel(const float* __restrict__ w, const float* __restrict__ bias, int cin, const float* __restrict__ x,
                                    long x_bs, long ldx, float* __restrict__ y, long y_bs, long ldy, long n, int act) {
   const long m = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int co = blockIdx.y, b = blockIdx.z;
@@ -266,7 +269,7 @@ __global__ void pointwise1d_kernel(const float* __restrict__ w, const float* __r
 //   inner axis (contiguous, n = nb): numpy's pairwise sum - n < 8 sequential from -0.0, else 8 running sums r[k] += a[i+k]
 //   combined ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) - divided by the count; outer axis: sequential sum of those nb means, divided by the count.
 // NaN entries count as missing (nanmean); an all-NaN group gives NaN.
-__global__ void block_mean_f64_kernel(const double* __restrict__ mat, long ld, long r0, long c0, int nb, int npix, double* __restrict__ mean_out,
+static __global__ void block_mean_f64_kernel(const double* __restrict__ mat, long ld, long r0, long c0, int nb, int npix, double* __restrict__ mean_out,
                                       float* __restrict__ log_out, int flip) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
   if (j >= npix) return;

@@ -340,6 +340,12 @@ class Net:
             raise ValueError(f"precision must be one of {sorted(_lib.PRECISIONS)}, got {name!r}")
         check(_lib.load().orca_net_set_precision(self.handle, _lib.PRECISIONS[name]), "orca_net_set_precision")
 
+    def set_encoder_form(self, name):
+        """Encoder nets: force a less composed form of stage 1-3's linear groups (include/orca_hip.h: ORCA_ENCODER_FORM_*; the parity suite's handle)."""
+        if name not in _lib.ENCODER_FORMS:
+            raise ValueError(f"form must be one of {sorted(_lib.ENCODER_FORMS)}, got {name!r}")
+        check(_lib.load().orca_net_set_encoder_form(self.handle, _lib.ENCODER_FORMS[name]), "orca_net_set_encoder_form")
+
 
 # ---------------------------------------------------------------------------
 # forward wrappers

@@ -162,6 +162,18 @@ class Encoder(_HipModule):
             items += [(f"lconv{i}", getattr(self, f"lconv{i}"), 1), (f"conv{i}", getattr(self, f"conv{i}"), 1)]
         return items
 
+    # Which of the algebraically equal forms of stage 1-3's linear groups the library runs: "default" (every composed form the weights allow),
+    # "stored_residual", "lconv1_only", "two_conv" (the reference's layer sequence, orca_modules.py:811-852).  The forced forms exist for the
+    # parity suite: they are what extreme weights / float input rows fall back to (include/orca_hip.h: ORCA_ENCODER_FORM_*).
+    form = "default"
+
+    def _net(self, device):
+        net = super()._net(device)
+        if getattr(net, "_form", "default") != self.form:
+            net.set_encoder_form(self.form)
+            net._form = self.form
+        return net
+
     def forward(self, x, bin_lo=0, bin_hi=0, chunk_bp=0):
         """x: [B,4,L] float32 ROCm tensor (any strides).  Returns [B,128,L//4000].
         ``bin_lo/bin_hi`` restrict the output to a bin range (multi-GPU sharding of

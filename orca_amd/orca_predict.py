@@ -58,6 +58,7 @@ import contextlib as _contextlib
 import threading as _threading
 
 _enc_scope = _threading.local()
+SHARE_ENCODINGS = True      # False: every view of a 256 Mb driver call is encoded on its own, as the reference does (the tests' A/B handle)
 
 
 @_contextlib.contextmanager
@@ -67,7 +68,7 @@ def shared_encodings():
     chromosome at the variant's left and right end, `orca_predict.py:1335 / :1389`; both views of an inversion) - the reference encodes it
     twice, 2 x 128 Mb strand pairs of Encoder work each.  Nothing outlives the scope."""
     prev = getattr(_enc_scope, "cache", None)
-    if os.environ.get("ORCA_NO_SHARED_ENCODINGS"):       # A/B switch (read per call)
+    if not SHARE_ENCODINGS:
         yield
         return
     _enc_scope.cache = {} if prev is None else prev

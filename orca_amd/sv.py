@@ -467,7 +467,7 @@ def sv_screen(models, genome_codes, svs, chrlen, mchr="chrS", rank=0, world=1, i
     the views of one call (1.3-1.6x).
     ``incremental=False`` is the reference's cost structure: two independent `genomepredict` calls per variant.
     ``on_result(i, entry)``: called per variant INSTEAD of collecting the entries (a 1 024-variant screen is 12 288 maps = 3 GB).
-    ``streams``: auxiliary contexts the local re-encodes of a variant are dealt to (`encode_windows`; default $ORCA_SV_STREAMS or 4, 0 = all
+    ``streams``: auxiliary contexts the local re-encodes of a variant are dealt to (`encode_windows`; default 4, 0 = all
     on the caller's stream).
     ``group``: variants per pass of Encoder2 + decoders (default 2 = batches of 8 maps per level: a Decoder forward costs 0.97 ms per map at
     B = 8 against 1.00 at B = 4 and 1.12 at B = 2, tools/prof_decoder.py; a map does not depend on the batch it is computed in, so the
@@ -501,7 +501,7 @@ def sv_screen(models, genome_codes, svs, chrlen, mchr="chrS", rank=0, world=1, i
             caches.append(cache)
         encoded = 0
         if streams is None:
-            streams = int(os.environ.get("ORCA_SV_STREAMS", "4"))
+            streams = 4
         pool = engine.context_pool(genome_codes.device, streams) if (streams > 0 and genome_codes.is_cuda) else None
         dev = genome_codes.device
         group = max(1, int(group))

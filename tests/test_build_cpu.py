@@ -20,12 +20,19 @@ def test_hot_kernels_do_not_spill(tmp_path):
     if not os.path.exists(hipcc):
         pytest.skip("no hipcc")
     src = os.path.join(ROOT, "orca_amd", "csrc")
-    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-Wno-unused-function", "-shared",
-                        os.path.join(src, "orca_hip.hip"), "-o", str(tmp_path / "t.so"), "-Rpass-analysis=kernel-resource-usage"],
-                       capture_output=True, text=True, cwd=src, timeout=900)
-    assert r.returncode == 0, r.stderr[-2000:]
+    from concurrent.futures import ThreadPoolExecutor
+
+    def compile_unit(unit):      # the two translation units that hold MFMA kernels
+        return subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-Wno-unused-function", "-c",
+                               os.path.join(src, unit), "-o", str(tmp_path / (unit + ".o")), "-Rpass-analysis=kernel-resource-usage"],
+                              capture_output=True, text=True, cwd=src, timeout=900)
+    with ThreadPoolExecutor(2) as ex:
+        runs = list(ex.map(compile_unit, ("orca_encoder.hip", "orca_decoder.hip")))
+    for r in runs:
+        assert r.returncode == 0, r.stderr[-2000:]
+    stderr = "\n".join(r.stderr for r in runs)
     name, seen, spilled = None, 0, []
-    for line in r.stderr.splitlines():
+    for line in stderr.splitlines():
         m = re.search(r"Function Name: (\S+)", line)
         if m:
             name = m.group(1)

@@ -263,14 +263,16 @@ def test_chromosome_encoding_built_in_a_pass_whose_range_check_fires_is_dropped(
     from orca_amd import engine, sv_drivers
     model = M.H1esc(synthetic_seed=0)
     g = synth.sv_driver_genome().to(cuda)
-    args, kw = ("chrS", 20_000_000, 20_404_000, g), dict(custom_models=[model], target=False)
+    # two deletions of one 4 kb phase whose windows lie 6 Mb apart: the second call's reference windows miss 1 500 bins of the first call's
+    # segments - the second window-sized miss of the phase, at which `build="auto"` encodes the whole chromosome (sv.ChromEncodings.cover)
+    first, args, kw = ("chrS", 17_000_000, 17_404_000, g), ("chrS", 23_000_000, 23_404_000, g), dict(custom_models=[model], target=False)
     sv_drivers.clear_encoding_cache()
-    base = [P.process_del(*args, **kw) for _ in range(3)][-1]        # the store's steady state: chromosome encodings of this phase held
+    base = [P.process_del(*a_, **kw) for a_ in (first, args, args)][-1]   # the store's steady state: chromosome encodings of this phase held
     store = sv_drivers._store(g, model.net0)
     held = {k: id(v) for k, v in store.of("chrS").entries.items()}
     assert held and store.builds == len(held)
     sv_drivers.clear_encoding_cache()
-    P.process_del(*args, **kw)                                         # call 1: segments only
+    P.process_del(*first, **kw)                                        # call 1: segments only
     store = sv_drivers._store(g, model.net0)
     assert not store.of("chrS").entries
     real, calls, seen = engine.Context.take_overflow, {"n": 0}, {}
@@ -296,11 +298,12 @@ def test_chromosome_encoding_built_in_a_pass_whose_range_check_fires_is_dropped(
                 assert maxabs(x, y) < 1e-4
     # the store holds its genome and Encoder weakly
     wg = weakref.ref(g)
-    del g, args, store, now, seen, fake
+    del g, first, args, store, now, seen, fake
     gc.collect()
     assert wg() is None
-    sv_drivers._store(synth.sv_driver_genome().to(cuda), model.net0)
-    assert all(h[0]() is not None for h in sv_drivers._tls.stores.values())
+    g2 = synth.sv_driver_genome().to(cuda)
+    sv_drivers._store(g2, model.net0)                                  # the next lookup drops the dead genome's store
+    assert len(sv_drivers._tls.stores) == 1 and all(h[0]() is g2 for h in sv_drivers._tls.stores.values())
     sv_drivers.clear_encoding_cache()
 
 
@@ -405,11 +408,11 @@ def test_sv_drivers_256mb_on_device(cuda):
     c0 = ctx.launch_counts()["planar"]
     again = P.process_del("chrL", mstart, mend, g, custom_models=[model], target=False, window_radius=128000000, padding_chr="chr1")
     c1 = ctx.launch_counts()["planar"]
-    os.environ["ORCA_NO_SHARED_ENCODINGS"] = "1"
+    P.SHARE_ENCODINGS = False
     try:
         each = P.process_del("chrL", mstart, mend, g, custom_models=[model], target=False, window_radius=128000000, padding_chr="chr1")
     finally:
-        del os.environ["ORCA_NO_SHARED_ENCODINGS"]
+        P.SHARE_ENCODINGS = True
     c2 = ctx.launch_counts()["planar"]
     assert 0 < (c1 - c0) * 3 == (c2 - c1) * 2, (c1 - c0, c2 - c1)
     for oa, ob in zip(again, each):

@@ -103,10 +103,10 @@ def test_conv1d_split_bf16_channel_last(cuda, cin, cout, n, precision, tol):
 
 @pytest.mark.parametrize("cin,cout,n", [(128, 128, 1), (128, 128, 7), (128, 128, 33), (128, 128, 55), (128, 128, 275), (128, 128, 2048), (64, 96, 100), (96, 64, 513)])
 @pytest.mark.parametrize("precision,tol", [("bf16x3", 2e-5), ("f16x2", 2e-5), ("bf16x2", 3e-4), ("bf16", 5e-2)])
-def test_conv1d_short_rows_channel_last(cuda, cin, cout, n, precision, tol, monkeypatch):
+def test_conv1d_short_rows_channel_last(cuda, cin, cout, n, precision, tol):
     """conv_small.h: rows of <= 2048 positions (the Encoder's stages 5-7 of a local re-encode) run the K-chunks of a tile side by side - against
-    torch fp32, and against the chunk-after-chunk kernel of conv_bf16s.h (ORCA_NO_SMALL_CONV=1) on the same inputs: same operand splits and
-    products, another fp32 summation order (per-chunk partials) - equal to fp32 rounding.  A batch row must not depend on the batch."""
+    torch fp32 (the chunk-after-chunk kernel of conv_bf16s.h, which longer rows run, has the same operand splits and products and another fp32
+    summation order).  A batch row must not depend on the batch."""
     rs = np.random.RandomState(cin + cout + n)
     B = 3
     x = torch.from_numpy(rs.randn(B, cin, n).astype(np.float32))
@@ -119,10 +119,6 @@ def test_conv1d_short_rows_channel_last(cuda, cin, cout, n, precision, tol, monk
         ref = _ref_conv1d(x, w, b, relu, ra, None)
         err = float((y.cpu().transpose(1, 2) - ref).abs().max())
         assert err < tol, (cin, cout, n, precision, relu, err)
-        monkeypatch.setenv("ORCA_NO_SMALL_CONV", "1")
-        y0 = engine.conv1d_nlc(xd, w, b, precision, relu, rad)
-        monkeypatch.delenv("ORCA_NO_SMALL_CONV")
-        assert float((y - y0).abs().max()) < 2e-5
         one = engine.conv1d_nlc(xd[1:2].contiguous(), w, b, precision, relu, None if rad is None else rad[1:2].contiguous())
         assert torch.equal(one, y[1:2])
 
@@ -158,11 +154,11 @@ def test_conv1d_p16_dma(cuda, cin, cout, n, out_mode):
         assert err < 2e-5, (cin, cout, n, out_mode, relu, err)
 
 
-@pytest.mark.parametrize("cin,k,n", [(96, 9, 300001), (64, 17, 70000)])
+@pytest.mark.parametrize("cin,k,n", [(96, 9, 300001), (64, 17, 70000), (96, 9, 30001), (64, 17, 9000)])
 @pytest.mark.parametrize("out_mode,res", [(0, False), (1, True)])
-def test_conv1d_p16_96_couts_on_32x32x16(cuda, monkeypatch, cin, k, n, out_mode, res):
-    """The 96-cout layers run on conv_p16x.h (16 x 16 x 32 MFMAs) by default; ORCA_NO_P16X=1 puts them back on conv_p16w1.h (32 x 32 x 16,
-    512-position tiles), ORCA_NO_P16W1=1 as well on the 256-position tile of conv_p16.h: all three against torch fp32."""
+def test_conv1d_p16_96_couts(cuda, cin, k, n, out_mode, res):
+    """The 96-cout layers of P16 planes run on conv_p16x.h (16 x 16 x 32 MFMAs, 512-position tiles) from 65 536 positions on and on the
+    256-position tile of conv_p16.h below: both against torch fp32 (k9 and the composed 17-tap form; plain and ReLU + residual + MaxPool1d(4))."""
     rs = np.random.RandomState(cin + k + n + out_mode)
     x = torch.from_numpy(rs.randn(1, cin, n).astype(np.float32))
     w = (rs.randn(96, cin, k) / np.sqrt(cin * k)).astype(np.float32)
@@ -171,14 +167,9 @@ def test_conv1d_p16_96_couts_on_32x32x16(cuda, monkeypatch, cin, k, n, out_mode,
     ref = F.conv1d(x.double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(), padding=k // 2)
     ref = F.relu(ref) + r1.double() if res else ref
     ref = F.max_pool1d(ref, 4, 4) if out_mode == 1 else ref
-    for envs in ((), ("ORCA_NO_P16X",), ("ORCA_NO_P16X", "ORCA_NO_P16W1")):
-        for e in envs:
-            monkeypatch.setenv(e, "1")
-        y = engine.conv1d_p16(x[0].t().contiguous().to(cuda), w, b, res, None if r1 is None else r1[0].t().contiguous().to(cuda), out_mode)
-        for e in envs:
-            monkeypatch.delenv(e)
-        err = float((y.cpu().t()[None].double() - ref).abs().max())
-        assert err < 2e-5, (cin, k, n, out_mode, envs, err)
+    y = engine.conv1d_p16(x[0].t().contiguous().to(cuda), w, b, res, None if r1 is None else r1[0].t().contiguous().to(cuda), out_mode)
+    err = float((y.cpu().t()[None].double() - ref).abs().max())
+    assert err < 2e-5, (cin, k, n, out_mode, err)
 
 
 @pytest.mark.parametrize("cin,n", [(128, 2000), (128, 323), (96, 1603), (128, 200004), (128, 4)])
@@ -265,13 +256,12 @@ def test_conv1d_b16_dma(cuda, cin, cout, n, out_mode):
 @pytest.mark.parametrize("cin,cout,dil,n", [(64, 32, 1, 250), (32, 64, 2, 250), (64, 64, 1, 250), (64, 32, 8, 250), (32, 64, 4, 250), (129, 64, 1, 250),
                                             (65, 64, 1, 250), (128, 32, 1, 250), (64, 32, 8, 126), (32, 64, 8, 64), (64, 64, 2, 256), (64, 32, 4, 30)])
 @pytest.mark.parametrize("kernel", ["four_row", "one_row"])
-def test_conv2d_m16_dilated(cuda, cin, cout, dil, n, kernel, monkeypatch):
+def test_conv2d_m16_dilated(cuda, cin, cout, dil, n, kernel):
     """conv2d_m16q.h / conv2d_m16.h: the Decoders' conv on M16 maps (two fp16 planes, LDS-DMA'd operands, 3 products) vs torch fp32, on
-    the four-row kernel (the default for batches; forced for single maps here) and on the one-row kernel.  The maps make a round trip
+    the four-row kernel (what a batch runs on: B = 2 here) and on the one-row kernel (a single map).  The maps make a round trip
     through the 22-bit storage (inputs, residual and output each rounded once: 2^-22 relative)."""
-    monkeypatch.setenv("ORCA_M16Q_ALWAYS" if kernel == "four_row" else "ORCA_NO_M16Q", "1")
     rs = np.random.RandomState(cin * 100 + cout + dil + n)
-    B = 2 if n < 250 else 1
+    B = 2 if kernel == "four_row" else 1
     x = torch.from_numpy(rs.randn(B, cin, n, n).astype(np.float32))
     w = (rs.randn(cout, cin, 3, 3) / np.sqrt(cin * 9)).astype(np.float32)
     b = rs.randn(cout).astype(np.float32) * 0.1
@@ -290,17 +280,17 @@ def test_conv2d_m16_dilated(cuda, cin, cout, dil, n, kernel, monkeypatch):
 @pytest.mark.parametrize("precision,ulp", [("bf16", 2.0 ** -8), ("f16", 2.0 ** -11)])
 @pytest.mark.parametrize("cin,cout,dil,n", [(64, 32, 1, 250), (32, 64, 8, 250), (144, 64, 1, 126), (64, 64, 4, 64)])
 @pytest.mark.parametrize("kernel", ["four_row", "one_row"])
-def test_conv2d_m16_single_plane(cuda, cin, cout, dil, n, precision, ulp, kernel, monkeypatch):
+def test_conv2d_m16_single_plane(cuda, cin, cout, dil, n, precision, ulp, kernel):
     """The single-plane modes: on operands that are exactly representable the only differences from torch fp32 are the
-    summation order and ONE final rounding of the output to the plane's 16-bit type."""
-    monkeypatch.setenv("ORCA_M16Q_ALWAYS" if kernel == "four_row" else "ORCA_NO_M16Q", "1")
+    summation order and ONE final rounding of the output to the plane's 16-bit type (four-row kernel: a batch of 2; one-row: a single map)."""
     rs = np.random.RandomState(cin + cout + dil + n)
     dt = torch.bfloat16 if precision == "bf16" else torch.float16
     q = lambda t: t.to(dt).to(torch.float32)
-    x = q(torch.from_numpy(rs.randn(1, cin, n, n).astype(np.float32)))
+    B = 2 if kernel == "four_row" else 1
+    x = q(torch.from_numpy(rs.randn(B, cin, n, n).astype(np.float32)))
     w = q(torch.from_numpy((rs.randn(cout, cin, 3, 3) / np.sqrt(cin * 9)).astype(np.float32))).numpy()
     b = rs.randn(cout).astype(np.float32) * 0.1
-    r = q(torch.from_numpy(rs.randn(1, cout, n, n).astype(np.float32)))
+    r = q(torch.from_numpy(rs.randn(B, cout, n, n).astype(np.float32)))
     y = engine.conv2d_m16(x.to(cuda), w, b, dil, True, r.to(cuda), precision=precision).cpu()
     ref = F.relu(F.conv2d(x, torch.from_numpy(w), torch.from_numpy(b), padding=dil, dilation=dil)) + r
     d = (y - ref).abs()

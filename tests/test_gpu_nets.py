@@ -48,12 +48,12 @@ def test_encoder_ragged_length_and_batch_vs_oracle(cuda):
 
 
 @pytest.mark.parametrize("precision", ["f16x2", "bf16", "f32", "bf16x3"])
-def test_encoder_composed_linear_pairs_vs_two_conv_form_and_oracle(cuda, precision, monkeypatch):
+def test_encoder_composed_linear_pairs_vs_two_conv_form_and_oracle(cuda, precision):
     """lconv1..3 run as single 17-tap convs and conv1.a o lconv1 as a 25-tap conv from the bases (weights composed on the host, ends
     redone by the edge-fix chain).  Against
     (a) the CPU oracle = the reference's two-conv form, on sequences so short that the 4 + 4 end positions of every stage
     carry weight (1 and 2 bins: 250 / 500 positions at stage 3), one-hot with N runs, reverse strand from codes, and raw
-    floats; (b) the library's own two-conv form (ORCA_NO_COMPOSE=1) on the same inputs."""
+    floats; (b) the library's own less composed forms (`Encoder.form`: what extreme weights and float rows fall back to) on the same inputs."""
     from orca_amd import engine
     enc = product_module("Encoder", 5)
     enc.precision = precision
@@ -74,18 +74,20 @@ def test_encoder_composed_linear_pairs_vs_two_conv_form_and_oracle(cuda, precisi
         refr = O.encoder_forward(sd, xr).numpy()
         yr = enc.forward_codes(codes, reverse=True).cpu().numpy()
         assert maxabs(yr, refr) < tol, (L, "reverse codes")
-        # two-conv form everywhere / conv1.a as its own launch / lout1 stored / MaxPool1d(5) as its own pass / (bf16 planes) stage 1 as two launches
-        # instead of the one kernel that produces conv1.b's input tiles from the bases (conv_stage1.h)
-        for switch in ("ORCA_NO_COMPOSE", "ORCA_NO_COMPOSE25", "ORCA_NO_RL", "ORCA_NO_POOL5_FUSE", "ORCA_NO_STAGE1_FUSE"):
-            monkeypatch.setenv(switch, "1")
-            y2 = enc(xc).cpu().numpy()
-            yc2 = enc.forward_codes(codes).cpu().numpy()
-            monkeypatch.delenv(switch)
-            assert maxabs(y2, ref) < tol and maxabs(yc2, ref) < tol, switch
+        # two-conv form everywhere / conv1.a as its own launch / lout1 stored (on bf16 planes that is also stage 1 as two launches instead of
+        # the one kernel that produces conv1.b's input tiles from the bases, conv_stage1.h)
+        for form in ("two_conv", "lconv1_only", "stored_residual"):
+            enc.form = form
+            try:
+                y2 = enc(xc).cpu().numpy()
+                yc2 = enc.forward_codes(codes).cpu().numpy()
+            finally:
+                enc.form = "default"
+            assert maxabs(y2, ref) < tol and maxabs(yc2, ref) < tol, form
             if precision != "bf16":
-                assert maxabs(y, y2) < 2e-5 and maxabs(yc, yc2) < 2e-5, switch
-            elif switch == "ORCA_NO_STAGE1_FUSE":    # same products but for the 25-tap weights' lo part; a1 rounded to bf16 either way
-                assert maxabs(yc, yc2) < 0.03, (switch, maxabs(yc, yc2))
+                assert maxabs(y, y2) < 2e-5 and maxabs(yc, yc2) < 2e-5, form
+            elif form == "stored_residual":    # same products but for the 25-tap weights' lo part; a1 rounded to bf16 either way
+                assert maxabs(yc, yc2) < 0.03, (form, maxabs(yc, yc2))
     xf = torch.from_numpy(np.random.RandomState(14).rand(1, 4, 4000 * 2).astype(np.float32))     # arbitrary float rows
     reff = O.encoder_forward(sd, xf).numpy()
     assert maxabs(enc(xf.to(cuda)).cpu().numpy(), reff) < tol
@@ -94,7 +96,7 @@ def test_encoder_composed_linear_pairs_vs_two_conv_form_and_oracle(cuda, precisi
 
 
 @pytest.mark.parametrize("seed,gain", [(1, 1.0), (2, 1.0), (3, 1.6), (4, 0.6)])
-def test_encoder_weight_seed_and_gain_sweep_vs_oracle(cuda, monkeypatch, seed, gain):
+def test_encoder_weight_seed_and_gain_sweep_vs_oracle(cuda, seed, gain):
     """The goldens pin ONE set of synthetic weights; the composed forms multiply weights together, so their error depends on the weight
     statistics: other seeds and other conv gains (activations 0.2x .. 4x as large) against the CPU oracle on the same input, both
     strands from packed bases, tolerance 1e-4 relative to the output's range."""
@@ -115,21 +117,35 @@ def test_encoder_weight_seed_and_gain_sweep_vs_oracle(cuda, monkeypatch, seed, g
         y = enc.forward_codes(codes, reverse=rev).cpu().numpy()
         scale = max(1.0, float(np.abs(ref).max()))
         assert maxabs(y, ref) < 1e-4 * scale and pearson(y, ref) > 0.999999, (seed, gain, rev, maxabs(y, ref), scale)
-        if seed == 1:   # stage 2 runs at 114 000 positions here: its kernel variants (256-position tiles / the fast-FIR form) on the same input
-            for switch in ("ORCA_NO_P16X", "ORCA_NO_P16W1", "ORCA_NO_POOL5_FUSE"):
-                monkeypatch.setenv(switch, "1")
-                y2 = enc.forward_codes(codes, reverse=rev).cpu().numpy()
-                monkeypatch.delenv(switch)
-                assert maxabs(y2, ref) < 1e-4 * scale and maxabs(y2, y) < 2e-5 * scale, (switch, rev, maxabs(y2, ref), maxabs(y2, y))
+
+
+@pytest.mark.parametrize("kind", ["Encoder", "Encoder2", "Decoder"])
+def test_gain_sweep_up_to_the_trip_point_of_the_fp16_range_guard(cuda, kind):
+    """Range evidence without the published checkpoints (tools/range_headroom.py): the synthetic weights' conv gain is raised
+    until the device range guard of the f16x2 arithmetic FIRES.  Below the trip gain the f16x2 forward must equal the exact-fp32 mode to
+    1e-4 of the output's range with no warning; AT the trip gain the module must warn, redo the forward in its range-safe arithmetic
+    (bf16x3 / f32) and still equal the fp32 mode - a tripped guard costs time (2.4 x per step), never a wrong result.  The trip has to
+    lie well above gain 1 (the weights every other test uses) and the fp32 walk's largest activation there has to be of the fp16 range's
+    order (the guard compares what the kernels split, which is not every tensor of the layer-by-layer walk: composed groups)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import range_headroom
+    rep = range_headroom.trip_sweep(kinds=(kind,), dev=cuda)[kind]
+    rows = rep["rows"]
+    assert rep["trip_gain"] is not None and rep["trip_gain"] > 1.0, rep
+    assert rows[-1]["guard_fired"] and not any(r["guard_fired"] for r in rows[:-1]), rows
+    for r in rows:
+        assert r["finite"] and r["rel_err_vs_f32"] < 1e-4, (kind, r)
+    assert rows[-1]["max_abs_activation"] > 65504.0 / 4 and all(r["max_abs_activation"] < 65504.0 * 4 for r in rows[:-1]), rows
+    assert rep["headroom_at_gain_1"] > 100, rep
 
 
 def test_encoder_default_dispatch_reaches_the_current_kernels(cuda):
-    """The kernel-variant switches make silent fallbacks easy: with no switch set, one Encoder forward from packed bases must put stage 2 on
+    """Dispatch by shape makes silent fallbacks easy: one Encoder forward from packed bases must put stage 2 on
     conv_p16x.h (timing tag -14), stage 3's pooled conv on conv_p16p5.h (-12) and stage 1's `conv1.b` / stage 3's other convs on the 64-cout
     tiles of conv_p16.h (-5), as recorded by the per-launch HIP-event timing (launches over >= 65 536 positions)."""
-    import os
     from orca_amd import engine
-    assert not [k for k in os.environ if k.startswith("ORCA_NO_")], "a kernel-variant switch is set"
     enc = product_module("Encoder", 0)
     codes, ok = engine.pack_sequence(torch.from_numpy(synth.synth_sequence(4000 * 300, seed=5)).transpose(1, 2).to(cuda))
     assert ok
@@ -141,14 +157,14 @@ def test_encoder_default_dispatch_reaches_the_current_kernels(cuda):
     ctx.set_timing(False)
     tags = {(cout, tile) for cout, cin, tile, batch, n, ms, ksize in recs}
     assert (96, -14) in tags and (128, -12) in tags and (64, -5) in tags and (128, -5) in tags, sorted(tags)
-    assert not any(tile in (-9, -11) for _, tile in tags), sorted(tags)     # (conv_p16w1.h / the fast-FIR form only behind their switches)
+    assert not any(tile in (-9, -10, -11) for _, tile in tags), sorted(tags)     # (conv_p16w1.h serves B16 planes only)
 
 
-def test_encoder_composed_weights_outside_fp16_keep_the_two_conv_form(cuda, monkeypatch):
+def test_encoder_composed_weights_outside_fp16_keep_the_two_conv_form(cuda):
     """A composed weight is a sum of products of folded weights and may leave the fp16 range although every single layer fits (extreme
     checkpoints): such a group must keep the reference's two-conv form instead of packing infinities.  lconv1's two convs are scaled by
     3000 each (singles ~5e2, composed ~1e6), the input by 1e-6 so that the activations stay in range; the result must be finite and
-    equal the ORCA_NO_COMPOSE form and the CPU oracle."""
+    equal the forced two-conv form and the CPU oracle."""
     from orca_amd import orca_modules as pm
     sd = {k: np.array(v, copy=True) for k, v in synth_sd("Encoder", 9).items()}
     for k in ("lconv1.0.weight", "lconv1.2.weight"):
@@ -164,15 +180,13 @@ def test_encoder_composed_weights_outside_fp16_keep_the_two_conv_form(cuda, monk
     assert np.isfinite(y).all()
     scale = float(np.abs(ref).max())
     assert maxabs(y, ref) < 1e-4 * max(1.0, scale)
-    monkeypatch.setenv("ORCA_NO_COMPOSE", "1")
+    enc.form = "two_conv"
     y2 = enc(x.to(cuda)).cpu().numpy()
-    monkeypatch.delenv("ORCA_NO_COMPOSE")
     assert maxabs(y, y2) <= 1e-5 * max(1.0, scale)      # lconv1 ran uncomposed in both (lconv2 / lconv3 still differ in form)
 
 
 @pytest.mark.parametrize("precision", ["f16x2", "f32", "bf16x3"])
-def test_encoder2_encoder3_vs_golden(cuda, precision, monkeypatch):
-    monkeypatch.setenv("ORCA_UNET_NLC_MIN", "0")     # (the default since round 4: the channel-last split-operand path at every size, short levels on conv_small.h)
+def test_encoder2_encoder3_vs_golden(cuda, precision):
     g = golden("G3_encoder23.npz")
     e2 = product_module("Encoder2", 0, precision=precision)
     x = torch.from_numpy((np.random.RandomState(21).rand(1, 128, 800) * 0.5).astype(np.float32)).to(cuda)
@@ -190,8 +204,7 @@ def test_encoder2_encoder3_vs_golden(cuda, precision, monkeypatch):
 
 
 @pytest.mark.parametrize("precision", ["f16x2", "f32"])
-def test_encoder2_batch_and_strided_input_vs_oracle(cuda, precision, monkeypatch):
-    monkeypatch.setenv("ORCA_UNET_NLC_MIN", "0")
+def test_encoder2_batch_and_strided_input_vs_oracle(cuda, precision):
     e2 = product_module("Encoder2", 1, precision=precision)
     sd = synth_sd("Encoder2", 1)
     big = torch.from_numpy((np.random.RandomState(7).rand(2, 128, 700) * 0.5).astype(np.float32))
@@ -234,11 +247,11 @@ def test_decoders_vs_golden(cuda, precision, monkeypatch):
 
 
 @pytest.mark.parametrize("precision", ["f16x2", "f16", "bf16"])
-def test_decoder_four_row_kernel_vs_one_row_kernel(cuda, precision, monkeypatch):
-    """conv2d_3x3_m16q_kernel (the default: tiles of four output rows x 128 pixels, whole batch per launch) against the reference fixture and
-    against the one-row kernel of rounds 2-3 (ORCA_NO_M16Q=1; the default for single maps) on the same inputs: batch of 1 and of 3.  Both
-    kernels add the same products in the same order (kernel-column-major taps, accumulators started from the bias) into fp32 accumulators:
-    the maps are bit-identical."""
+def test_decoder_four_row_kernel_vs_one_row_kernel(cuda, precision):
+    """conv2d_3x3_m16q_kernel (what a BATCH runs on: tiles of four output rows x 128 pixels, whole batch per launch) against the reference
+    fixture and against the one-row kernel of rounds 2-3 (what a SINGLE map runs on) on the same inputs: a batch of 3 and its rows one by one.
+    Both kernels add the same products in the same order (kernel-column-major taps, accumulators started from the bias) into fp32
+    accumulators: the maps are bit-identical."""
     g = golden("G5_decoder.npz")
     nm, _ = synth.synth_normmats_32m()
     x = torch.from_numpy((np.random.RandomState(31).rand(1, 128, 250) * 0.5).astype(np.float32)).to(cuda)
@@ -246,38 +259,31 @@ def test_decoder_four_row_kernel_vs_one_row_kernel(cuda, precision, monkeypatch)
     yc = torch.from_numpy(g["noy"][None, None]).to(cuda)[:, :, 37:162, 37:162]
     dec = product_module("Decoder", 0, upsample_mode="bilinear", precision=precision)
     xb = torch.cat([x, x.flip(2), 0.5 * x], dim=0)
-    monkeypatch.setenv("ORCA_M16Q_ALWAYS", "1")      # a single map goes to the one-row kernel by default
-    p1 = dec(x, de, yc)
-    monkeypatch.delenv("ORCA_M16Q_ALWAYS")
-    p3 = dec(xb, de.expand(3, -1, -1, -1), yc.expand(3, -1, -1, -1))
-    monkeypatch.setenv("ORCA_NO_M16Q", "1")
-    ref1 = dec(x, de, yc)
-    ref3 = dec(xb, de.expand(3, -1, -1, -1), yc.expand(3, -1, -1, -1))
-    monkeypatch.delenv("ORCA_NO_M16Q")
+    p3 = dec(xb, de.expand(3, -1, -1, -1), yc.expand(3, -1, -1, -1))            # four-row kernel
+    rows = [dec(xb[b: b + 1], de, yc) for b in range(3)]                          # one-row kernel
     if precision == "f16x2":
-        assert maxabs(p1[0, 0].cpu().numpy(), g["y_bilinear"]) < TOL
-    assert torch.equal(p1, ref1) and torch.equal(p3, ref3)      # bit for bit: a batch size must not change a map (multi-GPU strand tails run B = 1)
+        assert maxabs(rows[0][0, 0].cpu().numpy(), g["y_bilinear"]) < TOL
+    for b in range(3):
+        assert torch.equal(p3[b: b + 1], rows[b]), b      # bit for bit: a batch size must not change a map (multi-GPU strand tails run B = 1)
 
 
 @pytest.mark.parametrize("precision", ["f16x2", "f16", "bf16"])
-def test_decoder_batches_of_several_rounds_walk_the_maps(cuda, precision, monkeypatch):
+def test_decoder_batches_of_several_rounds_walk_the_maps(cuda, precision):
     """Batches of more than one round of workgroups (the SV screen's 4 strands, config 3's 8): the four-row kernel's grid holds one round and a
     workgroup walks the maps b, b + grid.y, ... of its tile, requesting the next map's first piece under the last piece of the current one
-    (conv2d_m16q.h).  Same arithmetic per map: batches of 5 (odd: the walkers have 3 and 2 maps) and 8 equal the one-workgroup-per-map
-    launches (ORCA_NO_M16Q_WALK=1) and the single-map forward bit for bit, with and without the coarse prediction."""
+    (conv2d_m16q.h).  Same arithmetic per map: the rows of batches of 5 (odd: the walkers have 3 and 2 maps) and 8 equal the same maps decoded
+    two by two (one workgroup per map and tile: no walk) and one by one (the one-row kernel) bit for bit, with and without the coarse prediction."""
     nm, _ = synth.synth_normmats_32m()
     rs = np.random.RandomState(77)
     x = torch.from_numpy((rs.rand(8, 128, 250) * 0.5).astype(np.float32)).to(cuda)
     de = torch.log(torch.from_numpy(nm[8][None, None].astype(np.float32))).to(cuda)
     yc = torch.from_numpy(rs.randn(8, 1, 125, 125).astype(np.float32)).to(cuda)
     dec = product_module("Decoder", 0, upsample_mode="bilinear", precision=precision)
-    for B in (5, 8):
-        for y in (yc[:B], None):
-            walk = dec(x[:B], de.expand(B, -1, -1, -1), y)
-            monkeypatch.setenv("ORCA_NO_M16Q_WALK", "1")
-            flat = dec(x[:B], de.expand(B, -1, -1, -1), y)
-            monkeypatch.delenv("ORCA_NO_M16Q_WALK")
-            assert torch.equal(walk, flat), (B, y is None)
+    for with_y in (True, False):
+        pairs = torch.cat([dec(x[b: b + 2], de.expand(2, -1, -1, -1), yc[b: b + 2] if with_y else None) for b in range(0, 8, 2)])
+        for B in (5, 8):
+            walk = dec(x[:B], de.expand(B, -1, -1, -1), yc[:B] if with_y else None)
+            assert torch.equal(walk, pairs[:B]), (B, with_y)
     one = dec(x[4:5], de, yc[4:5])
     assert torch.equal(dec(x[:5], de.expand(5, -1, -1, -1), yc[:5])[4:5], one)
 
@@ -385,14 +391,13 @@ def test_net_1mb_model_vs_reference_and_oracle(cuda):
     assert maxabs(net2.to(cuda)(x)[0].cpu().numpy(), pred.cpu().numpy()) == 0.0
 
 
-@pytest.mark.parametrize("nlc_min", ["0", "32000"])
-def test_encoder2b_vs_reference_and_hctnoc_container(cuda, nlc_min, monkeypatch):
+@pytest.mark.parametrize("precision", ["f16x2", "f32"])
+def test_encoder2b_vs_reference_and_hctnoc_container(cuda, precision):
     """Encoder2b (the HCTnoc variant: contracting path only) vs the reference fixture G15 and, batched and strided,
     vs the oracle; the HCTnoc container exposes the reference's attributes (no denet_1_pt, nearest-upsampling decoders)."""
     from orca_amd import orca_models as M
-    monkeypatch.setenv("ORCA_UNET_NLC_MIN", nlc_min)     # split-operand channel-last path / exact fp32 kernels
     g = golden("G15_encoder2b.npz")
-    e2b = product_module("Encoder2b", 0, device=cuda)
+    e2b = product_module("Encoder2b", 0, device=cuda, precision=precision)     # split-operand channel-last path / exact fp32 kernels
     x = torch.from_numpy((np.random.RandomState(33).rand(1, 128, 2048) * 0.5).astype(np.float32))
     outs = e2b(x.to(cuda))
     assert len(outs) == 6 and maxabs(outs[0].cpu().numpy(), x.numpy()) == 0.0

@@ -20,4 +20,4 @@ ev0.record()
 for _ in range(10):
     out = dec(x, de, y)
 ev1.record(); torch.cuda.synchronize()
-print(f"decoder {prec} B={B} one_stream={os.environ.get('ORCA_DECODER_ONE_STREAM', '0')}: {ev0.elapsed_time(ev1) / 10:.3f} ms per forward")
+print(f"decoder {prec} B={B}: {ev0.elapsed_time(ev1) / 10:.3f} ms per forward")

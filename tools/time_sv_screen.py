@@ -28,7 +28,7 @@ if inc and align == 4000:   # where an on-grid variant's time goes
         cache.get(*k)
     enc0 = torch.empty((4, 128, 8000), device=dev)
     from orca_amd import engine
-    ns = int(os.environ.get("ORCA_SV_STREAMS", "4")) if streams is None else streams
+    ns = 4 if streams is None else streams
     pool = engine.context_pool(dev, ns) if ns > 0 else None
     acc = {"assemble": 0.0, "encode_window": 0.0, "cascade": 0.0, "to_host": 0.0}
     for v in svs[2:18]:
