@@ -457,14 +457,16 @@ def config3_section(dev):
     return out
 
 
-def config5_section(dev, n_svs=256, n_unaligned=64):
+def config5_section(dev, n_svs=256, n_unaligned=256):
     """BASELINE.json configs[4] on this rank: synthetic structural variants (orca_amd.sv.synth_svs: del / dup / inv, 10 kb - 5 Mb) x reference +
     alternative allele, 6 maps each, from a packed 40 Mb chromosome in HBM, through the screen of orca_amd/sv.py.
     TWO sets: the workload as SURVEY 8(d) defines it - log-uniform sizes, NO alignment (`n_unaligned` of the 1024; the top-level
     figures) - and rounds 3-5's set with every coordinate on the 4 kb grid (`aligned_4kb`, `n_svs` of the 1024).  The incremental encoder reuses a
     chromosome encoding per 4 kb PHASE: on the grid every window shares one phase (the chromosome's strands are encoded once, a window
-    re-encodes only its ends and junctions); off the grid every window has a phase of its own and goes through the Encoder whole - what is
-    left of the screen there is the batching of the decoders (two variants = 8 maps per level).  Per set, 8 variants are also run as the
+    re-encodes only its ends and junctions); off the grid every window has a phase of its own - there the screen takes stages 1-3 of the
+    Encoder (99 % of its work, covariant on a 16-base grid) from the chromosome's stage-3 cache (sv.Stage3Cache, round 6: 16 phases x 2 strands
+    = 41 GB of HBM, built inside the timed region) and runs only the window's ends, junctions and stages 4-7; `whole_window_route` times the
+    same variants without it (round 5's route off the grid: every window through the whole Encoder).  Per set, 8 variants are also run as the
     reference does it - two whole `genomepredict` calls each - for the speed-up and the agreement of the maps.
     Variants are independent: N GPUs take every N-th (replicas, no collective)."""
     from orca_amd import engine, orca_models, sv
@@ -477,7 +479,7 @@ def config5_section(dev, n_svs=256, n_unaligned=64):
         torch.cuda.synchronize(dev)
         stats = {}
         t0 = time.perf_counter()
-        res = sv.sv_screen([h1], genome, svs[2:], 40_000_000, stats=stats)     # includes the chromosome encodings (4 on the grid, none off it)
+        res = sv.sv_screen([h1], genome, svs[2:], 40_000_000, stats=stats)     # includes the chromosome encodings (4 on the grid) / the stage-3 cache (off it)
         torch.cuda.synchronize(dev)
         dt = time.perf_counter() - t0
         n = len(svs) - 2
@@ -493,17 +495,25 @@ def config5_section(dev, n_svs=256, n_unaligned=64):
         return {"svs": n, "s_per_sv": round(dt / n, 4), "svs_per_s": round(n / dt, 2), "window_Mb_per_s": round(n * 2 * 2 * 32 / dt, 1),
                 "projected_1024_svs_s_one_gpu": round(1024 * dt / n, 1),
                 "encoder_bins_encoded_frac": round(stats["bins_encoded"] / stats["bins_total"], 4), "chromosome_encodings": stats["chromosome_encodings"],
-                "whole_window_runs": stats.get("whole_window_runs"),
+                "whole_window_runs": stats.get("whole_window_runs"), "stage3_cache": stats.get("stage3_cache"),
                 "as_the_reference_does_it": {"svs": n_full, "s_per_sv": round(dt_full / n_full, 4), "svs_per_s": round(n_full / dt_full, 2),
                                              "what": "two whole genomepredict calls per variant (every window through the whole Encoder, decoders at B = 2)"},
                 "speedup": round((dt_full / n_full) / (dt / n), 2), "max_abs_vs_whole_window_encoding": diff,
                 "kinds": "".join(v.kind[0] for v in svs[2:]), "level32_maps_checksum": round(chk, 3)}
 
-    out = run(sv.synth_svs(n_unaligned + 2, 40_000_000))
+    una = sv.synth_svs(n_unaligned + 2, 40_000_000)
+    out = run(una)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    sv.sv_screen([h1], genome, una[2:34], 40_000_000, stage3=False)      # round 5's route off the grid: every window through the whole Encoder
+    torch.cuda.synchronize(dev)
+    out["whole_window_route"] = {"svs": 32, "svs_per_s": round(32 / (time.perf_counter() - t0), 2),
+                                 "what": "the same screen without the stage-3 cache (stage3=False): every window of an off-grid variant encoded whole, decoders batched"}
     out = {"workload": f"{n_unaligned} of the 1024 synthetic SVs AS SURVEY 8(d) DRAWS THEM (log-uniform size, arbitrary base positions: align = 1) x (reference + "
                        "alternative allele) x 6 maps of a 32 Mb window (both strands), from a packed 40 Mb chromosome in HBM, through orca_amd.sv.sv_screen: off the 4 kb "
-                       "grid every window keeps its own phase (as the reference's windows do, orca_predict.py:1613) and is encoded whole; ref + alt of TWO variants are "
-                       "decoded as one batch of 8 maps per level", "coordinates": "unaligned (align=1)", **out}
+                       "grid every window keeps its own phase (as the reference's windows do, orca_predict.py:1613): stages 1-3 of the Encoder come from the "
+                       "chromosome's stage-3 cache (16 phases x 2 strands, built inside the timed region), a window runs its ends, junctions and stages 4-7; ref + alt "
+                       "of TWO variants are decoded as one batch of 8 maps per level", "coordinates": "unaligned (align=1)", **out}
     out["aligned_4kb"] = {"workload": f"{n_svs} of the 1024 with every coordinate rounded down to the 4 kb grid (synth_svs(align=4000): rounds 3-5's set - the incremental "
                                       "screen's best case: chromosome encoded once per strand and phase, windows re-encode ends + junctions only)",
                           "coordinates": "4 kb-aligned (align=4000)", **run(sv.synth_svs(n_svs + 2, 40_000_000, align=4000))}

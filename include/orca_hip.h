@@ -209,6 +209,31 @@ int orca_encoder_forward_codes_window(orca_ctx* ctx, orca_net* net, const uint8_
 int orca_encoder_forward_2bit(orca_ctx* ctx, orca_net* net, const uint8_t* two, const uint8_t* nmask, int64_t start, int reverse, int64_t L,
                               int64_t bin_lo, int64_t bin_hi, float* out, int64_t so_c, int64_t chunk_bp);
 
+/* ---- the Encoder in two parts: structural-variant screens at arbitrary base positions ----------------------------
+ * The reference's drivers place every window at the variant's own phase (orca_predict.py:1613: wpos = coord_clip(mstart) - no rounding to
+ * the 4 kb grid) and push each 32 Mb window through the whole Encoder (orca_predict.py:231).  Stages 1-3 of the Encoder - 99 % of its work -
+ * are translation-covariant on a 16-BASE grid (MaxPool1d(4) twice, orca_modules.py:829, :846) with a reach of 351 bases, so their output on a
+ * chromosome, computed once per strand and per phase mod 16, serves every window of every allele made of pieces of that chromosome:
+ * 512 bytes per base and strand of HBM (41 GB for both strands of a 40 Mb chromosome), against 24.6 ms of Encoder per strand and window.
+ *   orca_encoder_stage3_planes  stage 3's output (ReLU + residual, BEFORE MaxPool1d(5)) of the L bases `codes` (reverse != 0: of their reverse
+ *                               complement) as P16 planes: 32 planes (16 channel octets x {hi, lo} fp16 parts) of plane_units =
+ *                               orca_p16_plane_units(L / 16) 16-byte units each, position j of the output at unit 8 + j of a plane.  L % 80 == 0.
+ *   orca_p16_pool5_into         MaxPool1d(5) (orca_modules.py:853) of positions [src_pos0, src_pos0 + 5 count) of such planes into positions
+ *                               [dst_pos0, dst_pos0 + count) of the planes of a stage-4 input (planes of dst_units units)
+ *   orca_encoder_front_snippet  stages 1-3 + MaxPool1d(5) on bases [base0, base0 + nbases) of the L-base sequence `codes` (an allele window; both
+ *                               ends of the snippet are treated as sequence ends, as the reference's zero padding treats a window's), pooled
+ *                               positions [skip, skip + count) written to positions [dst_pos0, ..) of the stage-4 input: window ends and
+ *                               junctions between pieces, where the cached values do not apply
+ *   orca_encoder_back           stages 4-7 from a stage-4 input of n4 positions (n4 % 50 == 0; planes of s4_units = orca_p16_plane_units(n4)
+ *                               units) -> out[c * so_c + bin], 128 x n4 / 50 bins
+ * ORCA_PRECISION_F16X2 nets only (the planes are the operand image of that arithmetic); the fp16-range guard applies as everywhere. */
+int64_t orca_p16_plane_units(int64_t n);
+int orca_encoder_stage3_planes(orca_ctx* ctx, orca_net* net, const uint8_t* codes, int64_t L, int reverse, float* planes, int64_t plane_units);
+int orca_p16_pool5_into(orca_ctx* ctx, const float* src, int64_t src_units, int64_t src_pos0, float* dst, int64_t dst_units, int64_t dst_pos0, int64_t count);
+int orca_encoder_front_snippet(orca_ctx* ctx, orca_net* net, const uint8_t* codes, int64_t L, int reverse, int64_t base0, int64_t nbases, int64_t skip,
+                               int64_t count, float* dst, int64_t dst_units, int64_t dst_pos0);
+int orca_encoder_back(orca_ctx* ctx, orca_net* net, const float* s4, int64_t s4_units, int64_t n4, float* out, int64_t so_c);
+
 /* Number of 4 kb bins Encoder emits for an L-bp input (floor through the
  * 4,4,5,5,5,2 pooling chain). */
 int64_t orca_encoder_num_bins(int64_t L);
@@ -232,9 +257,7 @@ int orca_unet_forward(orca_ctx* ctx, orca_net* net, const float* x, int64_t sx_b
  * crop of the coarser prediction (orca_predict.py:374-379).
  * out: contiguous [B,1,n,n].  accumulate!=0 adds into out instead of
  * overwriting (used for `+ denet_1_pt(...)`, orca_predict.py:362-366).
- * Streams: an even batch >= 2 runs as two half-batches, the second on an INTERNAL non-blocking stream of the context
- * (forked from / joined back into the caller's stream by events inside the call: on return all work is ordered behind
- * the caller's stream again; callers that capture the stream into a graph set ORCA_DECODER_ONE_STREAM=1). */
+ * Streams: every launch of the call goes to the context's stream (a launch carries the whole batch; the call can be captured into a graph). */
 int orca_decoder_forward(orca_ctx* ctx, orca_net* net, const float* x, int64_t sx_b, int64_t sx_c,
                          int64_t sx_l, const float* distenc, int64_t sd_b, int64_t sd_h, int64_t sd_w,
                          const float* y, int64_t sy_b, int64_t sy_h, int64_t sy_w, int B, int n,

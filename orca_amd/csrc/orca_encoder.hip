@@ -12,6 +12,7 @@
 #include "conv_p16x.h"
 #include "conv_small.h"
 #include "misc_kernels.h"
+#include "p16_planes.h"
 
 // ---------------------------------------------------------------------------
 // kernel launch helpers
@@ -469,8 +470,12 @@ struct SeqSource {            // where a chunk's input comes from: a float [.,4]
   int reverse = 0;
 };
 
+// `part` (P16 planes only, SV screens off the 4 kb grid - orca_encoder_stage3_planes and friends below): the FRONT of the Encoder is stages 1-3
+// (99 % of its FLOPs; translation-covariant on a 16-base grid with a reach of 351 bases), the BACK stages 4-7 from the MaxPool1d(5)'d stage-3 output
+enum { ENC_FULL = 0, ENC_FRONT_POOLED = 1, ENC_FRONT_UNPOOLED = 2, ENC_BACK = 3 };
+
 static int encoder_chunk(orca_ctx* ctx, orca_net* net, const SeqSource& src, long n1, float* const buf[3],
-                         long ld1, float** out, long* out_ld, long* out_n) {
+                         long ld1, float** out, long* out_ld, long* out_n, int part = ENC_FULL) {
   hipStream_t s = ctx->stream;
   int P = 0;
   long n = n1, ld = ld1;
@@ -481,6 +486,7 @@ static int encoder_chunk(orca_ctx* ctx, orca_net* net, const SeqSource& src, lon
   const bool use_b16 = net->precision == ORCA_PRECISION_BF16;
   const bool use_p16 = net->precision == ORCA_PRECISION_F16X2 || use_b16;
   const int fmt = use_b16 ? 1 : 0;
+  if (part != ENC_FULL && !(use_p16 && fmt == 0)) return fail(ORCA_EINVAL, "the Encoder's front / back parts exist in the f16x2 arithmetic (P16 planes) only");
   // the channel-last split-operand pipeline (bf16x3 / bf16x2): stage 1 composed - from PACKED bases only: the
   // first-layer GEMM splits its X operand into fp16 parts, exact for 0 / 0.25 / 1, while these modes promise fp32 range for arbitrary float rows
   const bool compose_nlc = !use_p16 && net->precision != ORCA_PRECISION_F32 && net->d_c1a_w16 && net->enc_form < ORCA_ENCODER_FORM_LCONV1_ONLY && src.codes;
@@ -566,6 +572,9 @@ static int encoder_chunk(orca_ctx* ctx, orca_net* net, const SeqSource& src, lon
         }
         return ORCA_OK;
       };
+      if (part == ENC_BACK) {
+        // stage 4's input (n1 positions, 128 channels) is in buf[S] already
+      } else {
       if (fuse1) {
         // nothing to launch: buf[1] is never materialised
       } else if (compose || flat || fmt == 1) {
@@ -607,12 +616,13 @@ static int encoder_chunk(orca_ctx* ctx, orca_net* net, const SeqSource& src, lon
           ORCA_TRY(launch_edge_chain(ctx, chain, relus, 2, 4, ef, n1, ys, st_, fmt));
         }
       }
+      }
       n = n1;
       const int nplanar = 4;                                                // stages on the planar kernels (pools 4, 4, 5 fused into the conv in front of them)
-      for (st0 = 0; st0 < nplanar; ++st0) {
+      for (st0 = part == ENC_BACK ? 3 : 0; st0 < nplanar; ++st0) {
         const ConvLayer* Ls = L + 4 * st0;
         const int C = Ls[3].cout;
-        if (kEncPools[st0] == 5) n /= 5;   // the previous stage's last conv already pooled (conv_p16p5.h): buf[S] holds n / 5 positions
+        if (kEncPools[st0] == 5 && part != ENC_BACK) n /= 5;   // the previous stage's last conv already pooled (conv_p16p5.h): buf[S] holds n / 5 positions
         // the stage's linear pair: (pooled) previous output buf[S] -> lout in buf[LO]
         const bool comp_st = compose && (st0 == 0 || (st0 <= 2 && net->comp[st0].d_wf16));
         if (comp_st && st0 > 0) {
@@ -686,8 +696,15 @@ static int encoder_chunk(orca_ctx* ctx, orca_net* net, const SeqSource& src, lon
           n /= 4;
         } else if (st0 + 1 < nplanar) {      // (the pool in front of stage 4)
           if (kEncPools[st0 + 1] != 5 || C != 128) return fail(ORCA_EINVAL, "internal: planar stage %d followed by an unexpected pool", st0 + 1);
+          if (part == ENC_FRONT_UNPOOLED) {   // stage 3's output as it is, every position: what a stage-3 cache keeps (the pool is the reader's)
+            ORCA_TRY(launch_conv1d_p16(ctx, Ls[3], buf[T], buf[S], buf[LO], n, 1, 0, nullptr, fmt));
+            ORCA_TRY(launch_p16_zero_pads(ctx, buf[S], C, n, fmt));
+            *out = buf[S]; *out_ld = 0; *out_n = n;
+            return ORCA_OK;
+          }
           ORCA_TRY(launch_conv1d_p16(ctx, Ls[3], buf[T], buf[S], buf[LO], n, 1, 3, nullptr, fmt));          // relu(.)+lout, MaxPool1d(5) (conv_p16p5.h)
           ORCA_TRY(launch_p16_zero_pads(ctx, buf[S], C, n / 5, fmt));
+          if (part == ENC_FRONT_POOLED) { *out = buf[S]; *out_ld = 0; *out_n = n / 5; return ORCA_OK; }
         } else {
           ORCA_TRY(launch_conv1d_p16(ctx, Ls[3], buf[T], buf[S], buf[LO], n, 1, 2, nullptr, fmt));          // fp32 channel-last hand-over
         }
@@ -889,6 +906,84 @@ extern "C" int orca_encoder_forward_2bit(orca_ctx* ctx, orca_net* net, const uin
                                          int64_t L, int64_t bin_lo, int64_t bin_hi, float* out, int64_t so_c, int64_t chunk_bp) {
   if (!two || !nmask || start < 0) return fail(ORCA_EINVAL, "orca_encoder_forward_2bit: NULL plane or negative start");
   return encoder_forward_impl(ctx, net, nullptr, 0, 0, 0, two, 0, reverse, 1, L, bin_lo, bin_hi, out, 0, so_c, chunk_bp, 0, -1, nmask, start);
+}
+
+// ---------------------------------------------------------------------------
+// The Encoder in two parts (f16x2 / P16 planes): stage-3 cache of a chromosome -> stage-4 input of a window -> bins.
+// Stages 1-3 hold 99 % of the Encoder's FLOPs and are translation-covariant on a 16-base grid (pools 4 x 4) with a reach of 351 bases
+// (orca_modules.py:811-852): their output on a chromosome, kept once per strand and per phase mod 16 (512 bytes per base and strand), serves
+// EVERY window of every allele built from pieces of that chromosome, whatever its phase on the 4 kb grid - the reference's structural-variant
+// drivers place their windows at the variant's own phase (orca_predict.py:1613).  A window then costs a MaxPool1d(5) gather from the cache, the
+// front on a few kb around its ends and junctions, and stages 4-7.
+// ---------------------------------------------------------------------------
+extern "C" int64_t orca_p16_plane_units(int64_t n) { return p16_plen(n); }
+
+static int front_run(orca_ctx* ctx, orca_net* net, const uint8_t* codes, int64_t L, int reverse, int64_t base0, int64_t nbases, int part, float** res, long* rn) {
+  if (!ctx || !net || !codes) return fail(ORCA_EINVAL, "encoder front: NULL argument");
+  if (net->kind != ORCA_NET_ENCODER) return fail(ORCA_EINVAL, "encoder front: net is not an Encoder");
+  if (net->precision != ORCA_PRECISION_F16X2) return fail(ORCA_EINVAL, "encoder front: f16x2 arithmetic only (P16 planes)");
+  if (nbases <= 0 || nbases % 80 || base0 < 0 || base0 + nbases > L) return fail(ORCA_EINVAL, "encoder front: bases [%ld,+%ld) of %ld: a positive multiple of 80 inside the sequence", (long)base0, (long)nbases, (long)L);
+  HIPCHECK(hipSetDevice(ctx->device));
+  const long ld1 = ru4(nbases) + 1024;
+  ORCA_TRY(ws_ensure(ctx, 3 * ru256((size_t)64 * ld1 * sizeof(float))));
+  float* buf[3];
+  for (int i = 0; i < 3; ++i) buf[i] = ws_take(ctx, (size_t)64 * ld1);
+  SeqSource src;
+  src.codes = codes; src.codes_L = L; src.codes_off = base0; src.reverse = reverse;
+  long rld;
+  return encoder_chunk(ctx, net, src, nbases, buf, ru4(nbases), res, &rld, rn, part);
+}
+
+extern "C" int orca_encoder_stage3_planes(orca_ctx* ctx, orca_net* net, const uint8_t* codes, int64_t L, int reverse, float* planes, int64_t plane_units) {
+  if (!planes) return fail(ORCA_EINVAL, "orca_encoder_stage3_planes: NULL argument");
+  float* res; long rn;
+  ORCA_TRY(front_run(ctx, net, codes, L, reverse, 0, L, ENC_FRONT_UNPOOLED, &res, &rn));
+  if (plane_units != p16_plen(rn)) return fail(ORCA_EINVAL, "orca_encoder_stage3_planes: planes of %ld units, %ld positions need %ld", (long)plane_units, rn, p16_plen(rn));
+  HIPCHECK(hipMemcpyAsync(planes, res, (size_t)32 * plane_units * 16, hipMemcpyDeviceToDevice, ctx->stream));
+  return ORCA_OK;
+}
+
+extern "C" int orca_p16_pool5_into(orca_ctx* ctx, const float* src, int64_t src_units, int64_t src_pos0, float* dst, int64_t dst_units, int64_t dst_pos0, int64_t count) {
+  if (!ctx || !src || !dst) return fail(ORCA_EINVAL, "orca_p16_pool5_into: NULL argument");
+  if (count <= 0) return ORCA_OK;
+  if (src_pos0 < 0 || dst_pos0 < 0 || P16_GUARD + src_pos0 + 5 * count > src_units || P16_GUARD + dst_pos0 + count > dst_units)
+    return fail(ORCA_EINVAL, "orca_p16_pool5_into: positions [%ld,+5 x %ld) / [%ld,+%ld) outside planes of %ld / %ld units", (long)src_pos0, (long)count, (long)dst_pos0, (long)count, (long)src_units, (long)dst_units);
+  HIPCHECK(hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(p16_pool5_into_kernel, dim3((unsigned)((count + 255) / 256), 16), dim3(256), 0, ctx->stream, reinterpret_cast<const f32x4*>(src), (long)src_units, (long)src_pos0,
+                     reinterpret_cast<f32x4*>(dst), (long)dst_units, (long)dst_pos0, (long)count);
+  LAUNCHCHECK("p16_pool5_into_kernel");
+  return ORCA_OK;
+}
+
+extern "C" int orca_encoder_front_snippet(orca_ctx* ctx, orca_net* net, const uint8_t* codes, int64_t L, int reverse, int64_t base0, int64_t nbases, int64_t skip,
+                                          int64_t count, float* dst, int64_t dst_units, int64_t dst_pos0) {
+  if (!dst) return fail(ORCA_EINVAL, "orca_encoder_front_snippet: NULL argument");
+  float* res; long rn;
+  ORCA_TRY(front_run(ctx, net, codes, L, reverse, base0, nbases, ENC_FRONT_POOLED, &res, &rn));
+  if (skip < 0 || count <= 0 || skip + count > rn || dst_pos0 < 0 || P16_GUARD + dst_pos0 + count > dst_units)
+    return fail(ORCA_EINVAL, "orca_encoder_front_snippet: pooled positions [%ld,+%ld) of %ld -> [%ld,..) of planes of %ld units", (long)skip, (long)count, rn, (long)dst_pos0, (long)dst_units);
+  hipLaunchKernelGGL(p16_copy_units_kernel, dim3((unsigned)((count + 255) / 256), 32), dim3(256), 0, ctx->stream, reinterpret_cast<const f32x4*>(res), p16_plen(rn), (long)skip,
+                     reinterpret_cast<f32x4*>(dst), (long)dst_units, (long)dst_pos0, (long)count);
+  LAUNCHCHECK("p16_copy_units_kernel");
+  return ORCA_OK;
+}
+
+extern "C" int orca_encoder_back(orca_ctx* ctx, orca_net* net, const float* s4, int64_t s4_units, int64_t n4, float* out, int64_t so_c) {
+  if (!ctx || !net || !s4 || !out) return fail(ORCA_EINVAL, "orca_encoder_back: NULL argument");
+  if (net->kind != ORCA_NET_ENCODER || net->precision != ORCA_PRECISION_F16X2) return fail(ORCA_EINVAL, "orca_encoder_back: an Encoder net in the f16x2 arithmetic");
+  if (n4 <= 0 || n4 % 50 || s4_units != p16_plen(n4)) return fail(ORCA_EINVAL, "orca_encoder_back: %ld stage-4 positions (a multiple of 50) in planes of %ld units (need %ld)", (long)n4, (long)s4_units, p16_plen(n4));
+  HIPCHECK(hipSetDevice(ctx->device));
+  const long ld = ru4(n4) + 1024;                         // per buffer: 128 channels x ld floats (P16 planes of 128 channels; fp32 [n][128] behind stage 4)
+  ORCA_TRY(ws_ensure(ctx, 3 * ru256((size_t)128 * ld * sizeof(float))));
+  float* buf[3];
+  for (int i = 0; i < 3; ++i) buf[i] = ws_take(ctx, (size_t)128 * ld);
+  HIPCHECK(hipMemcpyAsync(buf[0], s4, (size_t)32 * s4_units * 16, hipMemcpyDeviceToDevice, ctx->stream));
+  ORCA_TRY(launch_p16_zero_pads(ctx, buf[0], 128, n4, 0));
+  SeqSource src;
+  float* res; long rld, rn;
+  ORCA_TRY(encoder_chunk(ctx, net, src, n4, buf, ru4(n4), &res, &rld, &rn, ENC_BACK));
+  if (rld >= 0 || rn != n4 / 50) return fail(ORCA_EINVAL, "internal: the Encoder's back part produced %ld bins for %ld positions", rn, (long)n4);
+  return launch_copy2d(ctx, res, 1, 128, out, so_c, 128, rn);
 }
 
 extern "C" int orca_pack_sequence(orca_ctx* ctx, const float* x, int64_t sx_c, int64_t sx_l, int64_t L, uint8_t* codes, int* packable) {

@@ -453,6 +453,66 @@ def encoder_forward_codes(net, codes, reverse=False, bin_lo=0, bin_hi=0, chunk_b
     return out
 
 
+# ---- the Encoder in two parts (include/orca_hip.h: orca_encoder_stage3_planes ...; sv.Stage3Cache is the user) -------------------------------------
+def p16_plane_units(n):
+    """16-byte units per plane of a P16 sequence tensor of n positions (guards and tile padding included)."""
+    return int(_lib.load().orca_p16_plane_units(int(n)))
+
+
+def _codes1d(codes):
+    if not (isinstance(codes, torch.Tensor) and codes.is_cuda and codes.dtype == torch.uint8 and codes.dim() == 1 and codes.is_contiguous()):
+        raise ValueError("codes must be a contiguous [L] uint8 ROCm tensor")
+    return codes
+
+
+def _planes(t, units, name):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and tuple(t.shape) == (32, units, 4)):
+        raise ValueError(f"{name}: a contiguous [32,{units},4] float32 ROCm tensor (32 P16 planes of {units} 16-byte units)")
+    return t
+
+
+def encoder_stage3_planes(net, codes, reverse=False):
+    """Stage 3's output (before MaxPool1d(5)) of the bases ``codes`` [L] (L % 80 == 0; ``reverse``: of their reverse complement) as 32 P16
+    planes: a [32, units, 4] float32 tensor, position j at unit 8 + j."""
+    codes = _codes1d(codes)
+    L = codes.numel()
+    if L <= 0 or L % 80:
+        raise ValueError("stage-3 planes: the number of bases must be a positive multiple of 80")
+    units = p16_plane_units(L // 16)
+    planes = torch.empty((32, units, 4), dtype=torch.float32, device=codes.device)
+    net.ctx.sync_stream()
+    check(_lib.load().orca_encoder_stage3_planes(net.ctx.handle, net.handle, _p(codes), L, 1 if reverse else 0, _p(planes), units), "orca_encoder_stage3_planes")
+    return planes
+
+
+def p16_pool5_into(ctx, src, src_pos0, dst, dst_pos0, count):
+    """MaxPool1d(5) of positions [src_pos0, src_pos0 + 5 count) of the planes ``src`` into positions [dst_pos0, dst_pos0 + count) of ``dst``."""
+    _planes(src, src.shape[1], "src")
+    _planes(dst, dst.shape[1], "dst")
+    ctx.sync_stream()
+    check(_lib.load().orca_p16_pool5_into(ctx.handle, _p(src), src.shape[1], int(src_pos0), _p(dst), dst.shape[1], int(dst_pos0), int(count)), "orca_p16_pool5_into")
+
+
+def encoder_front_snippet(net, codes, reverse, base0, nbases, skip, count, dst, dst_pos0):
+    """Stages 1-3 + MaxPool1d(5) on strand positions [base0, base0 + nbases) of ``codes`` [L]; pooled positions [skip, skip + count) go to
+    positions [dst_pos0, ..) of the stage-4 input planes ``dst``."""
+    codes = _codes1d(codes)
+    _planes(dst, dst.shape[1], "dst")
+    net.ctx.sync_stream()
+    check(_lib.load().orca_encoder_front_snippet(net.ctx.handle, net.handle, _p(codes), codes.numel(), 1 if reverse else 0, int(base0), int(nbases), int(skip), int(count),
+                                                 _p(dst), dst.shape[1], int(dst_pos0)), "orca_encoder_front_snippet")
+
+
+def encoder_back(net, s4, n4, out):
+    """Stages 4-7 from the stage-4 input planes ``s4`` ([32, p16_plane_units(n4), 4]) into ``out`` [128, n4 / 50] (unit stride along the bins)."""
+    _planes(s4, p16_plane_units(n4), "s4")
+    if not (out.is_cuda and out.dtype == torch.float32 and tuple(out.shape) == (128, n4 // 50) and out.stride(1) == 1):
+        raise ValueError(f"out must be a [128,{n4 // 50}] float32 view with unit stride along the bins")
+    net.ctx.sync_stream()
+    check(_lib.load().orca_encoder_back(net.ctx.handle, net.handle, _p(s4), s4.shape[1], int(n4), _p(out), out.stride(0)), "orca_encoder_back")
+    return out
+
+
 def encoder_forward_2bit(net, two, nmask, start, L, reverse=False, bin_lo=0, bin_hi=0, chunk_bp=0, out=None):
     """Encoder on bases [start, start + L) of a chromosome stored as 2 bits per base + N mask in HBM (genome.TwoBitGenome planes): no
     unpacked window is made (orca_encoder_forward_2bit).  Returns [1,128,bins]."""

@@ -207,6 +207,36 @@ class Encoder(_HipModule):
 
     forward_codes.__doc__ += "  (Replaces the float [B,4,L] input of orca_predict.py:334.)"
 
+    # ---- the Encoder in two parts (sv.Stage3Cache; include/orca_hip.h: orca_encoder_stage3_planes ...).  f16x2 arithmetic only: the planes are
+    # its operand image.  No retry inside: the caller's chain carries the fp16-range check (engine.run_with_overflow_retry, sv.sv_screen) and
+    # takes the whole-window route under engine.force_safe_precision() ----
+    def two_part_ok(self):
+        return self.precision == "f16x2" and self.form == "default" and not engine._guard["force_safe"]
+
+    def _parts_net(self, device):
+        if not self.two_part_ok():
+            raise RuntimeError("the Encoder's two-part form (stage-3 cache) exists in the default f16x2 arithmetic only")
+        net = self._net(device)
+        self._apply_precision(net, "f16x2")
+        return net
+
+    def stage3_planes(self, codes, reverse=False):
+        """Stage 3's output of ``codes`` [L] uint8 (before MaxPool1d(5); orca_modules.py:846-852) as P16 planes [32, units, 4]; None (and a
+        warning) when an activation left the fp16 range and the check is immediate."""
+        net = self._parts_net(codes.device)
+        planes = engine.encoder_stage3_planes(net, codes, reverse)
+        if not engine._guard["defer"] and net.ctx.take_overflow():
+            import warnings
+            warnings.warn("orca_amd.Encoder: an activation left the fp16 range while building a stage-3 cache entry; windows will be encoded whole")
+            return None
+        return planes
+
+    def front_snippet(self, codes, reverse, base0, nbases, skip, count, dst, dst_pos0):
+        engine.encoder_front_snippet(self._parts_net(codes.device), codes, reverse, base0, nbases, skip, count, dst, dst_pos0)
+
+    def back(self, s4, n4, out):
+        return engine.encoder_back(self._parts_net(s4.device), s4, n4, out)
+
     def forward_2bit(self, genome, chrom, start, end, reverse=False, bin_lo=0, bin_hi=0, out=None):
         """Encoder on `chrom`[start:end) of a genome.TwoBitGenome resident on the MI355X, read in place: 2 bits per base + N mask straight
         into the first-layer kernels (one-hot expansion in LDS) - no unpacked 1 byte/base window, no float window (selene_utils2.py:216-222)."""

@@ -156,6 +156,9 @@ class ChromEncodings:
         self.miss_bins = 1000     # bins a run must miss to count as a request for a chromosome encoding (an eighth of a 32 Mb window)
         self.requests = {}        # (strand, phase) -> window-sized runs that no source could serve so far (`build="auto"`)
         self.builds = 0
+        self.s3_misses = 0        # window strands of this chromosome that nobody could serve since the last attempt to build `stage3` (GenomeEncodings)
+        self.stage3 = None        # a Stage3Cache of this chromosome (sv_screen builds one for variants off the 4 kb grid): `encode_windows` sends
+                                  # strands whose bins nobody holds through it instead of through the whole Encoder
 
     @property
     def codes(self):
@@ -262,6 +265,8 @@ class GenomeEncodings:
         self.net0, self.chrom_codes, self.chrlens, self.max_entries, self.max_chroms = net0, chrom_codes, dict(chrlens), max_entries, max_chroms
         self.chroms = {}           # least recently used first; at most max_chroms chromosomes keep encodings (<= 24 segments of 4 MB + max_entries
         self._builds_gone = 0      # whole-chromosome encodings each: a bound on what a long session over a whole genome holds in HBM)
+        self.s3_budget = 120e9     # bytes of stage-3 caches (1 KB per base of a chromosome) this store may hold: a chromosome that does not fit
+        self.s3_after = 16         # beside the others' is served without one; built after this many window strands nobody could serve
 
     def of(self, chrom):
         if chrom not in self.chrlens:
@@ -277,6 +282,32 @@ class GenomeEncodings:
     @property
     def builds(self):
         return self._builds_gone + sum(c.builds for c in self.chroms.values())
+
+    def stage3_caches(self, chroms, build):
+        """{chrom: Stage3Cache} of those of ``chroms`` that hold a stage-3 cache.  ``build``: a window strand of these chromosomes just went
+        unserved - count it, and after `s3_after` of them build the chromosome's cache if it fits the budget (least recently used ones go)
+        and the device (beside 40 GB of workspace)."""
+        out = {}
+        for chrom in chroms:
+            ce = self.of(chrom)
+            if ce is None:
+                continue
+            if ce.stage3 is None and build and self.net0.two_part_ok():
+                ce.s3_misses += 1
+                need = Stage3Cache.bytes_needed(ce.C)
+                if ce.s3_misses >= self.s3_after and need <= self.s3_budget:
+                    held = [(c, k) for c, k in self.chroms.items() if k.stage3 is not None and c != chrom]
+                    while held and sum(Stage3Cache.bytes_needed(k.C) for _, k in held) + need > self.s3_budget:
+                        held.pop(0)[1].stage3 = None
+                    dev = ce.codes.device
+                    if dev.type == "cuda" and need + 40e9 < torch.cuda.mem_get_info(dev)[0]:
+                        s3 = Stage3Cache(self.net0, ce.codes)
+                        ce.stage3 = s3 if s3.build_all() else None
+                        engine.get_context(dev).release_workspace()
+                    ce.s3_misses = 0
+            if ce.stage3 is not None:
+                out[chrom] = ce.stage3
+        return out
 
 
 def _p4(piece):
@@ -317,6 +348,133 @@ def reuse_plan(pieces, chrlen, nbins):
     return out
 
 
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Stage-3 cache (round 6): windows at ARBITRARY base positions.  The bins above are reusable only between windows that share a 4 kb phase -
+# and the reference's drivers place every window at the variant's own phase (orca_predict.py:1613), so a screen of real breakpoints shares
+# nothing at that level.  Two stages of pooling further up the Encoder the grid is 16 bases: stages 1-3 (MaxPool1d(4) twice,
+# orca_modules.py:811-852; 99 % of the Encoder's FLOPs) are translation-covariant on it with a reach of 351 bases.  Their output on the
+# chromosome, kept once per strand and phase mod 16 as the P16 planes the next conv reads (512 bytes per base and strand: 41 GB for both strands
+# of a 40 Mb chromosome - what 288 GB of HBM are for), serves every window of every allele: a strand of a window is a MaxPool1d(5) gather
+# from the cache, the front of the Encoder on a few kb at its ends and junctions, and stages 4-7 (`orca_encoder_back`): ~3 instead of 24.6 ms.
+# ---------------------------------------------------------------------------------------------------------------------------------
+S3_GRID = 16             # bases per stage-3 position
+S3_POOL = 5              # MaxPool1d(5) in front of stage 4: a stage-4 position is 80 bases
+S3_MARGIN_BP = 512       # >= reach of a stage-3 position beyond its 16 bases (16 + 3 + 64 + 12 + 256 = 351), in bases, a multiple of 16
+S3_PAD_BP = 1600         # bases a snippet extends beyond the pooled positions it is run for (>= S3_MARGIN_BP, a multiple of 80)
+S3_MIN_SNIPPET_BP = 4000
+
+
+def s3_plan(pcs, chrlens, L, margin=S3_MARGIN_BP):
+    """Stage-4 input of a window given as strand-oriented pieces (3-tuples of ONE chromosome of length ``chrlens``, or 4-tuples with
+    ``chrlens`` a {chrom: length} mapping): (takes, snippets).  takes = [(m_lo, m_hi, chrom, strand, phase, j0)]: pooled positions
+    [m_lo, m_hi) are the MaxPool1d(5) of cache entry (chrom, strand, phase) from its position j0 on; snippets = [(ga, gb, base0, nbases,
+    skip)]: pooled positions [ga, gb) come from the Encoder's front run on window bases [base0, base0 + nbases), whose pooled position
+    ``skip`` is position ga.  Every pooled position is in exactly one of them."""
+    if L % (S3_GRID * S3_POOL):
+        raise ValueError("window length must be a multiple of 80")
+    n4, cell = L // (S3_GRID * S3_POOL), S3_GRID * S3_POOL
+    takes, o = [], 0
+    for piece in pcs:
+        chrom, src, ln, strand = _p4(piece)
+        C = chrlens.get(chrom) if isinstance(chrlens, dict) else chrlens
+        if C is not None:
+            c0 = strand_coord(piece, C)
+            i_lo = -(-(o + margin) // S3_GRID)                         # first / one-past-last stage-3 position whose reach lies inside the piece
+            i_hi = (o + ln - margin) // S3_GRID
+            i_lo = max(i_lo, -(-(margin - c0 + o) // S3_GRID))        # ... and inside the chromosome's own interior (the cache saw ITS ends' padding)
+            i_hi = min(i_hi, (C - margin - c0 + o) // S3_GRID)
+            m_lo, m_hi = max(-(-i_lo // S3_POOL), 0), min(i_hi // S3_POOL, n4)
+            if m_hi > m_lo:
+                c = c0 + cell * m_lo - o                               # strand coordinate of pooled position m_lo's first base
+                takes.append((m_lo, m_hi, chrom, strand, c % S3_GRID, c // S3_GRID))
+        o += ln
+    if o != L:
+        raise ValueError("pieces do not add up to the window")
+    snippets, pos = [], 0
+    for ga, gb in [(t[1], u[0]) for t, u in zip([(0, 0)] + takes, takes + [(n4, n4)])]:
+        if gb <= ga:
+            continue
+        b0 = 0 if ga == 0 else max(0, ga * cell - S3_PAD_BP)
+        b1 = L if gb == n4 else min(L, gb * cell + S3_PAD_BP)
+        while b1 - b0 < S3_MIN_SNIPPET_BP and (b0 > 0 or b1 < L):      # very short runs: a snippet of at least one bin
+            if b1 < L:
+                b1 = min(L, b1 + cell)
+            else:
+                b0 = max(0, b0 - cell)
+        snippets.append((ga, gb, b0, b1 - b0, (ga * cell - b0) // cell))
+    return takes, snippets
+
+
+class Stage3Cache:
+    """Stage-3 output of ONE chromosome's two strands at the 16 phases of the 16-base grid, as P16 planes in HBM (`Encoder.stage3_planes`),
+    and the route from it to the bins of a window (`encode`).  Entry (strand, phase) covers strand coordinates [phase, phase + 80 k): position
+    j = the 16 bases from phase + 16 j.  ``codes``: the chromosome's [chrlen] uint8 codes on the device."""
+
+    def __init__(self, net0, codes):
+        if not (isinstance(codes, torch.Tensor) and codes.dtype == torch.uint8 and codes.dim() == 1 and codes.is_cuda):
+            raise ValueError("codes: a [chrlen] uint8 tensor on the MI355X")
+        self.net0, self.codes, self.C = net0, codes, int(codes.shape[0])
+        self.entries = {}
+        self.builds = 0
+
+    @staticmethod
+    def bytes_needed(chrlen):
+        return 2 * 16 * 32 * 16 * (chrlen // S3_GRID + 1100)          # strands x phases x planes x bytes per unit x units
+
+    def get(self, strand, phase):
+        key = (strand, int(phase))
+        e = self.entries.get(key)
+        if e is None:
+            n = (self.C - key[1]) // 80 * 80
+            seg = self.codes[key[1]: key[1] + n] if strand == "+" else self.codes[self.C - key[1] - n: self.C - key[1]]
+            e = self.net0.stage3_planes(seg.contiguous(), reverse=(strand == "-"))
+            if e is None:
+                return None
+            self.entries[key] = e
+            self.builds += 1
+            engine.tentative(lambda key=key, e=e: self._drop(key, e))     # built inside a deferred range check: must not survive it firing
+        return e
+
+    def _drop(self, key, e):
+        if self.entries.get(key) is e:
+            del self.entries[key]
+            self.builds -= 1
+
+    def build_all(self):
+        """All 32 entries; False (nothing kept) if the fp16-range guard fired on one of them."""
+        for strand in "+-":
+            for phase in range(S3_GRID):
+                if self.get(strand, phase) is None:
+                    self.entries.clear()
+                    return False
+        return True
+
+    def encode(self, pcs, codes_w, reverse, out_row):
+        """Bins of one strand of a window: ``pcs`` = the strand-oriented pieces (of this chromosome) of the window whose FORWARD codes are
+        ``codes_w`` [L] (``reverse``: the strand is the reverse complement of those codes), ``out_row`` [128, L / 4000].  Returns the number
+        of bases that went through the Encoder's front again (window ends and junctions)."""
+        return s3_encode(self.net0, {None: self}, pcs, codes_w, reverse, out_row)
+
+
+def s3_encode(net0, caches, pcs, codes_w, reverse, out_row):
+    """`Stage3Cache.encode` for pieces of several chromosomes: ``caches`` = {chrom: Stage3Cache} (key None: 3-tuple pieces of the one
+    chromosome); pieces of anything else (an inserted string, padding, a chromosome without a cache) go through the Encoder's front."""
+    L = int(codes_w.numel())
+    n4 = L // (S3_GRID * S3_POOL)
+    takes, snippets = s3_plan(pcs, caches[None].C if None in caches else {c: k.C for c, k in caches.items()}, L)
+    s4 = torch.empty((32, engine.p16_plane_units(n4), 4), dtype=torch.float32, device=codes_w.device)
+    ctx = engine.get_context(codes_w.device)
+    for m_lo, m_hi, chrom, strand, phase, j0 in takes:
+        src = caches[chrom].get(strand, phase)
+        if src is None:
+            raise RuntimeError("stage-3 cache entry unavailable (fp16 range)")
+        engine.p16_pool5_into(ctx, src, j0, s4, m_lo, m_hi - m_lo)
+    for ga, gb, b0, nb, skip in snippets:
+        net0.front_snippet(codes_w, reverse, b0, nb, skip, gb - ga, s4, ga)
+    net0.back(s4, n4, out_row)
+    return sum(sn[3] for sn in snippets)
+
+
 POOL_MAX_BINS = 500     # longer runs (whole windows: phases that are not held) are not spread over the pool's contexts - they fill the chip on their own
 
 
@@ -337,6 +495,13 @@ def encode_windows(cache, pieces_list, win_codes, out, merge_gap=2 * RF_BINS, bu
     multi = isinstance(cache, GenomeEncodings)
     W = len(pieces_list)
     runs = {}                                                           # (reverse, lo, hi) -> [window]
+    # strands whose bins are NOT held (a phase of their own: variants off the 4 kb grid) go through the stage-3 cache when the caller has
+    # built one (`cache.stage3`: sv_screen) and the Encoder is in its default arithmetic - never inside a range-safe retry
+    s3 = None if multi else getattr(cache, "stage3", None)
+    s3_able = win_codes.is_cuda and getattr(cache.net0, "two_part_ok", lambda: False)()
+    if not s3_able:
+        s3 = None
+    s3_jobs = []
     for w, pieces in enumerate(pieces_list):
         for rev, pcs in ((False, pieces), (True, revcomp_pieces(pieces))):
             row = 2 * w + int(rev)
@@ -363,6 +528,14 @@ def encode_windows(cache, pieces_list, win_codes, out, merge_gap=2 * RF_BINS, bu
                     merged[-1][1] = r[1]
                 else:
                     merged.append(r)
+            if sum(hi - lo for lo, hi in merged) > POOL_MAX_BINS and s3_able:
+                if multi:       # the drivers' store: per-chromosome caches, built once enough strands went unserved (`build="auto"`)
+                    s3w = cache.stage3_caches({_p4(p)[0] for p in pcs if _p4(p)[0] in cache.chrlens}, build == "auto")
+                else:
+                    s3w = {None: s3} if s3 is not None else {}
+                if s3w:
+                    s3_jobs.append((w, rev, pcs, s3w))                  # the whole strand (what was copied above is overwritten)
+                    continue
             for lo, hi in merged:
                 runs.setdefault((rev, lo, hi), []).append(w)
     encoded = sum((hi - lo) * len(ws) for (rev, lo, hi), ws in runs.items())
@@ -370,6 +543,9 @@ def encode_windows(cache, pieces_list, win_codes, out, merge_gap=2 * RF_BINS, bu
         jobs = sorted(((hi - lo, rev, lo, hi, w) for (rev, lo, hi), ws in runs.items() for w in ws), reverse=True)
         pool.fork()                                                     # the windows' codes are complete on the caller's stream
         k = 0
+        for w, rev, pcs, s3w in s3_jobs:                                # ~3 ms each, the last third latency-bound: one context each, side by side
+            encoded += -(-pool.run(k, lambda w=w, rev=rev, pcs=pcs, s3w=s3w: s3_encode(cache.net0, s3w, pcs, win_codes[w], rev, out[2 * w + int(rev)])) // BIN)
+            k += 1
         for n_, rev, lo, hi, w in jobs:
             row = 2 * w + int(rev)
             if n_ > POOL_MAX_BINS and big_on_caller:      # a whole window fills the chip on its own: the caller's context and stream
@@ -386,6 +562,8 @@ def encode_windows(cache, pieces_list, win_codes, out, merge_gap=2 * RF_BINS, bu
         if not defer_join:
             pool.wait_join()
         return encoded
+    for w, rev, pcs, s3w in s3_jobs:
+        encoded += -(-s3_encode(cache.net0, s3w, pcs, win_codes[w], rev, out[2 * w + int(rev)]) // BIN)
     for (rev, lo, hi), ws in runs.items():
         if len(ws) == W and W > 1:                                      # every window: the rows of one strand are a strided view of `out`
             cache.net0.forward_codes(win_codes, reverse=rev, bin_lo=lo, bin_hi=hi, out=out[int(rev)::2, :, lo:hi])
@@ -451,7 +629,7 @@ def _window_outputs(model, merged, starts, params, mchr):
 
 
 def sv_screen(models, genome_codes, svs, chrlen, mchr="chrS", rank=0, world=1, incremental=True, min_uses=3, stats=None, on_result=None,
-              streams=None, group=2):
+              streams=None, group=2, stage3="auto"):
     """Predict reference and alternative allele (6 maps each, per model) for this rank's share of ``svs``
     (independent windows: replicas, no collective).  genome_codes: [chrlen] uint8 tensor on the MI355X.
     Returns {sv_index: {"sv": SV, "ref": output_dict, "alt": output_dict}} with genomepredict's output dicts.
@@ -471,8 +649,12 @@ def sv_screen(models, genome_codes, svs, chrlen, mchr="chrS", rank=0, world=1, i
     on the caller's stream).
     ``group``: variants per pass of Encoder2 + decoders (default 2 = batches of 8 maps per level: a Decoder forward costs 0.97 ms per map at
     B = 8 against 1.00 at B = 4 and 1.12 at B = 2, tools/prof_decoder.py; a map does not depend on the batch it is computed in, so the
-    results are the same bit for bit - tests/test_gpu_sv_incremental.py)."""
-    import os
+    results are the same bit for bit - tests/test_gpu_sv_incremental.py).
+    ``stage3``: the stage-3 cache (`Stage3Cache`: windows at arbitrary base positions take stages 1-3 of the Encoder from the chromosome's
+    cached planes - 1 KB of HBM per base of the chromosome and model).  "auto" (default): built when the screen has at least 32 window
+    strands per 32 Mb of chromosome whose 4 kb phase is not shared, the Encoders run the default arithmetic and the planes fit beside 40 GB of
+    workspace; True / False force / forbid it."""
+    import time
     from . import dist, orca_predict
     res = {}
     mine = list(dist.shard_indices(len(svs), rank, world))
@@ -499,6 +681,20 @@ def sv_screen(models, genome_codes, svs, chrlen, mchr="chrS", rank=0, world=1, i
                 if n >= min_uses:
                     cache.get(*key)
             caches.append(cache)
+        # windows whose phase is held by nobody: the stage-3 cache serves them at ANY phase
+        whole_runs = int(sum(n for key, n in want.items() if n < min_uses))
+        s3_info = None
+        if stage3 and genome_codes.is_cuda and all(getattr(m.net0, "two_part_ok", lambda: False)() for m in models):
+            need = Stage3Cache.bytes_needed(chrlen) * len(models)
+            if stage3 is True or (whole_runs >= 32 * -(-chrlen // WINDOW) and need + 40e9 < torch.cuda.mem_get_info(genome_codes.device)[0]):
+                t0 = time.perf_counter()
+                for cache in caches:
+                    s3c = Stage3Cache(cache.net0, genome_codes)
+                    cache.stage3 = s3c if s3c.build_all() else None
+                engine.get_context(genome_codes.device).release_workspace()      # (the front on a whole chromosome: 768 B per base)
+                torch.cuda.synchronize(genome_codes.device)
+                s3_info = {"entries": sum(len(c.stage3.entries) for c in caches if c.stage3 is not None), "GB": round(need / 1e9, 1),
+                           "build_s": round(time.perf_counter() - t0, 3)}
         encoded = 0
         if streams is None:
             streams = 4
@@ -593,5 +789,5 @@ def sv_screen(models, genome_codes, svs, chrlen, mchr="chrS", rank=0, world=1, i
         stats.update({"bins_encoded": encoded, "bins_total": len(mine) * len(models) * 4 * nbins,
                       "chromosome_encodings": sum(c.builds for c in caches),
                       "phases_wanted": len(want), "phases_held": sum(len(c.entries) for c in caches) // max(1, len(caches)),
-                      "whole_window_runs": int(sum(n for key, n in want.items() if n < min_uses))})
+                      "whole_window_runs": whole_runs, "stage3_cache": s3_info})
     return res

@@ -165,3 +165,53 @@ def test_screen_groups_of_variants_per_decoder_batch_are_bit_identical(setup):
             for m in range(2):
                 for j in range(6):
                     assert np.array_equal(two1[i][allele]["predictions"][m][j], two2[i][allele]["predictions"][m][j])
+
+
+UNALIGNED = [sv.SV("del", 18_000_123, 19_200_777), sv.SV("dup", 21_004_001, 21_500_017), sv.SV("inv", 15_000_013, 18_000_002),
+             sv.SV("inv", 20_000_003, 20_012_345), sv.SV("del", 17_001_234, 17_803_210), sv.SV("dup", 9_999_999, 10_020_020)]
+
+
+def test_stage3_route_equals_the_whole_encoder(setup):
+    """`sv.Stage3Cache` (round 6): a window at an ARBITRARY base position - MaxPool1d(5) gather of stages 1-3 from the chromosome's cached planes
+    (16 phases x 2 strands), the Encoder's front on its ends and junctions, stages 4-7 - against the Encoder on the assembled window, both
+    strands, for reference and alternative alleles of deletions, duplications and inversions off the 4 kb grid (an N run inside).  Not bit for
+    bit (the snippets run other tile instantiations than a 32 Mb sequence; the pool re-splits a stored value): the bound is 1e-5 on encodings of
+    range 0..8, an order below what the maps' 1e-4 needs."""
+    model, genome = setup
+    s3 = sv.Stage3Cache(model.net0, genome)
+    worst, front_bases = 0.0, 0
+    for v in UNALIGNED:
+        rp, rw, rm, ap, aw, am = sv.sv_windows(v, CHR)
+        for pieces in (rp, ap):
+            w = sv.assemble_codes(genome, pieces)
+            for rev in (False, True):
+                whole = model.net0.forward_codes(w[None], reverse=rev)[0]
+                out = torch.full((128, 8000), float("nan"), device=genome.device)
+                front_bases += s3.encode(sv.revcomp_pieces(pieces) if rev else pieces, w, rev, out)
+                worst = max(worst, float((out - whole).abs().max()))
+                assert worst <= 1e-5, (v, rev, worst)
+    assert len(s3.entries) <= 32 and front_bases < 0.002 * len(UNALIGNED) * 4 * sv.WINDOW       # a few kb per end and junction, not windows
+
+
+def test_screen_off_the_grid_through_the_stage3_cache(setup):
+    """The screen on variants at arbitrary base positions: no two windows share a 4 kb phase (every window of the plain incremental route is
+    encoded whole), the stage-3 cache serves all of them - same dictionaries as two whole `genomepredict` calls per variant, maps within 2e-5;
+    and the range-safe retry of a unit (forced) takes the whole-window route and gives the same maps."""
+    from orca_amd import engine
+    model, genome = setup
+    stats = {}
+    inc = sv.sv_screen([model], genome, UNALIGNED, CHR, stats=stats, stage3=True)
+    full = sv.sv_screen([model], genome, UNALIGNED, CHR, incremental=False)
+    assert stats["stage3_cache"]["entries"] == 32
+    assert stats["bins_encoded"] < 0.01 * stats["bins_total"], stats
+    for i in range(len(UNALIGNED)):
+        for allele in ("ref", "alt"):
+            a, b = inc[i][allele], full[i][allele]
+            assert a["start_coords"] == b["start_coords"] and a["end_coords"] == b["end_coords"]
+            for j in range(6):
+                assert float(np.abs(a["predictions"][0][j] - b["predictions"][0][j]).max()) <= 2e-5, (UNALIGNED[i], allele, j)
+    plain = {}
+    sv.sv_screen([model], genome, UNALIGNED[:2], CHR, stats=plain, stage3=False)
+    assert plain["stage3_cache"] is None and plain["bins_encoded"] == plain["bins_total"]
+    with engine.force_safe_precision():
+        assert not model.net0.two_part_ok()

@@ -158,3 +158,68 @@ def test_segments_persist_and_a_repeated_phase_gets_a_chromosome_encoding():
     out4 = torch.zeros_like(out)
     sv.encode_windows(store, [far], sv.assemble_codes(codes, [p[1:] for p in far])[None], out4, build="auto")
     assert store.builds == 2 and torch.equal(out4, _window_whole(ToyNet0(), codes, [p[1:] for p in far])[0])
+
+
+def test_stage3_plan_is_exact_on_a_toy_front():
+    """`sv.s3_plan` (the stage-3 cache's route, round 6) on CPU: a toy "front" - a LINEAR integer filter with the real reach (351 bases
+    either side of a 16-base cell, zero padded at the ends of whatever sequence it runs on) and MaxPool1d(5) - so that equality is exact.
+    For windows of one piece, deletions, inversions ('-' pieces from the other strand's cache), short duplicated pieces, both strands, and
+    windows at the chromosome's ends: every pooled position comes from exactly one source - a cache entry of the right (strand, phase mod 16)
+    at the right offset, or a snippet of the assembled window - and equals the front on the whole assembled window."""
+    rs = np.random.RandomState(0)
+    C, L = 400_000, 160_000
+    chrom = rs.randint(0, 4, C).astype(np.int64)
+    wts = rs.randint(-3, 4, size=(351 * 2 + 16,)).astype(np.int64)
+
+    def revcomp(c):
+        return (3 - c)[::-1]
+
+    def stage3(codes):
+        x = np.concatenate([np.zeros(351, np.int64), codes + 1, np.zeros(351, np.int64)])
+        idx = np.arange(len(codes) // 16)[:, None] * 16 + np.arange(len(wts))[None, :]
+        return (x[idx] * wts[None, :]).sum(1)
+
+    def pool5(v):
+        return v[: len(v) // 5 * 5].reshape(-1, 5).max(1)
+
+    cache = {}
+
+    def entry(strand, phase):
+        if (strand, phase) not in cache:
+            n = (C - phase) // 80 * 80
+            cache[(strand, phase)] = stage3((chrom if strand == "+" else revcomp(chrom))[phase: phase + n])
+        return cache[(strand, phase)]
+
+    def check(pieces):
+        for rev in (False, True):
+            pcs = sv.revcomp_pieces(pieces) if rev else pieces
+            win = np.concatenate([chrom[s: s + n] if st == "+" else revcomp(chrom[s: s + n]) for s, n, st in pcs])
+            ref = pool5(stage3(win))
+            takes, snips = sv.s3_plan(pcs, C, L)
+            got, cov = np.zeros(L // 80, np.int64), np.zeros(L // 80, int)
+            for m_lo, m_hi, _, strand, phase, j0 in takes:
+                got[m_lo:m_hi] = pool5(entry(strand, phase)[j0: j0 + 5 * (m_hi - m_lo)])
+                cov[m_lo:m_hi] += 1
+            for ga, gb, b0, nb, skip in snips:
+                assert nb % 80 == 0 and b0 % 80 == 0 and 0 <= b0 and b0 + nb <= L and nb >= min(L, sv.S3_MIN_SNIPPET_BP)
+                got[ga:gb] = pool5(stage3(win[b0: b0 + nb]))[skip: skip + gb - ga]
+                cov[ga:gb] += 1
+            assert (cov == 1).all() and (got == ref).all(), (pieces, rev)
+            assert sum(sn[3] for sn in snips) < 0.2 * L
+
+    for trial in range(24):
+        s = int(rs.randint(1000, C - L - 60000))
+        if trial % 4 == 0:
+            pieces = [(s, L, "+")]
+        elif trial % 4 == 1:
+            a, d = int(rs.randint(20000, L - 20000)), int(rs.randint(1, 50000))
+            pieces = [(s, a, "+"), (s + a + d, L - a, "+")]
+        elif trial % 4 == 2:
+            a, b = int(rs.randint(20000, 60000)), int(rs.randint(1, 40000))
+            pieces = [(s, a, "+"), (s + a, b, "-"), (s + a + b, L - a - b, "+")]
+        else:
+            a, b = int(rs.randint(20000, 60000)), 5 * int(rs.randint(1, 300))
+            pieces = [(s, a, "+"), (s + a - b, b, "+"), (s + a, L - a - b, "+")]
+        check(pieces)
+    check([(0, L, "+")])
+    check([(C - L, L, "+")])
