@@ -551,6 +551,44 @@ def test_process_ins_breakpoint_custom_against_the_reference_with_real_networks(
         print(f"{fn} vs the reference with real networks (call {attempt + 1}): {views} views, worst max-abs on the sampled pixels {worst:.3g}")
 
 
+@pytest.mark.parametrize("case", ["inv", "ins", "bp"])
+def test_drivers_through_the_stage3_cache_against_the_reference_with_real_networks(cuda, case):
+    """The stage-3 route (round 6: sv.Stage3Cache - stages 1-3 of the Encoder from a chromosome's cached planes, the front on window ends and
+    junctions, stages 4-7 per window) against the ORACLE, not route against route: the reference's own `process_inv` (G23: every breakpoint off
+    the 4 kb grid), `process_ins` (G24: an inserted string with N on the '-' strand at base 18 000 123) and `process_single_breakpoint` (G24:
+    chrS joined to the reverse complement of a piece of chrT - two chromosomes' caches in one window) with its real networks.  The drivers'
+    store builds a chromosome's cache at the first window strand nobody can serve (`s3_after = 1`; 16 by default), so the reference views of
+    the first call already run through it; the second call finds the kept segments.  Coordinates exactly, maps at the north-star 1e-4."""
+    from orca_amd import sv_drivers
+    model = M.H1esc(synthetic_seed=0)
+    if case == "inv":
+        g = golden("G23_sv_dup_inv_real_nets.npz")
+        name, fn, a = next(c for c in synth.SV_REAL_CASES_G23 if c[0] == case)
+        kw = {}
+    else:
+        g = golden("G24_sv_ins_bp_custom_real_nets.npz")
+        name, fn, a, kw = next(c for c in synth.sv_real_cases_g24() if c[0] == case)
+    dev = synth.sv_driver_genome().to(cuda)
+    sv_drivers.clear_encoding_cache()
+    store = sv_drivers._store(dev, model.net0)
+    store.s3_after = 1
+    for attempt in range(2):
+        outs = getattr(P, fn)(*a, dev, custom_models=[model], target=False, use_cuda=True, **kw)
+        got = synth.summarize_outputs(outs, stride=5)
+        worst = 0.0
+        for k, v in got.items():
+            ref = g[f"{case}.{k}"]
+            if k.endswith(("_start", "_end")):
+                assert np.array_equal(v, ref), k
+            elif "_sub_" in k:
+                worst = max(worst, maxabs(v, ref))
+                assert maxabs(v, ref) < 1e-4 and pearson(v, ref) > 0.999999, (k, attempt, maxabs(v, ref))
+        held = {c: len(ce.stage3.entries) for c, ce in store.chroms.items() if ce.stage3 is not None}
+        assert held and all(1 <= n <= 32 for n in held.values()), held
+        print(f"{fn} through the stage-3 cache vs the reference with real networks (call {attempt + 1}): worst max-abs {worst:.3g}; caches {held}")
+    sv_drivers.clear_encoding_cache()
+
+
 @pytest.mark.parametrize("case", ["del256", "inv256", "bp256_short"])
 def test_process_256mb_drivers_against_the_reference_with_real_networks(cuda, case):
     """The 256 Mb branch of SURVEY 8(f1) against the ORACLE: the reference's own `process_del(..., window_radius=128000000)`
