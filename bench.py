@@ -904,7 +904,7 @@ def main():
                                            "achieved": round(dtf, 1), "peak": PEAK_16BIT_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(dtf / PEAK_16BIT_MFMA_TFLOPS, 4),
                                            "mfma_products_per_algorithmic_mac": 3, "mfma_pipe_frac": round(3 * dtf / PEAK_16BIT_MFMA_TFLOPS, 4),
                                            "decoders_share_of_step": round(7 * dms / ms_per_step, 3),
-                                           "mfma_busy_source": "profiles/r05_pmc_dec_sq.txt (SQ_VALU_MFMA_BUSY_CYCLES / SIMD cycles per kernel)"}
+                                           "mfma_busy_source": "profiles/r06_pmc_dec_sq.txt (SQ_VALU_MFMA_BUSY_CYCLES / SIMD cycles per kernel)"}
             else:      # the SV drivers' and the screen's batch: ref + alt x two strands (workgroups of one resident round walk the maps)
                 res["roofline_decoder"]["batch_of_4"] = {"ms_per_forward": round(dms, 3), "achieved": round(dtf, 1), "frac": round(dtf / PEAK_16BIT_MFMA_TFLOPS, 4),
                                                          "ms_per_map": round(dms / 4, 3)}

@@ -364,12 +364,14 @@ S3_PAD_BP = 1600         # bases a snippet extends beyond the pooled positions i
 S3_MIN_SNIPPET_BP = 4000
 
 
-def s3_plan(pcs, chrlens, L, margin=S3_MARGIN_BP):
+def s3_plan(pcs, chrlens, L, margin=S3_MARGIN_BP, regions=None):
     """Stage-4 input of a window given as strand-oriented pieces (3-tuples of ONE chromosome of length ``chrlens``, or 4-tuples with
-    ``chrlens`` a {chrom: length} mapping): (takes, snippets).  takes = [(m_lo, m_hi, chrom, strand, phase, j0)]: pooled positions
-    [m_lo, m_hi) are the MaxPool1d(5) of cache entry (chrom, strand, phase) from its position j0 on; snippets = [(ga, gb, base0, nbases,
-    skip)]: pooled positions [ga, gb) come from the Encoder's front run on window bases [base0, base0 + nbases), whose pooled position
-    ``skip`` is position ga.  Every pooled position is in exactly one of them."""
+    ``chrlens`` a {chrom: length} mapping): (takes, snippets).  takes = [(m_lo, m_hi, chrom, strand, phase, c)]: pooled positions
+    [m_lo, m_hi) are the MaxPool1d(5) of cache entry (chrom, strand, phase) from the stage-3 position that starts at strand coordinate c;
+    snippets = [(ga, gb, base0, nbases, skip)]: pooled positions [ga, gb) come from the Encoder's front run on window bases [base0, base0 +
+    nbases), whose pooled position ``skip`` is position ga.  Every pooled position is in exactly one of them.  ``regions``: the part of a
+    chromosome the cache holds, (r0, r1) in forward coordinates (or {chrom: (r0, r1)}; default the whole chromosome) - bases outside it
+    go through the front like anything else the cache does not know."""
     if L % (S3_GRID * S3_POOL):
         raise ValueError("window length must be a multiple of 80")
     n4, cell = L // (S3_GRID * S3_POOL), S3_GRID * S3_POOL
@@ -379,14 +381,16 @@ def s3_plan(pcs, chrlens, L, margin=S3_MARGIN_BP):
         C = chrlens.get(chrom) if isinstance(chrlens, dict) else chrlens
         if C is not None:
             c0 = strand_coord(piece, C)
+            r0, r1 = (regions.get(chrom, (0, C)) if isinstance(regions, dict) else regions) if regions else (0, C)
+            lo_s, hi_s = (r0, r1) if strand == "+" else (C - r1, C - r0)      # what the cache holds, in this strand's coordinates
             i_lo = -(-(o + margin) // S3_GRID)                         # first / one-past-last stage-3 position whose reach lies inside the piece
             i_hi = (o + ln - margin) // S3_GRID
-            i_lo = max(i_lo, -(-(margin - c0 + o) // S3_GRID))        # ... and inside the chromosome's own interior (the cache saw ITS ends' padding)
-            i_hi = min(i_hi, (C - margin - c0 + o) // S3_GRID)
+            i_lo = max(i_lo, -(-(lo_s + margin - c0 + o) // S3_GRID)) # ... and inside the cached range's own interior (the cache saw ITS ends' padding)
+            i_hi = min(i_hi, (hi_s - margin - c0 + o) // S3_GRID)
             m_lo, m_hi = max(-(-i_lo // S3_POOL), 0), min(i_hi // S3_POOL, n4)
             if m_hi > m_lo:
                 c = c0 + cell * m_lo - o                               # strand coordinate of pooled position m_lo's first base
-                takes.append((m_lo, m_hi, chrom, strand, c % S3_GRID, c // S3_GRID))
+                takes.append((m_lo, m_hi, chrom, strand, c % S3_GRID, c))
         o += ln
     if o != L:
         raise ValueError("pieces do not add up to the window")
@@ -406,27 +410,38 @@ def s3_plan(pcs, chrlens, L, margin=S3_MARGIN_BP):
 
 
 class Stage3Cache:
-    """Stage-3 output of ONE chromosome's two strands at the 16 phases of the 16-base grid, as P16 planes in HBM (`Encoder.stage3_planes`),
-    and the route from it to the bins of a window (`encode`).  Entry (strand, phase) covers strand coordinates [phase, phase + 80 k): position
-    j = the 16 bases from phase + 16 j.  ``codes``: the chromosome's [chrlen] uint8 codes on the device."""
+    """Stage-3 output of ONE chromosome's two strands (or of a ``region`` (r0, r1) of it, forward coordinates) at the 16 phases of the
+    16-base grid, as P16 planes in HBM (`Encoder.stage3_planes`), and the route from it to the bins of a window (`encode`).  Entry (strand,
+    phase) starts at the first strand coordinate e0 >= the region's start with e0 % 16 == phase: position j = the 16 bases from e0 + 16 j.
+    ``codes``: the chromosome's [chrlen] uint8 codes on the device."""
 
-    def __init__(self, net0, codes):
+    def __init__(self, net0, codes, region=None):
         if not (isinstance(codes, torch.Tensor) and codes.dtype == torch.uint8 and codes.dim() == 1 and codes.is_cuda):
             raise ValueError("codes: a [chrlen] uint8 tensor on the MI355X")
         self.net0, self.codes, self.C = net0, codes, int(codes.shape[0])
+        r0, r1 = (0, self.C) if region is None else (max(0, int(region[0])), min(self.C, int(region[1])))
+        if r1 - r0 < 2 * S3_MARGIN_BP + 80:
+            raise ValueError("stage-3 cache: empty region")
+        self.region = (r0, r1)
         self.entries = {}
         self.builds = 0
 
     @staticmethod
-    def bytes_needed(chrlen):
-        return 2 * 16 * 32 * 16 * (chrlen // S3_GRID + 1100)          # strands x phases x planes x bytes per unit x units
+    def bytes_needed(nbases):
+        return 2 * 16 * 32 * 16 * (nbases // S3_GRID + 1100)          # strands x phases x planes x bytes per unit x units
+
+    def _origin(self, strand, phase):
+        lo = self.region[0] if strand == "+" else self.C - self.region[1]
+        return lo + (phase - lo) % S3_GRID
 
     def get(self, strand, phase):
         key = (strand, int(phase))
         e = self.entries.get(key)
         if e is None:
-            n = (self.C - key[1]) // 80 * 80
-            seg = self.codes[key[1]: key[1] + n] if strand == "+" else self.codes[self.C - key[1] - n: self.C - key[1]]
+            e0 = self._origin(*key)
+            hi = self.region[1] if strand == "+" else self.C - self.region[0]
+            n = (hi - e0) // 80 * 80
+            seg = self.codes[e0: e0 + n] if strand == "+" else self.codes[self.C - e0 - n: self.C - e0]
             e = self.net0.stage3_planes(seg.contiguous(), reverse=(strand == "-"))
             if e is None:
                 return None
@@ -461,14 +476,17 @@ def s3_encode(net0, caches, pcs, codes_w, reverse, out_row):
     chromosome); pieces of anything else (an inserted string, padding, a chromosome without a cache) go through the Encoder's front."""
     L = int(codes_w.numel())
     n4 = L // (S3_GRID * S3_POOL)
-    takes, snippets = s3_plan(pcs, caches[None].C if None in caches else {c: k.C for c, k in caches.items()}, L)
+    if None in caches:
+        takes, snippets = s3_plan(pcs, caches[None].C, L, regions=caches[None].region)
+    else:
+        takes, snippets = s3_plan(pcs, {c: k.C for c, k in caches.items()}, L, regions={c: k.region for c, k in caches.items()})
     s4 = torch.empty((32, engine.p16_plane_units(n4), 4), dtype=torch.float32, device=codes_w.device)
     ctx = engine.get_context(codes_w.device)
-    for m_lo, m_hi, chrom, strand, phase, j0 in takes:
+    for m_lo, m_hi, chrom, strand, phase, c in takes:
         src = caches[chrom].get(strand, phase)
         if src is None:
             raise RuntimeError("stage-3 cache entry unavailable (fp16 range)")
-        engine.p16_pool5_into(ctx, src, j0, s4, m_lo, m_hi - m_lo)
+        engine.p16_pool5_into(ctx, src, (c - caches[chrom]._origin(strand, phase)) // S3_GRID, s4, m_lo, m_hi - m_lo)
     for ga, gb, b0, nb, skip in snippets:
         net0.front_snippet(codes_w, reverse, b0, nb, skip, gb - ga, s4, ga)
     net0.back(s4, n4, out_row)
@@ -685,15 +703,18 @@ def sv_screen(models, genome_codes, svs, chrlen, mchr="chrS", rank=0, world=1, i
         whole_runs = int(sum(n for key, n in want.items() if n < min_uses))
         s3_info = None
         if stage3 and genome_codes.is_cuda and all(getattr(m.net0, "two_part_ok", lambda: False)() for m in models):
-            need = Stage3Cache.bytes_needed(chrlen) * len(models)
-            if stage3 is True or (whole_runs >= 32 * -(-chrlen // WINDOW) and need + 40e9 < torch.cuda.mem_get_info(genome_codes.device)[0]):
+            # the part of the chromosome this rank's windows touch (a whole 40 Mb chromosome for a screen across it; a locus of a real one)
+            spans = [(p[0], p[0] + p[1]) for i in mine for pcs in sv_windows(svs[i], chrlen)[0:4:3] for p in pcs]
+            region = (max(0, min(a for a, _ in spans) // 80 * 80), min(chrlen, -(-max(b for _, b in spans) // 80) * 80)) if spans else (0, chrlen)
+            need = Stage3Cache.bytes_needed(region[1] - region[0]) * len(models)
+            if (stage3 is True or whole_runs >= 32 * -(-(region[1] - region[0]) // WINDOW)) and need + 40e9 < torch.cuda.mem_get_info(genome_codes.device)[0]:
                 t0 = time.perf_counter()
                 for cache in caches:
-                    s3c = Stage3Cache(cache.net0, genome_codes)
+                    s3c = Stage3Cache(cache.net0, genome_codes, region)
                     cache.stage3 = s3c if s3c.build_all() else None
                 engine.get_context(genome_codes.device).release_workspace()      # (the front on a whole chromosome: 768 B per base)
                 torch.cuda.synchronize(genome_codes.device)
-                s3_info = {"entries": sum(len(c.stage3.entries) for c in caches if c.stage3 is not None), "GB": round(need / 1e9, 1),
+                s3_info = {"entries": sum(len(c.stage3.entries) for c in caches if c.stage3 is not None), "GB": round(need / 1e9, 1), "region": list(region),
                            "build_s": round(time.perf_counter() - t0, 3)}
         encoded = 0
         if streams is None:

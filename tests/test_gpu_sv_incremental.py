@@ -191,6 +191,14 @@ def test_stage3_route_equals_the_whole_encoder(setup):
                 worst = max(worst, float((out - whole).abs().max()))
                 assert worst <= 1e-5, (v, rev, worst)
     assert len(s3.entries) <= 32 and front_bases < 0.002 * len(UNALIGNED) * 4 * sv.WINDOW       # a few kb per end and junction, not windows
+    # a cache of a REGION of the chromosome (a locus of a real one): what lies outside goes through the Encoder's front
+    part = sv.Stage3Cache(model.net0, genome, region=(9_000_000, 33_000_000))
+    rp, rw, rm, ap, aw, am = sv.sv_windows(UNALIGNED[0], CHR)
+    w = sv.assemble_codes(genome, ap)
+    for rev in (False, True):
+        out = torch.full((128, 8000), float("nan"), device=genome.device)
+        n = part.encode(sv.revcomp_pieces(ap) if rev else ap, w, rev, out)
+        assert float((out - model.net0.forward_codes(w[None], reverse=rev)[0]).abs().max()) <= 1e-5 and 4_000_000 < n < 12_000_000, (rev, n)
 
 
 def test_screen_off_the_grid_through_the_stage3_cache(setup):

@@ -184,28 +184,33 @@ def test_stage3_plan_is_exact_on_a_toy_front():
 
     cache = {}
 
-    def entry(strand, phase):
-        if (strand, phase) not in cache:
-            n = (C - phase) // 80 * 80
-            cache[(strand, phase)] = stage3((chrom if strand == "+" else revcomp(chrom))[phase: phase + n])
-        return cache[(strand, phase)]
+    def entry(strand, phase, region):      # (planes, strand coordinate of position 0): what sv.Stage3Cache.get / _origin keep
+        if (strand, phase, region) not in cache:
+            lo, hi = region if strand == "+" else (C - region[1], C - region[0])
+            e0 = lo + (phase - lo) % 16
+            n = (hi - e0) // 80 * 80
+            cache[(strand, phase, region)] = (stage3((chrom if strand == "+" else revcomp(chrom))[e0: e0 + n]), e0)
+        return cache[(strand, phase, region)]
 
-    def check(pieces):
+    def check(pieces, region=None):
         for rev in (False, True):
             pcs = sv.revcomp_pieces(pieces) if rev else pieces
             win = np.concatenate([chrom[s: s + n] if st == "+" else revcomp(chrom[s: s + n]) for s, n, st in pcs])
             ref = pool5(stage3(win))
-            takes, snips = sv.s3_plan(pcs, C, L)
+            takes, snips = sv.s3_plan(pcs, C, L, regions=region)
             got, cov = np.zeros(L // 80, np.int64), np.zeros(L // 80, int)
-            for m_lo, m_hi, _, strand, phase, j0 in takes:
-                got[m_lo:m_hi] = pool5(entry(strand, phase)[j0: j0 + 5 * (m_hi - m_lo)])
+            for m_lo, m_hi, _, strand, phase, c in takes:
+                e, e0 = entry(strand, phase, region or (0, C))
+                j0 = (c - e0) // 16
+                assert (c - e0) % 16 == 0 and j0 >= 0 and j0 + 5 * (m_hi - m_lo) <= len(e)
+                got[m_lo:m_hi] = pool5(e[j0: j0 + 5 * (m_hi - m_lo)])
                 cov[m_lo:m_hi] += 1
             for ga, gb, b0, nb, skip in snips:
                 assert nb % 80 == 0 and b0 % 80 == 0 and 0 <= b0 and b0 + nb <= L and nb >= min(L, sv.S3_MIN_SNIPPET_BP)
                 got[ga:gb] = pool5(stage3(win[b0: b0 + nb]))[skip: skip + gb - ga]
                 cov[ga:gb] += 1
             assert (cov == 1).all() and (got == ref).all(), (pieces, rev)
-            assert sum(sn[3] for sn in snips) < 0.2 * L
+            assert region is not None or sum(sn[3] for sn in snips) < 0.2 * L
 
     for trial in range(24):
         s = int(rs.randint(1000, C - L - 60000))
@@ -223,3 +228,6 @@ def test_stage3_plan_is_exact_on_a_toy_front():
         check(pieces)
     check([(0, L, "+")])
     check([(C - L, L, "+")])
+    # a cache that holds a REGION of the chromosome only: what lies outside goes through the front
+    check([(100_000, L, "+")], region=(120_000, 250_000))
+    check([(100_000, 70_000, "+"), (200_003, 40_000, "-"), (290_000, 50_000, "+")], region=(150_000, 330_000))

@@ -3,7 +3,7 @@
 # bench command, then separate rocprofv3 --pmc passes (SQ / FETCH_SIZE / WRITE_SIZE: one pass each, MI355X_MICROARCH.md
 # "rocprofv3 PMC slots") over one 32 Mb Encoder forward in both arithmetic modes and over one Decoder forward.
 # Everything lands in gpurun_out/<tag>/; tools/profile_collect.py turns it into the summaries committed under profiles/.
-TAG=${1:-r05}
+TAG=${1:-r06}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
@@ -23,6 +23,10 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_dec_wr
 python $ROOT/tools/run_configs.py config3 > $OUT/configs.json 2> $OUT/configs.err
 python $ROOT/tools/run_configs.py config5_1024 > $OUT/config5_1024.json 2> $OUT/config5_1024.err
 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_enc_bf16_lds -o p -- python $ROOT/tools/prof_encoder.py 32 bf16 1 codes > $OUT/pmc_enc_bf16_lds.log 2>&1
+python $ROOT/tools/time_sv_drivers.py 12 > $OUT/sv_drivers.json 2> $OUT/sv_drivers.err
+python $ROOT/tools/range_headroom.py > $OUT/range_headroom.json 2> $OUT/range_headroom.err
+# VERDICT r5 #5 (stage 1 off HBM on the P16 path): timing-only ablations of the 64 -> 64 planar conv at n = 32 M, random activations
+[ -x $ROOT/tools/microbench_p16 ] && timeout 300 $ROOT/tools/microbench_p16 32000000 r > $OUT/microbench_p16_conv1b.txt 2>&1
 ( rocm-smi --showpower --showclocks --showtemp > $OUT/rocm_smi_idle.txt 2>&1 ) || true
 find $OUT -name "*.csv" | head -40 > $OUT/files.txt
 # keep the merge-back under 64 MiB: drop the per-dispatch traces of the counter passes (the collected counters stay)

@@ -30,9 +30,10 @@ if len(sys.argv) > 1 and sys.argv[1] == "config5_1024":
         out[label] = {"svs": 1024, "coordinates": f"synth_svs(align={align})", "s_total": round(dt, 2), "s_per_sv_ref_plus_alt": round(dt / 1024, 4), "svs_per_s": round(1024 / dt, 2),
                       "strand_Mb_per_s": round(1024 * 4 * 32 / dt, 1), "kinds": acc["kinds"], "maps": 1024 * 12, "maps_checksum": round(acc["chk"], 3),
                       "encoder_bins_encoded_frac": round(stats["bins_encoded"] / stats["bins_total"], 4), "chromosome_encodings": stats["chromosome_encodings"],
-                      "whole_window_runs": stats.get("whole_window_runs")}
+                      "whole_window_runs": stats.get("whole_window_runs"), "stage3_cache": stats.get("stage3_cache")}
     out["mode"] = ("orca_amd/sv.py sv_screen: chromosome encoded once per strand and 4 kb phase that >= 3 window runs share, windows re-encode ends + junctions; windows whose "
-                   "phase is not held (every window of the unaligned set) are encoded whole; ref + alt of two variants as one decoder batch")
+                   "phase is not held (every window of the unaligned set) take stages 1-3 of the Encoder from the chromosome's stage-3 cache (sv.Stage3Cache: 16 phases x 2 "
+                   "strands, built inside the timed region) and run their ends, junctions and stages 4-7; ref + alt of two variants as one decoder batch")
     print(json.dumps({"config5_sv_screen_1024_1gpu": out}))
     sys.exit(0)
 def rand_codes(B, L, seed):

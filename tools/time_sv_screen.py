@@ -21,11 +21,17 @@ torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 print(f"incremental={inc} streams={streams} {n} SVs: {dt / n * 1e3:.1f} ms per SV = {n / dt:.2f} SV/s  {st}")
 
-if inc and align == 4000:   # where an on-grid variant's time goes
+if inc:   # where a variant's time goes (on the grid: bins from the chromosome encodings; off it: the stage-3 cache)
     import time as T
     cache = sv.ChromEncodings(h1.net0, genome)
-    for k in (("+", 0), ("-", 0), ("+", 2000), ("-", 2000)):
-        cache.get(*k)
+    if align == 4000:
+        for k in (("+", 0), ("-", 0), ("+", 2000), ("-", 2000)):
+            cache.get(*k)
+    else:
+        cache.stage3 = sv.Stage3Cache(h1.net0, genome)
+        torch.cuda.synchronize(); t = T.perf_counter()
+        cache.stage3.build_all()
+        torch.cuda.synchronize(); print(f"stage-3 cache: 32 entries in {T.perf_counter() - t:.2f} s")
     enc0 = torch.empty((4, 128, 8000), device=dev)
     from orca_amd import engine
     ns = 4 if streams is None else streams
