@@ -233,6 +233,20 @@ int orca_p16_pool5_into(orca_ctx* ctx, const float* src, int64_t src_units, int6
 int orca_encoder_front_snippet(orca_ctx* ctx, orca_net* net, const uint8_t* codes, int64_t L, int reverse, int64_t base0, int64_t nbases, int64_t skip,
                                int64_t count, float* dst, int64_t dst_units, int64_t dst_pos0);
 int orca_encoder_back(orca_ctx* ctx, orca_net* net, const float* s4, int64_t s4_units, int64_t n4, float* out, int64_t so_c);
+/* One level further up (what sv.Stage4Cache keeps): stage 4 - 1.2 of the back's 2.0 ms per window strand - is covariant on the 80-BASE grid of its
+ * input (MaxPool1d(5) behind stage 3) with a reach of 1 631 bases; its output as fp32 rows [n][128] per strand and phase mod 80 costs the same 512 bytes
+ * per base and strand, and a window strand is then a MaxPool1d(5) gather of rows, the front + stage 4 on its ends and junctions, and stages 5-7.
+ *   orca_encoder_stage4_rows     stage 4 alone: a stage-4 input of n4 positions (P16 planes, as for orca_encoder_back) -> rows[n4][128] (ReLU + residual,
+ *                                before the MaxPool1d(5) in front of stage 5, orca_modules.py:866-872)
+ *   orca_rows_pool5_into         MaxPool1d(5) of rows [src_pos0, src_pos0 + 5 count) of src[src_rows][128] into rows [dst_pos0, ..) of dst[dst_rows][128]
+ *   orca_encoder_front4_snippet  stages 1-4 on bases [base0, base0 + nbases) (multiples of 400) of the L-base sequence `codes`, MaxPool1d(5); pooled rows
+ *                                [skip, skip + count) -> rows [dst_pos0, ..) of the stage-5 input dst[dst_rows][128]
+ *   orca_encoder_back5           stages 5-7 from a stage-5 input of n5 rows (n5 % 10 == 0) -> out[c * so_c + bin], 128 x n5 / 10 bins */
+int orca_encoder_stage4_rows(orca_ctx* ctx, orca_net* net, const float* s4, int64_t s4_units, int64_t n4, float* rows);
+int orca_rows_pool5_into(orca_ctx* ctx, const float* src, int64_t src_rows, int64_t src_pos0, float* dst, int64_t dst_rows, int64_t dst_pos0, int64_t count);
+int orca_encoder_front4_snippet(orca_ctx* ctx, orca_net* net, const uint8_t* codes, int64_t L, int reverse, int64_t base0, int64_t nbases, int64_t skip,
+                                int64_t count, float* dst, int64_t dst_rows, int64_t dst_pos0);
+int orca_encoder_back5(orca_ctx* ctx, orca_net* net, const float* rows, int64_t n5, float* out, int64_t so_c);
 
 /* Number of 4 kb bins Encoder emits for an L-bp input (floor through the
  * 4,4,5,5,5,2 pooling chain). */

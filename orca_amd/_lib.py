@@ -56,6 +56,10 @@ SIGNATURES = {
     "orca_p16_pool5_into": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64]),
     "orca_encoder_front_snippet": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64]),
     "orca_encoder_back": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64]),
+    "orca_encoder_stage4_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
+    "orca_rows_pool5_into": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64]),
+    "orca_encoder_front4_snippet": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64]),
+    "orca_encoder_back5": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64]),
     "orca_encoder_forward_2bit": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64]),
     "orca_pack_sequence": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, POINTER(c_int)]),
     "orca_encoder_forward_codes": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int64, c_int64, c_int64,

@@ -472,7 +472,9 @@ struct SeqSource {            // where a chunk's input comes from: a float [.,4]
 
 // `part` (P16 planes only, SV screens off the 4 kb grid - orca_encoder_stage3_planes and friends below): the FRONT of the Encoder is stages 1-3
 // (99 % of its FLOPs; translation-covariant on a 16-base grid with a reach of 351 bases), the BACK stages 4-7 from the MaxPool1d(5)'d stage-3 output
-enum { ENC_FULL = 0, ENC_FRONT_POOLED = 1, ENC_FRONT_UNPOOLED = 2, ENC_BACK = 3 };
+// (stage 4 - 1.2 of the back's 2.0 ms per window - moves into the cache too: ENC_STAGE4 runs it alone on a stage-4 input and hands its fp32 rows over,
+// ENC_FRONT4 = the front + stage 4 for the snippets, ENC_BACK5 = stages 5-7 from the MaxPool1d(5)'d rows: covariant on an 80-base grid, reach 1 631 bases)
+enum { ENC_FULL = 0, ENC_FRONT_POOLED = 1, ENC_FRONT_UNPOOLED = 2, ENC_BACK = 3, ENC_STAGE4 = 4, ENC_FRONT4 = 5, ENC_BACK5 = 6 };
 
 static int encoder_chunk(orca_ctx* ctx, orca_net* net, const SeqSource& src, long n1, float* const buf[3],
                          long ld1, float** out, long* out_ld, long* out_n, int part = ENC_FULL) {
@@ -507,8 +509,8 @@ static int encoder_chunk(orca_ctx* ctx, orca_net* net, const SeqSource& src, lon
     // channel-last pipeline on the bf16 matrix cores (conv_bf16s.h); the 4-channel first layer stays on
     // the fp32 kernel (K = 36, 1 % of the FLOPs) and writes channel-last.
     const int prec = net->precision;
-    int st0 = 0;
-    if (use_p16) {
+    int st0 = part == ENC_BACK5 ? 4 : 0;          // (ENC_BACK5: stage 5's input - n1 positions, fp32 channel-last - is in buf[0])
+    if (use_p16 && part != ENC_BACK5) {
       // stages 1-3 on planar 16-bit activations with LDS-DMA staging (conv_p16.h)
       const ConvLayer* L = net->convs.data();
       FirstP16Args fa;
@@ -572,7 +574,7 @@ static int encoder_chunk(orca_ctx* ctx, orca_net* net, const SeqSource& src, lon
         }
         return ORCA_OK;
       };
-      if (part == ENC_BACK) {
+      if (part == ENC_BACK || part == ENC_STAGE4) {
         // stage 4's input (n1 positions, 128 channels) is in buf[S] already
       } else {
       if (fuse1) {
@@ -619,10 +621,11 @@ static int encoder_chunk(orca_ctx* ctx, orca_net* net, const SeqSource& src, lon
       }
       n = n1;
       const int nplanar = 4;                                                // stages on the planar kernels (pools 4, 4, 5 fused into the conv in front of them)
-      for (st0 = part == ENC_BACK ? 3 : 0; st0 < nplanar; ++st0) {
+      const bool from4 = part == ENC_BACK || part == ENC_STAGE4;
+      for (st0 = from4 ? 3 : 0; st0 < nplanar; ++st0) {
         const ConvLayer* Ls = L + 4 * st0;
         const int C = Ls[3].cout;
-        if (kEncPools[st0] == 5 && part != ENC_BACK) n /= 5;   // the previous stage's last conv already pooled (conv_p16p5.h): buf[S] holds n / 5 positions
+        if (kEncPools[st0] == 5 && !from4) n /= 5;   // the previous stage's last conv already pooled (conv_p16p5.h): buf[S] holds n / 5 positions
         // the stage's linear pair: (pooled) previous output buf[S] -> lout in buf[LO]
         const bool comp_st = compose && (st0 == 0 || (st0 <= 2 && net->comp[st0].d_wf16));
         if (comp_st && st0 > 0) {
@@ -710,12 +713,13 @@ static int encoder_chunk(orca_ctx* ctx, orca_net* net, const SeqSource& src, lon
         }
       }
       P = S;
+      if (part == ENC_STAGE4 || part == ENC_FRONT4) { *out = buf[P]; *out_ld = -128; *out_n = n; return ORCA_OK; }     // stage 4's output, fp32 [n][128], before MaxPool1d(5)
     }
     for (int st = st0; st < 7; ++st) {
       const ConvLayer* L = &net->convs[4 * st];
       if (kEncPools[st] == 4 && st0 == 0) {
         n = n / 4;  // MaxPool1d(4) was fused into the epilogue of the previous stage's last conv
-      } else if (kEncPools[st] > 1) {
+      } else if (kEncPools[st] > 1 && !(part == ENC_BACK5 && st == 4)) {
         const long n2 = n / kEncPools[st];
         const int Q = (P + 1) % 3;
         ORCA_TRY(launch_pool_nlc(ctx, buf[P], buf[Q], n2, L[0].cin, kEncPools[st]));
@@ -983,6 +987,70 @@ extern "C" int orca_encoder_back(orca_ctx* ctx, orca_net* net, const float* s4, 
   float* res; long rld, rn;
   ORCA_TRY(encoder_chunk(ctx, net, src, n4, buf, ru4(n4), &res, &rld, &rn, ENC_BACK));
   if (rld >= 0 || rn != n4 / 50) return fail(ORCA_EINVAL, "internal: the Encoder's back part produced %ld bins for %ld positions", rn, (long)n4);
+  return launch_copy2d(ctx, res, 1, 128, out, so_c, 128, rn);
+}
+
+// ---- one level further: stage 4 in the cache (fp32 rows [n][128] on the 80-base grid, phases mod 80; same 512 bytes per base and strand) ----
+extern "C" int orca_encoder_stage4_rows(orca_ctx* ctx, orca_net* net, const float* s4, int64_t s4_units, int64_t n4, float* rows) {
+  if (!ctx || !net || !s4 || !rows) return fail(ORCA_EINVAL, "orca_encoder_stage4_rows: NULL argument");
+  if (net->kind != ORCA_NET_ENCODER || net->precision != ORCA_PRECISION_F16X2) return fail(ORCA_EINVAL, "orca_encoder_stage4_rows: an Encoder net in the f16x2 arithmetic");
+  if (n4 <= 0 || s4_units != p16_plen(n4)) return fail(ORCA_EINVAL, "orca_encoder_stage4_rows: %ld positions in planes of %ld units (need %ld)", (long)n4, (long)s4_units, p16_plen(n4));
+  HIPCHECK(hipSetDevice(ctx->device));
+  const long ld = ru4(n4) + 1024;
+  ORCA_TRY(ws_ensure(ctx, 3 * ru256((size_t)128 * ld * sizeof(float))));
+  float* buf[3];
+  for (int i = 0; i < 3; ++i) buf[i] = ws_take(ctx, (size_t)128 * ld);
+  HIPCHECK(hipMemcpyAsync(buf[0], s4, (size_t)32 * s4_units * 16, hipMemcpyDeviceToDevice, ctx->stream));
+  ORCA_TRY(launch_p16_zero_pads(ctx, buf[0], 128, n4, 0));
+  SeqSource src;
+  float* res; long rld, rn;
+  ORCA_TRY(encoder_chunk(ctx, net, src, n4, buf, ru4(n4), &res, &rld, &rn, ENC_STAGE4));
+  if (rld >= 0 || rn != n4) return fail(ORCA_EINVAL, "internal: stage 4 produced %ld rows for %ld positions", rn, (long)n4);
+  HIPCHECK(hipMemcpyAsync(rows, res, (size_t)n4 * 128 * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+  return ORCA_OK;
+}
+
+static int launch_rows_pool5(orca_ctx* ctx, const float* src, long src_pos0, float* dst, long dst_pos0, long count) {
+  if (count <= 0) return ORCA_OK;
+  hipLaunchKernelGGL(rows_pool5_into_kernel, dim3((unsigned)((count * 32 + 255) / 256)), dim3(256), 0, ctx->stream, reinterpret_cast<const f32x4*>(src), src_pos0,
+                     reinterpret_cast<f32x4*>(dst), dst_pos0, count);
+  LAUNCHCHECK("rows_pool5_into_kernel");
+  return ORCA_OK;
+}
+
+extern "C" int orca_rows_pool5_into(orca_ctx* ctx, const float* src, int64_t src_rows, int64_t src_pos0, float* dst, int64_t dst_rows, int64_t dst_pos0, int64_t count) {
+  if (!ctx || !src || !dst) return fail(ORCA_EINVAL, "orca_rows_pool5_into: NULL argument");
+  if (count < 0 || src_pos0 < 0 || dst_pos0 < 0 || src_pos0 + 5 * count > src_rows || dst_pos0 + count > dst_rows)
+    return fail(ORCA_EINVAL, "orca_rows_pool5_into: rows [%ld,+5 x %ld) of %ld -> [%ld,+%ld) of %ld", (long)src_pos0, (long)count, (long)src_rows, (long)dst_pos0, (long)count, (long)dst_rows);
+  HIPCHECK(hipSetDevice(ctx->device));
+  return launch_rows_pool5(ctx, src, (long)src_pos0, dst, (long)dst_pos0, (long)count);
+}
+
+extern "C" int orca_encoder_front4_snippet(orca_ctx* ctx, orca_net* net, const uint8_t* codes, int64_t L, int reverse, int64_t base0, int64_t nbases, int64_t skip,
+                                           int64_t count, float* dst, int64_t dst_rows, int64_t dst_pos0) {
+  if (!dst) return fail(ORCA_EINVAL, "orca_encoder_front4_snippet: NULL argument");
+  if (base0 % 400 || nbases % 400) return fail(ORCA_EINVAL, "orca_encoder_front4_snippet: bases [%ld,+%ld): multiples of 400 (the pooled rows must line up with the window's)", (long)base0, (long)nbases);
+  float* res; long rn;
+  ORCA_TRY(front_run(ctx, net, codes, L, reverse, base0, nbases, ENC_FRONT4, &res, &rn));
+  if (skip < 0 || count <= 0 || 5 * (skip + count) > rn || dst_pos0 < 0 || dst_pos0 + count > dst_rows)
+    return fail(ORCA_EINVAL, "orca_encoder_front4_snippet: pooled rows [%ld,+%ld) of %ld -> [%ld,..) of %ld", (long)skip, (long)count, rn / 5, (long)dst_pos0, (long)dst_rows);
+  return launch_rows_pool5(ctx, res, 5 * (long)skip, dst, (long)dst_pos0, (long)count);
+}
+
+extern "C" int orca_encoder_back5(orca_ctx* ctx, orca_net* net, const float* rows, int64_t n5, float* out, int64_t so_c) {
+  if (!ctx || !net || !rows || !out) return fail(ORCA_EINVAL, "orca_encoder_back5: NULL argument");
+  if (net->kind != ORCA_NET_ENCODER || net->precision != ORCA_PRECISION_F16X2) return fail(ORCA_EINVAL, "orca_encoder_back5: an Encoder net in the f16x2 arithmetic");
+  if (n5 <= 0 || n5 % 10) return fail(ORCA_EINVAL, "orca_encoder_back5: %ld stage-5 positions (a multiple of 10)", (long)n5);
+  HIPCHECK(hipSetDevice(ctx->device));
+  const long ld = ru4(n5) + 1024;
+  ORCA_TRY(ws_ensure(ctx, 3 * ru256((size_t)128 * ld * sizeof(float))));
+  float* buf[3];
+  for (int i = 0; i < 3; ++i) buf[i] = ws_take(ctx, (size_t)128 * ld);
+  HIPCHECK(hipMemcpyAsync(buf[0], rows, (size_t)n5 * 128 * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+  SeqSource src;
+  float* res; long rld, rn;
+  ORCA_TRY(encoder_chunk(ctx, net, src, n5, buf, ru4(n5), &res, &rld, &rn, ENC_BACK5));
+  if (rld >= 0 || rn != n5 / 10) return fail(ORCA_EINVAL, "internal: stages 5-7 produced %ld bins for %ld positions", rn, (long)n5);
   return launch_copy2d(ctx, res, 1, 128, out, so_c, 128, rn);
 }
 

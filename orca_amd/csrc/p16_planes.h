@@ -38,3 +38,20 @@ static __global__ void p16_copy_units_kernel(const f32x4* __restrict__ x, long x
   if (m >= count) return;
   y[(long)blockIdx.y * y_plen + P16_GUARD + y_pos0 + m] = x[(long)blockIdx.y * x_plen + P16_GUARD + x_pos0 + m];
 }
+
+// the same pool on fp32 channel-last rows [n][128] (stage 4's output -> stage 5's input): rows src_pos0 + 5 m .. + 4 of x -> row y_pos0 + m of y.
+// One thread = 4 channels of one output row; grid ceil(count * 32 / 256), block 256.
+static __global__ void rows_pool5_into_kernel(const f32x4* __restrict__ x, long x_pos0, f32x4* __restrict__ y, long y_pos0, long count) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long m = t >> 5;
+  const int q = (int)(t & 31);
+  if (m >= count) return;
+  const f32x4* xp = x + (x_pos0 + 5 * m) * 32 + q;
+  f32x4 v = xp[0];
+#pragma unroll
+  for (int j = 1; j < 5; ++j) {
+    const f32x4 u = xp[j * 32];
+    v.x = fmaxf(v.x, u.x); v.y = fmaxf(v.y, u.y); v.z = fmaxf(v.z, u.z); v.w = fmaxf(v.w, u.w);
+  }
+  y[(y_pos0 + m) * 32 + q] = v;
+}

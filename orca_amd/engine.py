@@ -513,6 +513,50 @@ def encoder_back(net, s4, n4, out):
     return out
 
 
+def _rows(t, name):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.dim() == 2 and t.shape[1] == 128):
+        raise ValueError(f"{name}: a contiguous [n,128] float32 ROCm tensor")
+    return t
+
+
+def encoder_stage4_rows(net, s4, n4):
+    """Stage 4 alone: stage-4 input planes ``s4`` ([32, p16_plane_units(n4), 4]) -> its output rows [n4, 128] (before the MaxPool1d(5) in front of stage 5)."""
+    _planes(s4, p16_plane_units(n4), "s4")
+    rows = torch.empty((n4, 128), dtype=torch.float32, device=s4.device)
+    net.ctx.sync_stream()
+    check(_lib.load().orca_encoder_stage4_rows(net.ctx.handle, net.handle, _p(s4), s4.shape[1], int(n4), _p(rows)), "orca_encoder_stage4_rows")
+    return rows
+
+
+def rows_pool5_into(ctx, src, src_pos0, dst, dst_pos0, count):
+    """MaxPool1d(5) of rows [src_pos0, src_pos0 + 5 count) of ``src`` [n,128] into rows [dst_pos0, dst_pos0 + count) of ``dst`` [m,128]."""
+    _rows(src, "src")
+    _rows(dst, "dst")
+    ctx.sync_stream()
+    check(_lib.load().orca_rows_pool5_into(ctx.handle, _p(src), src.shape[0], int(src_pos0), _p(dst), dst.shape[0], int(dst_pos0), int(count)), "orca_rows_pool5_into")
+
+
+def encoder_front4_snippet(net, codes, reverse, base0, nbases, skip, count, dst, dst_pos0):
+    """Stages 1-4 + MaxPool1d(5) on strand positions [base0, base0 + nbases) of ``codes`` [L] (multiples of 400); pooled rows [skip, skip + count)
+    go to rows [dst_pos0, ..) of the stage-5 input ``dst`` [n5,128]."""
+    codes = _codes1d(codes)
+    _rows(dst, "dst")
+    net.ctx.sync_stream()
+    check(_lib.load().orca_encoder_front4_snippet(net.ctx.handle, net.handle, _p(codes), codes.numel(), 1 if reverse else 0, int(base0), int(nbases), int(skip), int(count),
+                                                  _p(dst), dst.shape[0], int(dst_pos0)), "orca_encoder_front4_snippet")
+
+
+def encoder_back5(net, rows, out):
+    """Stages 5-7 from the stage-5 input ``rows`` [n5,128] into ``out`` [128, n5 / 10] (unit stride along the bins)."""
+    _rows(rows, "rows")
+    n5 = rows.shape[0]
+    if not (out.is_cuda and out.dtype == torch.float32 and tuple(out.shape) == (128, n5 // 10) and out.stride(1) == 1):
+        raise ValueError(f"out must be a [128,{n5 // 10}] float32 view with unit stride along the bins")
+    net.ctx.sync_stream()
+    check(_lib.load().orca_encoder_back5(net.ctx.handle, net.handle, _p(rows), n5, _p(out), out.stride(0)), "orca_encoder_back5")
+    return out
+
+
 def encoder_forward_2bit(net, two, nmask, start, L, reverse=False, bin_lo=0, bin_hi=0, chunk_bp=0, out=None):
     """Encoder on bases [start, start + L) of a chromosome stored as 2 bits per base + N mask in HBM (genome.TwoBitGenome planes): no
     unpacked window is made (orca_encoder_forward_2bit).  Returns [1,128,bins]."""

@@ -237,6 +237,15 @@ class Encoder(_HipModule):
     def back(self, s4, n4, out):
         return engine.encoder_back(self._parts_net(s4.device), s4, n4, out)
 
+    def stage4_rows(self, s4, n4):
+        return engine.encoder_stage4_rows(self._parts_net(s4.device), s4, n4)
+
+    def front4_snippet(self, codes, reverse, base0, nbases, skip, count, dst, dst_pos0):
+        engine.encoder_front4_snippet(self._parts_net(codes.device), codes, reverse, base0, nbases, skip, count, dst, dst_pos0)
+
+    def back5(self, rows, out):
+        return engine.encoder_back5(self._parts_net(rows.device), rows, out)
+
     def forward_2bit(self, genome, chrom, start, end, reverse=False, bin_lo=0, bin_hi=0, out=None):
         """Encoder on `chrom`[start:end) of a genome.TwoBitGenome resident on the MI355X, read in place: 2 bits per base + N mask straight
         into the first-layer kernels (one-hot expansion in LDS) - no unpacked 1 byte/base window, no float window (selene_utils2.py:216-222)."""

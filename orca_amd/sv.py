@@ -301,7 +301,7 @@ class GenomeEncodings:
                         held.pop(0)[1].stage3 = None
                     dev = ce.codes.device
                     if dev.type == "cuda" and need + 40e9 < torch.cuda.mem_get_info(dev)[0]:
-                        s3 = Stage3Cache(self.net0, ce.codes)
+                        s3 = Stage4Cache(self.net0, ce.codes)
                         ce.stage3 = s3 if s3.build_all() else None
                         engine.get_context(dev).release_workspace()
                     ce.s3_misses = 0
@@ -362,18 +362,26 @@ S3_POOL = 5              # MaxPool1d(5) in front of stage 4: a stage-4 position 
 S3_MARGIN_BP = 512       # >= reach of a stage-3 position beyond its 16 bases (16 + 3 + 64 + 12 + 256 = 351), in bases, a multiple of 16
 S3_PAD_BP = 1600         # bases a snippet extends beyond the pooled positions it is run for (>= S3_MARGIN_BP, a multiple of 80)
 S3_MIN_SNIPPET_BP = 4000
+# ... and one level further (Stage4Cache): stage 4's output on the 80-base grid of ITS input, reach 351 + 16 * 80 = 1 631 bases
+S4_GRID = 80
+S4_MARGIN_BP = 1760      # >= 1 631, a multiple of 80
+S4_PAD_BP = 2400         # >= S4_MARGIN_BP, a multiple of 400 (a snippet's pooled rows must line up with the window's)
+S4_MIN_SNIPPET_BP = 8000
 
 
-def s3_plan(pcs, chrlens, L, margin=S3_MARGIN_BP, regions=None):
+def s3_plan(pcs, chrlens, L, margin=S3_MARGIN_BP, regions=None, grid=S3_GRID, pad=S3_PAD_BP, min_snippet=S3_MIN_SNIPPET_BP):
     """Stage-4 input of a window given as strand-oriented pieces (3-tuples of ONE chromosome of length ``chrlens``, or 4-tuples with
     ``chrlens`` a {chrom: length} mapping): (takes, snippets).  takes = [(m_lo, m_hi, chrom, strand, phase, c)]: pooled positions
     [m_lo, m_hi) are the MaxPool1d(5) of cache entry (chrom, strand, phase) from the stage-3 position that starts at strand coordinate c;
     snippets = [(ga, gb, base0, nbases, skip)]: pooled positions [ga, gb) come from the Encoder's front run on window bases [base0, base0 +
     nbases), whose pooled position ``skip`` is position ga.  Every pooled position is in exactly one of them.  ``regions``: the part of a
     chromosome the cache holds, (r0, r1) in forward coordinates (or {chrom: (r0, r1)}; default the whole chromosome) - bases outside it
-    go through the front like anything else the cache does not know."""
+    go through the front like anything else the cache does not know.  ``grid`` = bases per cached position (16: stage 3, 80: stage 4 -
+    "stage-3 position" then reads stage-4 position and the pooled positions are stage 5's input), with its ``margin`` / ``pad``."""
+    S3_GRID = grid          # (the body below is written for stage 3; the grid is its only constant)
+    S3_PAD_BP, S3_MIN_SNIPPET_BP = pad, min_snippet
     if L % (S3_GRID * S3_POOL):
-        raise ValueError("window length must be a multiple of 80")
+        raise ValueError(f"window length must be a multiple of {S3_GRID * S3_POOL}")
     n4, cell = L // (S3_GRID * S3_POOL), S3_GRID * S3_POOL
     takes, o = [], 0
     for piece in pcs:
@@ -414,6 +422,7 @@ class Stage3Cache:
     16-base grid, as P16 planes in HBM (`Encoder.stage3_planes`), and the route from it to the bins of a window (`encode`).  Entry (strand,
     phase) starts at the first strand coordinate e0 >= the region's start with e0 % 16 == phase: position j = the 16 bases from e0 + 16 j.
     ``codes``: the chromosome's [chrlen] uint8 codes on the device."""
+    level, grid = 3, S3_GRID
 
     def __init__(self, net0, codes, region=None):
         if not (isinstance(codes, torch.Tensor) and codes.dtype == torch.uint8 and codes.dim() == 1 and codes.is_cuda):
@@ -432,17 +441,21 @@ class Stage3Cache:
 
     def _origin(self, strand, phase):
         lo = self.region[0] if strand == "+" else self.C - self.region[1]
-        return lo + (phase - lo) % S3_GRID
+        return lo + (phase - lo) % self.grid
+
+    def _planes3(self, strand, p16):
+        """Stage-3 planes of the region at phase ``p16`` of the 16-base grid: (planes or None, origin, positions)."""
+        lo, hi = (self.region[0], self.region[1]) if strand == "+" else (self.C - self.region[1], self.C - self.region[0])
+        e0 = lo + (p16 - lo) % S3_GRID
+        n = (hi - e0) // 80 * 80
+        seg = self.codes[e0: e0 + n] if strand == "+" else self.codes[self.C - e0 - n: self.C - e0]
+        return self.net0.stage3_planes(seg.contiguous(), reverse=(strand == "-")), e0, n // S3_GRID
 
     def get(self, strand, phase):
         key = (strand, int(phase))
         e = self.entries.get(key)
         if e is None:
-            e0 = self._origin(*key)
-            hi = self.region[1] if strand == "+" else self.C - self.region[0]
-            n = (hi - e0) // 80 * 80
-            seg = self.codes[e0: e0 + n] if strand == "+" else self.codes[self.C - e0 - n: self.C - e0]
-            e = self.net0.stage3_planes(seg.contiguous(), reverse=(strand == "-"))
+            e = self._planes3(*key)[0]
             if e is None:
                 return None
             self.entries[key] = e
@@ -456,9 +469,9 @@ class Stage3Cache:
             self.builds -= 1
 
     def build_all(self):
-        """All 32 entries; False (nothing kept) if the fp16-range guard fired on one of them."""
+        """All entries (32; 160 one level up); False (nothing kept) if the fp16-range guard fired on one of them."""
         for strand in "+-":
-            for phase in range(S3_GRID):
+            for phase in range(self.grid):
                 if self.get(strand, phase) is None:
                     self.entries.clear()
                     return False
@@ -471,9 +484,60 @@ class Stage3Cache:
         return s3_encode(self.net0, {None: self}, pcs, codes_w, reverse, out_row)
 
 
+class Stage4Cache(Stage3Cache):
+    """The same one level further up the Encoder: stage 4's output (ReLU + residual, before the MaxPool1d(5) in front of stage 5) as fp32
+    rows [n, 128] per strand and phase mod 80 - the same 512 bytes per base and strand, 160 entries - so that a window strand runs only
+    stages 5-7 (0.8 instead of 2.0 ms) behind a gather of rows and the front + stage 4 on its ends and junctions (reach 1 631 bases).
+    Entries are DERIVED: the stage-3 planes of a phase mod 16 exist while its five phases mod 80 are pooled and run through stage 4."""
+    level, grid = 4, S4_GRID
+
+    def get(self, strand, phase):
+        key = (strand, int(phase))
+        if key not in self.entries:
+            self._build_group(strand, key[1] % S3_GRID)
+        return self.entries.get(key)
+
+    def _build_group(self, strand, p16):
+        planes, e0, n3 = self._planes3(strand, p16)
+        if planes is None:
+            return
+        hi = self.region[1] if strand == "+" else self.C - self.region[0]
+        ctx = engine.get_context(self.codes.device)
+        for k in range(S4_GRID // S3_GRID):
+            key = (strand, (p16 + S3_GRID * k) % S4_GRID)
+            e4 = self._origin(*key)
+            j0 = (e4 - e0) // S3_GRID
+            n4 = min((hi - e4) // S4_GRID, (n3 - j0) // S3_POOL)
+            if n4 <= 0:
+                continue
+            s4 = torch.empty((32, engine.p16_plane_units(n4), 4), dtype=torch.float32, device=self.codes.device)
+            engine.p16_pool5_into(ctx, planes, j0, s4, 0, n4)
+            e = self.net0.stage4_rows(s4, n4)
+            self.entries[key] = e
+            self.builds += 1
+            engine.tentative(lambda key=key, e=e: self._drop(key, e))
+        if not engine._guard["defer"] and ctx.take_overflow():
+            import warnings
+            warnings.warn("orca_amd: an activation left the fp16 range while building a stage-4 cache entry; windows will be encoded whole")
+            for k in range(S4_GRID // S3_GRID):
+                self.entries.pop((strand, (p16 + S3_GRID * k) % S4_GRID), None)
+
+    def build_all(self):
+        for strand in "+-":
+            for p16 in range(S3_GRID):
+                self._build_group(strand, p16)
+                if (strand, p16) not in self.entries:
+                    self.entries.clear()
+                    return False
+        return True
+
+
 def s3_encode(net0, caches, pcs, codes_w, reverse, out_row):
     """`Stage3Cache.encode` for pieces of several chromosomes: ``caches`` = {chrom: Stage3Cache} (key None: 3-tuple pieces of the one
-    chromosome); pieces of anything else (an inserted string, padding, a chromosome without a cache) go through the Encoder's front."""
+    chromosome); pieces of anything else (an inserted string, padding, a chromosome without a cache) go through the Encoder's front.
+    `Stage4Cache`s (all of ``caches`` one kind): the same with rows, the front + stage 4, and stages 5-7."""
+    if next(iter(caches.values())).level == 4:
+        return _s4_encode(net0, caches, pcs, codes_w, reverse, out_row)
     L = int(codes_w.numel())
     n4 = L // (S3_GRID * S3_POOL)
     if None in caches:
@@ -490,6 +554,27 @@ def s3_encode(net0, caches, pcs, codes_w, reverse, out_row):
     for ga, gb, b0, nb, skip in snippets:
         net0.front_snippet(codes_w, reverse, b0, nb, skip, gb - ga, s4, ga)
     net0.back(s4, n4, out_row)
+    return sum(sn[3] for sn in snippets)
+
+
+def _s4_encode(net0, caches, pcs, codes_w, reverse, out_row):
+    L = int(codes_w.numel())
+    n5 = L // (S4_GRID * S3_POOL)
+    kw = dict(margin=S4_MARGIN_BP, grid=S4_GRID, pad=S4_PAD_BP, min_snippet=S4_MIN_SNIPPET_BP)
+    if None in caches:
+        takes, snippets = s3_plan(pcs, caches[None].C, L, regions=caches[None].region, **kw)
+    else:
+        takes, snippets = s3_plan(pcs, {c: k.C for c, k in caches.items()}, L, regions={c: k.region for c, k in caches.items()}, **kw)
+    s5 = torch.empty((n5, 128), dtype=torch.float32, device=codes_w.device)
+    ctx = engine.get_context(codes_w.device)
+    for m_lo, m_hi, chrom, strand, phase, c in takes:
+        src = caches[chrom].get(strand, phase)
+        if src is None:
+            raise RuntimeError("stage-4 cache entry unavailable (fp16 range)")
+        engine.rows_pool5_into(ctx, src, (c - caches[chrom]._origin(strand, phase)) // S4_GRID, s5, m_lo, m_hi - m_lo)
+    for ga, gb, b0, nb, skip in snippets:
+        net0.front4_snippet(codes_w, reverse, b0, nb, skip, gb - ga, s5, ga)
+    net0.back5(s5, out_row)
     return sum(sn[3] for sn in snippets)
 
 
@@ -710,7 +795,7 @@ def sv_screen(models, genome_codes, svs, chrlen, mchr="chrS", rank=0, world=1, i
             if (stage3 is True or whole_runs >= 32 * -(-(region[1] - region[0]) // WINDOW)) and need + 40e9 < torch.cuda.mem_get_info(genome_codes.device)[0]:
                 t0 = time.perf_counter()
                 for cache in caches:
-                    s3c = Stage3Cache(cache.net0, genome_codes, region)
+                    s3c = Stage4Cache(cache.net0, genome_codes, region)
                     cache.stage3 = s3c if s3c.build_all() else None
                 engine.get_context(genome_codes.device).release_workspace()      # (the front on a whole chromosome: 768 B per base)
                 torch.cuda.synchronize(genome_codes.device)

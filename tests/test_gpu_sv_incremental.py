@@ -171,14 +171,17 @@ UNALIGNED = [sv.SV("del", 18_000_123, 19_200_777), sv.SV("dup", 21_004_001, 21_5
              sv.SV("inv", 20_000_003, 20_012_345), sv.SV("del", 17_001_234, 17_803_210), sv.SV("dup", 9_999_999, 10_020_020)]
 
 
-def test_stage3_route_equals_the_whole_encoder(setup):
-    """`sv.Stage3Cache` (round 6): a window at an ARBITRARY base position - MaxPool1d(5) gather of stages 1-3 from the chromosome's cached planes
+@pytest.mark.parametrize("level", [3, 4])
+def test_stage3_route_equals_the_whole_encoder(setup, level):
+    """`sv.Stage3Cache` / `sv.Stage4Cache` (round 6; level 4 = stage 4 in the cache too: rows on the 80-base grid, the front + stage 4 on the snippets,
+    stages 5-7 per window - what the screen and the drivers use): a window at an ARBITRARY base position - MaxPool1d(5) gather of stages 1-3 from the chromosome's cached planes
     (16 phases x 2 strands), the Encoder's front on its ends and junctions, stages 4-7 - against the Encoder on the assembled window, both
     strands, for reference and alternative alleles of deletions, duplications and inversions off the 4 kb grid (an N run inside).  Not bit for
     bit (the snippets run other tile instantiations than a 32 Mb sequence; the pool re-splits a stored value): the bound is 1e-5 on encodings of
     range 0..8, an order below what the maps' 1e-4 needs."""
     model, genome = setup
-    s3 = sv.Stage3Cache(model.net0, genome)
+    Cache = sv.Stage3Cache if level == 3 else sv.Stage4Cache
+    s3 = Cache(model.net0, genome)
     worst, front_bases = 0.0, 0
     for v in UNALIGNED:
         rp, rw, rm, ap, aw, am = sv.sv_windows(v, CHR)
@@ -190,9 +193,10 @@ def test_stage3_route_equals_the_whole_encoder(setup):
                 front_bases += s3.encode(sv.revcomp_pieces(pieces) if rev else pieces, w, rev, out)
                 worst = max(worst, float((out - whole).abs().max()))
                 assert worst <= 1e-5, (v, rev, worst)
-    assert len(s3.entries) <= 32 and front_bases < 0.002 * len(UNALIGNED) * 4 * sv.WINDOW       # a few kb per end and junction, not windows
+    assert len(s3.entries) <= (32 if level == 3 else 160) and front_bases < 0.004 * len(UNALIGNED) * 4 * sv.WINDOW       # a few kb per end and junction, not windows
     # a cache of a REGION of the chromosome (a locus of a real one): what lies outside goes through the Encoder's front
-    part = sv.Stage3Cache(model.net0, genome, region=(9_000_000, 33_000_000))
+    del s3
+    part = Cache(model.net0, genome, region=(9_000_000, 33_000_000))
     rp, rw, rm, ap, aw, am = sv.sv_windows(UNALIGNED[0], CHR)
     w = sv.assemble_codes(genome, ap)
     for rev in (False, True):
@@ -210,7 +214,7 @@ def test_screen_off_the_grid_through_the_stage3_cache(setup):
     stats = {}
     inc = sv.sv_screen([model], genome, UNALIGNED, CHR, stats=stats, stage3=True)
     full = sv.sv_screen([model], genome, UNALIGNED, CHR, incremental=False)
-    assert stats["stage3_cache"]["entries"] == 32
+    assert stats["stage3_cache"]["entries"] == 160
     assert stats["bins_encoded"] < 0.01 * stats["bins_total"], stats
     for i in range(len(UNALIGNED)):
         for allele in ("ref", "alt"):

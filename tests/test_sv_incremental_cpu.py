@@ -160,23 +160,25 @@ def test_segments_persist_and_a_repeated_phase_gets_a_chromosome_encoding():
     assert store.builds == 2 and torch.equal(out4, _window_whole(ToyNet0(), codes, [p[1:] for p in far])[0])
 
 
-def test_stage3_plan_is_exact_on_a_toy_front():
+@pytest.mark.parametrize("grid,reach,kw", [(16, 351, {}), (80, 1631, dict(margin=sv.S4_MARGIN_BP, grid=sv.S4_GRID, pad=sv.S4_PAD_BP, min_snippet=sv.S4_MIN_SNIPPET_BP))])
+def test_stage3_plan_is_exact_on_a_toy_front(grid, reach, kw):
     """`sv.s3_plan` (the stage-3 cache's route, round 6) on CPU: a toy "front" - a LINEAR integer filter with the real reach (351 bases
     either side of a 16-base cell, zero padded at the ends of whatever sequence it runs on) and MaxPool1d(5) - so that equality is exact.
     For windows of one piece, deletions, inversions ('-' pieces from the other strand's cache), short duplicated pieces, both strands, and
     windows at the chromosome's ends: every pooled position comes from exactly one source - a cache entry of the right (strand, phase mod 16)
-    at the right offset, or a snippet of the assembled window - and equals the front on the whole assembled window."""
+    at the right offset, or a snippet of the assembled window - and equals the front on the whole assembled window.  Second parameter set:
+    the same plan one level up (sv.Stage4Cache: stage 4's output on the 80-base grid, reach 1 631 bases, phases mod 80, snippets on the 400-base grid)."""
     rs = np.random.RandomState(0)
     C, L = 400_000, 160_000
     chrom = rs.randint(0, 4, C).astype(np.int64)
-    wts = rs.randint(-3, 4, size=(351 * 2 + 16,)).astype(np.int64)
+    wts = rs.randint(-3, 4, size=(reach * 2 + grid,)).astype(np.int64)
 
     def revcomp(c):
         return (3 - c)[::-1]
 
     def stage3(codes):
-        x = np.concatenate([np.zeros(351, np.int64), codes + 1, np.zeros(351, np.int64)])
-        idx = np.arange(len(codes) // 16)[:, None] * 16 + np.arange(len(wts))[None, :]
+        x = np.concatenate([np.zeros(reach, np.int64), codes + 1, np.zeros(reach, np.int64)])
+        idx = np.arange(len(codes) // grid)[:, None] * grid + np.arange(len(wts))[None, :]
         return (x[idx] * wts[None, :]).sum(1)
 
     def pool5(v):
@@ -187,8 +189,8 @@ def test_stage3_plan_is_exact_on_a_toy_front():
     def entry(strand, phase, region):      # (planes, strand coordinate of position 0): what sv.Stage3Cache.get / _origin keep
         if (strand, phase, region) not in cache:
             lo, hi = region if strand == "+" else (C - region[1], C - region[0])
-            e0 = lo + (phase - lo) % 16
-            n = (hi - e0) // 80 * 80
+            e0 = lo + (phase - lo) % grid
+            n = (hi - e0) // (5 * grid) * (5 * grid)
             cache[(strand, phase, region)] = (stage3((chrom if strand == "+" else revcomp(chrom))[e0: e0 + n]), e0)
         return cache[(strand, phase, region)]
 
@@ -197,20 +199,20 @@ def test_stage3_plan_is_exact_on_a_toy_front():
             pcs = sv.revcomp_pieces(pieces) if rev else pieces
             win = np.concatenate([chrom[s: s + n] if st == "+" else revcomp(chrom[s: s + n]) for s, n, st in pcs])
             ref = pool5(stage3(win))
-            takes, snips = sv.s3_plan(pcs, C, L, regions=region)
-            got, cov = np.zeros(L // 80, np.int64), np.zeros(L // 80, int)
+            takes, snips = sv.s3_plan(pcs, C, L, regions=region, **kw)
+            got, cov = np.zeros(L // (5 * grid), np.int64), np.zeros(L // (5 * grid), int)
             for m_lo, m_hi, _, strand, phase, c in takes:
                 e, e0 = entry(strand, phase, region or (0, C))
-                j0 = (c - e0) // 16
-                assert (c - e0) % 16 == 0 and j0 >= 0 and j0 + 5 * (m_hi - m_lo) <= len(e)
+                j0 = (c - e0) // grid
+                assert phase == c % grid and (c - e0) % grid == 0 and j0 >= 0 and j0 + 5 * (m_hi - m_lo) <= len(e)
                 got[m_lo:m_hi] = pool5(e[j0: j0 + 5 * (m_hi - m_lo)])
                 cov[m_lo:m_hi] += 1
             for ga, gb, b0, nb, skip in snips:
-                assert nb % 80 == 0 and b0 % 80 == 0 and 0 <= b0 and b0 + nb <= L and nb >= min(L, sv.S3_MIN_SNIPPET_BP)
+                assert nb % (5 * grid) == 0 and b0 % (5 * grid) == 0 and 0 <= b0 and b0 + nb <= L and nb >= min(L, kw.get("min_snippet", sv.S3_MIN_SNIPPET_BP))
                 got[ga:gb] = pool5(stage3(win[b0: b0 + nb]))[skip: skip + gb - ga]
                 cov[ga:gb] += 1
             assert (cov == 1).all() and (got == ref).all(), (pieces, rev)
-            assert region is not None or sum(sn[3] for sn in snips) < 0.2 * L
+            assert region is not None or sum(sn[3] for sn in snips) < 0.3 * L
 
     for trial in range(24):
         s = int(rs.randint(1000, C - L - 60000))

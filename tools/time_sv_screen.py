@@ -28,10 +28,10 @@ if inc:   # where a variant's time goes (on the grid: bins from the chromosome e
         for k in (("+", 0), ("-", 0), ("+", 2000), ("-", 2000)):
             cache.get(*k)
     else:
-        cache.stage3 = sv.Stage3Cache(h1.net0, genome)
+        cache.stage3 = sv.Stage4Cache(h1.net0, genome)
         torch.cuda.synchronize(); t = T.perf_counter()
         cache.stage3.build_all()
-        torch.cuda.synchronize(); print(f"stage-3 cache: 32 entries in {T.perf_counter() - t:.2f} s")
+        torch.cuda.synchronize(); print(f"stage-4 cache: 160 entries in {T.perf_counter() - t:.2f} s")
     enc0 = torch.empty((4, 128, 8000), device=dev)
     from orca_amd import engine
     ns = 4 if streams is None else streams
