@@ -378,11 +378,10 @@ def s3_plan(pcs, chrlens, L, margin=S3_MARGIN_BP, regions=None, grid=S3_GRID, pa
     chromosome the cache holds, (r0, r1) in forward coordinates (or {chrom: (r0, r1)}; default the whole chromosome) - bases outside it
     go through the front like anything else the cache does not know.  ``grid`` = bases per cached position (16: stage 3, 80: stage 4 -
     "stage-3 position" then reads stage-4 position and the pooled positions are stage 5's input), with its ``margin`` / ``pad``."""
-    S3_GRID = grid          # (the body below is written for stage 3; the grid is its only constant)
-    S3_PAD_BP, S3_MIN_SNIPPET_BP = pad, min_snippet
-    if L % (S3_GRID * S3_POOL):
-        raise ValueError(f"window length must be a multiple of {S3_GRID * S3_POOL}")
-    n4, cell = L // (S3_GRID * S3_POOL), S3_GRID * S3_POOL
+    cell = grid * S3_POOL
+    if L % cell:
+        raise ValueError(f"window length must be a multiple of {cell}")
+    n4 = L // cell
     takes, o = [], 0
     for piece in pcs:
         chrom, src, ln, strand = _p4(piece)
@@ -391,14 +390,14 @@ def s3_plan(pcs, chrlens, L, margin=S3_MARGIN_BP, regions=None, grid=S3_GRID, pa
             c0 = strand_coord(piece, C)
             r0, r1 = (regions.get(chrom, (0, C)) if isinstance(regions, dict) else regions) if regions else (0, C)
             lo_s, hi_s = (r0, r1) if strand == "+" else (C - r1, C - r0)      # what the cache holds, in this strand's coordinates
-            i_lo = -(-(o + margin) // S3_GRID)                         # first / one-past-last stage-3 position whose reach lies inside the piece
-            i_hi = (o + ln - margin) // S3_GRID
-            i_lo = max(i_lo, -(-(lo_s + margin - c0 + o) // S3_GRID)) # ... and inside the cached range's own interior (the cache saw ITS ends' padding)
-            i_hi = min(i_hi, (hi_s - margin - c0 + o) // S3_GRID)
+            i_lo = -(-(o + margin) // grid)                         # first / one-past-last stage-3 position whose reach lies inside the piece
+            i_hi = (o + ln - margin) // grid
+            i_lo = max(i_lo, -(-(lo_s + margin - c0 + o) // grid)) # ... and inside the cached range's own interior (the cache saw ITS ends' padding)
+            i_hi = min(i_hi, (hi_s - margin - c0 + o) // grid)
             m_lo, m_hi = max(-(-i_lo // S3_POOL), 0), min(i_hi // S3_POOL, n4)
             if m_hi > m_lo:
                 c = c0 + cell * m_lo - o                               # strand coordinate of pooled position m_lo's first base
-                takes.append((m_lo, m_hi, chrom, strand, c % S3_GRID, c))
+                takes.append((m_lo, m_hi, chrom, strand, c % grid, c))
         o += ln
     if o != L:
         raise ValueError("pieces do not add up to the window")
@@ -406,9 +405,9 @@ def s3_plan(pcs, chrlens, L, margin=S3_MARGIN_BP, regions=None, grid=S3_GRID, pa
     for ga, gb in [(t[1], u[0]) for t, u in zip([(0, 0)] + takes, takes + [(n4, n4)])]:
         if gb <= ga:
             continue
-        b0 = 0 if ga == 0 else max(0, ga * cell - S3_PAD_BP)
-        b1 = L if gb == n4 else min(L, gb * cell + S3_PAD_BP)
-        while b1 - b0 < S3_MIN_SNIPPET_BP and (b0 > 0 or b1 < L):      # very short runs: a snippet of at least one bin
+        b0 = 0 if ga == 0 else max(0, ga * cell - pad)
+        b1 = L if gb == n4 else min(L, gb * cell + pad)
+        while b1 - b0 < min_snippet and (b0 > 0 or b1 < L):      # very short runs: a snippet of at least one bin
             if b1 < L:
                 b1 = min(L, b1 + cell)
             else:

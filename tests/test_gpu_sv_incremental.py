@@ -227,3 +227,27 @@ def test_screen_off_the_grid_through_the_stage3_cache(setup):
     assert plain["stage3_cache"] is None and plain["bins_encoded"] == plain["bins_total"]
     with engine.force_safe_precision():
         assert not model.net0.two_part_ok()
+
+
+def test_stage4_route_over_many_random_variants(setup):
+    """A wider net for the route the screen uses: 36 variants of `synth_svs` (log-uniform sizes 10 kb - 5 Mb, arbitrary bases, all three kinds) plus
+    the extremes - a variant hard against either end of the chromosome (windows clipped by `coord_clip`: a window end IS the chromosome end), a
+    3-base deletion, a duplication shorter than the cache's margin (its middle piece has no interior: three pieces' worth of snippets merge) - both
+    alleles, both strands, against the Encoder on the assembled window at 1e-5."""
+    model, genome = setup
+    cache = sv.Stage4Cache(model.net0, genome)
+    assert cache.build_all() and len(cache.entries) == 160
+    variants = sv.synth_svs(36, CHR, seed=4242) + [sv.SV("del", 1_000_003, 1_400_001), sv.SV("inv", 38_700_011, 39_900_007), sv.SV("del", 20_000_001, 20_000_004),
+                                               sv.SV("dup", 12_345_678, 12_346_000), sv.SV("inv", 25_000_000, 25_000_900), sv.SV("dup", 30_000_001, 34_999_999)]
+    worst = 0.0
+    for v in variants:
+        rp, rw, rm, ap, aw, am = sv.sv_windows(v, CHR)
+        for pieces in (rp, ap):
+            w = sv.assemble_codes(genome, pieces)
+            for rev in (False, True):
+                out = torch.full((128, 8000), float("nan"), device=genome.device)
+                cache.encode(sv.revcomp_pieces(pieces) if rev else pieces, w, rev, out)
+                d = float((out - model.net0.forward_codes(w[None], reverse=rev)[0]).abs().max())
+                worst = max(worst, d)
+                assert d <= 1e-5, (v, rev, d)
+    print(f"stage-4 route vs the whole Encoder over {len(variants)} variants x 2 alleles x 2 strands: worst max-abs {worst:.3g}")
