@@ -300,7 +300,7 @@ class GenomeEncodings:
                     while held and sum(Stage3Cache.bytes_needed(k.C) for _, k in held) + need > self.s3_budget:
                         held.pop(0)[1].stage3 = None
                     dev = ce.codes.device
-                    if dev.type == "cuda" and need + 40e9 < torch.cuda.mem_get_info(dev)[0]:
+                    if dev.type == "cuda" and need + 40e9 < _hbm_available(dev):
                         s3 = Stage4Cache(self.net0, ce.codes)
                         ce.stage3 = s3 if s3.build_all() else None
                         engine.get_context(dev).release_workspace()
@@ -367,6 +367,11 @@ S4_GRID = 80
 S4_MARGIN_BP = 1760      # >= 1 631, a multiple of 80
 S4_PAD_BP = 2400         # >= S4_MARGIN_BP, a multiple of 400 (a snippet's pooled rows must line up with the window's)
 S4_MIN_SNIPPET_BP = 8000
+
+
+def _hbm_available(dev):
+    """Bytes a new tensor can get on ``dev``: what the driver reports free plus what torch's caching allocator holds without using it."""
+    return torch.cuda.mem_get_info(dev)[0] + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
 
 
 def s3_plan(pcs, chrlens, L, margin=S3_MARGIN_BP, regions=None, grid=S3_GRID, pad=S3_PAD_BP, min_snippet=S3_MIN_SNIPPET_BP):
@@ -791,7 +796,7 @@ def sv_screen(models, genome_codes, svs, chrlen, mchr="chrS", rank=0, world=1, i
             spans = [(p[0], p[0] + p[1]) for i in mine for pcs in sv_windows(svs[i], chrlen)[0:4:3] for p in pcs]
             region = (max(0, min(a for a, _ in spans) // 80 * 80), min(chrlen, -(-max(b for _, b in spans) // 80) * 80)) if spans else (0, chrlen)
             need = Stage3Cache.bytes_needed(region[1] - region[0]) * len(models)
-            if (stage3 is True or whole_runs >= 32 * -(-(region[1] - region[0]) // WINDOW)) and need + 40e9 < torch.cuda.mem_get_info(genome_codes.device)[0]:
+            if (stage3 is True or whole_runs >= 32 * -(-(region[1] - region[0]) // WINDOW)) and need + 40e9 < _hbm_available(genome_codes.device):
                 t0 = time.perf_counter()
                 for cache in caches:
                     s3c = Stage4Cache(cache.net0, genome_codes, region)

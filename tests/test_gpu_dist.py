@@ -224,10 +224,12 @@ def test_bench_two_ranks_on_one_gpu_over_gloo(cuda):
     assert rd["single_plane_b8"]["ms_per_forward"] > 0 and rd["single_plane_b8"]["mfma_products_per_algorithmic_mac"] == 1
     # config 5 on the workload as SURVEY 8(d) draws it (unaligned) AND on rounds 3-5's 4 kb-aligned set, each with its comparator
     c5 = one["config5"]
-    assert "error" not in c5 and c5["coordinates"].startswith("unaligned") and c5["svs"] == 64 and c5["max_abs_vs_whole_window_encoding"] < 1e-4, c5
+    assert "error" not in c5 and c5["coordinates"].startswith("unaligned") and c5["svs"] == 256 and c5["max_abs_vs_whole_window_encoding"] < 1e-4, c5
     a5 = c5["aligned_4kb"]
     assert a5["svs"] == 256 and a5["as_the_reference_does_it"]["svs"] == 8 and a5["max_abs_vs_whole_window_encoding"] < 1e-4, a5
-    assert a5["svs_per_s"] > c5["svs_per_s"] and a5["encoder_bins_encoded_frac"] < 0.1 < c5["encoder_bins_encoded_frac"]
+    # (round 6: off the grid the windows go through the stage-4 cache - a fraction of a per cent of the bins through the Encoder's front again)
+    assert a5["encoder_bins_encoded_frac"] < 0.1 and c5["encoder_bins_encoded_frac"] < 0.01 and c5["stage3_cache"]["entries"] == 160 and a5["stage3_cache"] is None
+    assert c5["svs_per_s"] > 2 * c5["whole_window_route"]["svs_per_s"] > 0 and a5["svs_per_s"] > 0.8 * c5["svs_per_s"]
     rc = one["reference_call_form"]                            # the reference's call: host float32 array in, numpy maps out (PCIe inclusive)
     assert "error" not in rc and rc["ms_per_call"] > one["ms_per_step"] and rc["two_models_ms"] > rc["ms_per_call"] and rc["maps_equal_timed_region"], rc
     assert one["dtype"].startswith("f16x2") and one["config"]["other_configs_in_this_line"]["config5_unaligned_svs_per_s"] == c5["svs_per_s"]
