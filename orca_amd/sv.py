@@ -157,6 +157,7 @@ class ChromEncodings:
         self.requests = {}        # (strand, phase) -> window-sized runs that no source could serve so far (`build="auto"`)
         self.builds = 0
         self.s3_misses = 0        # window strands of this chromosome that nobody could serve since the last attempt to build `stage3` (GenomeEncodings)
+        self.s3_spans = []        # ... and what each of them took from the chromosome, (lo, hi) in forward coordinates: the region to cache
         self.stage3 = None        # a Stage3Cache of this chromosome (sv_screen builds one for variants off the 4 kb grid): `encode_windows` sends
                                   # strands whose bins nobody holds through it instead of through the whole Encoder
 
@@ -283,31 +284,60 @@ class GenomeEncodings:
     def builds(self):
         return self._builds_gone + sum(c.builds for c in self.chroms.values())
 
-    def stage3_caches(self, chroms, build):
-        """{chrom: Stage3Cache} of those of ``chroms`` that hold a stage-3 cache.  ``build``: a window strand of these chromosomes just went
-        unserved - count it, and after `s3_after` of them build the chromosome's cache if it fits the budget (least recently used ones go)
-        and the device (beside 40 GB of workspace)."""
+    def stage3_caches(self, pcs, build, make=None):
+        """{chrom: stage cache} for a window strand given as strand-oriented 4-tuple pieces: the caches of its chromosomes that cover at least
+        half of what the window takes from them.  ``build``: the strand just went unserved - where no cache covers it, count it (and remember
+        the span of the chromosome it touched), and after `s3_after` of them build a cache of the REGION those strands spanned (+- 4 Mb; the
+        whole chromosome when that is what they spanned; grown from the region already held if both fit) - 1 KB of HBM per base, so a real
+        chromosome is cached a locus at a time: whatever exceeds `s3_budget` (least recently used chromosomes go first) or the device (beside
+        40 GB of workspace) is served without one.  ``make(chrom_encodings, region, nbytes)``: builds the cache (tests substitute it)."""
+        spans = {}
+        for p in pcs:
+            chrom, src, ln, _ = _p4(p)
+            if chrom in self.chrlens:
+                a, b = spans.get(chrom, (src, src + ln))
+                spans[chrom] = (min(a, src), max(b, src + ln))
         out = {}
-        for chrom in chroms:
+        for chrom, (lo, hi) in spans.items():
             ce = self.of(chrom)
-            if ce is None:
-                continue
-            if ce.stage3 is None and build and self.net0.two_part_ok():
+            s3 = ce.stage3
+            covered = s3 is not None and s3.region[0] <= lo and hi <= s3.region[1]
+            if not covered and build and self.net0.two_part_ok():
                 ce.s3_misses += 1
-                need = Stage3Cache.bytes_needed(ce.C)
-                if ce.s3_misses >= self.s3_after and need <= self.s3_budget:
-                    held = [(c, k) for c, k in self.chroms.items() if k.stage3 is not None and c != chrom]
-                    while held and sum(Stage3Cache.bytes_needed(k.C) for _, k in held) + need > self.s3_budget:
-                        held.pop(0)[1].stage3 = None
-                    dev = ce.codes.device
-                    if dev.type == "cuda" and need + 40e9 < _hbm_available(dev):
-                        s3 = Stage4Cache(self.net0, ce.codes)
-                        ce.stage3 = s3 if s3.build_all() else None
-                        engine.get_context(dev).release_workspace()
-                    ce.s3_misses = 0
-            if ce.stage3 is not None:
-                out[chrom] = ce.stage3
+                ce.s3_spans = (ce.s3_spans + [(lo, hi)])[-64:]
+                if ce.s3_misses >= self.s3_after:
+                    region = self._s3_region(ce, ce.s3_spans, s3.region if s3 is not None else None)
+                    if region is None and s3 is not None:
+                        region = self._s3_region(ce, ce.s3_spans)                     # the old region and the new one do not fit together
+                    if region is not None:
+                        need = Stage3Cache.bytes_needed(region[1] - region[0])
+                        ce.stage3 = s3 = None                                         # (its planes are free for the new one)
+                        held = [(c, k) for c, k in self.chroms.items() if k.stage3 is not None]
+                        while held and sum(Stage3Cache.bytes_needed(k.stage3.region[1] - k.stage3.region[0]) for _, k in held) + need > self.s3_budget:
+                            held.pop(0)[1].stage3 = None
+                        ce.stage3 = s3 = (make or self._s3_make)(ce, region, need)
+                    ce.s3_misses, ce.s3_spans = 0, []
+            if s3 is not None and min(hi, s3.region[1]) - max(lo, s3.region[0]) >= (hi - lo) // 2:
+                out[chrom] = s3
         return out
+
+    def _s3_region(self, ce, spans, keep=None):
+        """(r0, r1), multiples of 80: the spans' hull + 4 Mb either side inside the chromosome (and the region ``keep``); None if that is
+        more than the budget holds."""
+        r0 = max(0, min(a for a, _ in spans) - 4_000_000) // 80 * 80
+        r1 = min(ce.C, -(-(max(b for _, b in spans) + 4_000_000) // 80) * 80)
+        if keep is not None:
+            r0, r1 = min(r0, keep[0]), max(r1, keep[1])
+        return (r0, r1) if Stage3Cache.bytes_needed(r1 - r0) <= self.s3_budget else None
+
+    def _s3_make(self, ce, region, need):
+        dev = ce.codes.device
+        if dev.type != "cuda" or need + 40e9 >= _hbm_available(dev):
+            return None
+        s3 = Stage4Cache(self.net0, ce.codes, region)
+        ok = s3.build_all()
+        engine.get_context(dev).release_workspace()
+        return s3 if ok else None
 
 
 def _p4(piece):
@@ -637,7 +667,7 @@ def encode_windows(cache, pieces_list, win_codes, out, merge_gap=2 * RF_BINS, bu
                     merged.append(r)
             if sum(hi - lo for lo, hi in merged) > POOL_MAX_BINS and s3_able:
                 if multi:       # the drivers' store: per-chromosome caches, built once enough strands went unserved (`build="auto"`)
-                    s3w = cache.stage3_caches({_p4(p)[0] for p in pcs if _p4(p)[0] in cache.chrlens}, build == "auto")
+                    s3w = cache.stage3_caches(pcs, build == "auto")
                 else:
                     s3w = {None: s3} if s3 is not None else {}
                 if s3w:

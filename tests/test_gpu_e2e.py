@@ -589,6 +589,34 @@ def test_drivers_through_the_stage3_cache_against_the_reference_with_real_networ
     sv_drivers.clear_encoding_cache()
 
 
+def test_drivers_cache_a_locus_of_a_long_chromosome(cuda):
+    """1 KB of HBM per base: a 250 Mb chromosome is cached a LOCUS at a time (`GenomeEncodings.stage3_caches`).  `process_del` (32 Mb windows)
+    at arbitrary bases around 100 Mb of chrX: the store caches the region its first unserved window strands spanned (+- 4 Mb: ~44 Mb, 45 GB),
+    later calls in the locus are served from it - same dictionaries as every view through a whole `genomepredict` call."""
+    from orca_amd import sv_drivers
+    model = M.H1esc(synthetic_seed=0)
+    g = synth.sv_driver_genome_256().to(cuda)
+    sv_drivers.clear_encoding_cache()
+    store = sv_drivers._store(g, model.net0)
+    store.s3_after = 4
+    calls = [(100_000_123 + 250_007 * k, 100_400_456 + 250_007 * k) for k in range(3)]
+    for a in calls:
+        outs = P.process_del("chrX", *a, g, custom_models=[model], target=False)
+    s4 = store.of("chrX").stage3
+    assert s4 is not None and len(s4.entries) == 160 and 40_000_000 < s4.region[1] - s4.region[0] < 48_000_000, None if s4 is None else s4.region
+    assert s4.region[0] <= calls[0][0] - 16_000_000 and calls[-1][1] + 16_000_000 <= s4.region[1]
+    os.environ["ORCA_SV_INCREMENTAL"] = "0"
+    try:
+        whole = P.process_del("chrX", *calls[-1], g, custom_models=[model], target=False)
+    finally:
+        del os.environ["ORCA_SV_INCREMENTAL"]
+    for oa, ob in zip(outs, whole):
+        assert oa["start_coords"] == ob["start_coords"] and oa["end_coords"] == ob["end_coords"]
+        for x, y in zip(oa["predictions"][0], ob["predictions"][0]):
+            assert maxabs(x, y) < 3e-5
+    sv_drivers.clear_encoding_cache()
+
+
 @pytest.mark.parametrize("case", ["del256", "inv256", "bp256_short"])
 def test_process_256mb_drivers_against_the_reference_with_real_networks(cuda, case):
     """The 256 Mb branch of SURVEY 8(f1) against the ORACLE: the reference's own `process_del(..., window_radius=128000000)`

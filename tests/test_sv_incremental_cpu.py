@@ -233,3 +233,56 @@ def test_stage3_plan_is_exact_on_a_toy_front(grid, reach, kw):
     # a cache that holds a REGION of the chromosome only: what lies outside goes through the front
     check([(100_000, L, "+")], region=(120_000, 250_000))
     check([(100_000, 70_000, "+"), (200_003, 40_000, "-"), (290_000, 50_000, "+")], region=(150_000, 330_000))
+
+
+def test_drivers_store_caches_a_chromosome_a_locus_at_a_time():
+    """`GenomeEncodings.stage3_caches` (round 6): 1 KB of HBM per base means a real chromosome (chr1: 248 Mb) cannot be cached whole under the
+    store's budget - after `s3_after` window strands nobody served, the REGION those strands spanned (+- 4 Mb) is cached; strands inside it
+    are served, a run of strands outside it makes the region grow (or move, when both do not fit), least recently used chromosomes give way.
+    The builder is substituted: no GPU here."""
+    class FakeNet:
+        def two_part_ok(self):
+            return True
+
+    class FakeCache:
+        def __init__(self, region):
+            self.region = region
+
+    built = []
+
+    def make(ce, region, need):
+        built.append((ce.C, region, need))
+        return FakeCache(region)
+
+    genc = sv.GenomeEncodings(FakeNet(), lambda c: None, {"chr1": 248_000_000, "chr2": 242_000_000, "chrS": 40_000_000})
+    genc.s3_after, genc.s3_budget = 4, 120e9
+    window = lambda chrom, start: [(chrom, start, 32_000_000, "+")]
+    # three unserved strands: nothing yet; the fourth builds the hull of the four windows +- 4 Mb
+    for k in range(3):
+        assert genc.stage3_caches(window("chr1", 100_000_000 + 1_000_003 * k), True, make) == {} and not built
+    got = genc.stage3_caches(window("chr1", 103_000_009), True, make)
+    assert built == [(248_000_000, (96_000_000, 139_000_080), sv.Stage3Cache.bytes_needed(43_000_080))] and got["chr1"].region == (96_000_000, 139_000_080)
+    # inside the region: served, nothing counted; build=False never builds
+    assert genc.stage3_caches(window("chr1", 101_234_567), True, make)["chr1"] is got["chr1"] and genc.of("chr1").s3_misses == 0
+    assert genc.stage3_caches(window("chr2", 5_000_000), False, make) == {} and len(built) == 1
+    # a run of windows beyond the region: the old cache still serves those it covers by half, then the region grows to hold both
+    for k in range(3):
+        out = genc.stage3_caches(window("chr1", 120_000_000 + k), True, make)
+        assert out["chr1"] is got["chr1"] and len(built) == 1
+    grown = genc.stage3_caches(window("chr1", 120_000_003), True, make)["chr1"]
+    assert grown.region == (96_000_000, 156_000_080) and len(built) == 2
+    # far away: hull with the held region = 200 Mb > budget (117 Mb): the cache MOVES to the new locus
+    for k in range(4):
+        out = genc.stage3_caches(window("chr1", 200_000_000 + 7 * k), True, make)
+    assert out["chr1"].region == (196_000_000, 236_000_080) and len(built) == 3
+    # a whole small chromosome, and the budget across chromosomes: chr1's 40 Mb + chrS's 40 Mb fit; chr2's 100 Mb (102 of the 120 GB) evicts both
+    for k in range(4):
+        out = genc.stage3_caches(window("chrS", 1_000 * k + (8_000_000 if k & 1 else 0)), True, make)
+    assert out["chrS"].region == (0, 40_000_000) and genc.of("chr1").stage3 is not None
+    for k in range(4):
+        out = genc.stage3_caches([("chr2", 10_000_000 + 20_000_000 * k, 32_000_000, "-")], True, make)
+    assert out["chr2"].region == (6_000_000, 106_000_000)
+    held = {c for c in ("chr1", "chr2", "chrS") if genc.of(c).stage3 is not None}
+    assert held == {"chr2"}, held
+    # pieces of anything that is not a chromosome of the genome (an inserted string, padding) do not count
+    assert genc.stage3_caches([("__pad__", 0, 32_000_000, "+")], True, make) == {}
