@@ -556,10 +556,19 @@ class Stage4Cache(Stage3Cache):
             for k in range(S4_GRID // S3_GRID):
                 self.entries.pop((strand, (p16 + S3_GRID * k) % S4_GRID), None)
 
-    def build_all(self):
+    def build_all(self, times=None):
+        """All 160 entries; False (nothing kept) if the fp16-range guard fired.  ``times``: a list that receives the seconds each of the 32
+        groups took (a stream sync per group: diagnostics only)."""
+        import time
         for strand in "+-":
             for p16 in range(S3_GRID):
+                if times is not None:
+                    torch.cuda.synchronize(self.codes.device)
+                    t0 = time.perf_counter()
                 self._build_group(strand, p16)
+                if times is not None:
+                    torch.cuda.synchronize(self.codes.device)
+                    times.append(time.perf_counter() - t0)
                 if (strand, p16) not in self.entries:
                     self.entries.clear()
                     return False
@@ -828,12 +837,14 @@ def sv_screen(models, genome_codes, svs, chrlen, mchr="chrS", rank=0, world=1, i
             need = Stage3Cache.bytes_needed(region[1] - region[0]) * len(models)
             if (stage3 is True or whole_runs >= 32 * -(-(region[1] - region[0]) // WINDOW)) and need + 40e9 < _hbm_available(genome_codes.device):
                 t0 = time.perf_counter()
+                group_s = []
                 for cache in caches:
                     s3c = Stage4Cache(cache.net0, genome_codes, region)
-                    cache.stage3 = s3c if s3c.build_all() else None
+                    cache.stage3 = s3c if s3c.build_all(group_s) else None
                 engine.get_context(genome_codes.device).release_workspace()      # (the front on a whole chromosome: 768 B per base)
                 torch.cuda.synchronize(genome_codes.device)
                 s3_info = {"entries": sum(len(c.stage3.entries) for c in caches if c.stage3 is not None), "GB": round(need / 1e9, 1), "region": list(region),
+                           "group_ms_min_median_max": [round(1e3 * x, 1) for x in (min(group_s), sorted(group_s)[len(group_s) // 2], max(group_s))] if group_s else None,
                            "build_s": round(time.perf_counter() - t0, 3)}
         encoded = 0
         if streams is None:
