@@ -27,6 +27,10 @@ int ws_ensure(orca_ctx* ctx, size_t bytes) {
   ctx->ws_stream = ctx->stream;
   ctx->ws_used = true;
   if (bytes <= ctx->ws_bytes) return ORCA_OK;
+  // grow in steps of 1 GiB (64 MiB below that): a call that needs a few kilobytes more than the last one must not free and re-allocate a 30 GB
+  // arena - that pair costs 1.1-1.5 s on some boxes of this platform (found in the stage cache's build right behind a 40 Mb Encoder call)
+  const size_t step = bytes >= (size_t(1) << 30) ? (size_t(1) << 30) : (size_t(64) << 20);
+  bytes = (bytes + step - 1) / step * step;
   if (ctx->ws) {
     HIPCHECK(hipStreamSynchronize(ctx->stream));
     HIPCHECK(hipFree(ctx->ws));

@@ -335,9 +335,7 @@ class GenomeEncodings:
         if dev.type != "cuda" or need + 40e9 >= _hbm_available(dev):
             return None
         s3 = Stage4Cache(self.net0, ce.codes, region)
-        ok = s3.build_all()
-        engine.get_context(dev).release_workspace()
-        return s3 if ok else None
+        return s3 if s3.build_all() else None
 
 
 def _p4(piece):
@@ -841,7 +839,6 @@ def sv_screen(models, genome_codes, svs, chrlen, mchr="chrS", rank=0, world=1, i
                 for cache in caches:
                     s3c = Stage4Cache(cache.net0, genome_codes, region)
                     cache.stage3 = s3c if s3c.build_all(group_s) else None
-                engine.get_context(genome_codes.device).release_workspace()      # (the front on a whole chromosome: 768 B per base)
                 torch.cuda.synchronize(genome_codes.device)
                 s3_info = {"entries": sum(len(c.stage3.entries) for c in caches if c.stage3 is not None), "GB": round(need / 1e9, 1), "region": list(region),
                            "group_ms_min_median_max": [round(1e3 * x, 1) for x in (min(group_s), sorted(group_s)[len(group_s) // 2], max(group_s))] if group_s else None,
