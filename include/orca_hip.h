@@ -246,6 +246,10 @@ int orca_encoder_stage4_rows(orca_ctx* ctx, orca_net* net, const float* s4, int6
 int orca_rows_pool5_into(orca_ctx* ctx, const float* src, int64_t src_rows, int64_t src_pos0, float* dst, int64_t dst_rows, int64_t dst_pos0, int64_t count);
 int orca_encoder_front4_snippet(orca_ctx* ctx, orca_net* net, const uint8_t* codes, int64_t L, int reverse, int64_t base0, int64_t nbases, int64_t skip,
                                 int64_t count, float* dst, int64_t dst_rows, int64_t dst_pos0);
+/* ... and for the snippets of one window strand CONCATENATED into one L-base sequence (the window's ends first and last): ranges_host = n_ranges triples
+ * (skip, count, dst_pos0) of pooled rows of that one run. */
+int orca_encoder_front4_ranges(orca_ctx* ctx, orca_net* net, const uint8_t* codes, int64_t L, int reverse, int n_ranges, const int64_t* ranges_host,
+                               float* dst, int64_t dst_rows);
 int orca_encoder_back5(orca_ctx* ctx, orca_net* net, const float* rows, int64_t n5, float* out, int64_t so_c);
 
 /* Number of 4 kb bins Encoder emits for an L-bp input (floor through the

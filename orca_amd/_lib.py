@@ -59,6 +59,7 @@ SIGNATURES = {
     "orca_encoder_stage4_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "orca_rows_pool5_into": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64]),
     "orca_encoder_front4_snippet": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64]),
+    "orca_encoder_front4_ranges": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, POINTER(ctypes.c_int64), c_void_p, c_int64]),
     "orca_encoder_back5": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64]),
     "orca_encoder_forward_2bit": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64]),
     "orca_pack_sequence": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, POINTER(c_int)]),

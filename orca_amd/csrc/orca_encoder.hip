@@ -1037,6 +1037,23 @@ extern "C" int orca_encoder_front4_snippet(orca_ctx* ctx, orca_net* net, const u
   return launch_rows_pool5(ctx, res, 5 * (long)skip, dst, (long)dst_pos0, (long)count);
 }
 
+// the same for SEVERAL ranges of one front run: the snippets of a window strand concatenated (the window's ends first and last, so that the run's own ends
+// are the window's; the seams between snippets lie inside the margins nobody reads) - one chain of ~44 small launches per strand instead of one per snippet
+extern "C" int orca_encoder_front4_ranges(orca_ctx* ctx, orca_net* net, const uint8_t* codes, int64_t L, int reverse, int n_ranges, const int64_t* ranges_host,
+                                          float* dst, int64_t dst_rows) {
+  if (!dst || !ranges_host || n_ranges <= 0) return fail(ORCA_EINVAL, "orca_encoder_front4_ranges: NULL / empty argument");
+  if (L % 400) return fail(ORCA_EINVAL, "orca_encoder_front4_ranges: %ld bases: a multiple of 400", (long)L);
+  float* res; long rn;
+  ORCA_TRY(front_run(ctx, net, codes, L, reverse, 0, L, ENC_FRONT4, &res, &rn));
+  for (int k = 0; k < n_ranges; ++k) {
+    const long skip = (long)ranges_host[3 * k], count = (long)ranges_host[3 * k + 1], pos0 = (long)ranges_host[3 * k + 2];
+    if (skip < 0 || count <= 0 || 5 * (skip + count) > rn || pos0 < 0 || pos0 + count > dst_rows)
+      return fail(ORCA_EINVAL, "orca_encoder_front4_ranges: range %d: pooled rows [%ld,+%ld) of %ld -> [%ld,..) of %ld", k, skip, count, rn / 5, pos0, (long)dst_rows);
+    ORCA_TRY(launch_rows_pool5(ctx, res, 5 * skip, dst, pos0, count));
+  }
+  return ORCA_OK;
+}
+
 extern "C" int orca_encoder_back5(orca_ctx* ctx, orca_net* net, const float* rows, int64_t n5, float* out, int64_t so_c) {
   if (!ctx || !net || !rows || !out) return fail(ORCA_EINVAL, "orca_encoder_back5: NULL argument");
   if (net->kind != ORCA_NET_ENCODER || net->precision != ORCA_PRECISION_F16X2) return fail(ORCA_EINVAL, "orca_encoder_back5: an Encoder net in the f16x2 arithmetic");

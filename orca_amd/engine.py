@@ -546,6 +546,17 @@ def encoder_front4_snippet(net, codes, reverse, base0, nbases, skip, count, dst,
                                                   _p(dst), dst.shape[0], int(dst_pos0)), "orca_encoder_front4_snippet")
 
 
+def encoder_front4_ranges(net, codes, reverse, ranges, dst):
+    """Stages 1-4 + MaxPool1d(5) on ALL of ``codes`` [L] (the snippets of one window strand, concatenated); ranges = [(skip, count, dst_pos0)]: pooled
+    rows [skip, skip + count) of that run go to rows [dst_pos0, ..) of ``dst`` [n5,128]."""
+    codes = _codes1d(codes)
+    _rows(dst, "dst")
+    flat = (ctypes.c_int64 * (3 * len(ranges)))(*[int(v) for r in ranges for v in r])
+    net.ctx.sync_stream()
+    check(_lib.load().orca_encoder_front4_ranges(net.ctx.handle, net.handle, _p(codes), codes.numel(), 1 if reverse else 0, len(ranges), flat, _p(dst), dst.shape[0]),
+          "orca_encoder_front4_ranges")
+
+
 def encoder_back5(net, rows, out):
     """Stages 5-7 from the stage-5 input ``rows`` [n5,128] into ``out`` [128, n5 / 10] (unit stride along the bins)."""
     _rows(rows, "rows")

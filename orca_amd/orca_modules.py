@@ -243,6 +243,9 @@ class Encoder(_HipModule):
     def front4_snippet(self, codes, reverse, base0, nbases, skip, count, dst, dst_pos0):
         engine.encoder_front4_snippet(self._parts_net(codes.device), codes, reverse, base0, nbases, skip, count, dst, dst_pos0)
 
+    def front4_ranges(self, codes, reverse, ranges, dst):
+        engine.encoder_front4_ranges(self._parts_net(codes.device), codes, reverse, ranges, dst)
+
     def back5(self, rows, out):
         return engine.encoder_back5(self._parts_net(rows.device), rows, out)
 

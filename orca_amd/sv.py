@@ -395,6 +395,7 @@ S4_GRID = 80
 S4_MARGIN_BP = 1760      # >= 1 631, a multiple of 80
 S4_PAD_BP = 2400         # >= S4_MARGIN_BP, a multiple of 400 (a snippet's pooled rows must line up with the window's)
 S4_MIN_SNIPPET_BP = 8000
+S4_CONCAT_MAX_BP = 400_000   # snippets of a strand longer than this in all (pieces the cache does not hold) run one by one
 
 
 def _hbm_available(dev):
@@ -613,8 +614,20 @@ def _s4_encode(net0, caches, pcs, codes_w, reverse, out_row):
         if src is None:
             raise RuntimeError("stage-4 cache entry unavailable (fp16 range)")
         engine.rows_pool5_into(ctx, src, (c - caches[chrom]._origin(strand, phase)) // S4_GRID, s5, m_lo, m_hi - m_lo)
-    for ga, gb, b0, nb, skip in snippets:
-        net0.front4_snippet(codes_w, reverse, b0, nb, skip, gb - ga, s5, ga)
+    if len(snippets) > 1 and snippets[0][0] == 0 and snippets[-1][1] == n5 and sum(sn[3] for sn in snippets) <= S4_CONCAT_MAX_BP:
+        # ONE front run for the strand's snippets, concatenated in strand order: the window's two ends are first and last (the run's ends ARE the
+        # window's, zero padding included), the seams between snippets lie inside the pads nobody reads.  A reverse-complement strand's sequence is
+        # read backwards from the forward codes: its concatenation is the forward slices in reverse order.
+        cat = torch.cat([codes_w[b0: b0 + nb] for _, _, b0, nb, _ in snippets] if not reverse else
+                        [codes_w[L - b0 - nb: L - b0] for _, _, b0, nb, _ in reversed(snippets)])
+        ranges, off = [], 0
+        for ga, gb, b0, nb, skip in snippets:
+            ranges.append((off // (S4_GRID * S3_POOL) + skip, gb - ga, ga))
+            off += nb
+        net0.front4_ranges(cat, reverse, ranges, s5)
+    else:
+        for ga, gb, b0, nb, skip in snippets:
+            net0.front4_snippet(codes_w, reverse, b0, nb, skip, gb - ga, s5, ga)
     net0.back5(s5, out_row)
     return sum(sn[3] for sn in snippets)
 
@@ -819,13 +832,8 @@ def sv_screen(models, genome_codes, svs, chrlen, mchr="chrS", rank=0, world=1, i
     want = needed_phases([svs[i] for i in mine], chrlen)
     caches = []
     with torch.no_grad():
-        for model in models:
-            cache = ChromEncodings(model.net0, genome_codes)
-            for key, n in sorted(want.items(), key=lambda kv: -kv[1]):
-                if n >= min_uses:
-                    cache.get(*key)
-            caches.append(cache)
-        # windows whose phase is held by nobody: the stage-3 cache serves them at ANY phase
+        caches = [ChromEncodings(model.net0, genome_codes) for model in models]
+        # windows whose phase is held by nobody: the stage cache serves them at ANY phase
         whole_runs = int(sum(n for key, n in want.items() if n < min_uses))
         s3_info = None
         if stage3 and genome_codes.is_cuda and all(getattr(m.net0, "two_part_ok", lambda: False)() for m in models):
@@ -843,6 +851,13 @@ def sv_screen(models, genome_codes, svs, chrlen, mchr="chrS", rank=0, world=1, i
                 s3_info = {"entries": sum(len(c.stage3.entries) for c in caches if c.stage3 is not None), "GB": round(need / 1e9, 1), "region": list(region),
                            "group_ms_min_median_max": [round(1e3 * x, 1) for x in (min(group_s), sorted(group_s)[len(group_s) // 2], max(group_s))] if group_s else None,
                            "build_s": round(time.perf_counter() - t0, 3)}
+        # whole-chromosome bins per 4 kb phase that enough runs share: an entry costs chrlen / 32 Mb windows' worth of Encoder time and serves a
+        # strand by a copy; with a stage cache behind it (2 ms per strand at any phase) it pays only from ~16 runs on
+        for cache in caches:
+            uses = max(min_uses, 16) if cache.stage3 is not None else min_uses
+            for key, n in sorted(want.items(), key=lambda kv: -kv[1]):
+                if n >= uses:
+                    cache.get(*key)
         encoded = 0
         if streams is None:
             streams = 4

@@ -212,6 +212,14 @@ def test_stage3_plan_is_exact_on_a_toy_front(grid, reach, kw):
                 got[ga:gb] = pool5(stage3(win[b0: b0 + nb]))[skip: skip + gb - ga]
                 cov[ga:gb] += 1
             assert (cov == 1).all() and (got == ref).all(), (pieces, rev)
+            if len(snips) > 1 and snips[0][0] == 0 and snips[-1][1] == L // (5 * grid):
+                # the strand's snippets as ONE run (sv._s4_encode): concatenated in strand order, the window's ends first and last - the seams
+                # between snippets lie inside the pads nobody reads
+                cat = pool5(stage3(np.concatenate([win[b0: b0 + nb] for _, _, b0, nb, _ in snips])))
+                off = 0
+                for ga, gb, b0, nb, skip in snips:
+                    assert (cat[off // (5 * grid) + skip: off // (5 * grid) + skip + gb - ga] == ref[ga:gb]).all(), (pieces, rev, ga)
+                    off += nb
             assert region is not None or sum(sn[3] for sn in snips) < 0.3 * L
 
     for trial in range(24):
