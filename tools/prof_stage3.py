@@ -37,8 +37,17 @@ with engine.defer_overflow_guard():
                     for m_lo, m_hi, _, strand, phase, c in takes:
                         (engine.p16_pool5_into if level == 3 else engine.rows_pool5_into)(ctx, s3.get(strand, phase), (c - s3._origin(strand, phase)) // s3.grid, s4, m_lo, m_hi - m_lo)
                     e[1].record()
-                    for ga, gb, b0, nb, skip in snips:
-                        (h1.net0.front_snippet if level == 3 else h1.net0.front4_snippet)(w, rev, b0, nb, skip, gb - ga, s4, ga)
+                    if level == 4 and len(snips) > 1:      # as sv._s4_encode: the strand's snippets as ONE front run
+                        L_ = w.numel()
+                        cat = torch.cat([w[b0: b0 + nb] for _, _, b0, nb, _ in snips] if not rev else [w[L_ - b0 - nb: L_ - b0] for _, _, b0, nb, _ in reversed(snips)])
+                        ranges, off = [], 0
+                        for ga, gb, b0, nb, skip in snips:
+                            ranges.append((off // 400 + skip, gb - ga, ga))
+                            off += nb
+                        h1.net0.front4_ranges(cat, rev, ranges, s4)
+                    else:
+                        for ga, gb, b0, nb, skip in snips:
+                            (h1.net0.front_snippet if level == 3 else h1.net0.front4_snippet)(w, rev, b0, nb, skip, gb - ga, s4, ga)
                     e[2].record()
                     h1.net0.back(s4, n4, out) if level == 3 else h1.net0.back5(s4, out)
                     e[3].record()
