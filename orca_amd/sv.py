@@ -301,6 +301,9 @@ class GenomeEncodings:
         for chrom, (lo, hi) in spans.items():
             ce = self.of(chrom)
             s3 = ce.stage3
+            if s3 is not None and getattr(s3, "poisoned", False):     # built inside a pass whose fp16-range check fired: gone, and not tried again soon
+                ce.stage3 = s3 = None
+                ce.s3_misses, ce.s3_spans = -16 * self.s3_after, []
             covered = s3 is not None and s3.region[0] <= lo and hi <= s3.region[1]
             if not covered and build and self.net0.two_part_ok():
                 ce.s3_misses += 1
@@ -467,6 +470,7 @@ class Stage3Cache:
         self.region = (r0, r1)
         self.entries = {}
         self.builds = 0
+        self.poisoned = False
 
     @staticmethod
     def bytes_needed(nbases):
@@ -497,9 +501,12 @@ class Stage3Cache:
         return e
 
     def _drop(self, key, e):
+        """(engine.tentative) the deferred range check of the pass that built this entry fired: the entry goes, and the cache is marked - its
+        owner stops using it (the weights overflow the fp16 range on this genome: every rebuild would end the same way)."""
         if self.entries.get(key) is e:
             del self.entries[key]
             self.builds -= 1
+        self.poisoned = True
 
     def build_all(self):
         """All entries (32; 160 one level up); False (nothing kept) if the fp16-range guard fired on one of them."""

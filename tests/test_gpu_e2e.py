@@ -589,6 +589,44 @@ def test_drivers_through_the_stage3_cache_against_the_reference_with_real_networ
     sv_drivers.clear_encoding_cache()
 
 
+def test_stage_cache_built_in_a_pass_whose_range_check_fires_is_abandoned(cuda, monkeypatch):
+    """The drivers' store builds a chromosome's stage-4 cache INSIDE a call's deferred fp16-range check.  Forced here: the call that builds it
+    reports a raised range flag - the entries of that pass must be gone (`engine.tentative`), the range-safe retry (whole windows, bf16x3 / f32)
+    must give the maps of an undisturbed call at 1e-4, and the store must give the cache up instead of rebuilding it call after call."""
+    from orca_amd import engine, sv_drivers
+    model = M.H1esc(synthetic_seed=0)
+    g = synth.sv_driver_genome().to(cuda)
+    args, kw = ("chrS", 21_000_123, 21_404_321, g), dict(custom_models=[model], target=False)
+    sv_drivers.clear_encoding_cache()
+    base = P.process_del(*args, **kw)
+    sv_drivers.clear_encoding_cache()
+    store = sv_drivers._store(g, model.net0)
+    store.s3_after = 1
+    real, calls, seen = engine.Context.take_overflow, {"n": 0}, {}
+
+    def fake(self):
+        calls["n"] += 1
+        if calls["n"] == 1:
+            s4 = store.of("chrS").stage3
+            seen["entries_at_check"] = 0 if s4 is None else len(s4.entries)
+            return True
+        return bool(real(self))
+    with monkeypatch.context() as mp_, pytest.warns(UserWarning, match="fp16 range"):
+        mp_.setattr(engine.Context, "take_overflow", fake)
+        redo = P.process_del(*args, **kw)
+    assert seen["entries_at_check"] == 160, seen
+    s4 = store.of("chrS").stage3
+    assert s4 is not None and s4.poisoned and not s4.entries
+    later = P.process_del(*args, **kw)
+    assert store.of("chrS").stage3 is None and store.of("chrS").s3_misses < 0
+    for outs in (redo, later):
+        for oa, ob in zip(outs, base):
+            assert oa["start_coords"] == ob["start_coords"]
+            for x, y in zip(oa["predictions"][0], ob["predictions"][0]):
+                assert maxabs(x, y) < 1e-4
+    sv_drivers.clear_encoding_cache()
+
+
 def test_drivers_cache_a_locus_of_a_long_chromosome(cuda):
     """1 KB of HBM per base: a 250 Mb chromosome is cached a LOCUS at a time (`GenomeEncodings.stage3_caches`).  `process_del` (32 Mb windows)
     at arbitrary bases around 100 Mb of chrX: the store caches the region its first unserved window strands spanned (+- 4 Mb: ~44 Mb, 45 GB),

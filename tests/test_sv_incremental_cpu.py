@@ -253,6 +253,8 @@ def test_drivers_store_caches_a_chromosome_a_locus_at_a_time():
             return True
 
     class FakeCache:
+        poisoned = False
+
         def __init__(self, region):
             self.region = region
 
@@ -292,5 +294,11 @@ def test_drivers_store_caches_a_chromosome_a_locus_at_a_time():
     assert out["chr2"].region == (6_000_000, 106_000_000)
     held = {c for c in ("chr1", "chr2", "chrS") if genc.of(c).stage3 is not None}
     assert held == {"chr2"}, held
+    # a cache whose entries were dropped because the range check of the pass that built it fired is abandoned, and not rebuilt at once
+    genc.of("chr2").stage3.poisoned = True
+    n_built = len(built)
+    for k in range(8):
+        assert genc.stage3_caches([("chr2", 10_000_000, 32_000_000, "+")], True, make) == {}
+    assert genc.of("chr2").stage3 is None and len(built) == n_built
     # pieces of anything that is not a chromosome of the genome (an inserted string, padding) do not count
     assert genc.stage3_caches([("__pad__", 0, 32_000_000, "+")], True, make) == {}
